@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""Regenerate the structural golden vectors from the reference implementation.
+
+Runs ONLY in the build container (needs /root/reference).  It imports the reference's
+``pyMPC.mpc.MPCController`` with a throw-away capture stub standing in for the absent
+``osqp`` module (the reference does ``import osqp`` at module top, pyMPC/mpc.py:4), calls
+``setup(solve=False)`` and a scripted ``update(..., solve=False)`` sequence, and stores what
+the reference hands to the solver: P, q, A, l, u (mpc.py:456-608) and the refreshed q, l, u
+(mpc.py:386-454).  Only arrays are stored -- no reference source travels.
+
+    python tests/golden/make_golden.py        # writes tests/golden/qp_<name>.npz
+"""
+import os
+import sys
+import tempfile
+import textwrap
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+
+STUB = textwrap.dedent('''
+    import numpy as np
+    class _Info:  # what pyMPC reads from res.info
+        status = 'solved'
+        obj_val = 0.0
+    class _Res:
+        def __init__(self, n):
+            self.x = np.zeros(n)
+            self.info = _Info()
+    class OSQP:
+        def __init__(self):
+            self.calls = []
+        def setup(self, P, q, A, l, u, **kw):
+            self.n = P.shape[0]
+            self.calls.append(('setup', dict(kw)))
+        def update(self, **kw):
+            self.calls.append(('update', {k: np.array(v, copy=True) for k, v in kw.items()}))
+        def solve(self):
+            return _Res(self.n)
+''')
+
+
+def load_reference():
+    stub_dir = tempfile.mkdtemp(prefix='osqp_stub_')
+    os.makedirs(os.path.join(stub_dir, 'osqp'))
+    with open(os.path.join(stub_dir, 'osqp', '__init__.py'), 'w') as f:
+        f.write(STUB)
+    sys.path.insert(0, stub_dir)
+    sys.path.insert(0, '/root/reference')
+    from pyMPC.mpc import MPCController  # noqa: E402  (the reference, read-only)
+    return MPCController
+
+
+def csc_parts(M):
+    M = M.tocsc()
+    return M.data.astype(float), M.indices.astype(np.int64), M.indptr.astype(np.int64), np.array(M.shape)
+
+
+def update_script(kw, rng):
+    """Three scripted update() calls: (x,u), (x only), (x,u,new xref)."""
+    nx = kw['Ad'].shape[0]
+    nu = kw['Bd'].shape[1]
+    xref = kw.get('xref')
+    steps = []
+    steps.append(dict(x=rng.standard_normal(nx) * 0.3, u=rng.standard_normal(nu) * 0.1, xref=None))
+    steps.append(dict(x=rng.standard_normal(nx) * 0.3, u=None, xref=None))
+    if xref is not None and np.ndim(xref) == 2:
+        newref = np.array(xref) * 0.5 + 0.1 * rng.standard_normal(np.shape(xref))
+    else:
+        newref = rng.standard_normal(nx) * 0.5
+    steps.append(dict(x=rng.standard_normal(nx) * 0.3, u=rng.standard_normal(nu) * 0.1, xref=newref))
+    return steps
+
+
+def main():
+    from pympc_amd import fixtures
+    MPCController = load_reference()
+    for name, make in fixtures.NAMED.items():
+        kw = make()
+        K = MPCController(**{k: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v) for k, v in kw.items()})
+        K.setup(solve=False)
+        out = {}
+        for k, v in kw.items():
+            out['in_' + k] = np.asarray(v, dtype=float) if not isinstance(v, (int, np.integer)) else np.int64(v)
+        Pd, Pi, Pp, Ps = csc_parts(K.P)
+        Ad_, Ai, Ap, As = csc_parts(K.A)
+        out.update(P_data=Pd, P_indices=Pi, P_indptr=Pp, P_shape=Ps,
+                   A_data=Ad_, A_indices=Ai, A_indptr=Ap, A_shape=As,
+                   q=K.q.copy(), l=K.l.copy(), u=K.u.copy(),
+                   setup_kwargs=np.array(repr(sorted(K.prob.calls[0][1].items()))))
+        rng = np.random.default_rng(4242)
+        for s, st in enumerate(update_script(kw, rng)):
+            K.update(st['x'], u=st['u'], xref=st['xref'], solve=False)
+            out['upd%d_x' % s] = st['x']
+            out['upd%d_u' % s] = st['u'] if st['u'] is not None else np.zeros(0)
+            out['upd%d_xref' % s] = st['xref'] if st['xref'] is not None else np.zeros(0)
+            out['upd%d_q' % s] = K.q.copy()
+            out['upd%d_l' % s] = K.l.copy()
+            out['upd%d_u_bound' % s] = K.u.copy()
+            # the output() side effect on uminus1_rh is exercised by the stub's zero solution
+            if s == 0:
+                K.solve()
+                u0 = K.output()
+                out['upd0_output_u'] = np.array(u0, copy=True)
+        path = os.path.join(HERE, 'qp_%s.npz' % name)
+        np.savez_compressed(path, **out)
+        print('%-20s n=%5d m=%5d nnzP=%6d nnzA=%6d -> %s (%d B)' % (
+            name, K.P.shape[0], K.A.shape[0], K.P.nnz, K.A.nnz, os.path.basename(path), os.path.getsize(path)))
+
+
+if __name__ == '__main__':
+    main()
