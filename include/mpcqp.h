@@ -1,0 +1,150 @@
+/*
+ * mpcqp.h -- C ABI of libmpcqp_hip.so: batched linear-MPC QP build + OSQP-style ADMM solve on
+ * AMD MI355X (gfx950).  Plain pointers and sizes only; every function returns 0 on success or a
+ * negative mpcqp_error; solver outcomes (solved / infeasible / max-iter ...) are reported in
+ * mpcqp_info.status, never as an error code.
+ *
+ * The entry points mirror, one to one, what the reference's controller does around its solver
+ * (file:line relative to the reference checkout):
+ *
+ *   mpcqp_create          osqp.OSQP()                                   pyMPC/mpc.py:241
+ *   mpcqp_setup           MPCController.setup():  _compute_QP_matrices_ pyMPC/mpc.py:254-266,456-608
+ *                         + prob.setup(P,q,A,l,u, warm_start=True, eps_abs=, eps_rel=)
+ *   mpcqp_update          MPCController.update(): _update_QP_matrices_  pyMPC/mpc.py:338-362,386-454
+ *                         + prob.update(l=,u=,q=)
+ *   mpcqp_solve           MPCController.solve():  prob.solve()          pyMPC/mpc.py:366-375
+ *   mpcqp_get_solution    res.x / res.y / res.info.*                    pyMPC/mpc.py:301-327
+ *   mpcqp_get_u0          output(): res.x[(Np+1)nx : (Np+1)nx+nu]        pyMPC/mpc.py:301-304
+ *   mpcqp_export_qp       the public attributes P,q,A,l,u               pyMPC/mpc.py:598-606
+ *
+ * The QP is the reference's sparse (non-condensed) formulation, bug-for-bug:
+ *   w = [x_0..x_Np | u_0..u_{Nc-1} | eps_0..eps_Np],  n = 2(Np+1)nx + Nc nu
+ *   rows: dynamics (Np+1)nx | soft state box (Np+1)nx | input box Nc nu | Delta-u (Nc+1)nu
+ * All numbers are float64.  A handle owns `batch` independent MPC instances of identical
+ * dimensions; per-instance arrays are instance-major and contiguous ([batch][...]).
+ * Input/output pointers may be host OR device pointers (copies use hipMemcpyDefault).
+ * One handle <-> one HIP stream; calls on one handle must be serialised by the caller.
+ */
+#ifndef MPCQP_H
+#define MPCQP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mpcqp_handle mpcqp_handle;
+
+enum mpcqp_error {
+    MPCQP_OK = 0,
+    MPCQP_ERR_ARG = -1,          /* bad dimension / NULL pointer / unsupported combination */
+    MPCQP_ERR_HIP = -2,          /* a HIP runtime call failed (see mpcqp_last_error)        */
+    MPCQP_ERR_NO_DEVICE = -3,    /* no usable GPU                                           */
+    MPCQP_ERR_UNSUPPORTED = -4,  /* valid reference configuration not implemented on device */
+    MPCQP_ERR_STATE = -5         /* call order (e.g. solve before setup)                    */
+};
+
+/* OSQP's status values and strings (what pyMPC compares against 'solved', mpc.py:301,372) */
+enum mpcqp_status {
+    MPCQP_SOLVED = 1, MPCQP_SOLVED_INACCURATE = 2, MPCQP_MAX_ITER_REACHED = -2,
+    MPCQP_PRIMAL_INFEASIBLE = -3, MPCQP_PRIMAL_INFEASIBLE_INACCURATE = 3,
+    MPCQP_DUAL_INFEASIBLE = -4, MPCQP_DUAL_INFEASIBLE_INACCURATE = 4,
+    MPCQP_NON_CVX = -7, MPCQP_UNSOLVED = -10
+};
+
+/* OSQP 0.6.x settings that influence the ADMM iteration (same names, same defaults). */
+typedef struct {
+    double rho, sigma, alpha;
+    double eps_abs, eps_rel, eps_prim_inf, eps_dual_inf;
+    double adaptive_rho_tolerance;
+    int32_t max_iter, check_termination, scaling;
+    int32_t adaptive_rho, adaptive_rho_interval;   /* interval 0 -> 4*check_termination */
+    int32_t warm_start;
+} mpcqp_settings;
+
+typedef struct {
+    int32_t status;        /* enum mpcqp_status */
+    int32_t iter;
+    int32_t rho_updates;
+    int32_t reserved;
+    double obj_val;        /* 1/2 w'Pw + q'w (without the reference's J_CNST)  */
+    double pri_res, dua_res;
+    double rho;            /* rho in force when the solve ended */
+} mpcqp_info;
+
+/* Per-instance controller data, every pointer [batch][...] float64, row-major matrices.
+ * Mirrors the constructor arguments of MPCController (mpc.py:76-80); +-inf bounds allowed. */
+typedef struct {
+    const double *Ad;      /* [nx*nx] */
+    const double *Bd;      /* [nx*nu] */
+    const double *Qx;      /* [nx*nx] */
+    const double *QxN;     /* [nx*nx] */
+    const double *Qu;      /* [nu*nu] */
+    const double *QDu;     /* [nu*nu] */
+    const double *xmin, *xmax;        /* [nx] */
+    const double *umin, *umax;        /* [nu] */
+    const double *Dumin, *Dumax;      /* [nu] */
+    const double *uref;               /* [nu] */
+    const double *eps_feas;           /* [1]  */
+} mpcqp_model;
+
+void mpcqp_default_settings(mpcqp_settings *s);
+const char *mpcqp_status_string(int status);
+const char *mpcqp_last_error(void);
+int mpcqp_device_count(void);
+
+int mpcqp_create(mpcqp_handle **h, int device, int batch, int nx, int nu, int Np, int Nc,
+                 const mpcqp_settings *s);
+void mpcqp_destroy(mpcqp_handle *h);
+
+/* Run all later work of this handle on an existing HIP stream (hipStream_t passed as void*). */
+int mpcqp_set_stream(mpcqp_handle *h, void *hip_stream);
+int mpcqp_synchronize(mpcqp_handle *h);
+
+/* setup(): upload the model, build the QP on the device, equilibrate, choose rho, factor the
+ * KKT system, cold-start the iterate.  x0 [batch][nx], uminus1 [batch][nu],
+ * xref [batch][xref_rows*nx] with xref_rows == 1 (constant reference, mpc.py:497-498) or
+ * xref_rows == Np+1 (time-varying reference, mpc.py:489-493). */
+int mpcqp_setup(mpcqp_handle *h, const mpcqp_model *model,
+                const double *x0, const double *uminus1, const double *xref, int xref_rows);
+
+/* update(): new x0 / u_{-1} / xref (any pointer may be NULL = unchanged); q, l, u are
+ * refreshed on the device at the start of the next solve. */
+int mpcqp_update(mpcqp_handle *h, const double *x0, const double *uminus1,
+                 const double *xref, int xref_rows);
+
+/* Replace the iterate (osqp.warm_start(x=, y=)); x [batch][n], y [batch][m], NULL = keep. */
+int mpcqp_warm_start(mpcqp_handle *h, const double *x, const double *y);
+
+/* Change tolerances / iteration limits after setup (osqp.update_settings). */
+int mpcqp_update_settings(mpcqp_handle *h, const mpcqp_settings *s);
+
+/* Enqueue one ADMM solve of every instance (asynchronous on the handle's stream). */
+int mpcqp_solve(mpcqp_handle *h);
+
+/* Results of the last solve (synchronises).  x [batch][n], y [batch][m], info [batch];
+ * any pointer may be NULL.  u0 [batch][nu] is the first optimal input of each instance. */
+int mpcqp_get_solution(mpcqp_handle *h, double *x, double *y, mpcqp_info *info);
+int mpcqp_get_u0(mpcqp_handle *h, double *u0);
+
+/* Problem sizes: n, m of one instance, bytes of the KKT factor per instance, and nnz(L). */
+int mpcqp_get_dims(mpcqp_handle *h, int *n, int *m, int64_t *factor_doubles, int64_t *nnzL);
+
+/* ---- verification surface (used by the parity tests) ------------------------------------ */
+/* Materialise what the device built: dense row-major P [batch][n*n], A [batch][m*n],
+ * q [batch][n], l,u [batch][m] (the reference's public attributes, mpc.py:598-606). */
+int mpcqp_export_qp(mpcqp_handle *h, double *P, double *A, double *q, double *l, double *u);
+/* Equilibration D [batch][n], E [batch][m], c [batch]; current rho [batch]. */
+int mpcqp_get_scaling(mpcqp_handle *h, double *D, double *E, double *c, double *rho);
+/* Solve the (reduced) KKT system of the current factor: K sol = rhs, [batch][n] each. */
+int mpcqp_debug_kkt_solve(mpcqp_handle *h, const double *rhs, double *sol);
+/* Current ADMM iterate in unscaled units: x [batch][n], z,y [batch][m]. */
+int mpcqp_get_iterate(mpcqp_handle *h, double *x, double *z, double *y);
+/* Run exactly `iters` ADMM iterations with no termination test and no rho adaptation. */
+int mpcqp_iterate(mpcqp_handle *h, int iters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,94 @@
+"""ctypes binding of libmpcqp_hip.so (C ABI declared in include/mpcqp.h).
+
+There is deliberately no fallback: if the shared library has not been built
+(``python -c 'import __graft_entry__ as g; g.build()'`` or ``pympc_amd/csrc/build.sh``)
+loading raises, and creating a problem without a GPU raises ``RuntimeError``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libmpcqp_hip.so')
+
+# every symbol declared in include/mpcqp.h
+SYMBOLS = [
+    'mpcqp_default_settings', 'mpcqp_status_string', 'mpcqp_last_error', 'mpcqp_device_count',
+    'mpcqp_create', 'mpcqp_destroy', 'mpcqp_set_stream', 'mpcqp_synchronize',
+    'mpcqp_setup', 'mpcqp_update', 'mpcqp_warm_start', 'mpcqp_update_settings', 'mpcqp_solve',
+    'mpcqp_get_solution', 'mpcqp_get_u0', 'mpcqp_get_dims',
+    'mpcqp_export_qp', 'mpcqp_get_scaling', 'mpcqp_debug_kkt_solve', 'mpcqp_get_iterate', 'mpcqp_iterate',
+]
+
+
+class Settings(C.Structure):
+    _fields_ = [('rho', C.c_double), ('sigma', C.c_double), ('alpha', C.c_double),
+                ('eps_abs', C.c_double), ('eps_rel', C.c_double),
+                ('eps_prim_inf', C.c_double), ('eps_dual_inf', C.c_double),
+                ('adaptive_rho_tolerance', C.c_double),
+                ('max_iter', C.c_int32), ('check_termination', C.c_int32), ('scaling', C.c_int32),
+                ('adaptive_rho', C.c_int32), ('adaptive_rho_interval', C.c_int32), ('warm_start', C.c_int32)]
+
+
+class Info(C.Structure):
+    _fields_ = [('status', C.c_int32), ('iter', C.c_int32), ('rho_updates', C.c_int32), ('reserved', C.c_int32),
+                ('obj_val', C.c_double), ('pri_res', C.c_double), ('dua_res', C.c_double), ('rho', C.c_double)]
+
+
+_pd = C.POINTER(C.c_double)
+
+
+class Model(C.Structure):
+    _fields_ = [(k, _pd) for k in ('Ad', 'Bd', 'Qx', 'QxN', 'Qu', 'QDu', 'xmin', 'xmax', 'umin', 'umax',
+                                   'Dumin', 'Dumax', 'uref', 'eps_feas')]
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP library (once) and declare the prototypes of include/mpcqp.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libmpcqp_hip.so is missing (%s). Build it with pympc_amd/csrc/build.sh; "
+            "pympc_amd has no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    H = C.c_void_p
+    L.mpcqp_default_settings.argtypes = [C.POINTER(Settings)]
+    L.mpcqp_default_settings.restype = None
+    L.mpcqp_status_string.argtypes = [C.c_int]
+    L.mpcqp_status_string.restype = C.c_char_p
+    L.mpcqp_last_error.restype = C.c_char_p
+    L.mpcqp_device_count.restype = C.c_int
+    L.mpcqp_create.argtypes = [C.POINTER(H), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Settings)]
+    L.mpcqp_destroy.argtypes = [H]
+    L.mpcqp_destroy.restype = None
+    L.mpcqp_set_stream.argtypes = [H, C.c_void_p]
+    L.mpcqp_synchronize.argtypes = [H]
+    L.mpcqp_setup.argtypes = [H, C.POINTER(Model), C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.mpcqp_update.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.mpcqp_warm_start.argtypes = [H, C.c_void_p, C.c_void_p]
+    L.mpcqp_update_settings.argtypes = [H, C.POINTER(Settings)]
+    L.mpcqp_solve.argtypes = [H]
+    L.mpcqp_get_solution.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.mpcqp_get_u0.argtypes = [H, C.c_void_p]
+    L.mpcqp_get_dims.argtypes = [H, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.mpcqp_export_qp.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.mpcqp_get_scaling.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.mpcqp_debug_kkt_solve.argtypes = [H, C.c_void_p, C.c_void_p]
+    L.mpcqp_get_iterate.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.mpcqp_iterate.argtypes = [H, C.c_int]
+    for name in SYMBOLS:
+        getattr(L, name)           # AttributeError here = header and library out of sync
+        if name not in ('mpcqp_default_settings', 'mpcqp_status_string', 'mpcqp_last_error', 'mpcqp_destroy'):
+            getattr(L, name).restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().mpcqp_last_error().decode()
+        raise RuntimeError('%s failed (%d): %s' % (what, rc, msg))

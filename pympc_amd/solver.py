@@ -1,0 +1,278 @@
+"""Python face of the HIP solver.
+
+``BatchProblem``  -- a batch of independent MPC instances of equal dimensions living on one GPU
+                     (thin, 1:1 wrapper over the C ABI of include/mpcqp.h).
+``DeviceProblem`` -- the object ``MPCController`` keeps in ``self.prob`` where the reference keeps
+                     ``osqp.OSQP()`` (pyMPC/mpc.py:241): ``setup / update / solve`` with the call
+                     shapes of mpc.py:266, 454, 369, returning an osqp-like result object.
+
+Arrays may be numpy ndarrays (host) or torch CUDA tensors (device-resident); both are passed as
+raw pointers, PyTorch being used only as a device-memory container.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+_SETTING_NAMES = [f[0] for f in _lib.Settings._fields_]
+# accepted for call compatibility with osqp, without effect on this solver
+_IGNORED_SETTINGS = ('verbose', 'polish', 'linsys_solver', 'time_limit', 'scaled_termination', 'delta',
+                     'polish_refine_iter', 'adaptive_rho_fraction')
+
+
+def _ptr(a):
+    if a is None:
+        return None
+    if hasattr(a, 'data_ptr'):             # torch tensor (device or host)
+        return C.c_void_p(a.data_ptr())
+    return C.c_void_p(a.ctypes.data)
+
+
+def _prep(a, shape, name):
+    """float64, C-contiguous, exact shape; returns an object that keeps the memory alive."""
+    if a is None:
+        raise ValueError('%s is required' % name)
+    if hasattr(a, 'data_ptr'):
+        import torch
+        if a.numel() != int(np.prod(shape)):
+            a = a.expand(shape)
+        if a.dtype != torch.float64 or not a.is_contiguous() or tuple(a.shape) != tuple(shape):
+            a = a.to(torch.float64).reshape(shape).contiguous()
+        return a
+    a = np.asarray(a, dtype=np.float64)
+    if a.size == int(np.prod(shape)):
+        return np.ascontiguousarray(a.reshape(shape))
+    return np.ascontiguousarray(np.broadcast_to(a, shape))
+
+
+def make_settings(**kw):
+    L = _lib.load()
+    s = _lib.Settings()
+    L.mpcqp_default_settings(C.byref(s))
+    for k, v in kw.items():
+        if k in _SETTING_NAMES:
+            setattr(s, k, v)
+        elif k in _IGNORED_SETTINGS:
+            if k == 'scaled_termination' and v:
+                raise NotImplementedError('scaled_termination=True is not implemented')
+        else:
+            raise TypeError('unknown solver setting %r' % k)
+    return s
+
+
+class Result:
+    """Mimics osqp's results object as far as pyMPC reads it (mpc.py:301-327)."""
+
+    class _Info:
+        pass
+
+    def __init__(self, x, y, info, status_str):
+        self.x = x
+        self.y = y
+        self.info = Result._Info()
+        self.info.status_val = int(info.status)
+        self.info.status = status_str
+        self.info.iter = int(info.iter)
+        self.info.rho_updates = int(info.rho_updates)
+        self.info.obj_val = float(info.obj_val)
+        self.info.pri_res = float(info.pri_res)
+        self.info.dua_res = float(info.dua_res)
+        self.info.rho_estimate = float(info.rho)
+
+
+class BatchProblem:
+    """``batch`` independent MPC problems (nx, nu, Np, Nc) on GPU ``device``."""
+
+    def __init__(self, batch, nx, nu, Np, Nc=None, device=0, stream=None, **settings):
+        self._L = _lib.load()
+        self._h = C.c_void_p()
+        if self._L.mpcqp_device_count() <= 0:
+            raise RuntimeError('pympc_amd needs an AMD GPU (no HIP device visible); there is no CPU fallback')
+        self.batch, self.nx, self.nu, self.Np = int(batch), int(nx), int(nu), int(Np)
+        self.Nc = int(Np if Nc is None else Nc)
+        self.settings = make_settings(**settings)
+        rc = self._L.mpcqp_create(C.byref(self._h), int(device), self.batch, self.nx, self.nu, self.Np, self.Nc,
+                                  C.byref(self.settings))
+        if rc == -4:
+            raise NotImplementedError(self._L.mpcqp_last_error().decode())
+        _lib.check(rc, 'mpcqp_create')
+        n, m, fd, nnzL = C.c_int(), C.c_int(), C.c_int64(), C.c_int64()
+        _lib.check(self._L.mpcqp_get_dims(self._h, C.byref(n), C.byref(m), C.byref(fd), C.byref(nnzL)), 'mpcqp_get_dims')
+        self.n, self.m, self.factor_doubles, self.nnzL = n.value, m.value, fd.value, nnzL.value
+        if stream is not None:
+            _lib.check(self._L.mpcqp_set_stream(self._h, C.c_void_p(int(stream))), 'mpcqp_set_stream')
+        self._keep = []
+
+    def close(self):
+        if getattr(self, '_h', None) and self._h.value:
+            self._L.mpcqp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- reference-shaped calls ---------------------------------------------------------------
+    def setup(self, Ad, Bd, Qx, QxN, Qu, QDu, xmin, xmax, umin, umax, Dumin, Dumax, uref, eps_feas,
+              x0, uminus1, xref):
+        B, nx, nu = self.batch, self.nx, self.nu
+        xref_rows = self._xref_rows(xref)
+        arrs = dict(
+            Ad=_prep(Ad, (B, nx, nx), 'Ad'), Bd=_prep(Bd, (B, nx, nu), 'Bd'),
+            Qx=_prep(Qx, (B, nx, nx), 'Qx'), QxN=_prep(QxN, (B, nx, nx), 'QxN'),
+            Qu=_prep(Qu, (B, nu, nu), 'Qu'), QDu=_prep(QDu, (B, nu, nu), 'QDu'),
+            xmin=_prep(xmin, (B, nx), 'xmin'), xmax=_prep(xmax, (B, nx), 'xmax'),
+            umin=_prep(umin, (B, nu), 'umin'), umax=_prep(umax, (B, nu), 'umax'),
+            Dumin=_prep(Dumin, (B, nu), 'Dumin'), Dumax=_prep(Dumax, (B, nu), 'Dumax'),
+            uref=_prep(uref, (B, nu), 'uref'), eps_feas=_prep(eps_feas, (B, 1), 'eps_feas'))
+        model = _lib.Model()
+        for k, v in arrs.items():
+            setattr(model, k, C.cast(_ptr(v), C.POINTER(C.c_double)))
+        x0a = _prep(x0, (B, nx), 'x0')
+        uma = _prep(uminus1, (B, nu), 'uminus1')
+        xra = _prep(xref, (B, xref_rows * nx), 'xref')
+        self._keep = [arrs, x0a, uma, xra]
+        _lib.check(self._L.mpcqp_setup(self._h, C.byref(model), _ptr(x0a), _ptr(uma), _ptr(xra), xref_rows), 'mpcqp_setup')
+        _lib.check(self._L.mpcqp_synchronize(self._h), 'mpcqp_synchronize')
+        self._keep = []
+
+    def _xref_rows(self, xref):
+        shape = tuple(xref.shape)
+        per = int(np.prod(shape[1:])) if len(shape) > 1 and shape[0] == self.batch else int(np.prod(shape))
+        if per == self.nx:
+            return 1
+        if per == (self.Np + 1) * self.nx:
+            return self.Np + 1
+        raise ValueError('xref must hold nx or (Np+1)*nx values per instance')
+
+    def update(self, x0=None, uminus1=None, xref=None):
+        B, nx, nu = self.batch, self.nx, self.nu
+        rows = 1
+        a = _prep(x0, (B, nx), 'x0') if x0 is not None else None
+        b = _prep(uminus1, (B, nu), 'uminus1') if uminus1 is not None else None
+        c = None
+        if xref is not None:
+            rows = self._xref_rows(xref)
+            c = _prep(xref, (B, rows * nx), 'xref')
+        self._keep = [a, b, c]
+        _lib.check(self._L.mpcqp_update(self._h, _ptr(a), _ptr(b), _ptr(c), rows), 'mpcqp_update')
+        if any(hasattr(v, 'ctypes') for v in self._keep if v is not None):
+            # pageable host memory: the async copy has completed or been staged when the call returns
+            pass
+
+    def update_settings(self, **kw):
+        for k, v in kw.items():
+            if k not in _SETTING_NAMES:
+                raise TypeError('unknown solver setting %r' % k)
+            setattr(self.settings, k, v)
+        _lib.check(self._L.mpcqp_update_settings(self._h, C.byref(self.settings)), 'mpcqp_update_settings')
+
+    def warm_start(self, x=None, y=None):
+        a = _prep(x, (self.batch, self.n), 'x') if x is not None else None
+        b = _prep(y, (self.batch, self.m), 'y') if y is not None else None
+        _lib.check(self._L.mpcqp_warm_start(self._h, _ptr(a), _ptr(b)), 'mpcqp_warm_start')
+        _lib.check(self._L.mpcqp_synchronize(self._h), 'mpcqp_synchronize')
+
+    def solve_async(self):
+        _lib.check(self._L.mpcqp_solve(self._h), 'mpcqp_solve')
+
+    def synchronize(self):
+        _lib.check(self._L.mpcqp_synchronize(self._h), 'mpcqp_synchronize')
+
+    def solution(self, want_y=True):
+        x = np.empty((self.batch, self.n))
+        y = np.empty((self.batch, self.m)) if want_y else None
+        info = (_lib.Info * self.batch)()
+        _lib.check(self._L.mpcqp_get_solution(self._h, _ptr(x), _ptr(y), C.cast(info, C.c_void_p)), 'mpcqp_get_solution')
+        return x, y, info
+
+    def infos(self):
+        info = (_lib.Info * self.batch)()
+        _lib.check(self._L.mpcqp_get_solution(self._h, None, None, C.cast(info, C.c_void_p)), 'mpcqp_get_solution')
+        return info
+
+    def u0(self, out=None):
+        """First optimal input of every instance, [batch, nu] (numpy, or written into a torch tensor)."""
+        if out is None:
+            out = np.empty((self.batch, self.nu))
+        _lib.check(self._L.mpcqp_get_u0(self._h, _ptr(out)), 'mpcqp_get_u0')
+        return out
+
+    def status_string(self, code):
+        return self._L.mpcqp_status_string(int(code)).decode()
+
+    # -- verification surface -----------------------------------------------------------------
+    def export_qp(self):
+        B, n, m = self.batch, self.n, self.m
+        P, A = np.empty((B, n, n)), np.empty((B, m, n))
+        q, l, u = np.empty((B, n)), np.empty((B, m)), np.empty((B, m))
+        _lib.check(self._L.mpcqp_export_qp(self._h, _ptr(P), _ptr(A), _ptr(q), _ptr(l), _ptr(u)), 'mpcqp_export_qp')
+        return P, q, A, l, u
+
+    def scaling(self):
+        D, E = np.empty((self.batch, self.n)), np.empty((self.batch, self.m))
+        c, rho = np.empty(self.batch), np.empty(self.batch)
+        _lib.check(self._L.mpcqp_get_scaling(self._h, _ptr(D), _ptr(E), _ptr(c), _ptr(rho)), 'mpcqp_get_scaling')
+        return D, E, c, rho
+
+    def kkt_solve(self, rhs):
+        rhs = _prep(rhs, (self.batch, self.n), 'rhs')
+        sol = np.empty((self.batch, self.n))
+        _lib.check(self._L.mpcqp_debug_kkt_solve(self._h, _ptr(rhs), _ptr(sol)), 'mpcqp_debug_kkt_solve')
+        return sol
+
+    def iterate(self, iters):
+        _lib.check(self._L.mpcqp_iterate(self._h, int(iters)), 'mpcqp_iterate')
+        self.synchronize()
+
+    def iterate_state(self):
+        x, z, y = np.empty((self.batch, self.n)), np.empty((self.batch, self.m)), np.empty((self.batch, self.m))
+        _lib.check(self._L.mpcqp_get_iterate(self._h, _ptr(x), _ptr(z), _ptr(y)), 'mpcqp_get_iterate')
+        return x, z, y
+
+
+class DeviceProblem:
+    """Single-instance adapter with osqp's call shapes, kept by ``MPCController.prob``."""
+
+    def __init__(self, device=0):
+        self.device = device
+        self._bp = None
+
+    def setup(self, P=None, q=None, A=None, l=None, u=None, mpc=None, **settings):
+        if mpc is None:
+            raise ValueError('DeviceProblem.setup needs the controller data (mpc=...): the device builds P,q,A,l,u itself')
+        xref = np.asarray(mpc['xref'], dtype=float)
+        if xref.ndim == 2 and xref.shape[0] != mpc['Np'] + 1:
+            raise ValueError('a time-varying xref must have exactly Np+1 rows')
+        self._bp = BatchProblem(1, mpc['nx'], mpc['nu'], mpc['Np'], mpc['Nc'], device=self.device, **settings)
+        one = lambda a: np.asarray(a, dtype=float)[None]
+        self._bp.setup(one(mpc['Ad']), one(mpc['Bd']), one(mpc['Qx']), one(mpc['QxN']), one(mpc['Qu']), one(mpc['QDu']),
+                       one(mpc['xmin']), one(mpc['xmax']), one(mpc['umin']), one(mpc['umax']),
+                       one(mpc['Dumin']), one(mpc['Dumax']), one(mpc['uref']), np.array([[mpc['eps_feas']]]),
+                       one(mpc['x0']), one(mpc['uminus1']), xref.reshape(1, -1))
+        self.n, self.m = self._bp.n, self._bp.m
+
+    def update(self, q=None, l=None, u=None, mpc_step=None):
+        if mpc_step is None:
+            raise ValueError('DeviceProblem.update needs mpc_step=dict(x0=, uminus1=, xref=)')
+        xref = np.asarray(mpc_step['xref'], dtype=float)
+        self._bp.update(np.asarray(mpc_step['x0'], dtype=float).reshape(1, -1),
+                        np.asarray(mpc_step['uminus1'], dtype=float).reshape(1, -1), xref.reshape(1, -1))
+
+    def update_settings(self, **kw):
+        self._bp.update_settings(**kw)
+
+    def warm_start(self, x=None, y=None):
+        self._bp.warm_start(None if x is None else np.asarray(x)[None], None if y is None else np.asarray(y)[None])
+
+    def solve(self):
+        self._bp.solve_async()
+        x, y, info = self._bp.solution()
+        return Result(x[0], y[0], info[0], self._bp.status_string(info[0].status))
+
+    @property
+    def batch_problem(self):
+        return self._bp

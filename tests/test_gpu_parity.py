@@ -1,0 +1,252 @@
+"""GPU parity tests: the HIP path (through the C ABI) against
+  (a) the structural golden vectors captured from the reference (tests/golden/qp_*.npz),
+  (b) the CPU oracle (oracle/osqp_ref.c) on the same inputs, iterate by iterate,
+  (c) the certified optimum golden vectors (tests/golden/opt_*.npz) -- the north-star criterion:
+      u* within 1e-6 relative of the reference QP's optimum.
+Run on the GPU box with:  python -m pytest tests -m gpu
+"""
+import warnings
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from util import golden_names, load_golden, golden_kwargs, golden_csc, update_steps
+
+pytestmark = pytest.mark.gpu
+
+DEVICE_FIXTURES = [n for n in golden_names() if n != 'point_mass_nc']     # Nc < Np: not on device yet
+
+
+def _gpu_controller(kw, **settings):
+    from pympc_amd import MPCController
+    K = MPCController(**kw)
+    K.solver_settings = dict(settings)
+    return K
+
+
+def _oracle_controller(kw, **settings):
+    from pympc_amd import MPCController
+    from oracle.osqp_oracle import OSQP
+    K = MPCController(**kw)
+    K.prob = OSQP()
+    K.solver_settings = dict(settings)
+    return K
+
+
+def _eff(P):
+    """P as a solver that keeps triu(P) sees it."""
+    U = sp.triu(P).toarray()
+    return U + np.triu(U, 1).T
+
+
+def _clip(v):
+    return np.clip(v, -1e30, 1e30)
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(1e-300, np.abs(b).max())
+
+
+@pytest.mark.parametrize('name', DEVICE_FIXTURES)
+def test_device_built_qp_matches_reference(name):
+    g = load_golden(name)
+    K = _gpu_controller(golden_kwargs(g))
+    K.setup(solve=False)
+    bp = K.prob.batch_problem
+    P, q, A, l, u = bp.export_qp()
+    assert np.array_equal(P[0], _eff(golden_csc(g, 'P')))
+    assert np.array_equal(A[0], golden_csc(g, 'A').toarray())
+    assert np.allclose(q[0], g['q'], rtol=4e-16, atol=1e-300)
+    assert np.array_equal(l[0], _clip(g['l'])) and np.array_equal(u[0], _clip(g['u']))
+    for st in update_steps(g):
+        K.update(st['x'], u=st['u'], xref=st['xref'], solve=False)
+        _, q, _, l, u = bp.export_qp()
+        assert np.allclose(q[0], st['q'], rtol=4e-16, atol=1e-300)
+        assert np.array_equal(l[0], _clip(st['l'])) and np.array_equal(u[0], _clip(st['u_bound']))
+        if st is update_steps(g)[0]:
+            with warnings.catch_warnings():
+                warnings.simplefilter('ignore')
+                K.solve()
+            K.output()
+
+
+@pytest.mark.parametrize('name', DEVICE_FIXTURES)
+def test_equilibration_matches_oracle(name):
+    g = load_golden(name)
+    kw = golden_kwargs(g)
+    K = _gpu_controller(kw); K.setup(solve=False)
+    Ko = _oracle_controller(kw); Ko.setup(solve=False)
+    D, E, c, rho = K.prob.batch_problem.scaling()
+    Do, Eo, co = Ko.prob.scaling()
+    assert _rel(D[0], Do) < 1e-12 and _rel(E[0], Eo) < 1e-12 and abs(c[0] - co) / co < 1e-12
+    assert rho[0] == 0.1
+
+
+@pytest.mark.parametrize('name', DEVICE_FIXTURES)
+def test_kkt_solve_matches_dense(name):
+    g = load_golden(name)
+    K = _gpu_controller(golden_kwargs(g)); K.setup(solve=False)
+    bp = K.prob.batch_problem
+    D, E, c, rho = bp.scaling()
+    P, A = _eff(golden_csc(g, 'P')), golden_csc(g, 'A').toarray()
+    l, u = _clip(g['l']), _clip(g['u'])
+    ls, us = E[0] * l, E[0] * u
+    rho_vec = np.where((ls < -1e26) & (us > 1e26), 1e-6, np.where(us - ls < 1e-4, 1e3 * rho[0], rho[0]))
+    Kmat = c[0] * P + np.diag(1e-6 / D[0] ** 2) + A.T @ np.diag(rho_vec * E[0] ** 2) @ A
+    rng = np.random.default_rng(5)
+    rhs = rng.standard_normal(P.shape[0])
+    sol = bp.kkt_solve(rhs[None])[0]
+    ref = np.linalg.solve(Kmat, rhs)
+    assert _rel(sol, ref) < 1e-8
+    assert np.abs(Kmat @ sol - rhs).max() < 1e-8 * max(1.0, np.abs(Kmat).max() * np.abs(sol).max())
+
+
+@pytest.mark.parametrize('name', DEVICE_FIXTURES)
+@pytest.mark.parametrize('iters', [1, 7, 40])
+def test_admm_iterates_match_oracle(name, iters):
+    g = load_golden(name)
+    kw = golden_kwargs(g)
+    K = _gpu_controller(kw); K.setup(solve=False)
+    Ko = _oracle_controller(kw); Ko.setup(solve=False)
+    K.prob.batch_problem.iterate(iters)
+    Ko.prob.iterate(iters)
+    x, z, y = K.prob.batch_problem.iterate_state()
+    xo, zo, yo, _ = Ko.prob.iterate_state()
+    assert _rel(x[0], xo) < 1e-8 and _rel(z[0], zo) < 1e-8
+    assert np.abs(y[0] - yo).max() < 1e-8 * max(1.0, np.abs(yo).max())
+
+
+@pytest.mark.parametrize('name', DEVICE_FIXTURES)
+def test_default_tolerance_solve_matches_oracle(name):
+    """Reference defaults (eps 1e-3, mpc.py:80): same status, same iteration count, same iterate."""
+    g = load_golden(name)
+    kw = golden_kwargs(g)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        K = _gpu_controller(kw); K.setup()
+        Ko = _oracle_controller(kw); Ko.setup()
+    assert K.res.info.status == Ko.res.info.status
+    assert K.res.info.iter == Ko.res.info.iter
+    assert K.res.info.rho_updates == Ko.res.info.rho_updates
+    assert _rel(K.res.x, Ko.res.x) < 1e-6
+    assert abs(K.res.info.obj_val - Ko.res.info.obj_val) <= 1e-7 * max(1.0, abs(Ko.res.info.obj_val))
+    assert np.allclose(K.output(), Ko.output(), rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize('name', DEVICE_FIXTURES)
+def test_optimum_parity_1e6(name):
+    """North-star criterion: u* within 1e-6 (relative) of the reference QP's certified optimum."""
+    g = load_golden(name)
+    opt = load_golden(name, prefix='opt_')
+    kw = golden_kwargs(g)
+    kw.update(eps_abs=1e-10, eps_rel=1e-10)
+    K = _gpu_controller(kw, max_iter=400000)
+    K.setup()
+    assert K.res.info.status == 'solved'
+    u0 = K.output()
+    scale = max(np.abs(opt['u0']).max(), 1e-3)
+    assert np.abs(u0 - opt['u0']).max() <= 1e-6 * scale
+    assert _rel(K.res.x, opt['x']) < 1e-6
+    assert abs(K.res.info.obj_val - float(opt['obj_val'])) <= 1e-8 * max(1.0, abs(float(opt['obj_val'])))
+
+
+@pytest.mark.parametrize('name', ['point_mass', 'cart_pole', 'quadcopter', 'random_12_4_30'])
+def test_closed_loop_matches_oracle(name):
+    """Warm-started receding horizon (examples/example_point_mass.py:88-101 pattern), tight tolerance."""
+    g = load_golden(name)
+    kw = golden_kwargs(g)
+    kw.update(eps_abs=1e-9, eps_rel=1e-9)
+    K = _gpu_controller(kw, max_iter=100000); K.setup()
+    Ko = _oracle_controller(kw, max_iter=100000); Ko.setup()
+    Ad, Bd = kw['Ad'], kw['Bd']
+    x = np.array(kw['x0'], dtype=float)
+    for step in range(12):
+        u = K.output()
+        uo = Ko.output()
+        assert np.abs(u - uo).max() <= 1e-6 * max(np.abs(uo).max(), 1e-3), step
+        x = Ad @ x + Bd @ uo
+        K.update(x, uo)
+        Ko.update(x, uo)
+        assert K.res.info.status == 'solved' and Ko.res.info.status == 'solved'
+
+
+def test_infeasible_problem_reports_like_oracle():
+    """u_{-1} far outside the input box with a tight rate limit: the hard rows conflict
+    (mpc.py:561-580) -> 'primal infeasible' -> output() falls back to uref (mpc.py:304)."""
+    from pympc_amd import fixtures
+    kw = fixtures.point_mass()
+    kw['uminus1'] = np.array([5.0])
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        K = _gpu_controller(kw); K.setup()
+        Ko = _oracle_controller(kw); Ko.setup()
+    assert Ko.res.info.status == 'primal infeasible'
+    assert K.res.info.status == Ko.res.info.status
+    assert K.res.info.iter == Ko.res.info.iter
+    assert any('OSQP did not solve the problem!' in str(x.message) for x in w)
+    assert np.all(np.isnan(K.res.x))
+    assert np.array_equal(K.output(), kw['uref'])
+    # the solver recovers (cold start) once the problem is feasible again
+    K.update(np.array([0.1, 0.2]), np.array([0.0]))
+    Ko.update(np.array([0.1, 0.2]), np.array([0.0]))
+    assert K.res.info.status == 'solved' and K.res.info.iter == Ko.res.info.iter
+    assert np.allclose(K.output(), Ko.output(), rtol=1e-6, atol=1e-9)
+
+
+def test_batch_matches_per_instance_oracle():
+    from pympc_amd import BatchMPCController, fixtures
+    B = 6
+    kws = [fixtures.random_lti(100 + i) for i in range(B)]
+    stack = lambda k: np.stack([kw[k] for kw in kws])
+    K = BatchMPCController(stack('Ad'), stack('Bd'), Np=30, x0=stack('x0'), xref=stack('xref'), uref=stack('uref'),
+                           uminus1=stack('uminus1'), Qx=stack('Qx'), QxN=stack('QxN'), Qu=stack('Qu'), QDu=stack('QDu'),
+                           xmin=stack('xmin'), xmax=stack('xmax'), umin=stack('umin'), umax=stack('umax'),
+                           Dumin=stack('Dumin'), Dumax=stack('Dumax'), eps_feas=1e6, eps_abs=1e-9, eps_rel=1e-9)
+    K.setup()
+    U, info = K.output(return_status=True, return_x_seq=True)
+    assert all(s == 'solved' for s in info['status'])
+    xs = []
+    for i, kw in enumerate(kws):
+        kw = dict(kw); kw.update(eps_abs=1e-9, eps_rel=1e-9)
+        Ko = _oracle_controller(kw); Ko.setup()
+        uo = Ko.output()
+        assert np.abs(U[i] - uo).max() <= 1e-6 * max(np.abs(uo).max(), 1e-3)
+        xs.append(kw['Ad'] @ kw['x0'] + kw['Bd'] @ uo)
+    # one warm-started step for the whole batch
+    K.update(np.stack(xs))
+    U2 = K.output()
+    for i, kw in enumerate(kws):
+        kw = dict(kw); kw.update(eps_abs=1e-9, eps_rel=1e-9)
+        Ko = _oracle_controller(kw); Ko.setup(); u1 = Ko.output(); Ko.update(xs[i]); uo = Ko.output()
+        assert np.abs(U2[i] - uo).max() <= 1e-6 * max(np.abs(uo).max(), 1e-3)
+
+
+def test_full_size_batch_properties():
+    """BASELINE cfg-3 size (1024 x (12,4,30)): size-independent properties of every returned solution:
+    exact dynamics consistency, bound satisfaction of the hard rows, and the KKT certificate on a sample."""
+    from pympc_amd import BatchMPCController, fixtures
+    from util import kkt_certificate
+    from pympc_amd.controller import MPCController
+    B = 1024
+    kws = [fixtures.random_lti(i) for i in range(B)]
+    stack = lambda k: np.stack([kw[k] for kw in kws])
+    K = BatchMPCController(stack('Ad'), stack('Bd'), Np=30, x0=stack('x0'), Qx=np.eye(12), QxN=np.eye(12),
+                           Qu=0.1 * np.eye(4), QDu=0.1 * np.eye(4), xmin=-10 * np.ones(12), xmax=10 * np.ones(12),
+                           umin=-np.ones(4), umax=np.ones(4), Dumin=-0.5 * np.ones(4), Dumax=0.5 * np.ones(4),
+                           eps_abs=1e-8, eps_rel=1e-8)
+    K.setup()
+    U, info = K.output(return_status=True, return_x_seq=True, return_u_seq=True)
+    assert all(s == 'solved' for s in info['status'])
+    X, Us = info['x_seq'], info['u_seq']
+    Ad, Bd = stack('Ad'), stack('Bd')
+    pred = np.einsum('bij,bkj->bki', Ad, X[:, :-1]) + np.einsum('bij,bkj->bki', Bd, Us)
+    assert np.abs(pred - X[:, 1:]).max() < 1e-6
+    assert np.abs(X[:, 0] - stack('x0')).max() < 1e-6
+    assert Us.max() <= 1 + 1e-6 and Us.min() >= -1 - 1e-6
+    x, y, _ = K.prob.solution()
+    for i in (0, 511, 1023):
+        C = MPCController(**kws[i]); C.prob = object(); C.x0_rh = C.x0; C.uminus1_rh = C.uminus1
+        C._compute_QP_matrices_()
+        stat, pv, comp = kkt_certificate(C.P, C.q, C.A, C.l, C.u, x[i], y[i])
+        assert stat < 1e-6 and pv < 1e-6 and comp < 1e-6

@@ -41,3 +41,16 @@ def update_steps(g):
                           q=g['upd%d_q' % s], l=g['upd%d_l' % s], u_bound=g['upd%d_u_bound' % s]))
         s += 1
     return steps
+
+
+def kkt_certificate(P, q, A, l, u, x, y):
+    """(stationarity, primal violation, complementarity) in the inf-norm, relative to data size."""
+    Ax = A @ x
+    stat = np.abs(P @ x + q + A.T @ y).max() / max(1.0, np.abs(P @ x).max(), np.abs(q).max(), np.abs(A.T @ y).max())
+    pv = max(0.0, (l - Ax).max(), (Ax - u).max()) / max(1.0, np.abs(Ax).max())
+    yp, ym = np.maximum(y, 0), np.minimum(y, 0)
+    ysc = max(1.0, np.abs(y).max())
+    with np.errstate(invalid='ignore'):
+        cu = np.where(np.isfinite(u), yp * (u - Ax), np.where(yp > 1e-9 * ysc, np.inf, 0.0)).max()
+        cl = np.where(np.isfinite(l), -ym * (Ax - l), np.where(ym < -1e-9 * ysc, np.inf, 0.0)).max()
+    return stat, pv, max(cu, cl) / ysc
