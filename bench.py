@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- QP-solves/s of the MPC hot path on MI355X (BASELINE.json metric).
+
+One "step" = one closed-loop MPC step of the whole batch: plant update x+ = Ad x + Bd u* + w,
+mpcqp_update (q,l,u refresh) and one warm-started ADMM solve of every instance, u* fetched.
+Workload (BASELINE.json configs[2]): 1024 seed-pinned random stable LTI
+systems nx=12, nu=4, Np=30 per GPU, reference-default tolerances (eps_abs=eps_rel=1e-3,
+pyMPC/mpc.py:80), synthetic data, FP64, all inputs resident in HBM when the timed region starts.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line.  With N > 1 the instances are sharded over ranks (weak scaling:
+1024 per GPU); RCCL is used only to scatter the problem data from rank 0 and to all-gather u*.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NX, NU, NP = 12, 4, 30
+HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md chip-level parameters
+
+
+def make_instances(first, count):
+    from pympc_amd import fixtures
+    kws = [fixtures.random_lti(first + i, nx=NX, nu=NU, Np=NP) for i in range(count)]
+    return {k: np.stack([np.asarray(kw[k], dtype=float) for kw in kws]) for k in ('Ad', 'Bd', 'x0')}
+
+
+def algorithmic_bytes(n, m, nnzL, iters, checks, solves, nnz_triuP, nnzA):
+    """FP64 values only.  per iteration 8(2 nnzL_strict + 6n + 10m); per residual
+    evaluation 8(nnz(triu P) + 2 nnz(A)); per solve 8(4n + 6m)."""
+    b_it = 8 * (2 * (nnzL - n) + 6 * n + 10 * m)
+    b_chk = 8 * (nnz_triuP + 2 * nnzA)
+    b_fix = 8 * (4 * n + 6 * m)
+    return iters * b_it + checks * b_chk + solves * b_fix, b_it
+
+
+def cpu_baseline(seconds_budget=20.0, inst=24, steps=40, eps=1e-3):
+    """Reference-style CPU path on this box's host cores: the C oracle (port of the OSQP algorithm),
+    1 thread, sequential over instances, warm-started receding horizon on the same workload recipe.
+    Only osqp-equivalent work is timed (update(q,l,u) + solve); the numpy q/l/u refresh is not."""
+    import warnings
+    from pympc_amd import MPCController, fixtures, qp_build
+    from oracle.osqp_oracle import OSQP
+    t_solve, n_solve, iters, done = 0.0, 0, 0, 0
+    t0 = time.perf_counter()
+    for i in range(inst):
+        kw = fixtures.random_lti(i, nx=NX, nu=NU, Np=NP)
+        kw.update(eps_abs=eps, eps_rel=eps)
+        K = MPCController(**kw)
+        K.prob = OSQP()
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            K.setup()
+        rng = fixtures.random_lti_noise_rng(i)
+        x = kw['x0']
+        for _ in range(steps):
+            u = K.output()
+            x = kw['Ad'] @ x + kw['Bd'] @ u + 0.01 * rng.standard_normal(NX)
+            K.x0_rh, K.uminus1_rh = x, u
+            q, _ = qp_build.refresh_vectors(K)
+            ts = time.perf_counter()
+            K.prob.update(q=q, l=K.l, u=K.u)
+            K.res = K.prob.solve()
+            t_solve += time.perf_counter() - ts
+            n_solve += 1
+            iters += K.res.info.iter
+        done = i + 1
+        if time.perf_counter() - t0 > seconds_budget:
+            break
+    return dict(value=n_solve / t_solve, unit='QP-solves/s', cores=1, kind='port',
+                sample='%d instances x %d warm-started steps of the same workload (oracle/osqp_ref.c: update+solve only, '
+                       'mean %.1f ADMM iterations/solve, %.1f s of CPU work)' % (done, steps, iters / max(1, n_solve), t_solve))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--batch', type=int, default=1024, help='instances per GPU')
+    ap.add_argument('--eps', type=float, default=1e-3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from pympc_amd.solver import BatchProblem
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an AMD GPU; pympc_amd has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', device_id=dev)
+    B = args.batch
+    f64 = torch.float64
+
+    # ---- problem data: generated on rank 0, scattered over RCCL (north_star: scatter problem data)
+    if rank == 0:
+        data = make_instances(0, B * world)
+        full = {k: torch.from_numpy(v).to(dev) for k, v in data.items()}
+    shapes = {'Ad': (B, NX, NX), 'Bd': (B, NX, NU), 'x0': (B, NX)}
+    loc = {}
+    for k, shp in shapes.items():
+        loc[k] = torch.empty(shp, dtype=f64, device=dev)
+        if world > 1:
+            dist.scatter(loc[k], list(full[k].split(B)) if rank == 0 else None, src=0)
+        else:
+            loc[k].copy_(full[k])
+    Ad, Bd, x = loc['Ad'], loc['Bd'], loc['x0'].clone()
+
+    stream = torch.cuda.current_stream(dev)
+    prob = BatchProblem(B, NX, NU, NP, device=local_rank, stream=stream.cuda_stream,
+                        eps_abs=args.eps, eps_rel=args.eps, warm_start=1)
+    eye = lambda k, s: (s * torch.eye(k, dtype=f64, device=dev)).expand(B, k, k).contiguous()
+    ones = lambda k, s: torch.full((B, k), s, dtype=f64, device=dev)
+    prob.setup(Ad, Bd, eye(NX, 1.0), eye(NX, 1.0), eye(NU, 0.1), eye(NU, 0.1),
+               ones(NX, -10.0), ones(NX, 10.0), ones(NU, -1.0), ones(NU, 1.0), ones(NU, -0.5), ones(NU, 0.5),
+               ones(NU, 0.0), torch.full((B, 1), 1e6, dtype=f64, device=dev),
+               x, ones(NU, 0.0), torch.zeros((B, NX), dtype=f64, device=dev))
+    prob.solve_async()                        # cold solve (setup(solve=True))
+    u = torch.empty((B, NU), dtype=f64, device=dev)
+    prob.u0(out=u)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    u_all = torch.empty((world * B, NU), dtype=f64, device=dev) if world > 1 else None
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
+    def step(i=None):
+        nonlocal x
+        w = 0.01 * torch.randn((B, NX), dtype=f64, device=dev, generator=gen)
+        x = torch.baddbmm(w.unsqueeze(2), Ad, x.unsqueeze(2)).add_(torch.bmm(Bd, u.unsqueeze(2))).squeeze(2)
+        prob.update(x, u)
+        if i is not None:
+            ev0[i].record(stream)
+        prob.solve_async()
+        if i is not None:
+            ev1[i].record(stream)
+        prob.u0(out=u)
+        if world > 1:
+            dist.all_gather_into_tensor(u_all, u)
+
+    for _ in range(args.warmup):
+        step()
+    prob.stats(reset=True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=f64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    iters, checks, refacts, solves = prob.stats()
+    infos = prob.infos()
+    n_solved = sum(1 for i in infos if i.status == 1)
+    kernel_ms = [a.elapsed_time(b) for a, b in zip(ev0, ev1)]
+    kernel_s = float(np.mean(kernel_ms)) * 1e-3
+
+    if rank == 0:
+        n, m, nnzL = prob.n, prob.m, prob.nnzL
+        nnz_triuP = (NP + 1) * NX * 2 + NP * NU + (NP - 1) * NU     # diagonal weights: diag + upper QDu coupling
+        nnzA = (NP + 1) * NX + NP * NX * NX + NP * NX * NU + 2 * (NP + 1) * NX + NP * NU + NU + 2 * NP * NU - 1
+        total_bytes, b_it = algorithmic_bytes(n, m, nnzL, iters, checks, solves, nnz_triuP, nnzA)
+        achieved = total_bytes / args.steps / kernel_s
+        out = {
+            'metric': 'QP-solves/sec (MPC steps/sec) at nx=12 nu=4 Np=30',
+            'value': B * world * args.steps / elapsed,
+            'unit': 'QP-solves/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'cfg-3: %d random stable LTI MPC instances per GPU (nx=12, nu=4, Np=Nc=30, n=%d, m=%d), '
+                                   'warm-started receding horizon x+=Ad x+Bd u*+w' % (B, n, m),
+                       'batch_per_gpu': B, 'eps_abs': args.eps, 'eps_rel': args.eps,
+                       'parallelism': 'instances sharded over %d GPU(s); RCCL scatter of data, all-gather of u*' % world},
+            'mean_admm_iters': iters / max(1, solves),
+            'solved_fraction_last_step': n_solved / B,
+            'refactorizations_per_solve': refacts / max(1, solves),
+            'roofline': {'bound': 'hbm', 'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK, 'traffic': None,
+                         'kernel': 'k_solve<16,true>', 'kernel_ms': kernel_s * 1e3,
+                         'algorithmic_bytes_per_iter_per_qp': b_it, 'nnzL': nnzL},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline(eps=args.eps)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

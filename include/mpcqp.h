@@ -128,6 +128,10 @@ int mpcqp_solve(mpcqp_handle *h);
 int mpcqp_get_solution(mpcqp_handle *h, double *x, double *y, mpcqp_info *info);
 int mpcqp_get_u0(mpcqp_handle *h, double *u0);
 
+/* Cumulative work counters since creation / last reset: out4 = { ADMM iterations, residual
+ * evaluations, refactorizations, instance-solves } summed over the batch (synchronises). */
+int mpcqp_get_stats(mpcqp_handle *h, uint64_t *out4, int reset);
+
 /* Problem sizes: n, m of one instance, bytes of the KKT factor per instance, and nnz(L). */
 int mpcqp_get_dims(mpcqp_handle *h, int *n, int *m, int64_t *factor_doubles, int64_t *nnzL);
 

@@ -64,6 +64,7 @@ struct Ptrs {
     double *dx, *dy, *rg;         // scratch: last increments, rhs
     double *Dt, *Et;              // Ruiz temporaries
     int *ctype;
+    unsigned long long *stats;    // [0] ADMM iterations, [1] residual evaluations, [2] refactorizations, [3] instance-solves
     mpcqp_info *info;
     long long fsz;                // factor doubles per instance
 };
@@ -646,7 +647,7 @@ __global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_solve(Lay L, Ptrs P,
     }
     __syncthreads();
 
-    int status = MPCQP_UNSOLVED, iter = 0, rho_updates = 0;
+    int status = MPCQP_UNSOLVED, iter = 0, rho_updates = 0, n_info = 0;
     double obj_val = 0.0, pri_res = 0.0, dua_res = 0.0;
     bool have_info = false;
 
@@ -679,7 +680,7 @@ __global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_solve(Lay L, Ptrs P,
 #pragma unroll
         for (int i = 0; i < 11; ++i) nrm[i] = vmax[i];
         obj_val = vsum[0]; pri_res = vmax[0]; dua_res = vmax[3];
-        have_info = true;
+        have_info = true; ++n_info;
     };
     auto rho_estimate = [&]() {
         double pri = nrm[7] / (nrm[8] + 1e-10), dua = nrm[9] / (nrm[10] + 1e-10);
@@ -821,6 +822,8 @@ __global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_solve(Lay L, Ptrs P,
         mpcqp_info inf; inf.status = status; inf.iter = iter; inf.rho_updates = rho_updates; inf.reserved = 0;
         inf.obj_val = obj_val; inf.pri_res = pri_res; inf.dua_res = dua_res; inf.rho = rho;
         P.info[b] = inf; P.rho[b] = rho;
+        atomicAdd(&P.stats[0], (unsigned long long)iter); atomicAdd(&P.stats[1], (unsigned long long)n_info);
+        atomicAdd(&P.stats[2], (unsigned long long)rho_updates); atomicAdd(&P.stats[3], 1ULL);
     }
 }
 
@@ -966,7 +969,7 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     rc |= dalloc(h, &P.xo, B * L.n); rc |= dalloc(h, &P.yo, B * L.m);
     rc |= dalloc(h, &P.dx, B * L.n); rc |= dalloc(h, &P.dy, B * L.m); rc |= dalloc(h, &P.rg, B * L.n);
     rc |= dalloc(h, &P.Dt, B * L.n); rc |= dalloc(h, &P.Et, B * L.m);
-    rc |= dalloc(h, &P.ctype, B * L.m); rc |= dalloc(h, &P.info, B);
+    rc |= dalloc(h, &P.ctype, B * L.m); rc |= dalloc(h, &P.info, B); rc |= dalloc(h, &P.stats, 8);
     rc |= dalloc(h, &h->u0_dev, B * L.nu);
     if (rc) { mpcqp_destroy(h); return MPCQP_ERR_HIP; }
     h->smem_setup = sizeof(double) * (size_t)smem_common_doubles(L);
@@ -1121,6 +1124,15 @@ extern "C" int mpcqp_get_u0(mpcqp_handle *h, double *u0) {
     hipLaunchKernelGGL(k_gather_u0, dim3((tot + 255) / 256), dim3(256), 0, h->stream, h->L, h->P.xo, h->u0_dev, h->batch);
     HIPCHK(hipGetLastError());
     if (get(h, u0, h->u0_dev, sizeof(double) * (size_t)tot)) return MPCQP_ERR_HIP;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MPCQP_OK;
+}
+
+extern "C" int mpcqp_get_stats(mpcqp_handle *h, uint64_t *out4, int reset) {
+    if (!h || !out4) return fail(MPCQP_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(out4, h->P.stats, 4 * sizeof(uint64_t), hipMemcpyDefault, h->stream));
+    if (reset) HIPCHK(hipMemsetAsync(h->P.stats, 0, 4 * sizeof(uint64_t), h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return MPCQP_OK;
 }

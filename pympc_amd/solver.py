@@ -201,6 +201,12 @@ class BatchProblem:
         _lib.check(self._L.mpcqp_get_u0(self._h, _ptr(out)), 'mpcqp_get_u0')
         return out
 
+    def stats(self, reset=False):
+        """Cumulative (iterations, residual evaluations, refactorizations, instance-solves) over the batch."""
+        out = (C.c_uint64 * 4)()
+        _lib.check(self._L.mpcqp_get_stats(self._h, out, int(bool(reset))), 'mpcqp_get_stats')
+        return tuple(int(v) for v in out)
+
     def status_string(self, code):
         return self._L.mpcqp_status_string(int(code)).decode()
 
