@@ -4,4 +4,4 @@ set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-unused-value "$@" \
-    -o ../libmpcqp_hip.so mpcqp.hip
+    -o "${MPCQP_OUT:-../libmpcqp_hip.so}" mpcqp.hip

@@ -9,9 +9,11 @@
 //     (OSQP's quasi-definite KKT with the constraint block eliminated, expressed in UNSCALED variables:
 //     Ruiz scaling D,E,c enters only through the metric vectors  s = sigma/D^2  and  omega = rho E^2);
 //     with the slack variables eliminated it is block tridiagonal along the horizon with (nx+nu)^2 blocks
-//     and is factored by a block Cholesky whose factor streams from HBM/L2 every iteration;
+//     and is factored by a block LDL' whose factor, stored in FP64-MFMA operand order, streams from HBM/L2
+//     every iteration;
 //   - one 256-thread workgroup owns one instance for the whole solve: iterate in LDS, wave 0 runs the
-//     sequential block forward/backward substitution, all waves run the stage-parallel parts.
+//     sequential block forward/backward sweeps on the matrix cores (v_mfma_f64_16x16x4_f64, stage output
+//     registers = next stage's B operand), all waves run the stage-parallel parts.
 //
 // FP64 throughout.  No CPU fallback exists in this library.
 
@@ -20,12 +22,16 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <algorithm>
 #include <string>
 #include <vector>
 
 #include "../../include/mpcqp.h"
 
-#define NT 256
+#ifndef NT
+#define NT 256                 // threads per workgroup (one workgroup = one MPC instance)
+#endif
+#define NWAVES (NT / 64)
 #define QP_INFTY 1e30
 #define MIN_SCALING 1e-4
 #define MAX_SCALING 1e4
@@ -62,12 +68,20 @@ struct Ptrs {
     double *x, *z, *y;            // iterate (unscaled units)
     double *xo, *yo;              // reported solution
     double *dx, *dy, *rg;         // scratch: last increments, rhs
+    double *qv;                   // linear cost of the x,u variables [n_x+n_u] (rebuilt by every kernel prologue)
     double *Dt, *Et;              // Ruiz temporaries
     int *ctype;
+    int *done;                    // per instance: finished in this solve
+    int *active;                  // [1] instances still running after the last k_check
     unsigned long long *stats;    // [0] ADMM iterations, [1] residual evaluations, [2] refactorizations, [3] instance-solves
     mpcqp_info *info;
     long long fsz;                // factor doubles per instance
 };
+
+// Everything a kernel needs, kept in device memory (one copy per handle): kernels take a pointer to it, so the
+// scalar registers hold only what the running phase actually uses (by-value kernel arguments of this size
+// overflow the SGPR file and spill into vector registers).
+struct KArgs { Lay L; Ptrs P; mpcqp_settings S; };
 
 __device__ __forceinline__ int idiv(int r, float rcp) { return __float2int_rd(((float)r + 0.5f) * rcp); }
 __device__ __forceinline__ double limit_scaling(double v) { v = v < MIN_SCALING ? 1.0 : v; return v > MAX_SCALING ? MAX_SCALING : v; }
@@ -224,6 +238,7 @@ __device__ void build_q(const Ctx &c, const double *step, double *Qv) {
         }
         Qv[j] = acc;
     }
+    __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -246,9 +261,9 @@ __device__ void block_reduce(double *vmax, double *vsum, double *red) {
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < KMAX; ++i) vmax[i] = fmax(fmax(red[i], red[K + i]), fmax(red[2 * K + i], red[3 * K + i]));
+    for (int i = 0; i < KMAX; ++i) { double v = red[i]; for (int w = 1; w < NWAVES; ++w) v = fmax(v, red[w * K + i]); vmax[i] = v; }
 #pragma unroll
-    for (int i = 0; i < KSUM; ++i) vsum[i] = (red[KMAX + i] + red[K + KMAX + i]) + (red[2 * K + KMAX + i] + red[3 * K + KMAX + i]);
+    for (int i = 0; i < KSUM; ++i) { double v = red[KMAX + i]; for (int w = 1; w < NWAVES; ++w) v += red[w * K + KMAX + i]; vsum[i] = v; }
     __syncthreads();
 }
 
@@ -314,31 +329,73 @@ __device__ __forceinline__ double kkt_sub_entry(const Ctx &c, const double *om, 
     return v;
 }
 
-// Block Cholesky of the block-tridiagonal K.  Per stage k the factor stores
-//   Lsub_k = L_{k,k-1}  (NB x NB, zero for k = 0)   and   Linv_k = L_kk^{-1} (lower triangular).
-// W: LDS workspace of 4*NB*NB doubles.  Returns (uniformly) 0, or 1 if a pivot was not positive.
+// ------------------------------------------------------------------------------------------------
+// Block LDL' of the block-tridiagonal K (stage blocks NB x NB, NB = 16 or 32):
+//      S_0 = K_00,   Mh_k = K_{k,k-1} S_{k-1}^-1,   S_k = K_kk - Mh_k K_{k,k-1}'
+// Solve K x = b:    yh_0 = b_0,  yh_k = b_k - Mh_k yh_{k-1};   w_k = S_k^-1 yh_k;
+//                   x_{N-1} = w_{N-1},  x_k = w_k - Mh_{k+1}' x_{k+1}.
+// The factor is stored in the operand order of v_mfma_f64_16x16x4_f64 ("fragments"): for a 16x16
+// block used as the A operand of D = A*B + C, lane l holds A[l&15][4s + (l>>4)], s = 0..3, and the
+// lane's four values are contiguous (32 B per lane, 2 KB per block, perfectly coalesced).
+// Per stage k:  [ -Mh_k | S_k^-1 | -Mh_{k+1}' ]   (3 NB^2 doubles).
+// A stage vector v in the C/D layout (lane l, register t: v[(l>>4) + 4t], identical over l&15) is at the
+// same time the B operand (B[k'][j] = v[4s+k'] -> lane l needs v[4s + (l>>4)] = register s): the output
+// registers of one stage feed the next stage's MFMAs with no cross-lane movement at all.
+// ------------------------------------------------------------------------------------------------
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) double gdouble;     // explicit global address space: plain global_load/store,
+typedef __attribute__((address_space(1))) const double cgdouble;  // not flat_* (which also counts on lgkmcnt)
+typedef __attribute__((address_space(1))) const d4 cgd4;
+
+template <int NB>
+__device__ __forceinline__ int frag_pos(int r, int cidx) {
+    constexpr int NBLK = NB / 16;
+    int bi = r >> 4, i = r & 15, bj = cidx >> 4, kk = cidx & 15;
+    return (bi * NBLK + bj) * 256 + (((kk & 3) << 4) + i) * 4 + (kk >> 2);
+}
+
+// W: LDS workspace of 5*NB*NB doubles.  Returns (uniformly) 0, or 1 if a pivot was not positive.
 template <int NB>
 __device__ int factor_all(const Ctx &c, const double *om, const double *sv, double cc, double *F, double *W, int *iflag) {
     const Lay &L = c.L;
-    double *S = W, *Cm = W + NB * NB, *Ls = W + 2 * NB * NB, *Li = W + 3 * NB * NB;
+    double *S = W, *Ks = W + NB * NB, *Mh = W + 2 * NB * NB, *Sp = W + 3 * NB * NB, *Li = W + 4 * NB * NB;
     const int tid = threadIdx.x;
     if (tid == 0) *iflag = 0;
     for (int k = 0; k < L.N; ++k) {
         __syncthreads();
         for (int e = tid; e < NB * NB; e += NT) {
             int a = e / NB, b = e % NB;
-            double v = kkt_diag_entry(c, om, sv, cc, k, a, b);
-            if (k > 0) { double acc = 0.0; for (int l = 0; l < NB; ++l) acc += Ls[a * NB + l] * Ls[b * NB + l]; v -= acc; }
-            S[e] = v;
-            Cm[e] = (k < L.N - 1) ? kkt_sub_entry(c, om, cc, k, a, b) : 0.0;
-            F[(size_t)k * L.fstage + e] = (k > 0) ? Ls[e] : 0.0;
+            S[e] = kkt_diag_entry(c, om, sv, cc, k, a, b);
+            Ks[e] = (k > 0) ? kkt_sub_entry(c, om, cc, k - 1, a, b) : 0.0;
             Li[e] = 0.0;
         }
         __syncthreads();
-        // right-looking Cholesky of S (lower triangle)
+        if (k > 0) {
+            for (int e = tid; e < NB * NB; e += NT) {          // Mh = Ks * Sp
+                int a = e / NB, b = e % NB;
+                double acc = 0.0;
+                for (int l = 0; l < NB; ++l) acc += Ks[a * NB + l] * Sp[l * NB + b];
+                Mh[e] = acc;
+            }
+            __syncthreads();
+            for (int e = tid; e < NB * NB; e += NT) {          // S -= Mh * Ks'
+                int a = e / NB, b = e % NB;
+                double acc = 0.0;
+                for (int l = 0; l < NB; ++l) acc += Mh[a * NB + l] * Ks[b * NB + l];
+                S[e] -= acc;
+                double mv = -Mh[e];
+                F[(size_t)k * L.fstage + frag_pos<NB>(a, b)] = mv;                        // -Mh_k      (forward)
+                F[(size_t)(k - 1) * L.fstage + 2 * NB * NB + frag_pos<NB>(b, a)] = mv;    // -Mh_k'     (backward, slot k-1)
+            }
+            __syncthreads();
+        } else {
+            for (int e = tid; e < NB * NB; e += NT) F[e] = 0.0;
+        }
+        if (k == L.N - 1) for (int e = tid; e < NB * NB; e += NT) F[(size_t)k * L.fstage + 2 * NB * NB + e] = 0.0;
+        // Cholesky of S (lower), right-looking
         for (int j = 0; j < NB; ++j) {
             double d = S[j * NB + j];
-            if (d <= 0.0) { if (tid == 0) *iflag = 1; d = 1e-300; }
+            if (!(d > 0.0)) { if (tid == 0) *iflag = 1; d = 1e-300; }
             d = sqrt(d);
             __syncthreads();
             for (int i = j + tid; i < NB; i += NT) S[i * NB + j] = (i == j) ? d : S[i * NB + j] / d;
@@ -350,8 +407,7 @@ __device__ int factor_all(const Ctx &c, const double *om, const double *sv, doub
             }
             __syncthreads();
         }
-        // Linv = S^{-1}: one thread per column, forward substitution on the identity
-        if (tid < NB) {
+        if (tid < NB) {                                       // Li = L^-1, one thread per column
             const int col = tid;
             Li[col * NB + col] = 1.0 / S[col * NB + col];
             for (int i = col + 1; i < NB; ++i) {
@@ -361,129 +417,158 @@ __device__ int factor_all(const Ctx &c, const double *om, const double *sv, doub
             }
         }
         __syncthreads();
-        for (int e = tid; e < NB * NB; e += NT) {
+        for (int e = tid; e < NB * NB; e += NT) {              // Sp = S^-1 = Li' Li
             int a = e / NB, b = e % NB;
-            F[(size_t)k * L.fstage + NB * NB + e] = Li[e];
-            double acc = 0.0;                         // Lsub_{k+1} = K_{k+1,k} Linv_k'
-            for (int l = 0; l <= b; ++l) acc += Cm[a * NB + l] * Li[b * NB + l];
-            Ls[e] = acc;
+            double acc = 0.0;
+            for (int l = max(a, b); l < NB; ++l) acc += Li[l * NB + a] * Li[l * NB + b];
+            Sp[e] = acc;
+            F[(size_t)k * L.fstage + NB * NB + frag_pos<NB>(a, b)] = acc;
         }
     }
     __syncthreads();
     return *iflag;
 }
 
-// ------------------------------------------------------------------------------------------------
-// Block forward/backward substitution, executed by ONE wave (no workgroup barriers inside).
-// T holds the right-hand side / solution of the x and u variables in the reference's flat layout.
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+// The sweeps work on Tc: the x,u part of the right-hand side / solution in STAGE-MAJOR PADDED layout,
+// Tc[k*NB + a] = element a of stage k (a < nx: x_k[a]; nx <= a < nb: u_k[a-nx]; everything else is padding
+// and stays exactly zero because the factor is the identity there).  In the C/D (= B operand) layout lane l
+// holds elements (l>>4) + 4t (+16 per block), i.e. four 8-byte LDS reads at constant offsets from one address.
+template <int NB>
+__device__ __forceinline__ void vec_load(const double *tb, int k, d4 *v) {
+#pragma unroll
+    for (int e = 0; e < NB / 4; ++e) v[e >> 2][e & 3] = tb[k * NB + (e >> 2) * 16 + 4 * (e & 3)];
+}
+template <int NB>
+__device__ __forceinline__ void vec_store(double *tb, int k, const d4 *v, bool writer) {
+    if (writer) {
+#pragma unroll
+        for (int e = 0; e < NB / 4; ++e) tb[k * NB + (e >> 2) * 16 + 4 * (e & 3)] = v[e >> 2][e & 3];
+    }
+}
+
+// out[bi] += sum_bj A(bi,bj) * in[bj]   with A given as fragments (one d4 per block per lane)
+template <int NB>
+__device__ __forceinline__ void frag_matvec(const d4 *A, const d4 *in, d4 *out) {
+    constexpr int NBLK = NB / 16;
+#pragma unroll
+    for (int bi = 0; bi < NBLK; ++bi)
+#pragma unroll
+        for (int bj = 0; bj < NBLK; ++bj)
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                out[bi] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[bi * NBLK + bj][s], in[bj][s], out[bi], 0, 0, 0);
 }
 
 template <int NB>
-__device__ void kkt_chain_solve(const Ctx &c, const double *F, double *T, double *tv) {
-    constexpr int CPL = (NB * NB / 64) > 0 ? (NB * NB / 64) : 1;   // matrix entries per lane per row
-    constexpr int LPR = NB / CPL;                                  // lanes per row
-    const Lay &L = c.L;
-    const int lane = threadIdx.x & 63;
-    const bool act = lane < NB * LPR;
-    auto vaddr = [&](int k, int a) { return a < L.nx ? k * L.nx + a : L.ou + k * L.nu + (a - L.nx); };
+__device__ __forceinline__ void frag_load(const double *Fm, int lane, d4 *A) {
+    constexpr int NBLK = NB / 16;
+#pragma unroll
+    for (int b = 0; b < NBLK * NBLK; ++b) A[b] = *(cgd4 *)(Fm + b * 256 + lane * 4);
+}
 
-    // ---- forward: y_k = Linv_k (b_k - Lsub_k y_{k-1}) ; lane = (row r, column group q)
-    {
-        const int r = lane / LPR, q = lane % LPR;
-        double m1[CPL], m2[CPL], n1[CPL], n2[CPL];
-        const double *Fk = F;
+template <int NB> struct SweepCfg {
+    static constexpr int NF = (NB / 16) * (NB / 16);
+    static constexpr int DEPTH = (NB == 16) ? 8 : 4;      // factor stages kept in flight in registers
+};
+
+// Sequential sweep over the stages by ONE wave.  DIR=+1: yh_k = b_k - Mh_k yh_{k-1} (slot 0 of each stage);
+// DIR=-1: x_k = w_k - Mh_{k+1}' x_{k+1} (slot 2).  In place on Tc.  The factor fragments of the next DEPTH
+// stages are prefetched into a register ring; the running vector ping-pongs between two register sets
+// (no copies between MFMAs).
+template <int NB, int DIR>
+__device__ __forceinline__ void chain_sweep(const int N, const int fstage, const double *F, double *Tc) {
+    constexpr int NBLK = NB / 16, NF = SweepCfg<NB>::NF, DEPTH = SweepCfg<NB>::DEPTH;
+    const int lane = threadIdx.x & 63;
+    double *tb = Tc + (lane >> 4);
+    const bool writer = (lane & 15) == 0;
+    const size_t slot = (DIR > 0) ? 0 : 2 * NB * NB;
+    // step i = 1..N-1 touches stage k(i): forward k = i (matrix of stage k), backward k = N-1-i (matrix stored at stage k)
+    auto stage_of = [&](int i) { return DIR > 0 ? i : N - 1 - i; };
+    d4 ring[DEPTH][NF];
 #pragma unroll
-        for (int j = 0; j < CPL; ++j) { m1[j] = act ? Fk[r * NB + q * CPL + j] : 0.0; m2[j] = act ? Fk[NB * NB + r * NB + q * CPL + j] : 0.0; }
-        for (int k = 0; k < L.N; ++k) {
-            const int nbk = (k < L.Nc) ? L.nb : L.nx;
-            if (k + 1 < L.N) {                        // prefetch the next stage's blocks
-                const double *Fn = F + (size_t)(k + 1) * L.fstage;
+    for (int d = 0; d < DEPTH; ++d)
+        if (1 + d < N) frag_load<NB>(F + (size_t)stage_of(1 + d) * fstage + slot, lane, ring[d]);
+    d4 va[NBLK], vb[NBLK];
+    vec_load<NB>(tb, stage_of(0), va);
+    for (int i0 = 1; i0 < N; i0 += DEPTH) {
 #pragma unroll
-                for (int j = 0; j < CPL; ++j) { n1[j] = act ? Fn[r * NB + q * CPL + j] : 0.0; n2[j] = act ? Fn[NB * NB + r * NB + q * CPL + j] : 0.0; }
+        for (int d = 0; d < DEPTH; ++d) {
+            const int i = i0 + d;
+            if (i < N) {
+                const int k = stage_of(i);
+                d4 *src = (d & 1) ? vb : va, *dst = (d & 1) ? va : vb;
+                vec_load<NB>(tb, k, dst);
+                frag_matvec<NB>(ring[d], src, dst);
+                vec_store<NB>(tb, k, dst, writer);
+                if (i + DEPTH < N) frag_load<NB>(F + (size_t)stage_of(i + DEPTH) * fstage + slot, lane, ring[d]);
             }
-            double s1 = 0.0;
-            if (k > 0) {
-#pragma unroll
-                for (int j = 0; j < CPL; ++j) { int a = q * CPL + j; double yv = (a < L.nb) ? T[vaddr(k - 1, a)] : 0.0; s1 += m1[j] * yv; }
-                for (int o = 1; o < LPR; o <<= 1) s1 += __shfl_xor(s1, o);
-            }
-            double t = ((act && r < nbk) ? T[vaddr(k, r)] : 0.0) - s1;
-            if (act && q == 0) tv[r] = t;
-            wave_lds_sync();
-            double s2 = 0.0;
-#pragma unroll
-            for (int j = 0; j < CPL; ++j) s2 += m2[j] * tv[(q * CPL + j) % NB];
-            for (int o = 1; o < LPR; o <<= 1) s2 += __shfl_xor(s2, o);
-            if (act && q == 0 && r < nbk) T[vaddr(k, r)] = s2;
-            wave_lds_sync();
-#pragma unroll
-            for (int j = 0; j < CPL; ++j) { m1[j] = n1[j]; m2[j] = n2[j]; }
-        }
-    }
-    // ---- backward: x_k = Linv_k' (y_k - Lsub_{k+1}' x_{k+1}) ; lane = (row group q, column cidx)
-    {
-        const int q = lane / NB, cidx = lane % NB;
-        double m1[CPL], m2[CPL], n1[CPL], n2[CPL];
-        {
-            const double *Fk = F + (size_t)(L.N - 1) * L.fstage;
-#pragma unroll
-            for (int j = 0; j < CPL; ++j) { m1[j] = 0.0; m2[j] = act ? Fk[NB * NB + (q * CPL + j) * NB + cidx] : 0.0; }
-        }
-        for (int k = L.N - 1; k >= 0; --k) {
-            const int nbk = (k < L.Nc) ? L.nb : L.nx;
-            if (k > 0) {                               // prefetch: Lsub_k (used at stage k-1) and Linv_{k-1}
-                const double *Fk = F + (size_t)k * L.fstage, *Fp = F + (size_t)(k - 1) * L.fstage;
-#pragma unroll
-                for (int j = 0; j < CPL; ++j) { n1[j] = act ? Fk[(q * CPL + j) * NB + cidx] : 0.0; n2[j] = act ? Fp[NB * NB + (q * CPL + j) * NB + cidx] : 0.0; }
-            }
-            double s1 = 0.0;
-            if (k < L.N - 1) {
-                const int nbn = (k + 1 < L.Nc) ? L.nb : L.nx;
-#pragma unroll
-                for (int j = 0; j < CPL; ++j) { int a = q * CPL + j; double xv = (a < nbn) ? T[vaddr(k + 1, a)] : 0.0; s1 += m1[j] * xv; }
-                for (int o = NB; o < NB * LPR; o <<= 1) s1 += __shfl_xor(s1, o);
-            }
-            double t = ((act && cidx < nbk) ? T[vaddr(k, cidx)] : 0.0) - s1;
-            if (act && q == 0) tv[cidx] = t;
-            wave_lds_sync();
-            double s2 = 0.0;
-#pragma unroll
-            for (int j = 0; j < CPL; ++j) s2 += m2[j] * tv[(q * CPL + j) % NB];
-            for (int o = NB; o < NB * LPR; o <<= 1) s2 += __shfl_xor(s2, o);
-            if (act && q == 0 && cidx < nbk) T[vaddr(k, cidx)] = s2;
-            wave_lds_sync();
-#pragma unroll
-            for (int j = 0; j < CPL; ++j) { m1[j] = n1[j]; m2[j] = n2[j]; }
         }
     }
 }
 
-// Solve K xt = rhs for all n variables.  On entry rg (global scratch) holds rhs; on exit T holds xt.
+// w_k = S_k^-1 yh_k for all stages, stages dealt round-robin to the four waves (independent MFMA groups).
+template <int NB>
+__device__ __forceinline__ void sinv_apply(const int N, const int fstage, const double *F, double *Tc) {
+    constexpr int NBLK = NB / 16;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double *tb = Tc + (lane >> 4);
+    const bool writer = (lane & 15) == 0;
+    for (int k = wv; k < N; k += NT / 64) {
+        d4 A[NBLK * NBLK], in[NBLK], out[NBLK];
+        frag_load<NB>(F + (size_t)k * fstage + NB * NB, lane, A);
+        vec_load<NB>(tb, k, in);
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) out[b] = d4{0.0, 0.0, 0.0, 0.0};
+        frag_matvec<NB>(A, in, out);
+        vec_store<NB>(tb, k, out, writer);
+    }
+}
+
+// Tc <- K_xu^-1 Tc (eps already eliminated).  All threads call; barriers inside.  Tc must be seen by the
+// compiler as an LDS pointer (a pointer laundered through an integer becomes FLAT: flat LDS accesses count on
+// vmcnt AND lgkmcnt and force a full s_waitcnt vmcnt(0) -- draining the factor prefetch -- before every stage).
+template <int NB>
+__device__ __forceinline__ void kkt_core(const int N, const int fstage, const double *F, double *Tc) {
+#ifndef MPCQP_ABL_NOCHAIN
+    if (threadIdx.x < 64) chain_sweep<NB, +1>(N, fstage, F, Tc);
+    __syncthreads();
+    sinv_apply<NB>(N, fstage, F, Tc);
+    __syncthreads();
+    if (threadIdx.x < 64) chain_sweep<NB, -1>(N, fstage, F, Tc);
+#endif
+    __syncthreads();
+}
+
+// Generic front end (verification kernel): flat rhs (global) -> flat solution `out` (global, n doubles).
+// Tc: LDS, N*NB doubles.
 template <int NB>
 __device__ void kkt_solve(const Ctx &c, const double *om, const double *sv, double cc, const double *F,
-                          const double *rg, double *T, double *tv) {
+                          const double *rg, double *Tc, double *out) {
     const Lay &L = c.L;
     const double cef = cc * c.eps_feas();
-    for (int e = threadIdx.x; e < L.n_x; e += NT) {      // eliminate eps_e against x_e
-        double ws = om[L.rs + e];
-        double kap = cef + sv[L.oe + e] + ws;
-        double te = rg[L.oe + e] / kap;
-        T[L.oe + e] = te;
-        T[e] = rg[e] - ws * te;
+    for (int idx = threadIdx.x; idx < L.N * NB; idx += NT) {
+        int k = idx / NB, a = idx % NB;
+        double v = 0.0;
+        if (a < L.nx) {
+            int e = k * L.nx + a;
+            double ws = om[L.rs + e];
+            double te = rg[L.oe + e] / (cef + sv[L.oe + e] + ws);
+            out[L.oe + e] = te;
+            v = rg[e] - ws * te;
+        } else if (a < L.nb && k < L.Nc) v = rg[L.ou + k * L.nu + (a - L.nx)];
+        Tc[idx] = v;
     }
-    for (int j = threadIdx.x; j < L.n_u; j += NT) T[L.ou + j] = rg[L.ou + j];
     __syncthreads();
-    if (threadIdx.x < 64) kkt_chain_solve<NB>(c, F, T, tv);
-    __syncthreads();
-    for (int e = threadIdx.x; e < L.n_x; e += NT) {
-        double ws = om[L.rs + e];
-        double kap = cef + sv[L.oe + e] + ws;
-        T[L.oe + e] -= (ws / kap) * T[e];
+    kkt_core<NB>(L.N, L.fstage, F, Tc);
+    for (int idx = threadIdx.x; idx < L.N * NB; idx += NT) {
+        int k = idx / NB, a = idx % NB;
+        if (a < L.nx) {
+            int e = k * L.nx + a;
+            double ws = om[L.rs + e];
+            double xe = Tc[idx];
+            out[e] = xe;
+            out[L.oe + e] -= (ws / (cef + sv[L.oe + e] + ws)) * xe;
+        } else if (a < L.nb && k < L.Nc) out[L.ou + k * L.nu + (a - L.nx)] = Tc[idx];
     }
     __syncthreads();
 }
@@ -503,9 +588,9 @@ struct Smem {
     int *iflag;
 };
 __device__ __forceinline__ double *carve(double *&p, int n) { double *r = p; p += n; return r; }
-__device__ void smem_common(const Lay &L, double *&p, Smem &S) {
+__device__ void smem_common(const Lay &L, const Ptrs &P, double *&p, Smem &S) {
     S.T = carve(p, L.tsz);
-    S.Qv = carve(p, L.n_x + L.n_u);
+    S.Qv = P.qv + (size_t)blockIdx.x * (L.n_x + L.n_u);
     S.hot = carve(p, L.hot_sz);
     S.x0s = carve(p, L.nx);
     S.um1s = carve(p, L.nu);
@@ -513,7 +598,7 @@ __device__ void smem_common(const Lay &L, double *&p, Smem &S) {
     S.tv = carve(p, 32);
     S.iflag = (int *)carve(p, 2);
 }
-__host__ __device__ inline int smem_common_doubles(const Lay &L) { return L.tsz + L.n_x + L.n_u + L.hot_sz + L.nx + L.nu + 64 + 32 + 2; }
+__host__ __device__ inline int smem_common_doubles(const Lay &L) { return L.tsz + L.hot_sz + L.nx + L.nu + 64 + 32 + 2; }
 
 __device__ void load_common(const Lay &L, const double *model, const double *step, Smem &S) {
     for (int i = threadIdx.x; i < L.hot_sz; i += NT) S.hot[i] = model[i];
@@ -528,7 +613,7 @@ __device__ void load_common(const Lay &L, const double *model, const double *ste
 template <int NB>
 __global__ __launch_bounds__(NT) void k_setup(Lay L, Ptrs P, mpcqp_settings S_) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
-    double *p = sh; Smem S; smem_common(L, p, S);
+    double *p = sh; Smem S; smem_common(L, P, p, S);
     const int b = blockIdx.x, tid = threadIdx.x;
     const double *model = P.model + (size_t)b * L.model_sz, *step = P.step + (size_t)b * L.step_sz;
     load_common(L, model, step, S);
@@ -595,102 +680,100 @@ __global__ __launch_bounds__(NT) void k_setup(Lay L, Ptrs P, mpcqp_settings S_) 
 }
 
 // ------------------------------------------------------------------------------------------------
-// solve kernel: the whole warm-started ADMM solve of one instance in one persistent workgroup.
+// The solve is three kernels driven by a short host loop (mpcqp_solve):
+//   k_begin  once per solve : q refresh from (x0, u_{-1}, xref), constraint types, per-solve bookkeeping
+//   k_admm   per round      : check_termination ADMM iterations -- the hot kernel, nothing else in it
+//   k_check  per round      : residuals, termination, infeasibility certificates, rho adaptation + refactor
+// Separate kernels give the hot loop a register allocation of its own (as one fused kernel the cold code
+// pushed it into scratch spills, and a spill reload inside the sweep stalls on vmcnt(0)).
 // ------------------------------------------------------------------------------------------------
-template <int NB, bool LDSSTATE>
-__global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_solve(Lay L, Ptrs P, mpcqp_settings S_, int plain_iters) {
+enum { COLD_CHECK = 1, COLD_RHO = 2, COLD_FINAL = 4, COLD_PLAIN = 8 };
+
+template <int NB>
+__global__ __launch_bounds__(NT) void k_begin(Lay L, Ptrs P, mpcqp_settings S_, int plain) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
-    double *p = sh; Smem S; smem_common(L, p, S);
+    double *p = sh; Smem S; smem_common(L, P, p, S);
     const int b = blockIdx.x, tid = threadIdx.x;
     const double *model = P.model + (size_t)b * L.model_sz, *step = P.step + (size_t)b * L.step_sz;
-    double *gx = P.x + (size_t)b * L.n, *gz = P.z + (size_t)b * L.m, *gy = P.y + (size_t)b * L.m;
-    double *X, *Z, *Y;
-    if (LDSSTATE) { X = carve(p, L.n); Z = carve(p, L.m); Y = carve(p, L.m); }
-    else { X = gx; Z = gz; Y = gy; }
     load_common(L, model, step, S);
     Ctx c{L, S.hot, model};
     build_q(c, step, S.Qv);
-
-    double *om = P.omega + (size_t)b * L.m, *sv = P.s + (size_t)b * L.n;
-    const double *D = P.D + (size_t)b * L.n, *E = P.E + (size_t)b * L.m;
-    double *F = P.F + (size_t)b * P.fsz;
-    double *rg = P.rg + (size_t)b * L.n, *dxg = P.dx + (size_t)b * L.n, *dyg = P.dy + (size_t)b * L.m;
+    double *gx = P.x + (size_t)b * L.n, *gz = P.z + (size_t)b * L.m, *gy = P.y + (size_t)b * L.m;
+    if (!(S_.warm_start || plain)) {
+        for (int j = tid; j < L.n; j += NT) gx[j] = 0.0;
+        for (int r = tid; r < L.m; r += NT) { gz[r] = 0.0; gy[r] = 0.0; }
+    }
+    // constraint types (bounds may have changed since the last factorization)
+    double *om = P.omega + (size_t)b * L.m;
+    const double *sv = P.s + (size_t)b * L.n, *E = P.E + (size_t)b * L.m;
     int *ctp = P.ctype + (size_t)b * L.m;
+    const double rho = P.rho[b];
+    int changed = 0;
+    for (int r = tid; r < L.m; r += NT) {
+        double lo, hi; row_bounds(c, S.x0s, S.um1s, r, lo, hi);
+        int t = row_type(E[r], lo, hi);
+        if (t != ctp[r]) { changed = 1; ctp[r] = t; om[r] = row_rho(t, rho) * E[r] * E[r]; }
+    }
+    changed = __syncthreads_or(changed);
+    if (changed) factor_all<NB>(c, om, sv, P.c[b], P.F + (size_t)b * P.fsz, S.T, S.iflag);
+    if (tid == 0) {
+        mpcqp_info inf; inf.status = MPCQP_UNSOLVED; inf.iter = 0; inf.rho_updates = 0; inf.reserved = 0;
+        inf.obj_val = 0.0; inf.pri_res = 0.0; inf.dua_res = 0.0; inf.rho = rho;
+        P.info[b] = inf; P.done[b] = 0;
+    }
+}
+
+template <int NB>
+__global__ __launch_bounds__(NT) void k_check(Lay L, Ptrs P, mpcqp_settings S_, int iter, int mode) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (P.done[b]) return;
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    double *p = sh; Smem S; smem_common(L, P, p, S);
+    const double *model = P.model + (size_t)b * L.model_sz, *step = P.step + (size_t)b * L.step_sz;
+    load_common(L, model, step, S);
+    Ctx c{L, S.hot, model};
+    double *gx = P.x + (size_t)b * L.n, *gz = P.z + (size_t)b * L.m, *gy = P.y + (size_t)b * L.m;
+    const double *X = gx, *Z = gz, *Y = gy;
+    double *om = P.omega + (size_t)b * L.m;
+    const double *sv = P.s + (size_t)b * L.n;
+    const double *D = P.D + (size_t)b * L.n, *E = P.E + (size_t)b * L.m;
+    const double *dxg = P.dx + (size_t)b * L.n, *dyg = P.dy + (size_t)b * L.m;
+    const int *ctp = P.ctype + (size_t)b * L.m;
     const double cc = P.c[b];
     double rho = P.rho[b];
-    const double alpha = S_.alpha, sigma = S_.sigma;
-    (void)sigma;
-    const bool plain = plain_iters > 0;
-    const int max_iter = plain ? plain_iters : S_.max_iter;
-    const int chk_every = plain ? 0 : S_.check_termination;
-    int rho_every = 0;
-    if (!plain && S_.adaptive_rho) rho_every = S_.adaptive_rho_interval ? S_.adaptive_rho_interval : (S_.check_termination ? 4 * S_.check_termination : 100);
+    int status = MPCQP_UNSOLVED;
+    double obj_val, pri_res, dua_res;
 
-    // ---- prologue: iterate, constraint types (bounds may have changed since the last factorization)
-    if (LDSSTATE) {
-        const bool ws = S_.warm_start || plain;
-        for (int j = tid; j < L.n; j += NT) X[j] = ws ? gx[j] : 0.0;
-        for (int r = tid; r < L.m; r += NT) { Z[r] = ws ? gz[r] : 0.0; Y[r] = ws ? gy[r] : 0.0; }
-    } else if (!(S_.warm_start || plain)) {
-        for (int j = tid; j < L.n; j += NT) X[j] = 0.0;
-        for (int r = tid; r < L.m; r += NT) { Z[r] = 0.0; Y[r] = 0.0; }
-    }
-    {
-        int changed = 0;
-        for (int r = tid; r < L.m; r += NT) {
-            double lo, hi; row_bounds(c, S.x0s, S.um1s, r, lo, hi);
-            int t = row_type(E[r], lo, hi);
-            if (t != ctp[r]) { changed = 1; ctp[r] = t; om[r] = row_rho(t, rho) * E[r] * E[r]; }
-        }
-        changed = __syncthreads_or(changed);
-        if (changed) factor_all<NB>(c, om, sv, cc, F, S.T, S.iflag);
-    }
-    __syncthreads();
-
-    int status = MPCQP_UNSOLVED, iter = 0, rho_updates = 0, n_info = 0;
-    double obj_val = 0.0, pri_res = 0.0, dua_res = 0.0;
-    bool have_info = false;
-
-    // residuals / objective / scaled norms for the rho estimate: OSQP's update_info + compute_rho_estimate
-    double nrm[12];
-    auto update_info = [&]() {
-        // vmax: 0 pri, 1 |Ax|, 2 |z|, 3 dua, 4 |Px|, 5 |A'y|, 6 |q|; scaled: 7 pri, 8 max(|EAx|,|Ez|), 9 dua, 10 max(|cD(..)|)
-        double vmax[11], vsum[1] = {0.0};
+    // ---- OSQP update_info: objective, unscaled residuals, and the scaled norms the rho estimate needs
+    // vmax: 0 pri, 1 |Ax|, 2 |z|, 3 dua, 4 |Px|, 5 |A'y|, 6 |q|; scaled: 7 pri, 8 max(|EAx|,|Ez|), 9 dua, 10 max(|cD(..)|)
+    double nrm[11], vsum[1] = {0.0};
 #pragma unroll
-        for (int i = 0; i < 11; ++i) vmax[i] = 0.0;
-        for (int r = tid; r < L.m; r += NT) {
-            double ax = 0.0;
-            A_row(c, r, [&](double co, int idx) { ax += co * X[idx]; });
-            double z = Z[r], d = ax - z, e = E[r];
-            vmax[0] = fmax(vmax[0], fabs(d)); vmax[1] = fmax(vmax[1], fabs(ax)); vmax[2] = fmax(vmax[2], fabs(z));
-            vmax[7] = fmax(vmax[7], fabs(e * d)); vmax[8] = fmax(vmax[8], fmax(fabs(e * ax), fabs(e * z)));
-        }
-        for (int j = tid; j < L.n; j += NT) {
-            double px = 0.0, aty = 0.0;
-            P_row(c, j, [&](double co, int idx) { px += co * X[idx]; });
-            AT_row(c, j, [&](double co, int row) { aty += co * Y[row]; });
-            double qj = (j < L.oe) ? S.Qv[j] : 0.0, xj = X[j];
-            double d = px + qj + aty, cd = cc * D[j];
-            vmax[3] = fmax(vmax[3], fabs(d)); vmax[4] = fmax(vmax[4], fabs(px)); vmax[5] = fmax(vmax[5], fabs(aty)); vmax[6] = fmax(vmax[6], fabs(qj));
-            vmax[9] = fmax(vmax[9], fabs(cd * d));
-            vmax[10] = fmax(vmax[10], fmax(fabs(cd * qj), fmax(fabs(cd * aty), fabs(cd * px))));
-            vsum[0] += xj * (0.5 * px + qj);
-        }
-        block_reduce<11, 1>(vmax, vsum, S.red);
-#pragma unroll
-        for (int i = 0; i < 11; ++i) nrm[i] = vmax[i];
-        obj_val = vsum[0]; pri_res = vmax[0]; dua_res = vmax[3];
-        have_info = true; ++n_info;
-    };
-    auto rho_estimate = [&]() {
-        double pri = nrm[7] / (nrm[8] + 1e-10), dua = nrm[9] / (nrm[10] + 1e-10);
-        double r = rho * sqrt(pri / (dua + 1e-10));
-        return fmin(fmax(r, RHO_MIN), RHO_MAX);
-    };
-    // OSQP's infeasibility certificates (paper section 3.5) on the last increments, in unscaled terms.
+    for (int i = 0; i < 11; ++i) nrm[i] = 0.0;
+    for (int r = tid; r < L.m; r += NT) {
+        double ax = 0.0;
+        A_row(c, r, [&](double co, int idx) { ax += co * X[idx]; });
+        double z = Z[r], d = ax - z, e = E[r];
+        nrm[0] = fmax(nrm[0], fabs(d)); nrm[1] = fmax(nrm[1], fabs(ax)); nrm[2] = fmax(nrm[2], fabs(z));
+        nrm[7] = fmax(nrm[7], fabs(e * d)); nrm[8] = fmax(nrm[8], fmax(fabs(e * ax), fabs(e * z)));
+    }
+    for (int j = tid; j < L.n; j += NT) {
+        double px = 0.0, aty = 0.0;
+        P_row(c, j, [&](double co, int idx) { px += co * X[idx]; });
+        AT_row(c, j, [&](double co, int row) { aty += co * Y[row]; });
+        double qj = (j < L.oe) ? S.Qv[j] : 0.0, xj = X[j];
+        double d = px + qj + aty, cd = cc * D[j];
+        nrm[3] = fmax(nrm[3], fabs(d)); nrm[4] = fmax(nrm[4], fabs(px)); nrm[5] = fmax(nrm[5], fabs(aty)); nrm[6] = fmax(nrm[6], fabs(qj));
+        nrm[9] = fmax(nrm[9], fabs(cd * d));
+        nrm[10] = fmax(nrm[10], fmax(fabs(cd * qj), fmax(fabs(cd * aty), fabs(cd * px))));
+        vsum[0] += xj * (0.5 * px + qj);
+    }
+    block_reduce<11, 1>(nrm, vsum, S.red);
+    obj_val = vsum[0]; pri_res = nrm[0]; dua_res = nrm[3];
+
+    // ---- OSQP's infeasibility certificates (paper section 3.5) on the last increments, in unscaled terms
     auto primal_infeasible = [&](double eps) -> bool {
         // v = c * delta_y (= E * scaled delta_y), projected on the polar of the recession cone of [l,u]
-        double vmax[1] = {0.0}, vsum[1] = {0.0};
+        double vmax[1] = {0.0}, vs[1] = {0.0};
         for (int r = tid; r < L.m; r += NT) {
             double lo, hi; row_bounds(c, S.x0s, S.um1s, r, lo, hi);
             double e = E[r], v = cc * dyg[r];
@@ -698,12 +781,12 @@ __global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_solve(Lay L, Ptrs P,
             else if (e * lo < -QP_INFTY * MIN_SCALING) v = fmax(v, 0.0);
             S.T[r] = v;
             vmax[0] = fmax(vmax[0], fabs(v));
-            vsum[0] += hi * fmax(v, 0.0) + lo * fmin(v, 0.0);
+            vs[0] += hi * fmax(v, 0.0) + lo * fmin(v, 0.0);
         }
-        block_reduce<1, 1>(vmax, vsum, S.red);
+        block_reduce<1, 1>(vmax, vs, S.red);
         double nd = vmax[0];
         if (!(nd > eps)) return false;
-        if (!(vsum[0] < -eps * nd)) return false;
+        if (!(vs[0] < -eps * nd)) return false;
         double amax[1] = {0.0}, dummy[1] = {0.0};
         for (int j = tid; j < L.n; j += NT) {
             double a = 0.0; AT_row(c, j, [&](double co, int row) { a += co * S.T[row]; });
@@ -713,16 +796,16 @@ __global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_solve(Lay L, Ptrs P,
         return amax[0] < eps * nd;
     };
     auto dual_infeasible = [&](double eps) -> bool {
-        double vmax[1] = {0.0}, vsum[1] = {0.0};
+        double vmax[1] = {0.0}, vs[1] = {0.0};
         for (int j = tid; j < L.n; j += NT) {
             double d = dxg[j];
             vmax[0] = fmax(vmax[0], fabs(d));
-            vsum[0] += ((j < L.oe) ? S.Qv[j] : 0.0) * d;
+            vs[0] += ((j < L.oe) ? S.Qv[j] : 0.0) * d;
         }
-        block_reduce<1, 1>(vmax, vsum, S.red);
+        block_reduce<1, 1>(vmax, vs, S.red);
         double nd = vmax[0];
         if (!(nd > eps)) return false;
-        if (!(vsum[0] < -eps * nd)) return false;
+        if (!(vs[0] < -eps * nd)) return false;
         double pmax[1] = {0.0}, bad[1] = {0.0};
         for (int j = tid; j < L.n; j += NT) {
             double a = 0.0; P_row(c, j, [&](double co, int idx) { a += co * dxg[idx]; });
@@ -752,78 +835,235 @@ __global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_solve(Lay L, Ptrs P,
         return false;
     };
 
-    bool done = false, can_check = false;
-    for (iter = 1; iter <= max_iter; ++iter) {
-        can_check = chk_every && (iter % chk_every == 0);
-        const bool rho_now = rho_every && (iter % rho_every == 0);
-        const bool keep_delta = can_check || iter == max_iter;
-        // (1) w = omega z - c y
-        for (int r = tid; r < L.m; r += NT) S.T[r] = om[r] * Z[r] - cc * Y[r];
-        __syncthreads();
-        // (2) rhs = s x - c q + A' w
-        for (int j = tid; j < L.n; j += NT) {
-            double acc = sv[j] * X[j] - ((j < L.oe) ? cc * S.Qv[j] : 0.0);
-            AT_row(c, j, [&](double co, int row) { acc += co * S.T[row]; });
-            rg[j] = acc;
+    int term = 0, rho_upd = 0;
+    if (mode & COLD_PLAIN) { status = MPCQP_UNSOLVED; term = 1; }
+    else {
+        if (mode & COLD_CHECK) term = check_termination(false) ? 1 : 0;
+        if (!term && (mode & COLD_FINAL)) {             // iteration limit: OSQP retries with 10x looser tolerances
+            if (!check_termination(true)) status = MPCQP_MAX_ITER_REACHED;
+            term = 1;
         }
-        __syncthreads();
-        // (3) xt = K^-1 rhs
-        kkt_solve<NB>(c, om, sv, cc, F, rg, S.T, S.tv);
-        // (4) zt = A xt, relaxation, projection, dual update
-        for (int r = tid; r < L.m; r += NT) {
-            double zt = 0.0;
-            A_row(c, r, [&](double co, int idx) { zt += co * S.T[idx]; });
-            double zr = alpha * zt + (1.0 - alpha) * Z[r];
-            double lo, hi; row_bounds(c, S.x0s, S.um1s, r, lo, hi);
-            double w = om[r], yr = Y[r];
-            double zn = fmin(fmax(zr + cc * yr / w, lo), hi);
-            double dy = (w / cc) * (zr - zn);
-            Y[r] = yr + dy; Z[r] = zn;
-            if (keep_delta) dyg[r] = dy;
-        }
-        for (int j = tid; j < L.n; j += NT) {
-            double xo = X[j];
-            double xn = alpha * S.T[j] + (1.0 - alpha) * xo;
-            X[j] = xn;
-            if (keep_delta) dxg[j] = xn - xo;
-        }
-        __syncthreads();
-        if (can_check) {
-            update_info();
-            if (check_termination(false)) { done = true; break; }
-        }
-        if (rho_now) {
-            if (!can_check) update_info();
-            double rn = rho_estimate();
+        if (!term && (mode & COLD_RHO)) {
+            double pri = nrm[7] / (nrm[8] + 1e-10), dua = nrm[9] / (nrm[10] + 1e-10);
+            double rn = fmin(fmax(rho * sqrt(pri / (dua + 1e-10)), RHO_MIN), RHO_MAX);
             if (rn > rho * S_.adaptive_rho_tolerance || rn < rho / S_.adaptive_rho_tolerance) {
                 rho = rn;
                 for (int r = tid; r < L.m; r += NT) om[r] = row_rho(ctp[r], rho) * E[r] * E[r];
                 __syncthreads();
-                factor_all<NB>(c, om, sv, cc, F, S.T, S.iflag);
-                ++rho_updates;
+                factor_all<NB>(c, om, sv, cc, P.F + (size_t)b * P.fsz, S.T, S.iflag);
+                rho_upd = 1;
             }
         }
     }
-    if (!done) {
-        iter = max_iter;
-        if (!can_check) update_info();
-        if (plain) status = MPCQP_UNSOLVED;
-        else if (!check_termination(true)) status = MPCQP_MAX_ITER_REACHED;
+    __syncthreads();
+    if (term) {      // solution, and the iterate the next warm start begins from
+        const bool has_sol = !(status == MPCQP_PRIMAL_INFEASIBLE || status == MPCQP_PRIMAL_INFEASIBLE_INACCURATE ||
+                               status == MPCQP_DUAL_INFEASIBLE || status == MPCQP_DUAL_INFEASIBLE_INACCURATE || status == MPCQP_NON_CVX);
+        double *xo = P.xo + (size_t)b * L.n, *yo = P.yo + (size_t)b * L.m;
+        for (int j = tid; j < L.n; j += NT) { double v = gx[j]; xo[j] = has_sol ? v : NAN; if (!has_sol) gx[j] = 0.0; }
+        for (int r = tid; r < L.m; r += NT) { double v = gy[r]; yo[r] = has_sol ? v : NAN; if (!has_sol) { gy[r] = 0.0; gz[r] = 0.0; } }
     }
-    (void)have_info;
-
-    // ---- epilogue: solution, iterate for the next warm start
-    const bool has_sol = !(status == MPCQP_PRIMAL_INFEASIBLE || status == MPCQP_PRIMAL_INFEASIBLE_INACCURATE ||
-                           status == MPCQP_DUAL_INFEASIBLE || status == MPCQP_DUAL_INFEASIBLE_INACCURATE || status == MPCQP_NON_CVX);
-    double *xo = P.xo + (size_t)b * L.n, *yo = P.yo + (size_t)b * L.m;
-    for (int j = tid; j < L.n; j += NT) { double v = X[j]; xo[j] = has_sol ? v : NAN; gx[j] = has_sol ? v : 0.0; }
-    for (int r = tid; r < L.m; r += NT) { double v = Y[r], zz = Z[r]; yo[r] = has_sol ? v : NAN; gy[r] = has_sol ? v : 0.0; gz[r] = has_sol ? zz : 0.0; }
     if (tid == 0) {
-        mpcqp_info inf; inf.status = status; inf.iter = iter; inf.rho_updates = rho_updates; inf.reserved = 0;
+        mpcqp_info inf = P.info[b];
+        inf.status = status; inf.iter = iter; inf.rho_updates += rho_upd; inf.reserved += 1;
         inf.obj_val = obj_val; inf.pri_res = pri_res; inf.dua_res = dua_res; inf.rho = rho;
-        P.info[b] = inf; P.rho[b] = rho;
-        atomicAdd(&P.stats[0], (unsigned long long)iter); atomicAdd(&P.stats[1], (unsigned long long)n_info);
-        atomicAdd(&P.stats[2], (unsigned long long)rho_updates); atomicAdd(&P.stats[3], 1ULL);
+        P.rho[b] = rho;
+        if (term) {
+            atomicAdd(&P.stats[0], (unsigned long long)iter); atomicAdd(&P.stats[1], (unsigned long long)inf.reserved);
+            atomicAdd(&P.stats[2], (unsigned long long)inf.rho_updates); atomicAdd(&P.stats[3], 1ULL);
+            inf.reserved = 0;
+            P.done[b] = 1;
+        } else atomicAdd(P.active, 1);
+        P.info[b] = inf;
+    }
+}
+
+// ---- hot-loop pieces.  NXT/NUT: compile-time nx/nu (0 = take them from the layout at run time).
+template <int NXT> __device__ __forceinline__ int hx(const Lay &L) { return NXT ? NXT : L.nx; }
+template <int NUT> __device__ __forceinline__ int hu(const Lay &L) { return NUT ? NUT : L.nu; }
+template <int NXT> __device__ __forceinline__ int divx(const Lay &L, int v) { return NXT ? v / NXT : idiv(v, L.rnx); }
+template <int NUT> __device__ __forceinline__ int divu(const Lay &L, int v) { return NUT ? v / NUT : idiv(v, L.rnu); }
+
+// Steps (1)-(2) of the ADMM iteration with the slack elimination fused in:
+//   W = omega z - c y                       (rows, flat)
+//   rhs = s x - c q + A' W                  (variables)
+//   te = rhs_eps / kappa -> W[soft row]     Tc[k][a] = rhs_x - omega_soft te  |  rhs_u  |  0 (padding)
+constexpr int RPT = 1024 / NT;  // rows per thread whose z,y live in registers (small-problem mode, m <= RPT*NT = 1024)
+
+template <int NB, int NXT, int NUT, bool REG>
+__device__ __forceinline__ void hot_rhs(const Lay &L, const double *hot, cgdouble *om, cgdouble *sv, cgdouble *qv, double cc,
+                                        const double *X, const double *Z, const double *Y, const double (&zr)[RPT], const double (&yr)[RPT],
+                                        double *W, double *Tc) {
+    const int tid = threadIdx.x;
+    const int nx = hx<NXT>(L), nu = hu<NUT>(L);
+    if (REG) {
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) { const int r = tid + j * NT; if (r < L.m) W[r] = om[r] * zr[j] - cc * yr[j]; }
+    } else {
+        for (int r = tid; r < L.m; r += NT) W[r] = om[r] * Z[r] - cc * Y[r];
+    }
+    __syncthreads();
+    const double *Ad = hot + L.oAd, *Bd = hot + L.oBd;
+    const double cef = cc * hot[L.oeps];
+    for (int idx = tid; idx < L.N * NB; idx += NT) {
+        const int k = idx / NB, a = idx % NB;
+        double v = 0.0;
+        if (a < nx) {
+            const int e = k * nx + a;
+            double rx = sv[e] * X[e] - cc * qv[e] - W[e];
+            if (k < L.Np) {
+                const double *w1 = W + (k + 1) * nx;
+#pragma unroll
+                for (int r = 0; r < (NXT ? NXT : 1); ++r) if (NXT) rx += Ad[r * nx + a] * w1[r];
+                if (!NXT) for (int r = 0; r < nx; ++r) rx += Ad[r * nx + a] * w1[r];
+            }
+            const double wsoft = W[L.rs + e];
+            const double ws = om[L.rs + e];
+            const double te = (sv[L.oe + e] * X[L.oe + e] + wsoft) / (cef + sv[L.oe + e] + ws);
+            W[L.rs + e] = te;                      // only this thread ever reads W[soft row e]
+            v = rx + wsoft - ws * te;
+        } else if (a < nx + nu && k < L.Nc) {
+            const int jj = a - nx, cu = k * nu + jj;
+            double ru = sv[L.ou + cu] * X[L.ou + cu] - cc * qv[L.n_x + cu] + W[L.ri + cu] - W[L.rdu + nu + cu];
+            if (k == 0) ru += W[L.rdu + jj];
+            if (cu > 0) ru += W[L.rdu + nu + cu - 1];
+            const int s_end = (k == L.Nc - 1) ? L.Np : k + 1;
+            for (int s = k + 1; s <= s_end; ++s) {
+                const double *w1 = W + s * nx;
+#pragma unroll
+                for (int r = 0; r < (NXT ? NXT : 1); ++r) if (NXT) ru += Bd[r * nu + jj] * w1[r];
+                if (!NXT) for (int r = 0; r < nx; ++r) ru += Bd[r * nu + jj] * w1[r];
+            }
+            v = ru;
+        }
+        Tc[idx] = v;
+    }
+    __syncthreads();
+}
+
+// Steps (4)-(6): slack back-substitution, zt = A xt, relaxation, projection on [l,u], dual update, x update.
+template <int NB, int NXT, int NUT, bool REG>
+__device__ __forceinline__ void hot_update(const Lay &L, const double *hot, const double *x0s, const double *um1s,
+                                           cgdouble *om, cgdouble *sv, double cc, double alpha,
+                                           double *X, double *Z, double *Y, double (&zreg)[RPT], double (&yreg)[RPT],
+                                           double *W, const double *Tc, bool keep_delta, gdouble *dxg, gdouble *dyg) {
+    const int tid = threadIdx.x;
+    const int nx = hx<NXT>(L), nu = hu<NUT>(L);
+    const double cef = cc * hot[L.oeps];
+    // eps_t = te - (omega_soft / kappa) x_t ; x update for the x and eps variables
+    for (int e = tid; e < L.n_x; e += NT) {
+        const int k = divx<NXT>(L, e), i = e - k * nx;
+        const double ws = om[L.rs + e];
+        const double xt = Tc[k * NB + i];
+        const double et = W[L.rs + e] - (ws / (cef + sv[L.oe + e] + ws)) * xt;
+        W[L.rs + e] = et;
+        const double xo = X[e], eo = X[L.oe + e];
+        const double xn = alpha * xt + (1.0 - alpha) * xo, en = alpha * et + (1.0 - alpha) * eo;
+        X[e] = xn; X[L.oe + e] = en;
+        if (keep_delta) { dxg[e] = xn - xo; dxg[L.oe + e] = en - eo; }
+    }
+    for (int cu = tid; cu < L.n_u; cu += NT) {
+        const int k = divu<NUT>(L, cu), jj = cu - k * nu;
+        const double uo = X[L.ou + cu];
+        const double un = alpha * Tc[k * NB + nx + jj] + (1.0 - alpha) * uo;
+        X[L.ou + cu] = un;
+        if (keep_delta) dxg[L.ou + cu] = un - uo;
+    }
+    __syncthreads();
+    const double *Ad = hot + L.oAd, *Bd = hot + L.oBd;
+    auto row_update = [&](int r, double &zv, double &yv) {
+        double zt, lo, hi;
+        if (r < L.rs) {                                   // dynamics
+            const int k = divx<NXT>(L, r), i = r - k * nx;
+            zt = -Tc[k * NB + i];
+            if (k > 0) {
+                const double *xp = Tc + (k - 1) * NB;
+                const double *up = Tc + min(k - 1, L.Nc - 1) * NB + nx;
+#pragma unroll
+                for (int j = 0; j < (NXT ? NXT : 1); ++j) if (NXT) zt += Ad[i * nx + j] * xp[j];
+                if (!NXT) for (int j = 0; j < nx; ++j) zt += Ad[i * nx + j] * xp[j];
+#pragma unroll
+                for (int j = 0; j < (NUT ? NUT : 1); ++j) if (NUT) zt += Bd[i * nu + j] * up[j];
+                if (!NUT) for (int j = 0; j < nu; ++j) zt += Bd[i * nu + j] * up[j];
+            }
+            lo = hi = (r < nx) ? -x0s[r] : 0.0;
+        } else if (r < L.ri) {                            // soft state box
+            const int e = r - L.rs, k = divx<NXT>(L, e), i = e - k * nx;
+            zt = Tc[k * NB + i] + W[r];
+            lo = hot[L.oxmin + i]; hi = hot[L.oxmax + i];
+        } else if (r < L.rdu) {                           // input box
+            const int cu = r - L.ri, k = divu<NUT>(L, cu), jj = cu - k * nu;
+            zt = Tc[k * NB + nx + jj];
+            lo = hot[L.oumin + jj]; hi = hot[L.oumax + jj];
+        } else {                                          // Delta-u rows
+            const int rr = r - L.rdu, kk = divu<NUT>(L, rr), jj = rr - kk * nu;
+            lo = hot[L.oDumin + jj]; hi = hot[L.oDumax + jj];
+            if (rr < nu) { zt = Tc[nx + rr]; lo += um1s[jj]; hi += um1s[jj]; }
+            else {
+                const int cu = rr - nu, k = kk - 1;       // cu = k*nu + jj
+                zt = -Tc[k * NB + nx + jj];
+                if (cu + 1 < L.n_u) zt += (jj + 1 < nu) ? Tc[k * NB + nx + jj + 1] : Tc[(k + 1) * NB + nx];
+            }
+        }
+        lo = lo < -QP_INFTY ? -QP_INFTY : lo;
+        hi = hi > QP_INFTY ? QP_INFTY : hi;
+        const double zr = alpha * zt + (1.0 - alpha) * zv;
+        const double w = om[r];
+        const double zn = fmin(fmax(zr + cc * yv / w, lo), hi);
+        const double dy = (w / cc) * (zr - zn);
+        yv += dy; zv = zn;
+        if (keep_delta) dyg[r] = dy;
+    };
+    if (REG) {
+#pragma unroll
+        for (int j = 0; j < RPT; ++j) { const int r = tid + j * NT; if (r < L.m) row_update(r, zreg[j], yreg[j]); }
+    } else {
+        for (int r = tid; r < L.m; r += NT) { double zv = Z[r], yv = Y[r]; row_update(r, zv, yv); Z[r] = zv; Y[r] = yv; }
+    }
+    __syncthreads();
+}
+
+// The hot kernel: `iters` ADMM iterations of every instance that is not finished yet.
+template <int NB, bool LDSSTATE, int NXT, int NUT>
+__global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_admm(Lay L, Ptrs P, double alpha, int iters) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (P.done[b]) return;
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    double *p = sh; Smem S; smem_common(L, P, p, S);
+    const double *model = P.model + (size_t)b * L.model_sz, *step = P.step + (size_t)b * L.step_sz;
+    double *gx = P.x + (size_t)b * L.n, *gz = P.z + (size_t)b * L.m, *gy = P.y + (size_t)b * L.m;
+    // small-problem mode (LDSSTATE): the iterate x, z, y lives in LDS for the whole round
+    double *X, *Z, *Y;
+    if (LDSSTATE) { X = carve(p, L.n); Z = carve(p, L.m); Y = carve(p, L.m); }
+    else { X = gx; Z = gz; Y = gy; }
+    double zr[RPT], yr[RPT];       // (register-resident z,y: experimental path, disabled -- see REGZY)
+    constexpr bool REGZY = false;
+#pragma unroll
+    for (int j = 0; j < RPT; ++j) { zr[j] = 0.0; yr[j] = 0.0; }
+    load_common(L, model, step, S);
+    double *W = S.T, *Tc = S.T + L.m;
+    if (LDSSTATE) {
+        for (int j = tid; j < L.n; j += NT) X[j] = gx[j];
+        for (int r = tid; r < L.m; r += NT) { Z[r] = gz[r]; Y[r] = gy[r]; }
+    }
+    __syncthreads();
+    cgdouble *gom = (cgdouble *)(P.omega + (size_t)b * L.m), *gsv = (cgdouble *)(P.s + (size_t)b * L.n), *gqv = (cgdouble *)S.Qv;
+    gdouble *dxg = (gdouble *)(P.dx + (size_t)b * L.n), *dyg = (gdouble *)(P.dy + (size_t)b * L.m);
+    const double *F = P.F + (size_t)b * P.fsz;
+    const double cc = P.c[b];
+    for (int it = 1; it <= iters; ++it) {
+        const bool keep_delta = it == iters;         // the increments feed the infeasibility certificates of k_check
+#ifndef MPCQP_ABL_NOPAR
+        hot_rhs<NB, NXT, NUT, REGZY>(L, S.hot, gom, gsv, gqv, cc, X, Z, Y, zr, yr, W, Tc);
+#endif
+        kkt_core<NB>(L.N, L.fstage, F, Tc);
+#ifndef MPCQP_ABL_NOPAR
+        hot_update<NB, NXT, NUT, REGZY>(L, S.hot, S.x0s, S.um1s, gom, gsv, cc, alpha, X, Z, Y, zr, yr, W, Tc, keep_delta, dxg, dyg);
+#endif
+    }
+    if (LDSSTATE) {
+        for (int j = tid; j < L.n; j += NT) gx[j] = X[j];
+        for (int r = tid; r < L.m; r += NT) { gz[r] = Z[r]; gy[r] = Y[r]; }
     }
 }
 
@@ -833,7 +1073,7 @@ __global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_solve(Lay L, Ptrs P,
 template <int NB>
 __global__ __launch_bounds__(NT) void k_export(Lay L, Ptrs P, double *Pd, double *Ad_, double *q, double *l, double *u) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
-    double *p = sh; Smem S; smem_common(L, p, S);
+    double *p = sh; Smem S; smem_common(L, P, p, S);
     const int b = blockIdx.x, tid = threadIdx.x;
     const double *model = P.model + (size_t)b * L.model_sz, *step = P.step + (size_t)b * L.step_sz;
     load_common(L, model, step, S);
@@ -849,13 +1089,13 @@ __global__ __launch_bounds__(NT) void k_export(Lay L, Ptrs P, double *Pd, double
 template <int NB>
 __global__ __launch_bounds__(NT) void k_kkt_solve(Lay L, Ptrs P, const double *rhs, double *sol) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
-    double *p = sh; Smem S; smem_common(L, p, S);
+    double *p = sh; Smem S; smem_common(L, P, p, S);
     const int b = blockIdx.x, tid = threadIdx.x;
     const double *model = P.model + (size_t)b * L.model_sz, *step = P.step + (size_t)b * L.step_sz;
     load_common(L, model, step, S);
     Ctx c{L, S.hot, model};
-    kkt_solve<NB>(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], P.F + (size_t)b * P.fsz, rhs + (size_t)b * L.n, S.T, S.tv);
-    for (int j = tid; j < L.n; j += NT) sol[(size_t)b * L.n + j] = S.T[j];
+    kkt_solve<NB>(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], P.F + (size_t)b * P.fsz, rhs + (size_t)b * L.n, S.T + L.m, sol + (size_t)b * L.n);
+    (void)tid;
 }
 
 __global__ void k_gather_u0(Lay L, const double *xo, double *u0, int batch) {
@@ -876,6 +1116,11 @@ struct mpcqp_handle {
     size_t smem_setup, smem_solve;
     std::vector<void *> allocs;
     double *u0_dev;
+    int *active_host;             // pinned
+    bool profiling;
+    hipEvent_t ev0, ev1;
+    double admm_ms;
+    long long admm_launches;
 };
 
 extern "C" void mpcqp_default_settings(mpcqp_settings *s) {
@@ -915,7 +1160,7 @@ static Lay make_layout(int nx, int nu, int Np, int Nc) {
     L.n = 2 * L.n_x + L.n_u; L.m = 2 * L.n_x + L.n_u + (Nc + 1) * nu;
     L.ou = L.n_x; L.oe = L.n_x + L.n_u;
     L.rs = L.n_x; L.ri = 2 * L.n_x; L.rdu = 2 * L.n_x + L.n_u;
-    L.NB = L.nb <= 4 ? 4 : (L.nb <= 8 ? 8 : (L.nb <= 16 ? 16 : 32));
+    L.NB = L.nb <= 16 ? 16 : 32;
     L.rnx = 1.0f / (float)nx; L.rnu = 1.0f / (float)nu;
     int o = 0;
     L.oAd = o; o += nx * nx; L.oBd = o; o += nx * nu;
@@ -927,8 +1172,8 @@ static Lay make_layout(int nx, int nu, int Np, int Nc) {
     L.model_sz = o;
     L.step_sz = nx + nu + L.N * nx;
     L.xref_rows = 1;
-    L.fstage = 2 * L.NB * L.NB;
-    L.tsz = L.m > 4 * L.NB * L.NB ? L.m : 4 * L.NB * L.NB;
+    L.fstage = 3 * L.NB * L.NB;
+    L.tsz = (L.m + L.N * L.NB) > 5 * L.NB * L.NB ? (L.m + L.N * L.NB) : 5 * L.NB * L.NB;   // [W (m) | Tc (N*NB)] or factor workspace
     return L;
 }
 
@@ -952,10 +1197,13 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     HIPCHK(hipSetDevice(device));
     mpcqp_handle *h = new mpcqp_handle();
     h->device = device; h->batch = batch; h->is_setup = false; h->u0_dev = nullptr;
+    h->active_host = nullptr; h->profiling = false; h->admm_ms = 0.0; h->admm_launches = 0;
     h->L = make_layout(nx, nu, Np, Nc);
     if (s) h->S = *s; else mpcqp_default_settings(&h->S);
     HIPCHK(hipStreamCreate(&h->stream));
     h->own_stream = true;
+    HIPCHK(hipHostMalloc((void **)&h->active_host, sizeof(int)));
+    HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1));
     const Lay &L = h->L;
     Ptrs &P = h->P; memset(&P, 0, sizeof(P));
     size_t B = (size_t)batch;
@@ -968,13 +1216,15 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     rc |= dalloc(h, &P.x, B * L.n); rc |= dalloc(h, &P.z, B * L.m); rc |= dalloc(h, &P.y, B * L.m);
     rc |= dalloc(h, &P.xo, B * L.n); rc |= dalloc(h, &P.yo, B * L.m);
     rc |= dalloc(h, &P.dx, B * L.n); rc |= dalloc(h, &P.dy, B * L.m); rc |= dalloc(h, &P.rg, B * L.n);
+    rc |= dalloc(h, &P.qv, B * (size_t)(L.n_x + L.n_u));
     rc |= dalloc(h, &P.Dt, B * L.n); rc |= dalloc(h, &P.Et, B * L.m);
     rc |= dalloc(h, &P.ctype, B * L.m); rc |= dalloc(h, &P.info, B); rc |= dalloc(h, &P.stats, 8);
+    rc |= dalloc(h, &P.done, B); rc |= dalloc(h, &P.active, 4);
     rc |= dalloc(h, &h->u0_dev, B * L.nu);
     if (rc) { mpcqp_destroy(h); return MPCQP_ERR_HIP; }
     h->smem_setup = sizeof(double) * (size_t)smem_common_doubles(L);
     size_t with_state = h->smem_setup + sizeof(double) * (size_t)(L.n + 2 * L.m);
-    h->lds_state = with_state <= 64 * 1024;      // keep >= 2 workgroups per CU; otherwise iterate in L2/HBM
+    h->lds_state = with_state <= 40 * 1024;      // four workgroups per CU; larger problems keep the iterate in L2/HBM   // small problems: x in LDS, z/y in registers; else iterate in L2/HBM
     h->smem_solve = h->lds_state ? with_state : h->smem_setup;
     if (h->smem_solve > 160 * 1024) { mpcqp_destroy(h); return fail(MPCQP_ERR_UNSUPPORTED, "problem too large for one workgroup's LDS"); }
     *out = h;
@@ -986,6 +1236,7 @@ extern "C" void mpcqp_destroy(mpcqp_handle *h) {
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
     for (void *p : h->allocs) hipFree(p);
+    if (h->active_host) { hipHostFree(h->active_host); hipEventDestroy(h->ev0); hipEventDestroy(h->ev1); }
     if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1014,8 +1265,6 @@ static int put(mpcqp_handle *h, double *dst, int stride, int off, const double *
 }
 
 #define DISPATCH_NB(NBV, EXPR) switch (NBV) { \
-    case 4:  { constexpr int NB = 4;  EXPR; } break; \
-    case 8:  { constexpr int NB = 8;  EXPR; } break; \
     case 16: { constexpr int NB = 16; EXPR; } break; \
     default: { constexpr int NB = 32; EXPR; } break; }
 
@@ -1078,19 +1327,60 @@ extern "C" int mpcqp_update_settings(mpcqp_handle *h, const mpcqp_settings *s) {
     return MPCQP_OK;
 }
 
+template <int NB, bool LDSS, int NXT, int NUT>
+static int launch_admm_t(mpcqp_handle *h, int iters) {
+    if (set_smem(k_admm<NB, LDSS, NXT, NUT>, h->smem_solve)) return MPCQP_ERR_HIP;
+    hipLaunchKernelGGL((k_admm<NB, LDSS, NXT, NUT>), dim3(h->batch), dim3(NT), h->smem_solve, h->stream, h->L, h->P, h->S.alpha, iters);
+    return 0;
+}
+
+static int launch_admm(mpcqp_handle *h, int iters) {
+    const Lay &L = h->L;
+    // specialisations with compile-time nx, nu for the BASELINE configurations; generic kernels otherwise
+    if (L.NB == 16 && h->lds_state && L.nx == 12 && L.nu == 4) return launch_admm_t<16, true, 12, 4>(h, iters);
+    if (L.NB == 32 && !h->lds_state && L.nx == 20 && L.nu == 8) return launch_admm_t<32, false, 20, 8>(h, iters);
+    if (L.NB == 16) return h->lds_state ? launch_admm_t<16, true, 0, 0>(h, iters) : launch_admm_t<16, false, 0, 0>(h, iters);
+    return h->lds_state ? launch_admm_t<32, true, 0, 0>(h, iters) : launch_admm_t<32, false, 0, 0>(h, iters);
+}
+
+// One solve of every instance: k_begin, then rounds of { k_admm (iterations up to the next termination /
+// rho-adaptation point), k_check } until no instance is left running.  Returns when the solve is complete.
 static int launch_solve(mpcqp_handle *h, int plain_iters) {
     if (!h->is_setup) return fail(MPCQP_ERR_STATE, "solve before mpcqp_setup");
     HIPCHK(hipSetDevice(h->device));
     const Lay &L = h->L;
+    const mpcqp_settings &S = h->S;
+    const bool plain = plain_iters > 0;
     DISPATCH_NB(L.NB, {
-        if (h->lds_state) {
-            if (set_smem(k_solve<NB, true>, h->smem_solve)) return MPCQP_ERR_HIP;
-            hipLaunchKernelGGL((k_solve<NB, true>), dim3(h->batch), dim3(NT), h->smem_solve, h->stream, h->L, h->P, h->S, plain_iters);
-        } else {
-            if (set_smem(k_solve<NB, false>, h->smem_solve)) return MPCQP_ERR_HIP;
-            hipLaunchKernelGGL((k_solve<NB, false>), dim3(h->batch), dim3(NT), h->smem_solve, h->stream, h->L, h->P, h->S, plain_iters);
-        }
+        if (set_smem(k_begin<NB>, h->smem_setup)) return MPCQP_ERR_HIP;
+        if (set_smem(k_check<NB>, h->smem_setup)) return MPCQP_ERR_HIP;
+        hipLaunchKernelGGL(k_begin<NB>, dim3(h->batch), dim3(NT), h->smem_setup, h->stream, h->L, h->P, h->S, (int)plain);
     });
+    const int max_iter = plain ? plain_iters : S.max_iter;
+    const int chk = plain ? 0 : S.check_termination;
+    int rho_every = 0;
+    if (!plain && S.adaptive_rho) rho_every = S.adaptive_rho_interval ? S.adaptive_rho_interval : (chk ? 4 * chk : 100);
+    int iter = 0;
+    while (iter < max_iter) {
+        int nxt = max_iter;
+        if (chk) nxt = std::min(nxt, (iter / chk + 1) * chk);
+        if (rho_every) nxt = std::min(nxt, (iter / rho_every + 1) * rho_every);
+        if (h->profiling) HIPCHK(hipEventRecord(h->ev0, h->stream));
+        int rc = launch_admm(h, nxt - iter);
+        if (rc) return rc;
+        if (h->profiling) HIPCHK(hipEventRecord(h->ev1, h->stream));
+        iter = nxt;
+        int mode = plain ? COLD_PLAIN : 0;
+        if (chk && iter % chk == 0) mode |= COLD_CHECK;
+        if (rho_every && iter % rho_every == 0) mode |= COLD_RHO;
+        if (iter == max_iter && !plain) mode |= COLD_FINAL;
+        HIPCHK(hipMemsetAsync(h->P.active, 0, sizeof(int), h->stream));
+        DISPATCH_NB(L.NB, { hipLaunchKernelGGL(k_check<NB>, dim3(h->batch), dim3(NT), h->smem_setup, h->stream, h->L, h->P, h->S, iter, mode); });
+        HIPCHK(hipMemcpyAsync(h->active_host, h->P.active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->profiling) { float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1)); h->admm_ms += ms; h->admm_launches += 1; }
+        if (*h->active_host == 0) break;
+    }
     HIPCHK(hipGetLastError());
     return MPCQP_OK;
 }
@@ -1134,6 +1424,15 @@ extern "C" int mpcqp_get_stats(mpcqp_handle *h, uint64_t *out4, int reset) {
     HIPCHK(hipMemcpyAsync(out4, h->P.stats, 4 * sizeof(uint64_t), hipMemcpyDefault, h->stream));
     if (reset) HIPCHK(hipMemsetAsync(h->P.stats, 0, 4 * sizeof(uint64_t), h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    return MPCQP_OK;
+}
+
+extern "C" int mpcqp_profile(mpcqp_handle *h, int enable, double *admm_ms, int64_t *admm_launches, int reset) {
+    if (!h) return fail(MPCQP_ERR_ARG, "null handle");
+    if (enable >= 0) h->profiling = enable != 0;
+    if (admm_ms) *admm_ms = h->admm_ms;
+    if (admm_launches) *admm_launches = h->admm_launches;
+    if (reset) { h->admm_ms = 0.0; h->admm_launches = 0; }
     return MPCQP_OK;
 }
 
