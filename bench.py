@@ -43,7 +43,7 @@ def algorithmic_bytes(n, m, nnzL, iters, checks, solves, nnz_triuP, nnzA):
     return iters * b_it + checks * b_chk + solves * b_fix, b_it
 
 
-def cpu_baseline(seconds_budget=20.0, inst=24, steps=40, eps=1e-3):
+def cpu_baseline(seconds_budget=20.0, inst=400, steps=100, eps=1e-3):
     """Reference-style CPU path on this box's host cores: the C oracle (port of the OSQP algorithm),
     1 thread, sequential over instances, warm-started receding horizon on the same workload recipe.
     Only osqp-equivalent work is timed (update(q,l,u) + solve); the numpy q/l/u refresh is not."""
@@ -81,6 +81,18 @@ def cpu_baseline(seconds_budget=20.0, inst=24, steps=40, eps=1e-3):
                        'mean %.1f ADMM iterations/solve, %.1f s of CPU work)' % (done, steps, iters / max(1, n_solve), t_solve))
 
 
+def pmc_traffic():
+    """HBM bytes per k_admm launch from the rocprofv3 PMC passes of this same command (FETCH_SIZE and WRITE_SIZE
+    collected in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); counters cannot
+    be collected from inside the process, so the committed summary of the last profiled run is reported."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_hbm_traffic.json')
+    try:
+        with open(path) as f:
+            return json.load(f)['k_admm']['hbm_bytes_per_launch']
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -109,17 +121,11 @@ def main():
     f64 = torch.float64
 
     # ---- problem data: generated on rank 0, scattered over RCCL (north_star: scatter problem data)
+    from pympc_amd import sharding
+    full = None
     if rank == 0:
-        data = make_instances(0, B * world)
-        full = {k: torch.from_numpy(v).to(dev) for k, v in data.items()}
-    shapes = {'Ad': (B, NX, NX), 'Bd': (B, NX, NU), 'x0': (B, NX)}
-    loc = {}
-    for k, shp in shapes.items():
-        loc[k] = torch.empty(shp, dtype=f64, device=dev)
-        if world > 1:
-            dist.scatter(loc[k], list(full[k].split(B)) if rank == 0 else None, src=0)
-        else:
-            loc[k].copy_(full[k])
+        full = {k: torch.from_numpy(v).to(dev) for k, v in make_instances(0, B * world).items()}
+    loc = sharding.scatter_instances(full, {'Ad': (NX, NX), 'Bd': (NX, NU), 'x0': (NX,)}, B, dev)
     Ad, Bd, x = loc['Ad'], loc['Bd'], loc['x0'].clone()
 
     stream = torch.cuda.current_stream(dev)
@@ -152,11 +158,12 @@ def main():
             ev1[i].record(stream)
         prob.u0(out=u)
         if world > 1:
-            dist.all_gather_into_tensor(u_all, u)
+            sharding.gather_inputs(u, out=u_all)
 
     for _ in range(args.warmup):
         step()
     prob.stats(reset=True)
+    prob.profile(enable=True, reset=True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -173,17 +180,20 @@ def main():
         elapsed = float(t.item())
 
     iters, checks, refacts, solves = prob.stats()
+    admm_ms, admm_launches = prob.profile()
     infos = prob.infos()
     n_solved = sum(1 for i in infos if i.status == 1)
-    kernel_ms = [a.elapsed_time(b) for a, b in zip(ev0, ev1)]
-    kernel_s = float(np.mean(kernel_ms)) * 1e-3
+    solve_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))     # whole mpcqp_solve span on the stream
 
     if rank == 0:
         n, m, nnzL = prob.n, prob.m, prob.nnzL
         nnz_triuP = (NP + 1) * NX * 2 + NP * NU + (NP - 1) * NU     # diagonal weights: diag + upper QDu coupling
         nnzA = (NP + 1) * NX + NP * NX * NX + NP * NX * NU + 2 * (NP + 1) * NX + NP * NU + NU + 2 * NP * NU - 1
         total_bytes, b_it = algorithmic_bytes(n, m, nnzL, iters, checks, solves, nnz_triuP, nnzA)
-        achieved = total_bytes / args.steps / kernel_s
+        # dominant kernel k_admm: it performs the ADMM iterations (b_it each); residual evaluations and the
+        # per-solve I/O belong to k_check / k_begin.  HIP events bracket every k_admm launch on its stream.
+        admm_bytes = iters * b_it
+        achieved = admm_bytes / (admm_ms * 1e-3)
         out = {
             'metric': 'QP-solves/sec (MPC steps/sec) at nx=12 nu=4 Np=30',
             'value': B * world * args.steps / elapsed,
@@ -200,9 +210,12 @@ def main():
             'solved_fraction_last_step': n_solved / B,
             'refactorizations_per_solve': refacts / max(1, solves),
             'roofline': {'bound': 'hbm', 'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK, 'traffic': None,
-                         'kernel': 'k_solve<16,true>', 'kernel_ms': kernel_s * 1e3,
-                         'algorithmic_bytes_per_iter_per_qp': b_it, 'nnzL': nnzL},
+                         'frac': achieved / HBM_PEAK, 'traffic': pmc_traffic(),
+                         'kernel': 'k_admm<16,true,12,4>', 'kernel_ms': admm_ms / max(1, admm_launches),
+                         'launches': admm_launches, 'algorithmic_bytes_per_launch': admm_bytes / max(1, admm_launches),
+                         'algorithmic_bytes_per_iter_per_qp': b_it, 'nnzL': nnzL,
+                         'all_kernels_algorithmic_GBps': total_bytes / args.steps / (solve_ms * 1e-3) / 1e9,
+                         'solve_ms': solve_ms},
         }
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(eps=args.eps)

@@ -1,0 +1,37 @@
+"""Summarise rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE collected in SEPARATE runs) per kernel.
+FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-byte requests at 64 B, so wide coalesced
+reads are under-reported by 2x (MI355X_MICROARCH.md, HBM section) -- both the raw and the doubled figure are printed."""
+import csv, sys, collections
+out = []
+for path in sys.argv[1:]:
+    agg = collections.defaultdict(lambda: [0, 0.0, 0])
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            k = (row['Kernel_Name'].split('(')[0], row['Counter_Name'])
+            a = agg[k]; a[0] += 1; a[1] += float(row['Counter_Value']); a[2] += int(row['End_Timestamp']) - int(row['Start_Timestamp'])
+    for (name, ctr), (n, tot, ns) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:6]:
+        kib = tot / n
+        line = '%-28s %-10s launches %4d  mean %12.1f KiB/launch  (x2 for wide reads: %10.1f MiB)  mean duration %8.1f us' % (
+            name[:28], ctr, n, kib, 2 * kib / 1024 if ctr == 'FETCH_SIZE' else kib / 1024, ns / n / 1e3)
+        out.append(line)
+print('\n'.join(out))
+
+import json, os
+res = {}
+for path in sys.argv[1:]:
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            name = row['Kernel_Name'].split('<')[0].replace('void ', '').strip()
+            if not name.startswith('k_'):
+                continue
+            d = res.setdefault(name, {'FETCH_SIZE': [0, 0.0], 'WRITE_SIZE': [0, 0.0]})
+            d[row['Counter_Name']][0] += 1; d[row['Counter_Name']][1] += float(row['Counter_Value'])
+summary = {}
+for name, d in res.items():
+    f = d['FETCH_SIZE'][1] / max(1, d['FETCH_SIZE'][0]); w = d['WRITE_SIZE'][1] / max(1, d['WRITE_SIZE'][0])
+    summary[name] = {'fetch_kib_per_launch_raw': f, 'write_kib_per_launch_raw': w,
+                     'hbm_bytes_per_launch': (2 * f + w) * 1024, 'launches': d['FETCH_SIZE'][0],
+                     'note': 'FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B for wide coalesced reads)'}
+out = os.environ.get('PMC_JSON')
+if out:
+    json.dump(summary, open(out, 'w'), indent=1)

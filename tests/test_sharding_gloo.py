@@ -1,0 +1,83 @@
+"""Multi-process (world_size 2, gloo, CPU) test of the instance sharding used by bench.py on N GPUs:
+scatter of the problem data from rank 0, per-shard work, all-gather of u*.  The per-shard "solve" here is
+the CPU oracle (tests may use it) so that the gathered result can be compared with a single-process run."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _solve_shard(Ad, Bd, x0):
+    sys.path.insert(0, ROOT)
+    from pympc_amd import MPCController, fixtures
+    from oracle.osqp_oracle import OSQP
+    us = []
+    for i in range(Ad.shape[0]):
+        kw = fixtures.random_lti(0, nx=5, nu=3, Np=8)
+        kw.update(Ad=Ad[i].numpy(), Bd=Bd[i].numpy(), x0=x0[i].numpy(), eps_abs=1e-8, eps_rel=1e-8)
+        K = MPCController(**kw); K.prob = OSQP(); K.setup()
+        us.append(K.output())
+    return torch.tensor(np.stack(us))
+
+
+def _make(total):
+    sys.path.insert(0, ROOT)
+    from pympc_amd import fixtures
+    kws = [fixtures.random_lti(40 + i, nx=5, nu=3, Np=8) for i in range(total)]
+    return {k: torch.tensor(np.stack([kw[k] for kw in kws])) for k in ('Ad', 'Bd', 'x0')}
+
+
+def _worker(rank, world_size, port, per, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world_size)
+    sys.path.insert(0, ROOT)
+    from pympc_amd import sharding
+    full = _make(per * world_size) if rank == 0 else None
+    loc = sharding.scatter_instances(full, {'Ad': (5, 5), 'Bd': (5, 3), 'x0': (5,)}, per, torch.device('cpu'))
+    lo, hi = sharding.shard_range(per * world_size, rank, world_size)
+    assert (lo, hi) == (rank * per, (rank + 1) * per)
+    u = _solve_shard(loc['Ad'], loc['Bd'], loc['x0'])
+    u_all = sharding.gather_inputs(u)
+    if rank == 0:
+        q.put(u_all.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_scatter_solve_gather_world2():
+    per, ws = 3, 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, ws, port, per, q)) for r in range(ws)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    full = _make(per * ws)
+    ref = _solve_shard(full['Ad'], full['Bd'], full['x0']).numpy()
+    assert got.shape == (per * ws, 3)
+    assert np.allclose(got, ref, rtol=1e-9, atol=1e-12)
+
+
+def test_shard_range_rejects_uneven():
+    sys.path.insert(0, ROOT)
+    from pympc_amd import sharding
+    with pytest.raises(ValueError):
+        sharding.shard_range(10, 0, 4)
+    assert sharding.world() == (0, 1)
