@@ -25,12 +25,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 NX, NU, NP = 12, 4, 30
+XBOX = 10.0
 HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md chip-level parameters
 
 
 def make_instances(first, count):
     from pympc_amd import fixtures
-    kws = [fixtures.random_lti(first + i, nx=NX, nu=NU, Np=NP) for i in range(count)]
+    kws = [fixtures.random_lti(first + i, nx=NX, nu=NU, Np=NP, xbox=XBOX) for i in range(count)]
     return {k: np.stack([np.asarray(kw[k], dtype=float) for kw in kws]) for k in ('Ad', 'Bd', 'x0')}
 
 
@@ -53,7 +54,7 @@ def cpu_baseline(seconds_budget=20.0, inst=400, steps=100, eps=1e-3):
     t_solve, n_solve, iters, done = 0.0, 0, 0, 0
     t0 = time.perf_counter()
     for i in range(inst):
-        kw = fixtures.random_lti(i, nx=NX, nu=NU, Np=NP)
+        kw = fixtures.random_lti(i, nx=NX, nu=NU, Np=NP, xbox=XBOX)
         kw.update(eps_abs=eps, eps_rel=eps)
         K = MPCController(**kw)
         K.prob = OSQP()
@@ -101,7 +102,14 @@ def main():
     ap.add_argument('--batch', type=int, default=1024, help='instances per GPU')
     ap.add_argument('--eps', type=float, default=1e-3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--workload', default='cfg3', choices=['cfg3', 'cfg5'],
+                    help='cfg3: 1024 x (12,4,30) (headline); cfg5: 512 x (20,8,100), tight state box (SURVEY 8d)')
     args = ap.parse_args()
+    global NX, NU, NP, XBOX
+    if args.workload == 'cfg5':
+        NX, NU, NP, XBOX = 20, 8, 100, 1.0
+        if args.batch == 1024:
+            args.batch = 512
 
     import torch
     import torch.distributed as dist
@@ -134,7 +142,7 @@ def main():
     eye = lambda k, s: (s * torch.eye(k, dtype=f64, device=dev)).expand(B, k, k).contiguous()
     ones = lambda k, s: torch.full((B, k), s, dtype=f64, device=dev)
     prob.setup(Ad, Bd, eye(NX, 1.0), eye(NX, 1.0), eye(NU, 0.1), eye(NU, 0.1),
-               ones(NX, -10.0), ones(NX, 10.0), ones(NU, -1.0), ones(NU, 1.0), ones(NU, -0.5), ones(NU, 0.5),
+               ones(NX, -XBOX), ones(NX, XBOX), ones(NU, -1.0), ones(NU, 1.0), ones(NU, -0.5), ones(NU, 0.5),
                ones(NU, 0.0), torch.full((B, 1), 1e6, dtype=f64, device=dev),
                x, ones(NU, 0.0), torch.zeros((B, NX), dtype=f64, device=dev))
     prob.solve_async()                        # cold solve (setup(solve=True))
@@ -195,15 +203,15 @@ def main():
         admm_bytes = iters * b_it
         achieved = admm_bytes / (admm_ms * 1e-3)
         out = {
-            'metric': 'QP-solves/sec (MPC steps/sec) at nx=12 nu=4 Np=30',
+            'metric': 'QP-solves/sec (MPC steps/sec) at nx=%d nu=%d Np=%d' % (NX, NU, NP),
             'value': B * world * args.steps / elapsed,
             'unit': 'QP-solves/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'cfg-3: %d random stable LTI MPC instances per GPU (nx=12, nu=4, Np=Nc=30, n=%d, m=%d), '
-                                   'warm-started receding horizon x+=Ad x+Bd u*+w' % (B, n, m),
+            'config': {'workload': '%s: %d random stable LTI MPC instances per GPU (nx=%d, nu=%d, Np=Nc=%d, n=%d, m=%d), '
+                                   'warm-started receding horizon x+=Ad x+Bd u*+w' % ('cfg-3' if args.workload == 'cfg3' else 'cfg-5', B, NX, NU, NP, n, m),
                        'batch_per_gpu': B, 'eps_abs': args.eps, 'eps_rel': args.eps,
                        'parallelism': 'instances sharded over %d GPU(s); RCCL scatter of data, all-gather of u*' % world},
             'mean_admm_iters': iters / max(1, solves),
@@ -211,7 +219,7 @@ def main():
             'refactorizations_per_solve': refacts / max(1, solves),
             'roofline': {'bound': 'hbm', 'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK, 'traffic': pmc_traffic(),
-                         'kernel': 'k_admm<16,true,12,4>', 'kernel_ms': admm_ms / max(1, admm_launches),
+                         'kernel': 'k_admm<16,true,12,4>' if args.workload == 'cfg3' else 'k_admm<32,false,20,8>', 'kernel_ms': admm_ms / max(1, admm_launches),
                          'launches': admm_launches, 'algorithmic_bytes_per_launch': admm_bytes / max(1, admm_launches),
                          'algorithmic_bytes_per_iter_per_qp': b_it, 'nnzL': nnzL,
                          'all_kernels_algorithmic_GBps': total_bytes / args.steps / (solve_ms * 1e-3) / 1e9,

@@ -354,44 +354,61 @@ __device__ __forceinline__ int frag_pos(int r, int cidx) {
     return (bi * NBLK + bj) * 256 + (((kk & 3) << 4) + i) * 4 + (kk >> 2);
 }
 
-// W: LDS workspace of 5*NB*NB doubles.  Returns (uniformly) 0, or 1 if a pivot was not positive.
+// TWISTED (two-sided) elimination: stages 0..mid-1 are eliminated top-down, stages N-1..mid+1 bottom-up, the
+// middle stage mid = N/2 last, so that two waves can sweep the two half-chains concurrently (half the
+// sequential depth).  With Sn = S^-1 of the neighbour eliminated just before,
+//   top    k < mid:  Mh_k = K_{k,k-1} Sn_{k-1},   S_k = K_kk - Mh_k K_{k,k-1}'
+//   bottom k > mid:  Mt_k = K_{k,k+1} Sn_{k+1},   S_k = K_kk - Mt_k K_{k,k+1}'        (K_{k,k+1} = K_{k+1,k}')
+//   middle        :  S_mid = K_mm - Mh_mid K_{mid,mid-1}' - Mt_mid K_{mid,mid+1}'
+// Per-stage factor slots (fragments, see above):   slot 0: forward matrix   slot 1: S_k^-1   slot 2: backward matrix
+//   top:    slot0 = -Mh_k        slot2 = -Mh_{k+1}'     bottom: slot0 = -Mt_k       slot2 = -Mt_{k-1}'
+//   middle: slot0 = -Mh_mid      slot2 = -Mt_mid  (its second forward matrix; the middle has no backward one)
+// W: LDS workspace of 6*NB*NB doubles.  Returns (uniformly) 0, or 1 if a pivot was not positive.
 template <int NB>
 __device__ int factor_all(const Ctx &c, const double *om, const double *sv, double cc, double *F, double *W, int *iflag) {
     const Lay &L = c.L;
-    double *S = W, *Ks = W + NB * NB, *Mh = W + 2 * NB * NB, *Sp = W + 3 * NB * NB, *Li = W + 4 * NB * NB;
+    double *S = W, *Ks = W + NB * NB, *Mh = W + 2 * NB * NB, *SnA = W + 3 * NB * NB, *Li = W + 4 * NB * NB, *SnB = W + 5 * NB * NB;
     const int tid = threadIdx.x;
+    const int N = L.N, mid = N / 2;
     if (tid == 0) *iflag = 0;
-    for (int k = 0; k < L.N; ++k) {
+    // S -= (Ks Sn) Ks' for the neighbour on side `up` (true: k-1, false: k+1); stores the two fragment copies
+    auto eliminate_neighbour = [&](int k, bool up, const double *Sn) {
         __syncthreads();
         for (int e = tid; e < NB * NB; e += NT) {
             int a = e / NB, b = e % NB;
-            S[e] = kkt_diag_entry(c, om, sv, cc, k, a, b);
-            Ks[e] = (k > 0) ? kkt_sub_entry(c, om, cc, k - 1, a, b) : 0.0;
-            Li[e] = 0.0;
+            Ks[e] = up ? kkt_sub_entry(c, om, cc, k - 1, a, b) : kkt_sub_entry(c, om, cc, k, b, a);
         }
         __syncthreads();
-        if (k > 0) {
-            for (int e = tid; e < NB * NB; e += NT) {          // Mh = Ks * Sp
-                int a = e / NB, b = e % NB;
-                double acc = 0.0;
-                for (int l = 0; l < NB; ++l) acc += Ks[a * NB + l] * Sp[l * NB + b];
-                Mh[e] = acc;
-            }
-            __syncthreads();
-            for (int e = tid; e < NB * NB; e += NT) {          // S -= Mh * Ks'
-                int a = e / NB, b = e % NB;
-                double acc = 0.0;
-                for (int l = 0; l < NB; ++l) acc += Mh[a * NB + l] * Ks[b * NB + l];
-                S[e] -= acc;
-                double mv = -Mh[e];
-                F[(size_t)k * L.fstage + frag_pos<NB>(a, b)] = mv;                        // -Mh_k      (forward)
-                F[(size_t)(k - 1) * L.fstage + 2 * NB * NB + frag_pos<NB>(b, a)] = mv;    // -Mh_k'     (backward, slot k-1)
-            }
-            __syncthreads();
-        } else {
-            for (int e = tid; e < NB * NB; e += NT) F[e] = 0.0;
+        for (int e = tid; e < NB * NB; e += NT) {              // Mh = Ks * Sn
+            int a = e / NB, b = e % NB;
+            double acc = 0.0;
+            for (int l = 0; l < NB; ++l) acc += Ks[a * NB + l] * Sn[l * NB + b];
+            Mh[e] = acc;
         }
-        if (k == L.N - 1) for (int e = tid; e < NB * NB; e += NT) F[(size_t)k * L.fstage + 2 * NB * NB + e] = 0.0;
+        __syncthreads();
+        const int fwd_slot = (k == mid && !up) ? 2 : 0;         // the middle keeps its second forward matrix in slot 2
+        const int nb = up ? k - 1 : k + 1;
+        for (int e = tid; e < NB * NB; e += NT) {              // S -= Mh * Ks'
+            int a = e / NB, b = e % NB;
+            double acc = 0.0;
+            for (int l = 0; l < NB; ++l) acc += Mh[a * NB + l] * Ks[b * NB + l];
+            S[e] -= acc;
+            double mv = -Mh[e];
+            F[(size_t)k * L.fstage + fwd_slot * NB * NB + frag_pos<NB>(a, b)] = mv;      // forward matrix of stage k
+            F[(size_t)nb * L.fstage + 2 * NB * NB + frag_pos<NB>(b, a)] = mv;            // its transpose: backward matrix of the neighbour
+        }
+        __syncthreads();
+    };
+    auto stage = [&](int k, bool use_up, bool use_down, double *SnOut) {
+        __syncthreads();
+        for (int e = tid; e < NB * NB; e += NT) {
+            S[e] = kkt_diag_entry(c, om, sv, cc, k, e / NB, e % NB);
+            Li[e] = 0.0;
+            if (!use_up && !use_down) F[(size_t)k * L.fstage + e] = 0.0;      // end stages have no forward matrix
+        }
+        if (use_up) eliminate_neighbour(k, true, SnA);
+        if (use_down) eliminate_neighbour(k, false, SnB);
+        __syncthreads();
         // Cholesky of S (lower), right-looking
         for (int j = 0; j < NB; ++j) {
             double d = S[j * NB + j];
@@ -417,14 +434,17 @@ __device__ int factor_all(const Ctx &c, const double *om, const double *sv, doub
             }
         }
         __syncthreads();
-        for (int e = tid; e < NB * NB; e += NT) {              // Sp = S^-1 = Li' Li
+        for (int e = tid; e < NB * NB; e += NT) {              // S^-1 = Li' Li
             int a = e / NB, b = e % NB;
             double acc = 0.0;
             for (int l = max(a, b); l < NB; ++l) acc += Li[l * NB + a] * Li[l * NB + b];
-            Sp[e] = acc;
+            SnOut[e] = acc;
             F[(size_t)k * L.fstage + NB * NB + frag_pos<NB>(a, b)] = acc;
         }
-    }
+    };
+    for (int k = 0; k < mid; ++k) stage(k, k > 0, false, SnA);
+    for (int k = N - 1; k > mid; --k) stage(k, false, k < N - 1, SnB);
+    stage(mid, true, true, SnA);
     __syncthreads();
     return *iflag;
 }
@@ -471,70 +491,113 @@ template <int NB> struct SweepCfg {
     static constexpr int DEPTH = (NB == 16) ? 8 : 4;      // factor stages kept in flight in registers
 };
 
-// Sequential sweep over the stages by ONE wave.  DIR=+1: yh_k = b_k - Mh_k yh_{k-1} (slot 0 of each stage);
-// DIR=-1: x_k = w_k - Mh_{k+1}' x_{k+1} (slot 2).  In place on Tc.  The factor fragments of the next DEPTH
-// stages are prefetched into a register ring; the running vector ping-pongs between two register sets
-// (no copies between MFMAs).
-template <int NB, int DIR>
-__device__ __forceinline__ void chain_sweep(const int N, const int fstage, const double *F, double *Tc) {
+// Sequential sweep over `nsteps` stages by ONE wave: for i = 1..nsteps, k = first + dir*i:
+//     Tc[k] <- Tc[k] + Frag(slot, k) * Tc[k - dir]        (Frag holds the negated factor block)
+// The factor fragments of the next DEPTH stages are prefetched into a register ring; the running vector
+// ping-pongs between two register sets (no copies between MFMAs).
+template <int NB>
+__device__ __forceinline__ void chain_sweep(const int first, const int dir, const int nsteps, const int slot,
+                                            const int fstage, const double *F, double *Tc) {
     constexpr int NBLK = NB / 16, NF = SweepCfg<NB>::NF, DEPTH = SweepCfg<NB>::DEPTH;
     const int lane = threadIdx.x & 63;
     double *tb = Tc + (lane >> 4);
     const bool writer = (lane & 15) == 0;
-    const size_t slot = (DIR > 0) ? 0 : 2 * NB * NB;
-    // step i = 1..N-1 touches stage k(i): forward k = i (matrix of stage k), backward k = N-1-i (matrix stored at stage k)
-    auto stage_of = [&](int i) { return DIR > 0 ? i : N - 1 - i; };
+    const double *Fs = F + (size_t)slot * NB * NB;
+    auto stage_of = [&](int i) { return first + dir * i; };
     d4 ring[DEPTH][NF];
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
-        if (1 + d < N) frag_load<NB>(F + (size_t)stage_of(1 + d) * fstage + slot, lane, ring[d]);
+        if (1 + d <= nsteps) frag_load<NB>(Fs + (size_t)stage_of(1 + d) * fstage, lane, ring[d]);
     d4 va[NBLK], vb[NBLK];
-    vec_load<NB>(tb, stage_of(0), va);
-    for (int i0 = 1; i0 < N; i0 += DEPTH) {
+    vec_load<NB>(tb, first, va);
+    for (int i0 = 1; i0 <= nsteps; i0 += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             const int i = i0 + d;
-            if (i < N) {
+            if (i <= nsteps) {
                 const int k = stage_of(i);
                 d4 *src = (d & 1) ? vb : va, *dst = (d & 1) ? va : vb;
                 vec_load<NB>(tb, k, dst);
                 frag_matvec<NB>(ring[d], src, dst);
                 vec_store<NB>(tb, k, dst, writer);
-                if (i + DEPTH < N) frag_load<NB>(F + (size_t)stage_of(i + DEPTH) * fstage + slot, lane, ring[d]);
+                if (i + DEPTH <= nsteps) frag_load<NB>(Fs + (size_t)stage_of(i + DEPTH) * fstage, lane, ring[d]);
             }
         }
     }
 }
 
-// w_k = S_k^-1 yh_k for all stages, stages dealt round-robin to the four waves (independent MFMA groups).
+// w_k = S_k^-1 yh_k for all stages (independent MFMA groups, dealt to the four waves).  Wave 0 first finishes the
+// forward elimination at the middle stage: yh_mid = b_mid - Mh_mid yh_{mid-1} - Mt_mid yh_{mid+1}; it owns the three
+// stages around the middle (it reads yh_{mid-1}, yh_{mid+1}, so no other wave may overwrite them with w meanwhile).
+// The other N-3 stages are spread so that the four waves finish together (wave 0 takes every 7th of them on top of
+// its 3.5 stage-equivalents).  Fragments are fetched two stages at a time.
 template <int NB>
-__device__ __forceinline__ void sinv_apply(const int N, const int fstage, const double *F, double *Tc) {
-    constexpr int NBLK = NB / 16;
+__device__ __forceinline__ void sinv_apply(const int N, const int mid, const int fstage, const double *F, double *Tc) {
+    constexpr int NBLK = NB / 16, NF = SweepCfg<NB>::NF;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     double *tb = Tc + (lane >> 4);
     const bool writer = (lane & 15) == 0;
-    for (int k = wv; k < N; k += NT / 64) {
-        d4 A[NBLK * NBLK], in[NBLK], out[NBLK];
-        frag_load<NB>(F + (size_t)k * fstage + NB * NB, lane, A);
+    auto apply = [&](int k, const d4 *A) {
+        d4 in[NBLK], out[NBLK];
         vec_load<NB>(tb, k, in);
 #pragma unroll
         for (int b = 0; b < NBLK; ++b) out[b] = d4{0.0, 0.0, 0.0, 0.0};
         frag_matvec<NB>(A, in, out);
         vec_store<NB>(tb, k, out, writer);
+    };
+    const double *Fs = F + NB * NB;
+    if (wv == 0) {
+        d4 A0[NF], A2[NF], Am[NF], up[NBLK], dn[NBLK], acc[NBLK];
+        frag_load<NB>(F + (size_t)mid * fstage, lane, A0);
+        frag_load<NB>(F + (size_t)mid * fstage + 2 * NB * NB, lane, A2);
+        frag_load<NB>(Fs + (size_t)mid * fstage, lane, Am);
+        vec_load<NB>(tb, mid, acc);
+        vec_load<NB>(tb, mid - 1, up);
+        vec_load<NB>(tb, mid + 1, dn);
+        frag_matvec<NB>(A0, up, acc);
+        frag_matvec<NB>(A2, dn, acc);
+        vec_store<NB>(tb, mid, acc, writer);
+        d4 B0[NF], B1[NF];
+        frag_load<NB>(Fs + (size_t)(mid - 1) * fstage, lane, B0);
+        frag_load<NB>(Fs + (size_t)(mid + 1) * fstage, lane, B1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        apply(mid, Am); apply(mid - 1, B0); apply(mid + 1, B1);
     }
+    static_assert(NWAVES == 4, "stage-to-wave map below assumes four waves");
+    int pend = -1;                                           // pair up this wave's stages: two loads in flight
+    d4 P0[NF];
+    for (int j = 0; j < N - 3; ++j) {                        // j-th stage outside {mid-1, mid, mid+1}
+        const int owner = (j % 7 == 0) ? 0 : 1 + ((j - j / 7 - 1) % 3);
+        if (owner != wv) continue;
+        const int k = j < mid - 1 ? j : j + 3;
+        if (pend < 0) { frag_load<NB>(Fs + (size_t)k * fstage, lane, P0); pend = k; }
+        else {
+            d4 P1[NF];
+            frag_load<NB>(Fs + (size_t)k * fstage, lane, P1);
+            apply(pend, P0); apply(k, P1);
+            pend = -1;
+        }
+    }
+    if (pend >= 0) apply(pend, P0);
 }
 
-// Tc <- K_xu^-1 Tc (eps already eliminated).  All threads call; barriers inside.  Tc must be seen by the
-// compiler as an LDS pointer (a pointer laundered through an integer becomes FLAT: flat LDS accesses count on
-// vmcnt AND lgkmcnt and force a full s_waitcnt vmcnt(0) -- draining the factor prefetch -- before every stage).
+// Tc <- K_xu^-1 Tc (eps already eliminated).  All threads call; barriers inside.  Waves 0 and 1 sweep the two
+// half-chains of the twisted factorization concurrently.  Tc must be seen by the compiler as an LDS pointer
+// (a pointer laundered through an integer becomes FLAT: flat LDS accesses count on vmcnt AND lgkmcnt and force a
+// full s_waitcnt vmcnt(0) -- draining the factor prefetch -- before every stage).
 template <int NB>
 __device__ __forceinline__ void kkt_core(const int N, const int fstage, const double *F, double *Tc) {
+    const int mid = N / 2, wv = threadIdx.x >> 6;
 #ifndef MPCQP_ABL_NOCHAIN
-    if (threadIdx.x < 64) chain_sweep<NB, +1>(N, fstage, F, Tc);
+    if (wv == 0) chain_sweep<NB>(0, +1, mid - 1, 0, fstage, F, Tc);                  // stages 1 .. mid-1
+    else if (wv == 1) chain_sweep<NB>(N - 1, -1, N - 2 - mid, 0, fstage, F, Tc);     // stages N-2 .. mid+1
     __syncthreads();
-    sinv_apply<NB>(N, fstage, F, Tc);
+    sinv_apply<NB>(N, mid, fstage, F, Tc);
     __syncthreads();
-    if (threadIdx.x < 64) chain_sweep<NB, -1>(N, fstage, F, Tc);
+    if (wv == 0) chain_sweep<NB>(mid, -1, mid, 2, fstage, F, Tc);                    // stages mid-1 .. 0
+    else if (wv == 1) chain_sweep<NB>(mid, +1, N - 1 - mid, 2, fstage, F, Tc);       // stages mid+1 .. N-1
 #endif
     __syncthreads();
 }
@@ -1173,7 +1236,7 @@ static Lay make_layout(int nx, int nu, int Np, int Nc) {
     L.step_sz = nx + nu + L.N * nx;
     L.xref_rows = 1;
     L.fstage = 3 * L.NB * L.NB;
-    L.tsz = (L.m + L.N * L.NB) > 5 * L.NB * L.NB ? (L.m + L.N * L.NB) : 5 * L.NB * L.NB;   // [W (m) | Tc (N*NB)] or factor workspace
+    L.tsz = (L.m + L.N * L.NB) > 6 * L.NB * L.NB ? (L.m + L.N * L.NB) : 6 * L.NB * L.NB;   // [W (m) | Tc (N*NB)] or factor workspace
     return L;
 }
 

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(NT) void ub_sweep(Lay L, const double *F, double *o
     long long w0 = wall_clock64();
     for (int r = 0; r < reps; ++r) {
         if (WHICH == 0) { if (threadIdx.x < 64) chain_sweep<16, +1>(L.N, L.fstage, F + (size_t)blockIdx.x * L.N * L.fstage , Tc); }
-        if (WHICH == 1) sinv_apply<16>(L.N, L.fstage, F + (size_t)blockIdx.x * L.N * L.fstage, Tc);
+        if (WHICH == 1) sinv_apply<16>(L.N, L.N / 2, L.fstage, F + (size_t)blockIdx.x * L.N * L.fstage, Tc);
         if (WHICH == 2) kkt_core<16>(L.N, L.fstage, F + (size_t)blockIdx.x * L.N * L.fstage, Tc);
         __syncthreads();
     }
