@@ -50,7 +50,10 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 // ------------------------------------------------------------------------------------------------
 struct Lay {
     int nx, nu, Np, Nc, N, nb, n, m, n_x, n_u, ou, oe, rs, ri, rdu;
-    int NB;                       // padded stage block size (4, 8, 16, 32)
+    int NB;                       // padded stage block size (16 or 32)
+    int NcT;                      // stages 0..NcT-1 carry their input u_k inside the block-tridiagonal part
+    int border;                   // 1 if Nc < Np: the held last input u_{Nc-1} couples to every later stage and is
+                                  // handled as a bordered (Schur-complement) correction, see border_* below
     float rnx, rnu;               // reciprocals for cheap index division
     // model blob: hot prefix [Ad|Bd|xmin|xmax|umin|umax|Dumin|Dumax|uref|eps_feas] then [Qx|QxN|Qu|QDu]
     int oAd, oBd, oxmin, oxmax, oumin, oumax, oDumin, oDumax, ouref, oeps, hot_sz;
@@ -68,6 +71,7 @@ struct Ptrs {
     double *x, *z, *y;            // iterate (unscaled units)
     double *xo, *yo;              // reported solution
     double *dx, *dy, *rg;         // scratch: last increments, rhs
+    double *Bb, *Zb, *Sig;        // border (Nc < Np): K[:,ubar] and T^-1 K[:,ubar] in padded layout [nu][N*NB], Schur inverse [nu*nu]
     double *qv;                   // linear cost of the x,u variables [n_x+n_u] (rebuilt by every kernel prologue)
     double *Dt, *Et;              // Ruiz temporaries
     int *ctype;
@@ -273,7 +277,7 @@ __device__ void block_reduce(double *vmax, double *vsum, double *red) {
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ double kkt_diag_entry(const Ctx &c, const double *om, const double *sv, double cc, int k, int a, int b) {
     const Lay &L = c.L;
-    const int nbk = (k < L.Nc) ? L.nb : L.nx;
+    const int nbk = (k < L.NcT) ? L.nb : L.nx;
     if (a >= nbk || b >= nbk) return a == b ? 1.0 : 0.0;
     const double *Ad = c.Ad(), *Bd = c.Bd();
     const double *omd = om + (k + 1) * L.nx;          // dynamics rows of stage k+1
@@ -314,8 +318,8 @@ __device__ __forceinline__ double kkt_diag_entry(const Ctx &c, const double *om,
 // K_{k+1,k}: rows = variables of stage k+1, cols = variables of stage k.
 __device__ __forceinline__ double kkt_sub_entry(const Ctx &c, const double *om, double cc, int k, int a, int b) {
     const Lay &L = c.L;
-    const int nbk = (k < L.Nc) ? L.nb : L.nx;
-    const int nbn = (k + 1 < L.Nc) ? L.nb : L.nx;
+    const int nbk = (k < L.NcT) ? L.nb : L.nx;
+    const int nbn = (k + 1 < L.NcT) ? L.nb : L.nx;
     if (a >= nbn || b >= nbk) return 0.0;
     const double *omd = om + (k + 1) * L.nx;
     if (a < L.nx) {
@@ -364,8 +368,12 @@ __device__ __forceinline__ int frag_pos(int r, int cidx) {
 //   top:    slot0 = -Mh_k        slot2 = -Mh_{k+1}'     bottom: slot0 = -Mt_k       slot2 = -Mt_{k-1}'
 //   middle: slot0 = -Mh_mid      slot2 = -Mt_mid  (its second forward matrix; the middle has no backward one)
 // W: LDS workspace of 6*NB*NB doubles.  Returns (uniformly) 0, or 1 if a pivot was not positive.
+struct BorderPtrs { double *Bb, *Zb, *Sig, *red; };
+
+template <int NB> __device__ void border_factor(const Ctx &, const double *, const double *, double, const double *, double *, double *, double *, double *, double *, double *);
+
 template <int NB>
-__device__ int factor_all(const Ctx &c, const double *om, const double *sv, double cc, double *F, double *W, int *iflag) {
+__device__ int factor_all(const Ctx &c, const double *om, const double *sv, double cc, double *F, double *W, int *iflag, BorderPtrs bp) {
     const Lay &L = c.L;
     double *S = W, *Ks = W + NB * NB, *Mh = W + 2 * NB * NB, *SnA = W + 3 * NB * NB, *Li = W + 4 * NB * NB, *SnB = W + 5 * NB * NB;
     const int tid = threadIdx.x;
@@ -446,6 +454,7 @@ __device__ int factor_all(const Ctx &c, const double *om, const double *sv, doub
     for (int k = N - 1; k > mid; --k) stage(k, false, k < N - 1, SnB);
     stage(mid, true, true, SnA);
     __syncthreads();
+    if (L.border) border_factor<NB>(c, om, sv, cc, F, bp.Bb, bp.Zb, bp.Sig, W, W + L.m, bp.red);
     return *iflag;
 }
 
@@ -602,11 +611,109 @@ __device__ __forceinline__ void kkt_core(const int N, const int fstage, const do
     __syncthreads();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Control horizon Nc < Np (mpc.py:513-517,540-543): the last input ub = u_{Nc-1} is held to the end of the
+// horizon, so it couples to every later stage and K is block tridiagonal plus a border:
+//     K = [ T  B ; B' C ],   T = K without ub (stage Nc-1 keeps only x),   B = K[:, ub],   C = K[ub, ub].
+// With Z = T^-1 B and Sigma = C - B'Z (computed at factor time):  ub = Sigma^-1 (r2 - Z' r1),  y = T^-1 (r1 - B ub).
+// B and C are taken entry by entry from the matrix-free operators (K = cP + diag(s) + A' diag(omega) A).
+// ------------------------------------------------------------------------------------------------
+__device__ double kkt_entry_generic(const Ctx &c, const double *om, const double *sv, double cc, int v, int w) {
+    double acc = 0.0;
+    P_row(c, v, [&](double co, int idx) { if (idx == w) acc += cc * co; });
+    if (v == w) acc += sv[v];
+    AT_row(c, v, [&](double cot, int r) {
+        double arw = 0.0;
+        A_row(c, r, [&](double co, int idx) { if (idx == w) arw += co; });
+        acc += cot * om[r] * arw;
+    });
+    return acc;
+}
+
+// flat variable index of padded slot (k, a), or -1 for padding / the border input
+__device__ __forceinline__ int padded_var(const Lay &L, int k, int a) {
+    if (a < L.nx) return k * L.nx + a;
+    if (a < L.nb && k < L.NcT) return L.ou + k * L.nu + (a - L.nx);
+    return -1;
+}
+
+template <int NB>
+__device__ void border_factor(const Ctx &c, const double *om, const double *sv, double cc, const double *F,
+                              double *Bb, double *Zb, double *Sig, double *W, double *Tc, double *red) {
+    const Lay &L = c.L;
+    const int tid = threadIdx.x, nu = L.nu, NP = L.N * NB;
+    const int ub0 = L.ou + (L.Nc - 1) * L.nu;
+    for (int idx = tid; idx < NP; idx += NT) {
+        const int v = padded_var(L, idx / NB, idx % NB);
+        for (int j = 0; j < nu; ++j) Bb[(size_t)j * NP + idx] = (v >= 0) ? kkt_entry_generic(c, om, sv, cc, v, ub0 + j) : 0.0;
+    }
+    __syncthreads();
+    for (int j = 0; j < nu; ++j) {                         // Z_j = T^-1 B_j
+        for (int idx = tid; idx < NP; idx += NT) Tc[idx] = Bb[(size_t)j * NP + idx];
+        __syncthreads();
+        kkt_core<NB>(L.N, L.fstage, F, Tc);
+        for (int idx = tid; idx < NP; idx += NT) Zb[(size_t)j * NP + idx] = Tc[idx];
+        __syncthreads();
+    }
+    // Sigma = C - B'Z, inverted by Gauss-Jordan (SPD, nu x nu) by one thread
+    double *Sg = W;                                        // nu*nu doubles (W, the row work vector, is free here)
+    for (int e = 0; e < nu * nu; ++e) {
+        const int i = e / nu, j = e % nu;
+        double vsum[1] = {0.0}, vmax[1] = {0.0};
+        for (int idx = tid; idx < NP; idx += NT) vsum[0] += Bb[(size_t)i * NP + idx] * Zb[(size_t)j * NP + idx];
+        block_reduce<1, 1>(vmax, vsum, red);
+        if (tid == 0) Sg[e] = kkt_entry_generic(c, om, sv, cc, ub0 + i, ub0 + j) - vsum[0];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        double *Iv = W + nu * nu;                          // scratch for the inverse
+        for (int e = 0; e < nu * nu; ++e) Iv[e] = (e / nu == e % nu) ? 1.0 : 0.0;
+        for (int p = 0; p < nu; ++p) {
+            double d = 1.0 / Sg[p * nu + p];
+            for (int j = 0; j < nu; ++j) { Sg[p * nu + j] *= d; Iv[p * nu + j] *= d; }
+            for (int i = 0; i < nu; ++i) if (i != p) {
+                double f = Sg[i * nu + p];
+                for (int j = 0; j < nu; ++j) { Sg[i * nu + j] -= f * Sg[p * nu + j]; Iv[i * nu + j] -= f * Iv[p * nu + j]; }
+            }
+        }
+        for (int e = 0; e < nu * nu; ++e) Sig[e] = Iv[e];
+    }
+    __syncthreads();
+}
+
+// Before the tridiagonal solve: Tc holds r1 in the padded slots and r2 in the (otherwise padding) u slots of stage
+// Nc-1.  Computes ub, leaves it in ubar[] (LDS, nu doubles) and replaces r1 by r1 - B ub.
+template <int NB>
+__device__ void border_pre(const Lay &L, const double *Bb, const double *Zb, const double *Sig, double *Tc, double *ubar, double *red) {
+    const int tid = threadIdx.x, nu = L.nu, NP = L.N * NB;
+    const int slot = (L.Nc - 1) * NB + L.nx;
+    for (int j = 0; j < nu; ++j) {
+        double vsum[1] = {0.0}, vmax[1] = {0.0};
+        for (int idx = tid; idx < NP; idx += NT) vsum[0] += Zb[(size_t)j * NP + idx] * Tc[idx];     // Z is zero in the r2 slots
+        block_reduce<1, 1>(vmax, vsum, red);
+        if (tid == 0) ubar[nu + j] = Tc[slot + j] - vsum[0];
+        __syncthreads();
+    }
+    if (tid < nu) { double a = 0.0; for (int j = 0; j < nu; ++j) a += Sig[tid * nu + j] * ubar[nu + j]; ubar[tid] = a; }
+    __syncthreads();
+    for (int idx = tid; idx < NP; idx += NT) {
+        double a = Tc[idx];
+        for (int j = 0; j < nu; ++j) a -= Bb[(size_t)j * NP + idx] * ubar[j];
+        Tc[idx] = a;
+    }
+    if (tid < nu) Tc[slot + tid] = 0.0;
+    __syncthreads();
+}
+__device__ __forceinline__ void border_post(const Lay &L, int NB, double *Tc, const double *ubar) {
+    if ((int)threadIdx.x < L.nu) Tc[(L.Nc - 1) * NB + L.nx + threadIdx.x] = ubar[threadIdx.x];
+    __syncthreads();
+}
+
 // Generic front end (verification kernel): flat rhs (global) -> flat solution `out` (global, n doubles).
 // Tc: LDS, N*NB doubles.
 template <int NB>
 __device__ void kkt_solve(const Ctx &c, const double *om, const double *sv, double cc, const double *F,
-                          const double *rg, double *Tc, double *out) {
+                          const double *rg, double *Tc, double *out, BorderPtrs bp, double *ubar) {
     const Lay &L = c.L;
     const double cef = cc * c.eps_feas();
     for (int idx = threadIdx.x; idx < L.N * NB; idx += NT) {
@@ -622,7 +729,9 @@ __device__ void kkt_solve(const Ctx &c, const double *om, const double *sv, doub
         Tc[idx] = v;
     }
     __syncthreads();
+    if (L.border) border_pre<NB>(L, bp.Bb, bp.Zb, bp.Sig, Tc, ubar, bp.red);
     kkt_core<NB>(L.N, L.fstage, F, Tc);
+    if (L.border) border_post(L, NB, Tc, ubar);
     for (int idx = threadIdx.x; idx < L.N * NB; idx += NT) {
         int k = idx / NB, a = idx % NB;
         if (a < L.nx) {
@@ -645,6 +754,15 @@ __device__ __forceinline__ int row_type(double E, double lo, double hi) {
 }
 __device__ __forceinline__ double row_rho(int type, double rho) { return type < 0 ? RHO_MIN : (type > 0 ? RHO_EQ_OVER_RHO_INEQ * rho : rho); }
 
+__device__ __forceinline__ BorderPtrs border_ptrs(const Lay &L, const Ptrs &P, double *red) {
+    BorderPtrs bp; bp.red = red;
+    const size_t npb = (size_t)L.nu * L.N * L.NB;
+    bp.Bb = L.border ? P.Bb + blockIdx.x * npb : nullptr;
+    bp.Zb = L.border ? P.Zb + blockIdx.x * npb : nullptr;
+    bp.Sig = L.border ? P.Sig + (size_t)blockIdx.x * L.nu * L.nu : nullptr;
+    return bp;
+}
+
 // Shared prologue: stage the hot model prefix and the step data in LDS.
 struct Smem {
     double *T, *Qv, *hot, *x0s, *um1s, *red, *tv;
@@ -658,10 +776,10 @@ __device__ void smem_common(const Lay &L, const Ptrs &P, double *&p, Smem &S) {
     S.x0s = carve(p, L.nx);
     S.um1s = carve(p, L.nu);
     S.red = carve(p, 64);
-    S.tv = carve(p, 32);
+    S.tv = carve(p, 64);
     S.iflag = (int *)carve(p, 2);
 }
-__host__ __device__ inline int smem_common_doubles(const Lay &L) { return L.tsz + L.hot_sz + L.nx + L.nu + 64 + 32 + 2; }
+__host__ __device__ inline int smem_common_doubles(const Lay &L) { return L.tsz + L.hot_sz + L.nx + L.nu + 64 + 64 + 2; }
 
 __device__ void load_common(const Lay &L, const double *model, const double *step, Smem &S) {
     for (int i = threadIdx.x; i < L.hot_sz; i += NT) S.hot[i] = model[i];
@@ -731,7 +849,7 @@ __global__ __launch_bounds__(NT) void k_setup(Lay L, Ptrs P, mpcqp_settings S_) 
     for (int j = tid; j < L.n; j += NT) sv[j] = S_.sigma / (D[j] * D[j]);
     if (tid == 0) { P.c[b] = cc; P.rho[b] = rho; }
     __syncthreads();
-    int bad = factor_all<NB>(c, om, sv, cc, P.F + (size_t)b * P.fsz, S.T, S.iflag);
+    int bad = factor_all<NB>(c, om, sv, cc, P.F + (size_t)b * P.fsz, S.T, S.iflag, border_ptrs(L, P, S.red));
     // cold start
     for (int j = tid; j < L.n; j += NT) { P.x[(size_t)b * L.n + j] = 0.0; P.xo[(size_t)b * L.n + j] = 0.0; }
     for (int r = tid; r < L.m; r += NT) { P.z[(size_t)b * L.m + r] = 0.0; P.y[(size_t)b * L.m + r] = 0.0; P.yo[(size_t)b * L.m + r] = 0.0; }
@@ -778,7 +896,7 @@ __global__ __launch_bounds__(NT) void k_begin(Lay L, Ptrs P, mpcqp_settings S_, 
         if (t != ctp[r]) { changed = 1; ctp[r] = t; om[r] = row_rho(t, rho) * E[r] * E[r]; }
     }
     changed = __syncthreads_or(changed);
-    if (changed) factor_all<NB>(c, om, sv, P.c[b], P.F + (size_t)b * P.fsz, S.T, S.iflag);
+    if (changed) factor_all<NB>(c, om, sv, P.c[b], P.F + (size_t)b * P.fsz, S.T, S.iflag, border_ptrs(L, P, S.red));
     if (tid == 0) {
         mpcqp_info inf; inf.status = MPCQP_UNSOLVED; inf.iter = 0; inf.rho_updates = 0; inf.reserved = 0;
         inf.obj_val = 0.0; inf.pri_res = 0.0; inf.dua_res = 0.0; inf.rho = rho;
@@ -913,7 +1031,7 @@ __global__ __launch_bounds__(NT) void k_check(Lay L, Ptrs P, mpcqp_settings S_, 
                 rho = rn;
                 for (int r = tid; r < L.m; r += NT) om[r] = row_rho(ctp[r], rho) * E[r] * E[r];
                 __syncthreads();
-                factor_all<NB>(c, om, sv, cc, P.F + (size_t)b * P.fsz, S.T, S.iflag);
+                factor_all<NB>(c, om, sv, cc, P.F + (size_t)b * P.fsz, S.T, S.iflag, border_ptrs(L, P, S.red));
                 rho_upd = 1;
             }
         }
@@ -1087,7 +1205,7 @@ __device__ __forceinline__ void hot_update(const Lay &L, const double *hot, cons
 }
 
 // The hot kernel: `iters` ADMM iterations of every instance that is not finished yet.
-template <int NB, bool LDSSTATE, int NXT, int NUT>
+template <int NB, bool LDSSTATE, int NXT, int NUT, bool BORDER>
 __global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_admm(Lay L, Ptrs P, double alpha, int iters) {
     const int b = blockIdx.x, tid = threadIdx.x;
     if (P.done[b]) return;
@@ -1119,7 +1237,10 @@ __global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_admm(Lay L, Ptrs P, 
 #ifndef MPCQP_ABL_NOPAR
         hot_rhs<NB, NXT, NUT, REGZY>(L, S.hot, gom, gsv, gqv, cc, X, Z, Y, zr, yr, W, Tc);
 #endif
+        BorderPtrs bp = border_ptrs(L, P, S.red);
+        if (BORDER) border_pre<NB>(L, bp.Bb, bp.Zb, bp.Sig, Tc, S.tv, S.red);
         kkt_core<NB>(L.N, L.fstage, F, Tc);
+        if (BORDER) border_post(L, NB, Tc, S.tv);
 #ifndef MPCQP_ABL_NOPAR
         hot_update<NB, NXT, NUT, REGZY>(L, S.hot, S.x0s, S.um1s, gom, gsv, cc, alpha, X, Z, Y, zr, yr, W, Tc, keep_delta, dxg, dyg);
 #endif
@@ -1157,7 +1278,7 @@ __global__ __launch_bounds__(NT) void k_kkt_solve(Lay L, Ptrs P, const double *r
     const double *model = P.model + (size_t)b * L.model_sz, *step = P.step + (size_t)b * L.step_sz;
     load_common(L, model, step, S);
     Ctx c{L, S.hot, model};
-    kkt_solve<NB>(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], P.F + (size_t)b * P.fsz, rhs + (size_t)b * L.n, S.T + L.m, sol + (size_t)b * L.n);
+    kkt_solve<NB>(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], P.F + (size_t)b * P.fsz, rhs + (size_t)b * L.n, S.T + L.m, sol + (size_t)b * L.n, border_ptrs(L, P, S.red), S.tv);
     (void)tid;
 }
 
@@ -1224,6 +1345,8 @@ static Lay make_layout(int nx, int nu, int Np, int Nc) {
     L.ou = L.n_x; L.oe = L.n_x + L.n_u;
     L.rs = L.n_x; L.ri = 2 * L.n_x; L.rdu = 2 * L.n_x + L.n_u;
     L.NB = L.nb <= 16 ? 16 : 32;
+    L.border = Nc < Np ? 1 : 0;
+    L.NcT = L.border ? Nc - 1 : Nc;
     L.rnx = 1.0f / (float)nx; L.rnu = 1.0f / (float)nu;
     int o = 0;
     L.oAd = o; o += nx * nx; L.oBd = o; o += nx * nu;
@@ -1253,7 +1376,6 @@ static int dalloc(mpcqp_handle *h, T **p, size_t count) {
 extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, int nu, int Np, int Nc, const mpcqp_settings *s) {
     if (!out || batch < 1 || nx < 1 || nu < 1 || Np < 2 || Nc < 1 || Nc > Np) return fail(MPCQP_ERR_ARG, "mpcqp_create: bad dimensions");
     if (nx + nu > 32) return fail(MPCQP_ERR_UNSUPPORTED, "mpcqp_create: nx+nu > 32 is not implemented");
-    if (Nc != Np) return fail(MPCQP_ERR_UNSUPPORTED, "mpcqp_create: control horizon Nc < Np is not implemented on the device yet");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MPCQP_ERR_NO_DEVICE, "no HIP device available");
     if (device < 0 || device >= ndev) return fail(MPCQP_ERR_ARG, "mpcqp_create: bad device index");
@@ -1280,6 +1402,7 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     rc |= dalloc(h, &P.xo, B * L.n); rc |= dalloc(h, &P.yo, B * L.m);
     rc |= dalloc(h, &P.dx, B * L.n); rc |= dalloc(h, &P.dy, B * L.m); rc |= dalloc(h, &P.rg, B * L.n);
     rc |= dalloc(h, &P.qv, B * (size_t)(L.n_x + L.n_u));
+    if (L.border) { rc |= dalloc(h, &P.Bb, B * (size_t)L.nu * L.N * L.NB); rc |= dalloc(h, &P.Zb, B * (size_t)L.nu * L.N * L.NB); rc |= dalloc(h, &P.Sig, B * (size_t)L.nu * L.nu); }
     rc |= dalloc(h, &P.Dt, B * L.n); rc |= dalloc(h, &P.Et, B * L.m);
     rc |= dalloc(h, &P.ctype, B * L.m); rc |= dalloc(h, &P.info, B); rc |= dalloc(h, &P.stats, 8);
     rc |= dalloc(h, &P.done, B); rc |= dalloc(h, &P.active, 4);
@@ -1390,20 +1513,25 @@ extern "C" int mpcqp_update_settings(mpcqp_handle *h, const mpcqp_settings *s) {
     return MPCQP_OK;
 }
 
-template <int NB, bool LDSS, int NXT, int NUT>
+template <int NB, bool LDSS, int NXT, int NUT, bool BORDER>
 static int launch_admm_t(mpcqp_handle *h, int iters) {
-    if (set_smem(k_admm<NB, LDSS, NXT, NUT>, h->smem_solve)) return MPCQP_ERR_HIP;
-    hipLaunchKernelGGL((k_admm<NB, LDSS, NXT, NUT>), dim3(h->batch), dim3(NT), h->smem_solve, h->stream, h->L, h->P, h->S.alpha, iters);
+    if (set_smem(k_admm<NB, LDSS, NXT, NUT, BORDER>, h->smem_solve)) return MPCQP_ERR_HIP;
+    hipLaunchKernelGGL((k_admm<NB, LDSS, NXT, NUT, BORDER>), dim3(h->batch), dim3(NT), h->smem_solve, h->stream, h->L, h->P, h->S.alpha, iters);
     return 0;
+}
+
+template <int NB, bool LDSS>
+static int launch_admm_generic(mpcqp_handle *h, int iters) {
+    return h->L.border ? launch_admm_t<NB, LDSS, 0, 0, true>(h, iters) : launch_admm_t<NB, LDSS, 0, 0, false>(h, iters);
 }
 
 static int launch_admm(mpcqp_handle *h, int iters) {
     const Lay &L = h->L;
     // specialisations with compile-time nx, nu for the BASELINE configurations; generic kernels otherwise
-    if (L.NB == 16 && h->lds_state && L.nx == 12 && L.nu == 4) return launch_admm_t<16, true, 12, 4>(h, iters);
-    if (L.NB == 32 && !h->lds_state && L.nx == 20 && L.nu == 8) return launch_admm_t<32, false, 20, 8>(h, iters);
-    if (L.NB == 16) return h->lds_state ? launch_admm_t<16, true, 0, 0>(h, iters) : launch_admm_t<16, false, 0, 0>(h, iters);
-    return h->lds_state ? launch_admm_t<32, true, 0, 0>(h, iters) : launch_admm_t<32, false, 0, 0>(h, iters);
+    if (L.NB == 16 && h->lds_state && L.nx == 12 && L.nu == 4 && !L.border) return launch_admm_t<16, true, 12, 4, false>(h, iters);
+    if (L.NB == 32 && !h->lds_state && L.nx == 20 && L.nu == 8 && !L.border) return launch_admm_t<32, false, 20, 8, false>(h, iters);
+    if (L.NB == 16) return h->lds_state ? launch_admm_generic<16, true>(h, iters) : launch_admm_generic<16, false>(h, iters);
+    return h->lds_state ? launch_admm_generic<32, true>(h, iters) : launch_admm_generic<32, false>(h, iters);
 }
 
 // One solve of every instance: k_begin, then rounds of { k_admm (iterations up to the next termination /
@@ -1507,9 +1635,11 @@ extern "C" int mpcqp_get_dims(mpcqp_handle *h, int *n, int *m, int64_t *factor_d
     if (factor_doubles) *factor_doubles = h->P.fsz;
     if (nnzL) {      // structural nonzeros of the block factor (diagonal included) + the eliminated eps pivots
         int64_t nb = L.nb, nx = L.nx;
-        int64_t full = (int64_t)(L.Nc) * (nb * (nb + 1) / 2) + (int64_t)(L.N - L.Nc) * (nx * (nx + 1) / 2);
-        int64_t sub = (int64_t)(L.Nc - 1) * (nx * nb + (int64_t)L.nu * L.nu) + (int64_t)(L.N - L.Nc) * nx * nb;
-        *nnzL = full + sub + 2 * (int64_t)L.n_x;
+        const int64_t T = L.NcT;                       // stages with an input inside the tridiagonal part
+        int64_t full = T * (nb * (nb + 1) / 2) + (int64_t)(L.N - T) * (nx * (nx + 1) / 2);
+        int64_t sub = (T > 0 ? (T - 1) * (nx * nb + (int64_t)L.nu * L.nu) + nx * nb : 0) + (int64_t)(L.N - 1 - T) * nx * nx;
+        int64_t border = L.border ? (int64_t)L.nu * (L.n_x + T * L.nu) + (int64_t)L.nu * (L.nu + 1) / 2 : 0;
+        *nnzL = full + sub + border + 2 * (int64_t)L.n_x;
     }
     return MPCQP_OK;
 }

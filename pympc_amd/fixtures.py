@@ -174,4 +174,7 @@ NAMED = {
     'random_12_4_30_b': lambda: random_lti(7),
     'random_20_8_12': lambda: random_lti(3, nx=20, nu=8, Np=12, xbox=1.0),
     'random_5_3_8': lambda: random_lti(11, nx=5, nu=3, Np=8, xbox=0.5),
+    'random_5_3_8_nc': lambda: dict(random_lti(12, nx=5, nu=3, Np=8, xbox=2.0), Nc=3),
+    'quadcopter_nc': lambda: dict(quadcopter(Np=10), Nc=4),
+    'cart_pole_nc1': lambda: dict(cart_pole(Np=12), Nc=1),
 }

@@ -15,7 +15,7 @@ from util import golden_names, load_golden, golden_kwargs, golden_csc, update_st
 
 pytestmark = pytest.mark.gpu
 
-DEVICE_FIXTURES = [n for n in golden_names() if n != 'point_mass_nc']     # Nc < Np: not on device yet
+DEVICE_FIXTURES = golden_names()
 
 
 def _gpu_controller(kw, **settings):
