@@ -12,7 +12,7 @@
 //     and is factored by a block LDL' whose factor, stored in FP64-MFMA operand order, streams from HBM/L2
 //     every iteration;
 //   - one 256-thread workgroup owns one instance for the whole solve: iterate in LDS, wave 0 runs the
-//     sequential block forward/backward sweeps on the matrix cores (v_mfma_f64_16x16x4_f64, stage output
+//     sequential block forward/backward sweeps on the matrix cores (v_mfma_f64_4x4x4_4b_f64, stage output
 //     registers = next stage's B operand), all waves run the stage-parallel parts.
 //
 // FP64 throughout.  No CPU fallback exists in this library.
@@ -338,13 +338,18 @@ __device__ __forceinline__ double kkt_sub_entry(const Ctx &c, const double *om, 
 //      S_0 = K_00,   Mh_k = K_{k,k-1} S_{k-1}^-1,   S_k = K_kk - Mh_k K_{k,k-1}'
 // Solve K x = b:    yh_0 = b_0,  yh_k = b_k - Mh_k yh_{k-1};   w_k = S_k^-1 yh_k;
 //                   x_{N-1} = w_{N-1},  x_k = w_k - Mh_{k+1}' x_{k+1}.
-// The factor is stored in the operand order of v_mfma_f64_16x16x4_f64 ("fragments"): for a 16x16
-// block used as the A operand of D = A*B + C, lane l holds A[l&15][4s + (l>>4)], s = 0..3, and the
-// lane's four values are contiguous (32 B per lane, 2 KB per block, perfectly coalesced).
-// Per stage k:  [ -Mh_k | S_k^-1 | -Mh_{k+1}' ]   (3 NB^2 doubles).
-// A stage vector v in the C/D layout (lane l, register t: v[(l>>4) + 4t], identical over l&15) is at the
-// same time the B operand (B[k'][j] = v[4s+k'] -> lane l needs v[4s + (l>>4)] = register s): the output
-// registers of one stage feed the next stage's MFMAs with no cross-lane movement at all.
+// The factor is stored in the operand order of the matrix-core instruction the sweeps use, v_mfma_f64_4x4x4_4b_f64
+// (four independent 4x4x4 products per instruction; 31 cycles dependent latency measured, against 83 for the
+// 16x16x4 shape, and a quarter of its pipe time).  Layouts probed on gfx950 (scripts/probe_mfma4.hip):
+//     A[blk][i][k] in lane 16k + 4blk + i,   B[blk][k][j] in lane 16k + 4blk + j,   D[blk][i][j] in lane 16i + 4blk + j.
+// A 16x16 block M times a 16-vector v, as 4x4 sub-blocks M_IJ: step s = 0..3 computes, in block slot b,
+// M_{b,(b+s)%4} * v_{(b+s)%4} (B operand = the sub-vector replicated over j) and accumulates y_b = sum_J M_bJ v_J.
+// The result y[4b+i] sits in lane 16i + 4b + j, which is exactly where step 0 of the NEXT product wants its B operand
+// (lane 16k + 4b + j holds v[4b+k]); steps 1..3 need the sub-vector of the neighbouring block slot, a rotation of each
+// 16-lane row by 4, 8, 12 lanes: DPP row_ror.  So a stage vector is ONE double per lane, stage outputs feed the next
+// stage through three DPP rotations and no LDS traffic, and a lane's four fragment values (one per step) are
+// contiguous: fragment element (r, c) -> lane 16(c&3) + 4(r>>2) + (r&3), step ((c>>2) - (r>>2)) & 3.
+// Per stage k:  [ forward matrix | S_k^-1 | backward matrix ]   (3 NB^2 doubles, 32 B per lane per block).
 // ------------------------------------------------------------------------------------------------
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) double gdouble;     // explicit global address space: plain global_load/store,
@@ -354,8 +359,11 @@ typedef __attribute__((address_space(1))) const d4 cgd4;
 template <int NB>
 __device__ __forceinline__ int frag_pos(int r, int cidx) {
     constexpr int NBLK = NB / 16;
-    int bi = r >> 4, i = r & 15, bj = cidx >> 4, kk = cidx & 15;
-    return (bi * NBLK + bj) * 256 + (((kk & 3) << 4) + i) * 4 + (kk >> 2);
+    const int bi = r >> 4, bj = cidx >> 4, rr = r & 15, cc = cidx & 15;
+    const int b = rr >> 2, i = rr & 3, J = cc >> 2, k = cc & 3;
+    const int sft = (J - b) & 3;                       // MFMA step in which 4x4 block (b, J) is used
+    const int lane = k * 16 + b * 4 + i;
+    return (bi * NBLK + bj) * 256 + lane * 4 + sft;
 }
 
 // TWISTED (two-sided) elimination: stages 0..mid-1 are eliminated top-down, stages N-1..mid+1 bottom-up, the
@@ -460,32 +468,51 @@ __device__ int factor_all(const Ctx &c, const double *om, const double *sv, doub
 
 // The sweeps work on Tc: the x,u part of the right-hand side / solution in STAGE-MAJOR PADDED layout,
 // Tc[k*NB + a] = element a of stage k (a < nx: x_k[a]; nx <= a < nb: u_k[a-nx]; everything else is padding
-// and stays exactly zero because the factor is the identity there).  In the C/D (= B operand) layout lane l
-// holds elements (l>>4) + 4t (+16 per block), i.e. four 8-byte LDS reads at constant offsets from one address.
+// and stays exactly zero because the factor is the identity there).  In the operand layout lane 16k + 4b + j
+// holds element 4b + k (+16 per block): one 8-byte LDS read per lane and block.
 template <int NB>
-__device__ __forceinline__ void vec_load(const double *tb, int k, d4 *v) {
+__device__ __forceinline__ void vec_load(const double *tb, int k, double *v) {
 #pragma unroll
-    for (int e = 0; e < NB / 4; ++e) v[e >> 2][e & 3] = tb[k * NB + (e >> 2) * 16 + 4 * (e & 3)];
+    for (int bi = 0; bi < NB / 16; ++bi) v[bi] = tb[k * NB + bi * 16];
 }
 template <int NB>
-__device__ __forceinline__ void vec_store(double *tb, int k, const d4 *v, bool writer) {
+__device__ __forceinline__ void vec_store(double *tb, int k, const double *v, bool writer) {
     if (writer) {
 #pragma unroll
-        for (int e = 0; e < NB / 4; ++e) tb[k * NB + (e >> 2) * 16 + 4 * (e & 3)] = v[e >> 2][e & 3];
+        for (int bi = 0; bi < NB / 16; ++bi) tb[k * NB + bi * 16] = v[bi];
     }
+}
+// per-lane base of a stage vector in Tc: lane 16k + 4b + j holds element 4b + k
+__device__ __forceinline__ int vec_lane_offset(int lane) { return 4 * ((lane >> 2) & 3) + (lane >> 4); }
+__device__ __forceinline__ bool vec_lane_writer(int lane) { return (lane & 3) == 0; }
+
+// rotate every 16-lane row by 4*sft lanes: lane (k, b, j) receives the value of lane (k, (b+sft)%4, j)
+template <int SFT>
+__device__ __forceinline__ double rot_blocks(double x) {
+    if (SFT == 0) return x;
+    constexpr int CTRL = 0x120 | (16 - 4 * SFT);          // row_ror:n gives dst[i] = src[(i - n) mod 16]
+    const long long xi = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)xi, CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(xi >> 32), CTRL, 0xF, 0xF, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
 }
 
 // out[bi] += sum_bj A(bi,bj) * in[bj]   with A given as fragments (one d4 per block per lane)
 template <int NB>
-__device__ __forceinline__ void frag_matvec(const d4 *A, const d4 *in, d4 *out) {
+__device__ __forceinline__ void frag_matvec(const d4 *A, const double *in, double *out) {
     constexpr int NBLK = NB / 16;
 #pragma unroll
-    for (int bi = 0; bi < NBLK; ++bi)
+    for (int bj = 0; bj < NBLK; ++bj) {
+        const double r0 = in[bj], r1 = rot_blocks<1>(in[bj]), r2 = rot_blocks<2>(in[bj]), r3 = rot_blocks<3>(in[bj]);
 #pragma unroll
-        for (int bj = 0; bj < NBLK; ++bj)
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-                out[bi] = __builtin_amdgcn_mfma_f64_16x16x4f64(A[bi * NBLK + bj][s], in[bj][s], out[bi], 0, 0, 0);
+        for (int bi = 0; bi < NBLK; ++bi) {
+            const d4 a = A[bi * NBLK + bj];
+            out[bi] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[0], r0, out[bi], 0, 0, 0);
+            out[bi] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[1], r1, out[bi], 0, 0, 0);
+            out[bi] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[2], r2, out[bi], 0, 0, 0);
+            out[bi] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[3], r3, out[bi], 0, 0, 0);
+        }
+    }
 }
 
 template <int NB>
@@ -494,11 +521,32 @@ __device__ __forceinline__ void frag_load(const double *Fm, int lane, d4 *A) {
 #pragma unroll
     for (int b = 0; b < NBLK * NBLK; ++b) A[b] = *(cgd4 *)(Fm + b * 256 + lane * 4);
 }
+#ifdef MPCQP_ABL_NOSINVLOAD
+template <int NB>
+__device__ __forceinline__ void frag_load_sinv(const double *Fm, int lane, d4 *A) {
+#pragma unroll
+    for (int b = 0; b < (NB / 16) * (NB / 16); ++b) A[b] = d4{1e-3 * lane, 1e-3, 2e-3, 3e-3};
+}
+#else
+#define frag_load_sinv frag_load
+#endif
 
 template <int NB> struct SweepCfg {
     static constexpr int NF = (NB / 16) * (NB / 16);
     static constexpr int DEPTH = (NB == 16) ? 8 : 4;      // factor stages kept in flight in registers
 };
+
+// The sweeping waves are dependent MFMA chains: two of them on one SIMD share its matrix pipe and slow each other
+// down.  Workgroups that are co-resident on a CU (dispatch order: block b -> XCD b%8, CU (b/8)%32) therefore rotate
+// which of their waves does what, so that the sweepers of the four co-resident workgroups spread over the four
+// SIMDs.  Purely a speed matter: any placement gives the same results.
+__device__ __forceinline__ int logical_wave() {
+#ifdef MPCQP_NO_WAVE_ROTATION
+    return threadIdx.x >> 6;
+#else
+    return ((threadIdx.x >> 6) - (blockIdx.x >> 8)) & (NWAVES - 1);
+#endif
+}
 
 // Sequential sweep over `nsteps` stages by ONE wave: for i = 1..nsteps, k = first + dir*i:
 //     Tc[k] <- Tc[k] + Frag(slot, k) * Tc[k - dir]        (Frag holds the negated factor block)
@@ -509,15 +557,15 @@ __device__ __forceinline__ void chain_sweep(const int first, const int dir, cons
                                             const int fstage, const double *F, double *Tc) {
     constexpr int NBLK = NB / 16, NF = SweepCfg<NB>::NF, DEPTH = SweepCfg<NB>::DEPTH;
     const int lane = threadIdx.x & 63;
-    double *tb = Tc + (lane >> 4);
-    const bool writer = (lane & 15) == 0;
+    double *tb = Tc + vec_lane_offset(lane);
+    const bool writer = vec_lane_writer(lane);
     const double *Fs = F + (size_t)slot * NB * NB;
     auto stage_of = [&](int i) { return first + dir * i; };
     d4 ring[DEPTH][NF];
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
         if (1 + d <= nsteps) frag_load<NB>(Fs + (size_t)stage_of(1 + d) * fstage, lane, ring[d]);
-    d4 va[NBLK], vb[NBLK];
+    double va[NBLK], vb[NBLK];
     vec_load<NB>(tb, first, va);
     for (int i0 = 1; i0 <= nsteps; i0 += DEPTH) {
 #pragma unroll
@@ -525,7 +573,7 @@ __device__ __forceinline__ void chain_sweep(const int first, const int dir, cons
             const int i = i0 + d;
             if (i <= nsteps) {
                 const int k = stage_of(i);
-                d4 *src = (d & 1) ? vb : va, *dst = (d & 1) ? va : vb;
+                double *src = (d & 1) ? vb : va, *dst = (d & 1) ? va : vb;
                 vec_load<NB>(tb, k, dst);
                 frag_matvec<NB>(ring[d], src, dst);
                 vec_store<NB>(tb, k, dst, writer);
@@ -543,23 +591,24 @@ __device__ __forceinline__ void chain_sweep(const int first, const int dir, cons
 template <int NB>
 __device__ __forceinline__ void sinv_apply(const int N, const int mid, const int fstage, const double *F, double *Tc) {
     constexpr int NBLK = NB / 16, NF = SweepCfg<NB>::NF;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    double *tb = Tc + (lane >> 4);
-    const bool writer = (lane & 15) == 0;
+    const int lane = threadIdx.x & 63, wv = logical_wave();
+    double *tb = Tc + vec_lane_offset(lane);
+    const bool writer = vec_lane_writer(lane);
     auto apply = [&](int k, const d4 *A) {
-        d4 in[NBLK], out[NBLK];
+        double in[NBLK], out[NBLK];
         vec_load<NB>(tb, k, in);
 #pragma unroll
-        for (int b = 0; b < NBLK; ++b) out[b] = d4{0.0, 0.0, 0.0, 0.0};
+        for (int b = 0; b < NBLK; ++b) out[b] = 0.0;
         frag_matvec<NB>(A, in, out);
         vec_store<NB>(tb, k, out, writer);
     };
     const double *Fs = F + NB * NB;
     if (wv == 0) {
-        d4 A0[NF], A2[NF], Am[NF], up[NBLK], dn[NBLK], acc[NBLK];
+        d4 A0[NF], A2[NF], Am[NF];
+        double up[NBLK], dn[NBLK], acc[NBLK];
         frag_load<NB>(F + (size_t)mid * fstage, lane, A0);
         frag_load<NB>(F + (size_t)mid * fstage + 2 * NB * NB, lane, A2);
-        frag_load<NB>(Fs + (size_t)mid * fstage, lane, Am);
+        frag_load_sinv<NB>(Fs + (size_t)mid * fstage, lane, Am);
         vec_load<NB>(tb, mid, acc);
         vec_load<NB>(tb, mid - 1, up);
         vec_load<NB>(tb, mid + 1, dn);
@@ -567,8 +616,8 @@ __device__ __forceinline__ void sinv_apply(const int N, const int mid, const int
         frag_matvec<NB>(A2, dn, acc);
         vec_store<NB>(tb, mid, acc, writer);
         d4 B0[NF], B1[NF];
-        frag_load<NB>(Fs + (size_t)(mid - 1) * fstage, lane, B0);
-        frag_load<NB>(Fs + (size_t)(mid + 1) * fstage, lane, B1);
+        frag_load_sinv<NB>(Fs + (size_t)(mid - 1) * fstage, lane, B0);
+        frag_load_sinv<NB>(Fs + (size_t)(mid + 1) * fstage, lane, B1);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -581,10 +630,10 @@ __device__ __forceinline__ void sinv_apply(const int N, const int mid, const int
         const int owner = (j % 7 == 0) ? 0 : 1 + ((j - j / 7 - 1) % 3);
         if (owner != wv) continue;
         const int k = j < mid - 1 ? j : j + 3;
-        if (pend < 0) { frag_load<NB>(Fs + (size_t)k * fstage, lane, P0); pend = k; }
+        if (pend < 0) { frag_load_sinv<NB>(Fs + (size_t)k * fstage, lane, P0); pend = k; }
         else {
             d4 P1[NF];
-            frag_load<NB>(Fs + (size_t)k * fstage, lane, P1);
+            frag_load_sinv<NB>(Fs + (size_t)k * fstage, lane, P1);
             apply(pend, P0); apply(k, P1);
             pend = -1;
         }
@@ -598,7 +647,7 @@ __device__ __forceinline__ void sinv_apply(const int N, const int mid, const int
 // full s_waitcnt vmcnt(0) -- draining the factor prefetch -- before every stage).
 template <int NB>
 __device__ __forceinline__ void kkt_core(const int N, const int fstage, const double *F, double *Tc) {
-    const int mid = N / 2, wv = threadIdx.x >> 6;
+    const int mid = N / 2, wv = logical_wave();
 #ifndef MPCQP_ABL_NOCHAIN
     if (wv == 0) chain_sweep<NB>(0, +1, mid - 1, 0, fstage, F, Tc);                  // stages 1 .. mid-1
     else if (wv == 1) chain_sweep<NB>(N - 1, -1, N - 2 - mid, 0, fstage, F, Tc);     // stages N-2 .. mid+1

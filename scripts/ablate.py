@@ -1,6 +1,6 @@
 """Time K plain ADMM iterations on the cfg-3 batch with the library named by MPCQP_LIB (ablation builds)."""
 import os, sys, time
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
 from pympc_amd.solver import BatchProblem

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(NT) void ub_sweep(Lay L, const double *F, double *o
     long long t0 = __builtin_amdgcn_s_memtime();
     long long w0 = wall_clock64();
     for (int r = 0; r < reps; ++r) {
-        if (WHICH == 0) { if (threadIdx.x < 64) chain_sweep<16, +1>(L.N, L.fstage, F + (size_t)blockIdx.x * L.N * L.fstage , Tc); }
+        if (WHICH == 0) { if (threadIdx.x < 64) chain_sweep<16>(0, +1, L.N - 1, 0, L.fstage, F + (size_t)blockIdx.x * L.N * L.fstage, Tc); }
         if (WHICH == 1) sinv_apply<16>(L.N, L.N / 2, L.fstage, F + (size_t)blockIdx.x * L.N * L.fstage, Tc);
         if (WHICH == 2) kkt_core<16>(L.N, L.fstage, F + (size_t)blockIdx.x * L.N * L.fstage, Tc);
         __syncthreads();
@@ -51,7 +51,7 @@ int main() {
     double h[3];
     hipLaunchKernelGGL(ub_mfma_chain, dim3(1), dim3(64), 0, 0, out, 1000);
     hipMemcpy(h, out, 16, hipMemcpyDeviceToHost);
-    printf("dependent f64 16x16x4 MFMA: %.1f shader-clock ticks each (s_memtime)\n", h[0]);
+    printf("dependent f64 16x16x4 MFMA (reference shape, not used by the sweeps any more): %.1f shader-clock ticks each (s_memtime)\n", h[0]);
     size_t smem = (L.N * 16 + 2048 + 64) * sizeof(double);
     const char *names[3] = {"chain_sweep fwd (1 wave)", "sinv_apply (4 waves)", "kkt_core"};
     for (int grid : {1, 256, 1024}) {
