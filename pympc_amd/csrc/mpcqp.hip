@@ -82,6 +82,14 @@ struct Ptrs {
     long long fsz;                // factor doubles per instance
 };
 
+// The hot kernel gets only the pointers it uses (fewer scalar registers -> no SGPR spills into vector lanes).
+struct HotPtrs {
+    const double *model, *step, *omega, *s, *qv, *F, *c, *Bb, *Zb, *Sig;
+    double *x, *z, *y, *dx, *dy;
+    const int *done;
+    long long fsz;
+};
+
 // Everything a kernel needs, kept in device memory (one copy per handle): kernels take a pointer to it, so the
 // scalar registers hold only what the running phase actually uses (by-value kernel arguments of this size
 // overflow the SGPR file and spill into vector registers).
@@ -533,7 +541,7 @@ __device__ __forceinline__ void frag_load_sinv(const double *Fm, int lane, d4 *A
 
 template <int NB> struct SweepCfg {
     static constexpr int NF = (NB / 16) * (NB / 16);
-    static constexpr int DEPTH = (NB == 16) ? 8 : 4;      // factor stages kept in flight in registers
+    static constexpr int DEPTH = 4;                            // factor stages kept in flight in registers (even)
 };
 
 // The sweeping waves are dependent MFMA chains: two of them on one SIMD share its matrix pipe and slow each other
@@ -818,9 +826,10 @@ struct Smem {
     int *iflag;
 };
 __device__ __forceinline__ double *carve(double *&p, int n) { double *r = p; p += n; return r; }
-__device__ void smem_common(const Lay &L, const Ptrs &P, double *&p, Smem &S) {
+template <class PT>
+__device__ void smem_common(const Lay &L, const PT &P, double *&p, Smem &S) {
     S.T = carve(p, L.tsz);
-    S.Qv = P.qv + (size_t)blockIdx.x * (L.n_x + L.n_u);
+    S.Qv = (double *)P.qv + (size_t)blockIdx.x * (L.n_x + L.n_u);
     S.hot = carve(p, L.hot_sz);
     S.x0s = carve(p, L.nx);
     S.um1s = carve(p, L.nu);
@@ -1255,7 +1264,7 @@ __device__ __forceinline__ void hot_update(const Lay &L, const double *hot, cons
 
 // The hot kernel: `iters` ADMM iterations of every instance that is not finished yet.
 template <int NB, bool LDSSTATE, int NXT, int NUT, bool BORDER>
-__global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_admm(Lay L, Ptrs P, double alpha, int iters) {
+__global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_admm(Lay L, HotPtrs P, double alpha, int iters) {
     const int b = blockIdx.x, tid = threadIdx.x;
     if (P.done[b]) return;
     extern __shared__ __attribute__((aligned(16))) double sh[];
@@ -1286,7 +1295,11 @@ __global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_admm(Lay L, Ptrs P, 
 #ifndef MPCQP_ABL_NOPAR
         hot_rhs<NB, NXT, NUT, REGZY>(L, S.hot, gom, gsv, gqv, cc, X, Z, Y, zr, yr, W, Tc);
 #endif
-        BorderPtrs bp = border_ptrs(L, P, S.red);
+        BorderPtrs bp; bp.red = S.red;
+        if (BORDER) {
+            const size_t npb = (size_t)L.nu * L.N * L.NB;
+            bp.Bb = (double *)P.Bb + blockIdx.x * npb; bp.Zb = (double *)P.Zb + blockIdx.x * npb; bp.Sig = (double *)P.Sig + (size_t)blockIdx.x * L.nu * L.nu;
+        }
         if (BORDER) border_pre<NB>(L, bp.Bb, bp.Zb, bp.Sig, Tc, S.tv, S.red);
         kkt_core<NB>(L.N, L.fstage, F, Tc);
         if (BORDER) border_post(L, NB, Tc, S.tv);
@@ -1565,7 +1578,10 @@ extern "C" int mpcqp_update_settings(mpcqp_handle *h, const mpcqp_settings *s) {
 template <int NB, bool LDSS, int NXT, int NUT, bool BORDER>
 static int launch_admm_t(mpcqp_handle *h, int iters) {
     if (set_smem(k_admm<NB, LDSS, NXT, NUT, BORDER>, h->smem_solve)) return MPCQP_ERR_HIP;
-    hipLaunchKernelGGL((k_admm<NB, LDSS, NXT, NUT, BORDER>), dim3(h->batch), dim3(NT), h->smem_solve, h->stream, h->L, h->P, h->S.alpha, iters);
+    const Ptrs &P = h->P;
+    HotPtrs hp; hp.model = P.model; hp.step = P.step; hp.omega = P.omega; hp.s = P.s; hp.qv = P.qv; hp.F = P.F; hp.c = P.c;
+    hp.Bb = P.Bb; hp.Zb = P.Zb; hp.Sig = P.Sig; hp.x = P.x; hp.z = P.z; hp.y = P.y; hp.dx = P.dx; hp.dy = P.dy; hp.done = P.done; hp.fsz = P.fsz;
+    hipLaunchKernelGGL((k_admm<NB, LDSS, NXT, NUT, BORDER>), dim3(h->batch), dim3(NT), h->smem_solve, h->stream, h->L, hp, h->S.alpha, iters);
     return 0;
 }
 
