@@ -32,6 +32,12 @@
 #define NT 256                 // threads per workgroup (one workgroup = one MPC instance)
 #endif
 #define NWAVES (NT / 64)
+// Linear-system scheme for NB = 16: 0 = three factor blocks per stage (forward | S^-1 | backward), separate S^-1 phase;
+// 1 = only S^-1 stored, off-diagonal blocks applied matrix-free (kkt_core_sinv).  See DESIGN.md section 5 for the numbers.
+#ifndef MPCQP_SINV_ONLY
+#define MPCQP_SINV_ONLY 0
+#endif
+#define SINV16(NB) (MPCQP_SINV_ONLY && (NB) == 16)
 #define QP_INFTY 1e30
 #define MIN_SCALING 1e-4
 #define MAX_SCALING 1e4
@@ -60,7 +66,7 @@ struct Lay {
     int oQx, oQxN, oQu, oQDu, model_sz;
     int step_sz;                  // [x0 | um1 | xref(N*nx)]
     int xref_rows;                // 1 or N
-    int fstage;                   // doubles per factor stage: Lsub (NB*NB) + Linv (NB*NB)
+    int fstage;                   // doubles per factor stage: NB*NB (S^-1 only, NB = 16) or 3*NB*NB
     int tsz;                      // LDS work vector length: max(m, 4*NB*NB)
 };
 
@@ -71,6 +77,7 @@ struct Ptrs {
     double *x, *z, *y;            // iterate (unscaled units)
     double *xo, *yo;              // reported solution
     double *dx, *dy, *rg;         // scratch: last increments, rhs
+    double *G;                    // [2*256] per instance (NB = 16): fragments of G = [[Ad,Bd],[0,c QDu']] and of G'
     double *Bb, *Zb, *Sig;        // border (Nc < Np): K[:,ubar] and T^-1 K[:,ubar] in padded layout [nu][N*NB], Schur inverse [nu*nu]
     double *qv;                   // linear cost of the x,u variables [n_x+n_u] (rebuilt by every kernel prologue)
     double *Dt, *Et;              // Ruiz temporaries
@@ -84,7 +91,7 @@ struct Ptrs {
 
 // The hot kernel gets only the pointers it uses (fewer scalar registers -> no SGPR spills into vector lanes).
 struct HotPtrs {
-    const double *model, *step, *omega, *s, *qv, *F, *c, *Bb, *Zb, *Sig;
+    const double *model, *step, *omega, *s, *qv, *F, *c, *G, *Bb, *Zb, *Sig;
     double *x, *z, *y, *dx, *dy;
     const int *done;
     long long fsz;
@@ -359,6 +366,11 @@ __device__ __forceinline__ double kkt_sub_entry(const Ctx &c, const double *om, 
 // contiguous: fragment element (r, c) -> lane 16(c&3) + 4(r>>2) + (r&3), step ((c>>2) - (r>>2)) & 3.
 // Per stage k:  [ forward matrix | S_k^-1 | backward matrix ]   (3 NB^2 doubles, 32 B per lane per block).
 // ------------------------------------------------------------------------------------------------
+// Optimisation barriers: values the compiler would otherwise hoist out of the ADMM iteration loop (loop-invariant
+// loads and address arithmetic of the sweeps) and keep live across ALL phases, pushing the kernel into scratch spills.
+template <class T> __device__ __forceinline__ T *opaque_ptr(T *p) { asm volatile("" : "+s"(p)); return p; }
+__device__ __forceinline__ int opaque_lane(int v) { asm volatile("" : "+v"(v)); return v; }
+
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) double gdouble;     // explicit global address space: plain global_load/store,
 typedef __attribute__((address_space(1))) const double cgdouble;  // not flat_* (which also counts on lgkmcnt)
@@ -384,9 +396,9 @@ __device__ __forceinline__ int frag_pos(int r, int cidx) {
 //   top:    slot0 = -Mh_k        slot2 = -Mh_{k+1}'     bottom: slot0 = -Mt_k       slot2 = -Mt_{k-1}'
 //   middle: slot0 = -Mh_mid      slot2 = -Mt_mid  (its second forward matrix; the middle has no backward one)
 // W: LDS workspace of 6*NB*NB doubles.  Returns (uniformly) 0, or 1 if a pivot was not positive.
-struct BorderPtrs { double *Bb, *Zb, *Sig, *red; };
+struct BorderPtrs { double *Bb, *Zb, *Sig, *red, *G; };
 
-template <int NB> __device__ void border_factor(const Ctx &, const double *, const double *, double, const double *, double *, double *, double *, double *, double *, double *);
+template <int NB> __device__ void border_factor(const Ctx &, const double *, const double *, double, const double *, double *, double *, double *, double *, double *, double *, const double *);
 
 template <int NB>
 __device__ int factor_all(const Ctx &c, const double *om, const double *sv, double cc, double *F, double *W, int *iflag, BorderPtrs bp) {
@@ -417,9 +429,11 @@ __device__ int factor_all(const Ctx &c, const double *om, const double *sv, doub
             double acc = 0.0;
             for (int l = 0; l < NB; ++l) acc += Mh[a * NB + l] * Ks[b * NB + l];
             S[e] -= acc;
-            double mv = -Mh[e];
-            F[(size_t)k * L.fstage + fwd_slot * NB * NB + frag_pos<NB>(a, b)] = mv;      // forward matrix of stage k
-            F[(size_t)nb * L.fstage + 2 * NB * NB + frag_pos<NB>(b, a)] = mv;            // its transpose: backward matrix of the neighbour
+            if constexpr (!SINV16(NB)) {                        // (the S^-1-only scheme applies the off-diagonal blocks matrix-free)
+                double mv = -Mh[e];
+                F[(size_t)k * L.fstage + fwd_slot * NB * NB + frag_pos<NB>(a, b)] = mv;      // forward matrix of stage k
+                F[(size_t)nb * L.fstage + 2 * NB * NB + frag_pos<NB>(b, a)] = mv;            // its transpose: backward matrix of the neighbour
+            }
         }
         __syncthreads();
     };
@@ -428,7 +442,7 @@ __device__ int factor_all(const Ctx &c, const double *om, const double *sv, doub
         for (int e = tid; e < NB * NB; e += NT) {
             S[e] = kkt_diag_entry(c, om, sv, cc, k, e / NB, e % NB);
             Li[e] = 0.0;
-            if (!use_up && !use_down) F[(size_t)k * L.fstage + e] = 0.0;      // end stages have no forward matrix
+            if (!SINV16(NB) && !use_up && !use_down) F[(size_t)k * L.fstage + e] = 0.0;      // end stages have no forward matrix
         }
         if (use_up) eliminate_neighbour(k, true, SnA);
         if (use_down) eliminate_neighbour(k, false, SnB);
@@ -463,14 +477,24 @@ __device__ int factor_all(const Ctx &c, const double *om, const double *sv, doub
             double acc = 0.0;
             for (int l = max(a, b); l < NB; ++l) acc += Li[l * NB + a] * Li[l * NB + b];
             SnOut[e] = acc;
-            F[(size_t)k * L.fstage + NB * NB + frag_pos<NB>(a, b)] = acc;
+            F[(size_t)k * L.fstage + (SINV16(NB) ? 0 : NB * NB) + frag_pos<NB>(a, b)] = acc;
         }
     };
     for (int k = 0; k < mid; ++k) stage(k, k > 0, false, SnA);
     for (int k = N - 1; k > mid; --k) stage(k, false, k < N - 1, SnB);
     stage(mid, true, true, SnA);
+    if constexpr (SINV16(NB)) {      // G = [[Ad, Bd], [0, c QDu']] and G' as fragments
+        for (int e = tid; e < NB * NB; e += NT) {
+            const int r = e / NB, q = e % NB;
+            double g = 0.0;
+            if (r < L.nx) g = q < L.nx ? c.Ad()[r * L.nx + q] : (q < L.nb ? c.Bd()[r * L.nu + (q - L.nx)] : 0.0);
+            else if (r < L.nb && q >= L.nx && q < L.nb) g = cc * c.QDu()[(q - L.nx) * L.nu + (r - L.nx)];
+            bp.G[frag_pos<NB>(r, q)] = g;
+            bp.G[256 + frag_pos<NB>(q, r)] = g;
+        }
+    }
     __syncthreads();
-    if (L.border) border_factor<NB>(c, om, sv, cc, F, bp.Bb, bp.Zb, bp.Sig, W, W + L.m, bp.red);
+    if (L.border) border_factor<NB>(c, om, sv, cc, F, bp.Bb, bp.Zb, bp.Sig, W, W + L.m, bp.red, bp.G);
     return *iflag;
 }
 
@@ -564,7 +588,7 @@ template <int NB>
 __device__ __forceinline__ void chain_sweep(const int first, const int dir, const int nsteps, const int slot,
                                             const int fstage, const double *F, double *Tc) {
     constexpr int NBLK = NB / 16, NF = SweepCfg<NB>::NF, DEPTH = SweepCfg<NB>::DEPTH;
-    const int lane = threadIdx.x & 63;
+    const int lane = opaque_lane(threadIdx.x & 63);
     double *tb = Tc + vec_lane_offset(lane);
     const bool writer = vec_lane_writer(lane);
     const double *Fs = F + (size_t)slot * NB * NB;
@@ -599,7 +623,7 @@ __device__ __forceinline__ void chain_sweep(const int first, const int dir, cons
 template <int NB>
 __device__ __forceinline__ void sinv_apply(const int N, const int mid, const int fstage, const double *F, double *Tc) {
     constexpr int NBLK = NB / 16, NF = SweepCfg<NB>::NF;
-    const int lane = threadIdx.x & 63, wv = logical_wave();
+    const int lane = opaque_lane(threadIdx.x & 63), wv = logical_wave();
     double *tb = Tc + vec_lane_offset(lane);
     const bool writer = vec_lane_writer(lane);
     auto apply = [&](int k, const d4 *A) {
@@ -649,14 +673,18 @@ __device__ __forceinline__ void sinv_apply(const int N, const int mid, const int
     if (pend >= 0) apply(pend, P0);
 }
 
-// Tc <- K_xu^-1 Tc (eps already eliminated).  All threads call; barriers inside.  Waves 0 and 1 sweep the two
-// half-chains of the twisted factorization concurrently.  Tc must be seen by the compiler as an LDS pointer
-// (a pointer laundered through an integer becomes FLAT: flat LDS accesses count on vmcnt AND lgkmcnt and force a
-// full s_waitcnt vmcnt(0) -- draining the factor prefetch -- before every stage).
+// What the linear-system core needs to know about one instance.
+struct CoreArgs { int N, fstage, nx, nu, nb, NcT, rdu; const double *F, *om, *G; };
+__device__ __forceinline__ CoreArgs core_args(const Lay &L, const double *F, const double *om, const double *G) {
+    CoreArgs a; a.N = L.N; a.fstage = L.fstage; a.nx = L.nx; a.nu = L.nu; a.nb = L.nb; a.NcT = L.NcT; a.rdu = L.rdu;
+    a.F = F; a.om = om; a.G = G; return a;
+}
+
+// ---- scheme for NB = 32: forward matrix | S^-1 | backward matrix per stage, separate S^-1 phase ---------------
 template <int NB>
-__device__ __forceinline__ void kkt_core(const int N, const int fstage, const double *F, double *Tc) {
-    const int mid = N / 2, wv = logical_wave();
-#ifndef MPCQP_ABL_NOCHAIN
+__device__ __forceinline__ void kkt_core_3slot(const CoreArgs &a, double *Tc) {
+    const int N = a.N, fstage = a.fstage, mid = N / 2, wv = logical_wave();
+    const double *F = a.F;
     if (wv == 0) chain_sweep<NB>(0, +1, mid - 1, 0, fstage, F, Tc);                  // stages 1 .. mid-1
     else if (wv == 1) chain_sweep<NB>(N - 1, -1, N - 2 - mid, 0, fstage, F, Tc);     // stages N-2 .. mid+1
     __syncthreads();
@@ -664,6 +692,142 @@ __device__ __forceinline__ void kkt_core(const int N, const int fstage, const do
     __syncthreads();
     if (wv == 0) chain_sweep<NB>(mid, -1, mid, 2, fstage, F, Tc);                    // stages mid-1 .. 0
     else if (wv == 1) chain_sweep<NB>(mid, +1, N - 1 - mid, 2, fstage, F, Tc);       // stages mid+1 .. N-1
+}
+
+// ---- scheme for NB = 16: ONLY S_k^-1 is stored and streamed (a third of the bytes) --------------------------------
+// The off-diagonal blocks are applied matrix-free.  With the constant block G = [[Ad, Bd], [0, c QDu']] (fragments
+// of G and G' stay in registers for the whole kernel), om_s = omega of the dynamics rows of stage s and
+// wd_s = omega of the Delta-u row that couples u_s[nu-1] with u_{s+1}[0] (mpc.py:570):
+//     -K_{k,k-1} v   = mask_k . ( om_k . (G v) )   + e_{nx}      wd_{k-1} v[nx+nu-1]          ("PA", neighbour above)
+//     -K_{k,k+1} v   = mask_k . ( G' (om_{k+1} . v) ) + e_{nx+nu-1} wd_k   v[nx]               ("PB", neighbour below)
+// (om acts on the x rows only, mask_k clears the u rows of stages that carry no input).  Twisted solve:
+//     forward   w_k = S_k^-1 ( b_k - K_{k,nbr} w_nbr )          top half with PA, bottom half with PB
+//     middle    x_m = S_m^-1 ( b_m - K_{m,m-1} w_{m-1} - K_{m,m+1} w_{m+1} )
+//     backward  x_k = w_k - S_k^-1 K_{k,nbr} x_nbr               top half with PB, bottom half with PA
+// i.e. per stage eight dependent 4x4x4 MFMAs and no separate S^-1 phase.
+struct SinvLane {                 // per-lane constants of the operand layout
+    int e; bool isx, isu; int src_pa, src_pb;      // own element; lanes holding elements nx+nu-1 / nx
+};
+__device__ __forceinline__ SinvLane sinv_lane(const CoreArgs &a, int lane) {
+    SinvLane q; q.e = vec_lane_offset(lane); q.isx = q.e < a.nx; q.isu = q.e >= a.nx && q.e < a.nb;
+    const int ea = a.nx + a.nu - 1, eb = a.nx;
+    q.src_pa = 16 * (ea & 3) + 4 * (ea >> 2); q.src_pb = 16 * (eb & 3) + 4 * (eb >> 2);
+    return q;
+}
+__device__ __forceinline__ double lane_bcast(double x, int src) {
+    const long long xi = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_readlane((int)xi, src), hi = __builtin_amdgcn_readlane((int)(xi >> 32), src);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+// t = -K_{k,nbr} v   (up: nbr = k-1, else nbr = k+1); sc = om of stage max(k,nbr) on x lanes (1 elsewhere), wd as above
+__device__ __forceinline__ double offdiag_apply(const CoreArgs &a, const SinvLane &q, const d4 &Gf, const d4 &GTf,
+                                                bool up, int k, double v, double sc, double wd) {
+    const double msk = (q.isx || (q.isu && k < a.NcT)) ? 1.0 : 0.0;
+    double t = 0.0;
+    if (up) {
+        d4 A[1] = {Gf}; double in[1] = {v}, out[1] = {0.0};
+        frag_matvec<16>(A, in, out);
+        t = msk * (sc * out[0]);
+        const double src = lane_bcast(v, q.src_pa);
+        if (q.e == a.nx) t += wd * src;
+    } else {
+        d4 A[1] = {GTf}; double in[1] = {sc * v}, out[1] = {0.0};
+        frag_matvec<16>(A, in, out);
+        t = msk * out[0];
+        const double src = lane_bcast(v, q.src_pb);
+        if (q.e == a.nx + a.nu - 1) t += wd * src;
+    }
+    return t;
+}
+
+struct SinvStep { d4 S; double sc, wd; };           // what one step streams: S_k^-1 fragment, om lanes, coupling weight
+__device__ __forceinline__ void sinv_step_load(const CoreArgs &a, const SinvLane &q, int lane, int k, int nbr, SinvStep &st) {
+    st.S = *(cgd4 *)(a.F + (size_t)k * a.fstage + lane * 4);
+    const int hi = max(k, nbr), lo = min(k, nbr);
+    const double o = ((cgdouble *)a.om)[hi * a.nx + (q.isx ? q.e : 0)];
+    st.sc = q.isx ? o : 1.0;
+    const int lc = min(lo, max(a.NcT - 2, 0));      // (clamped: the row only exists for lo <= NcT-2)
+    const double w = ((cgdouble *)a.om)[a.rdu + a.nu + lc * a.nu + a.nu - 1];
+    st.wd = (hi < a.NcT) ? w : 0.0;                 // the coupling row exists only between two stages that carry inputs
+}
+
+// One half-chain: stages first+dir, first+2dir, ... (nsteps of them).  FWD: w_k = S_k^-1 (b_k + t_k), first stage gets
+// w_first = S^-1 b_first;  BWD: x_k = w_k + S_k^-1 t_k, starting from x_first already in Tc.
+template <bool FWD>
+__device__ __forceinline__ void half_sweep(const CoreArgs &a, double *Tc, const d4 &Gf, const d4 &GTf,
+                                           const int first, const int dir, const int nsteps) {
+    constexpr int DEPTH = SweepCfg<16>::DEPTH;
+    const int lane = opaque_lane(threadIdx.x & 63);
+    const SinvLane q = sinv_lane(a, lane);
+    double *tb = Tc + q.e;
+    const bool writer = vec_lane_writer(lane);
+    const bool up = dir > 0;                                   // neighbour k - dir lies above (smaller index) iff dir > 0
+    SinvStep ring[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (1 + d <= nsteps) sinv_step_load(a, q, lane, first + dir * (1 + d), first + dir * d, ring[d]);
+    double run;
+    if (FWD) {
+        const d4 S0 = *(cgd4 *)(a.F + (size_t)first * a.fstage + lane * 4);
+        d4 A[1] = {S0}; double in[1] = {tb[first * 16]}, out[1] = {0.0};
+        frag_matvec<16>(A, in, out);
+        run = out[0];
+        if (writer) tb[first * 16] = run;
+    } else {
+        run = tb[first * 16];
+    }
+    for (int i0 = 1; i0 <= nsteps; i0 += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int i = i0 + d;
+            if (i <= nsteps) {
+                const int k = first + dir * i;
+                const double own = tb[k * 16];                 // b_k (FWD) or w_k (BWD)
+                const double t = offdiag_apply(a, q, Gf, GTf, up, k, run, ring[d].sc, ring[d].wd);
+                d4 A[1] = {ring[d].S};
+                double in[1], out[1];
+                if (FWD) { in[0] = own + t; out[0] = 0.0; } else { in[0] = t; out[0] = own; }
+                frag_matvec<16>(A, in, out);
+                run = out[0];
+                if (writer) tb[k * 16] = run;
+                if (i + DEPTH <= nsteps) sinv_step_load(a, q, lane, first + dir * (i + DEPTH), first + dir * (i + DEPTH - 1), ring[d]);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void kkt_core_sinv(const CoreArgs &a, double *Tc) {
+    const int N = a.N, mid = N / 2, wv = logical_wave(), lane = opaque_lane(threadIdx.x & 63);
+    d4 Gf = d4{0.0, 0.0, 0.0, 0.0}, GTf = Gf;
+    if (wv < 2) { Gf = *(cgd4 *)(a.G + lane * 4); GTf = *(cgd4 *)(a.G + 256 + lane * 4); }
+    if (wv == 0) half_sweep<true>(a, Tc, Gf, GTf, 0, +1, mid - 1);                 // w_0 .. w_{mid-1}
+    else if (wv == 1) half_sweep<true>(a, Tc, Gf, GTf, N - 1, -1, N - 2 - mid);     // w_{N-1} .. w_{mid+1}
+    __syncthreads();
+    if (wv == 0) {                                                                  // the middle stage sees both halves
+        const SinvLane q = sinv_lane(a, lane);
+        double *tb = Tc + q.e;
+        SinvStep su, sd;
+        sinv_step_load(a, q, lane, mid, mid - 1, su);
+        sinv_step_load(a, q, lane, mid, mid + 1, sd);
+        const double tu = offdiag_apply(a, q, Gf, GTf, true, mid, tb[(mid - 1) * 16], su.sc, su.wd);
+        const double td = offdiag_apply(a, q, Gf, GTf, false, mid, tb[(mid + 1) * 16], sd.sc, sd.wd);
+        d4 A[1] = {su.S}; double in[1] = {tb[mid * 16] + tu + td}, out[1] = {0.0};
+        frag_matvec<16>(A, in, out);
+        if (vec_lane_writer(lane)) tb[mid * 16] = out[0];
+    }
+    __syncthreads();
+    if (wv == 0) half_sweep<false>(a, Tc, Gf, GTf, mid, -1, mid);                   // x_{mid-1} .. x_0
+    else if (wv == 1) half_sweep<false>(a, Tc, Gf, GTf, mid, +1, N - 1 - mid);      // x_{mid+1} .. x_{N-1}
+}
+
+// Tc <- K_xu^-1 Tc (eps already eliminated).  All threads call; barriers inside.  Waves 0 and 1 sweep the two
+// half-chains of the twisted factorization concurrently.  Tc must be seen by the compiler as an LDS pointer
+// (a pointer laundered through an integer becomes FLAT: flat LDS accesses count on vmcnt AND lgkmcnt and force a
+// full s_waitcnt vmcnt(0) -- draining the factor prefetch -- before every stage).
+template <int NB>
+__device__ __forceinline__ void kkt_core(const CoreArgs &a, double *Tc) {
+#ifndef MPCQP_ABL_NOCHAIN
+    if constexpr (SINV16(NB)) kkt_core_sinv(a, Tc); else kkt_core_3slot<NB>(a, Tc);
 #endif
     __syncthreads();
 }
@@ -696,7 +860,7 @@ __device__ __forceinline__ int padded_var(const Lay &L, int k, int a) {
 
 template <int NB>
 __device__ void border_factor(const Ctx &c, const double *om, const double *sv, double cc, const double *F,
-                              double *Bb, double *Zb, double *Sig, double *W, double *Tc, double *red) {
+                              double *Bb, double *Zb, double *Sig, double *W, double *Tc, double *red, const double *G) {
     const Lay &L = c.L;
     const int tid = threadIdx.x, nu = L.nu, NP = L.N * NB;
     const int ub0 = L.ou + (L.Nc - 1) * L.nu;
@@ -708,7 +872,7 @@ __device__ void border_factor(const Ctx &c, const double *om, const double *sv, 
     for (int j = 0; j < nu; ++j) {                         // Z_j = T^-1 B_j
         for (int idx = tid; idx < NP; idx += NT) Tc[idx] = Bb[(size_t)j * NP + idx];
         __syncthreads();
-        kkt_core<NB>(L.N, L.fstage, F, Tc);
+        kkt_core<NB>(core_args(L, F, om, G), Tc);
         for (int idx = tid; idx < NP; idx += NT) Zb[(size_t)j * NP + idx] = Tc[idx];
         __syncthreads();
     }
@@ -787,7 +951,7 @@ __device__ void kkt_solve(const Ctx &c, const double *om, const double *sv, doub
     }
     __syncthreads();
     if (L.border) border_pre<NB>(L, bp.Bb, bp.Zb, bp.Sig, Tc, ubar, bp.red);
-    kkt_core<NB>(L.N, L.fstage, F, Tc);
+    kkt_core<NB>(core_args(L, F, om, bp.G), Tc);
     if (L.border) border_post(L, NB, Tc, ubar);
     for (int idx = threadIdx.x; idx < L.N * NB; idx += NT) {
         int k = idx / NB, a = idx % NB;
@@ -812,7 +976,7 @@ __device__ __forceinline__ int row_type(double E, double lo, double hi) {
 __device__ __forceinline__ double row_rho(int type, double rho) { return type < 0 ? RHO_MIN : (type > 0 ? RHO_EQ_OVER_RHO_INEQ * rho : rho); }
 
 __device__ __forceinline__ BorderPtrs border_ptrs(const Lay &L, const Ptrs &P, double *red) {
-    BorderPtrs bp; bp.red = red;
+    BorderPtrs bp; bp.red = red; bp.G = P.G + (size_t)blockIdx.x * 512;
     const size_t npb = (size_t)L.nu * L.N * L.NB;
     bp.Bb = L.border ? P.Bb + blockIdx.x * npb : nullptr;
     bp.Zb = L.border ? P.Zb + blockIdx.x * npb : nullptr;
@@ -1301,7 +1465,7 @@ __global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_admm(Lay L, HotPtrs 
             bp.Bb = (double *)P.Bb + blockIdx.x * npb; bp.Zb = (double *)P.Zb + blockIdx.x * npb; bp.Sig = (double *)P.Sig + (size_t)blockIdx.x * L.nu * L.nu;
         }
         if (BORDER) border_pre<NB>(L, bp.Bb, bp.Zb, bp.Sig, Tc, S.tv, S.red);
-        kkt_core<NB>(L.N, L.fstage, F, Tc);
+        kkt_core<NB>(core_args(L, opaque_ptr(F), opaque_ptr((const double *)gom), opaque_ptr(P.G + (size_t)b * 512)), Tc);
         if (BORDER) border_post(L, NB, Tc, S.tv);
 #ifndef MPCQP_ABL_NOPAR
         hot_update<NB, NXT, NUT, REGZY>(L, S.hot, S.x0s, S.um1s, gom, gsv, cc, alpha, X, Z, Y, zr, yr, W, Tc, keep_delta, dxg, dyg);
@@ -1420,7 +1584,7 @@ static Lay make_layout(int nx, int nu, int Np, int Nc) {
     L.model_sz = o;
     L.step_sz = nx + nu + L.N * nx;
     L.xref_rows = 1;
-    L.fstage = 3 * L.NB * L.NB;
+    L.fstage = (SINV16(L.NB) ? 1 : 3) * L.NB * L.NB;
     L.tsz = (L.m + L.N * L.NB) > 6 * L.NB * L.NB ? (L.m + L.N * L.NB) : 6 * L.NB * L.NB;   // [W (m) | Tc (N*NB)] or factor workspace
     return L;
 }
@@ -1464,6 +1628,7 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     rc |= dalloc(h, &P.xo, B * L.n); rc |= dalloc(h, &P.yo, B * L.m);
     rc |= dalloc(h, &P.dx, B * L.n); rc |= dalloc(h, &P.dy, B * L.m); rc |= dalloc(h, &P.rg, B * L.n);
     rc |= dalloc(h, &P.qv, B * (size_t)(L.n_x + L.n_u));
+    rc |= dalloc(h, &P.G, B * 512);
     if (L.border) { rc |= dalloc(h, &P.Bb, B * (size_t)L.nu * L.N * L.NB); rc |= dalloc(h, &P.Zb, B * (size_t)L.nu * L.N * L.NB); rc |= dalloc(h, &P.Sig, B * (size_t)L.nu * L.nu); }
     rc |= dalloc(h, &P.Dt, B * L.n); rc |= dalloc(h, &P.Et, B * L.m);
     rc |= dalloc(h, &P.ctype, B * L.m); rc |= dalloc(h, &P.info, B); rc |= dalloc(h, &P.stats, 8);
@@ -1579,7 +1744,7 @@ template <int NB, bool LDSS, int NXT, int NUT, bool BORDER>
 static int launch_admm_t(mpcqp_handle *h, int iters) {
     if (set_smem(k_admm<NB, LDSS, NXT, NUT, BORDER>, h->smem_solve)) return MPCQP_ERR_HIP;
     const Ptrs &P = h->P;
-    HotPtrs hp; hp.model = P.model; hp.step = P.step; hp.omega = P.omega; hp.s = P.s; hp.qv = P.qv; hp.F = P.F; hp.c = P.c;
+    HotPtrs hp; hp.model = P.model; hp.step = P.step; hp.omega = P.omega; hp.s = P.s; hp.qv = P.qv; hp.F = P.F; hp.c = P.c; hp.G = P.G;
     hp.Bb = P.Bb; hp.Zb = P.Zb; hp.Sig = P.Sig; hp.x = P.x; hp.z = P.z; hp.y = P.y; hp.dx = P.dx; hp.dy = P.dy; hp.done = P.done; hp.fsz = P.fsz;
     hipLaunchKernelGGL((k_admm<NB, LDSS, NXT, NUT, BORDER>), dim3(h->batch), dim3(NT), h->smem_solve, h->stream, h->L, hp, h->S.alpha, iters);
     return 0;
