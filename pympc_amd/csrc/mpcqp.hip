@@ -76,7 +76,7 @@ struct Ptrs {
     double *F;
     double *x, *z, *y;            // iterate (unscaled units)
     double *xo, *yo;              // reported solution
-    double *dx, *dy, *rg;         // scratch: last increments, rhs
+    double *dx, *dy;              // last primal / dual increments (infeasibility certificates)
     double *G;                    // [2*256] per instance (NB = 16): fragments of G = [[Ad,Bd],[0,c QDu']] and of G'
     double *Bb, *Zb, *Sig;        // border (Nc < Np): K[:,ubar] and T^-1 K[:,ubar] in padded layout [nu][N*NB], Schur inverse [nu*nu]
     double *qv;                   // linear cost of the x,u variables [n_x+n_u] (rebuilt by every kernel prologue)
@@ -96,11 +96,6 @@ struct HotPtrs {
     const int *done;
     long long fsz;
 };
-
-// Everything a kernel needs, kept in device memory (one copy per handle): kernels take a pointer to it, so the
-// scalar registers hold only what the running phase actually uses (by-value kernel arguments of this size
-// overflow the SGPR file and spill into vector registers).
-struct KArgs { Lay L; Ptrs P; mpcqp_settings S; };
 
 __device__ __forceinline__ int idiv(int r, float rcp) { return __float2int_rd(((float)r + 0.5f) * rcp); }
 __device__ __forceinline__ double limit_scaling(double v) { v = v < MIN_SCALING ? 1.0 : v; return v > MAX_SCALING ? MAX_SCALING : v; }
@@ -1291,20 +1286,12 @@ template <int NUT> __device__ __forceinline__ int divu(const Lay &L, int v) { re
 //   W = omega z - c y                       (rows, flat)
 //   rhs = s x - c q + A' W                  (variables)
 //   te = rhs_eps / kappa -> W[soft row]     Tc[k][a] = rhs_x - omega_soft te  |  rhs_u  |  0 (padding)
-constexpr int RPT = 1024 / NT;  // rows per thread whose z,y live in registers (small-problem mode, m <= RPT*NT = 1024)
-
-template <int NB, int NXT, int NUT, bool REG>
+template <int NB, int NXT, int NUT>
 __device__ __forceinline__ void hot_rhs(const Lay &L, const double *hot, cgdouble *om, cgdouble *sv, cgdouble *qv, double cc,
-                                        const double *X, const double *Z, const double *Y, const double (&zr)[RPT], const double (&yr)[RPT],
-                                        double *W, double *Tc) {
+                                        const double *X, const double *Z, const double *Y, double *W, double *Tc) {
     const int tid = threadIdx.x;
     const int nx = hx<NXT>(L), nu = hu<NUT>(L);
-    if (REG) {
-#pragma unroll
-        for (int j = 0; j < RPT; ++j) { const int r = tid + j * NT; if (r < L.m) W[r] = om[r] * zr[j] - cc * yr[j]; }
-    } else {
-        for (int r = tid; r < L.m; r += NT) W[r] = om[r] * Z[r] - cc * Y[r];
-    }
+    for (int r = tid; r < L.m; r += NT) W[r] = om[r] * Z[r] - cc * Y[r];
     __syncthreads();
     const double *Ad = hot + L.oAd, *Bd = hot + L.oBd;
     const double cef = cc * hot[L.oeps];
@@ -1345,11 +1332,10 @@ __device__ __forceinline__ void hot_rhs(const Lay &L, const double *hot, cgdoubl
 }
 
 // Steps (4)-(6): slack back-substitution, zt = A xt, relaxation, projection on [l,u], dual update, x update.
-template <int NB, int NXT, int NUT, bool REG>
+template <int NB, int NXT, int NUT>
 __device__ __forceinline__ void hot_update(const Lay &L, const double *hot, const double *x0s, const double *um1s,
                                            cgdouble *om, cgdouble *sv, double cc, double alpha,
-                                           double *X, double *Z, double *Y, double (&zreg)[RPT], double (&yreg)[RPT],
-                                           double *W, const double *Tc, bool keep_delta, gdouble *dxg, gdouble *dyg) {
+                                           double *X, double *Z, double *Y, double *W, const double *Tc, bool keep_delta, gdouble *dxg, gdouble *dyg) {
     const int tid = threadIdx.x;
     const int nx = hx<NXT>(L), nu = hu<NUT>(L);
     const double cef = cc * hot[L.oeps];
@@ -1417,12 +1403,7 @@ __device__ __forceinline__ void hot_update(const Lay &L, const double *hot, cons
         yv += dy; zv = zn;
         if (keep_delta) dyg[r] = dy;
     };
-    if (REG) {
-#pragma unroll
-        for (int j = 0; j < RPT; ++j) { const int r = tid + j * NT; if (r < L.m) row_update(r, zreg[j], yreg[j]); }
-    } else {
-        for (int r = tid; r < L.m; r += NT) { double zv = Z[r], yv = Y[r]; row_update(r, zv, yv); Z[r] = zv; Y[r] = yv; }
-    }
+    for (int r = tid; r < L.m; r += NT) { double zv = Z[r], yv = Y[r]; row_update(r, zv, yv); Z[r] = zv; Y[r] = yv; }
     __syncthreads();
 }
 
@@ -1439,10 +1420,6 @@ __global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_admm(Lay L, HotPtrs 
     double *X, *Z, *Y;
     if (LDSSTATE) { X = carve(p, L.n); Z = carve(p, L.m); Y = carve(p, L.m); }
     else { X = gx; Z = gz; Y = gy; }
-    double zr[RPT], yr[RPT];       // (register-resident z,y: experimental path, disabled -- see REGZY)
-    constexpr bool REGZY = false;
-#pragma unroll
-    for (int j = 0; j < RPT; ++j) { zr[j] = 0.0; yr[j] = 0.0; }
     load_common(L, model, step, S);
     double *W = S.T, *Tc = S.T + L.m;
     if (LDSSTATE) {
@@ -1457,7 +1434,7 @@ __global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_admm(Lay L, HotPtrs 
     for (int it = 1; it <= iters; ++it) {
         const bool keep_delta = it == iters;         // the increments feed the infeasibility certificates of k_check
 #ifndef MPCQP_ABL_NOPAR
-        hot_rhs<NB, NXT, NUT, REGZY>(L, S.hot, gom, gsv, gqv, cc, X, Z, Y, zr, yr, W, Tc);
+        hot_rhs<NB, NXT, NUT>(L, S.hot, gom, gsv, gqv, cc, X, Z, Y, W, Tc);
 #endif
         BorderPtrs bp; bp.red = S.red;
         if (BORDER) {
@@ -1468,7 +1445,7 @@ __global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_admm(Lay L, HotPtrs 
         kkt_core<NB>(core_args(L, opaque_ptr(F), opaque_ptr((const double *)gom), opaque_ptr(P.G + (size_t)b * 512)), Tc);
         if (BORDER) border_post(L, NB, Tc, S.tv);
 #ifndef MPCQP_ABL_NOPAR
-        hot_update<NB, NXT, NUT, REGZY>(L, S.hot, S.x0s, S.um1s, gom, gsv, cc, alpha, X, Z, Y, zr, yr, W, Tc, keep_delta, dxg, dyg);
+        hot_update<NB, NXT, NUT>(L, S.hot, S.x0s, S.um1s, gom, gsv, cc, alpha, X, Z, Y, W, Tc, keep_delta, dxg, dyg);
 #endif
     }
     if (LDSSTATE) {
@@ -1626,7 +1603,7 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     rc |= dalloc(h, &P.F, B * (size_t)P.fsz);
     rc |= dalloc(h, &P.x, B * L.n); rc |= dalloc(h, &P.z, B * L.m); rc |= dalloc(h, &P.y, B * L.m);
     rc |= dalloc(h, &P.xo, B * L.n); rc |= dalloc(h, &P.yo, B * L.m);
-    rc |= dalloc(h, &P.dx, B * L.n); rc |= dalloc(h, &P.dy, B * L.m); rc |= dalloc(h, &P.rg, B * L.n);
+    rc |= dalloc(h, &P.dx, B * L.n); rc |= dalloc(h, &P.dy, B * L.m);
     rc |= dalloc(h, &P.qv, B * (size_t)(L.n_x + L.n_u));
     rc |= dalloc(h, &P.G, B * 512);
     if (L.border) { rc |= dalloc(h, &P.Bb, B * (size_t)L.nu * L.N * L.NB); rc |= dalloc(h, &P.Zb, B * (size_t)L.nu * L.N * L.NB); rc |= dalloc(h, &P.Sig, B * (size_t)L.nu * L.nu); }

@@ -248,3 +248,37 @@ def test_full_size_batch_properties():
         C._compute_QP_matrices_()
         stat, pv, comp = kkt_certificate(C.P, C.q, C.A, C.l, C.u, x[i], y[i])
         assert stat < 1e-6 and pv < 1e-6 and comp < 1e-6
+
+
+def test_device_resident_inputs_match_host_inputs():
+    """bench.py drives the library with torch ROCm tensors (device pointers, caller's stream): same results as
+    the numpy (host pointer) path, step by step."""
+    import torch
+    from pympc_amd import fixtures
+    from pympc_amd.solver import BatchProblem
+    B, nx, nu, Np = 5, 12, 4, 30
+    kws = [fixtures.random_lti(200 + i) for i in range(B)]
+    stack = lambda k: np.stack([kw[k] for kw in kws])
+    dev = torch.device('cuda', 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    common = dict(eps_abs=1e-6, eps_rel=1e-6)
+    ph = BatchProblem(B, nx, nu, Np, **common)
+    pd = BatchProblem(B, nx, nu, Np, stream=torch.cuda.current_stream(dev).cuda_stream, **common)
+    args = [stack('Ad'), stack('Bd'), stack('Qx'), stack('QxN'), stack('Qu'), stack('QDu'), stack('xmin'), stack('xmax'),
+            stack('umin'), stack('umax'), stack('Dumin'), stack('Dumax'), stack('uref'), np.full((B, 1), 1e6),
+            stack('x0'), stack('uminus1'), stack('xref')]
+    ph.setup(*args)
+    pd.setup(*[t(a) for a in args])
+    x = stack('x0')
+    u_dev = torch.empty((B, nu), dtype=torch.float64, device=dev)
+    for step in range(4):
+        ph.solve_async(); pd.solve_async()
+        uh = ph.u0()
+        pd.u0(out=u_dev)
+        assert np.array_equal(uh, u_dev.cpu().numpy()), step
+        assert [i.iter for i in ph.infos()] == [i.iter for i in pd.infos()]
+        x = np.einsum('bij,bj->bi', stack('Ad'), x) + np.einsum('bij,bj->bi', stack('Bd'), uh)
+        ph.update(x, uh)
+        pd.update(t(x), u_dev)
+    it, chk, ref, sol = pd.stats()
+    assert sol == 4 * B and it >= 25 * sol and chk >= sol
