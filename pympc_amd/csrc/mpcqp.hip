@@ -1493,6 +1493,8 @@ __global__ void k_gather_u0(Lay L, const double *xo, double *u0, int batch) {
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+constexpr int MAXEV = 8;          // rounds that may be in flight between two host syncs
+
 struct mpcqp_handle {
     int device, batch;
     Lay L;
@@ -1501,11 +1503,12 @@ struct mpcqp_handle {
     hipStream_t stream;
     bool own_stream, is_setup, lds_state;
     size_t smem_setup, smem_solve;
+    int last_rounds;              // rounds the previous solve needed (that many are enqueued without a host sync)
     std::vector<void *> allocs;
     double *u0_dev;
     int *active_host;             // pinned
     bool profiling;
-    hipEvent_t ev0, ev1;
+    hipEvent_t ev0[8], ev1[8];
     double admm_ms;
     long long admm_launches;
 };
@@ -1591,7 +1594,7 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     HIPCHK(hipStreamCreate(&h->stream));
     h->own_stream = true;
     HIPCHK(hipHostMalloc((void **)&h->active_host, sizeof(int)));
-    HIPCHK(hipEventCreate(&h->ev0)); HIPCHK(hipEventCreate(&h->ev1));
+    for (int e = 0; e < MAXEV; ++e) { HIPCHK(hipEventCreate(&h->ev0[e])); HIPCHK(hipEventCreate(&h->ev1[e])); }
     const Lay &L = h->L;
     Ptrs &P = h->P; memset(&P, 0, sizeof(P));
     size_t B = (size_t)batch;
@@ -1616,6 +1619,7 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     size_t with_state = h->smem_setup + sizeof(double) * (size_t)(L.n + 2 * L.m);
     h->lds_state = with_state <= 40 * 1024;      // four workgroups per CU; larger problems keep the iterate in L2/HBM   // small problems: x in LDS, z/y in registers; else iterate in L2/HBM
     h->smem_solve = h->lds_state ? with_state : h->smem_setup;
+    h->last_rounds = 1;
     if (h->smem_solve > 160 * 1024) { mpcqp_destroy(h); return fail(MPCQP_ERR_UNSUPPORTED, "problem too large for one workgroup's LDS"); }
     *out = h;
     return MPCQP_OK;
@@ -1626,7 +1630,7 @@ extern "C" void mpcqp_destroy(mpcqp_handle *h) {
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
     for (void *p : h->allocs) hipFree(p);
-    if (h->active_host) { hipHostFree(h->active_host); hipEventDestroy(h->ev0); hipEventDestroy(h->ev1); }
+    if (h->active_host) { hipHostFree(h->active_host); for (int e = 0; e < MAXEV; ++e) { hipEventDestroy(h->ev0[e]); hipEventDestroy(h->ev1[e]); } }
     if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1758,15 +1762,19 @@ static int launch_solve(mpcqp_handle *h, int plain_iters) {
     const int chk = plain ? 0 : S.check_termination;
     int rho_every = 0;
     if (!plain && S.adaptive_rho) rho_every = S.adaptive_rho_interval ? S.adaptive_rho_interval : (chk ? 4 * chk : 100);
-    int iter = 0;
-    while (iter < max_iter) {
+    // Rounds are enqueued back to back; the host only looks at the "still running" counter after as many rounds as
+    // the previous solve needed (kernels of finished instances exit at once, so an over-estimate costs two empty
+    // launches, an under-estimate one extra round trip).
+    int iter = 0, rounds = 0, unsynced = 0;
+    bool finished = false;
+    while (iter < max_iter && !finished) {
         int nxt = max_iter;
         if (chk) nxt = std::min(nxt, (iter / chk + 1) * chk);
         if (rho_every) nxt = std::min(nxt, (iter / rho_every + 1) * rho_every);
-        if (h->profiling) HIPCHK(hipEventRecord(h->ev0, h->stream));
+        if (h->profiling) HIPCHK(hipEventRecord(h->ev0[unsynced % MAXEV], h->stream));
         int rc = launch_admm(h, nxt - iter);
         if (rc) return rc;
-        if (h->profiling) HIPCHK(hipEventRecord(h->ev1, h->stream));
+        if (h->profiling) HIPCHK(hipEventRecord(h->ev1[unsynced % MAXEV], h->stream));
         iter = nxt;
         int mode = plain ? COLD_PLAIN : 0;
         if (chk && iter % chk == 0) mode |= COLD_CHECK;
@@ -1774,11 +1782,19 @@ static int launch_solve(mpcqp_handle *h, int plain_iters) {
         if (iter == max_iter && !plain) mode |= COLD_FINAL;
         HIPCHK(hipMemsetAsync(h->P.active, 0, sizeof(int), h->stream));
         DISPATCH_NB(L.NB, { hipLaunchKernelGGL(k_check<NB>, dim3(h->batch), dim3(NT), h->smem_setup, h->stream, h->L, h->P, h->S, iter, mode); });
-        HIPCHK(hipMemcpyAsync(h->active_host, h->P.active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-        HIPCHK(hipStreamSynchronize(h->stream));
-        if (h->profiling) { float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1)); h->admm_ms += ms; h->admm_launches += 1; }
-        if (*h->active_host == 0) break;
+        ++rounds; ++unsynced;
+        if (rounds >= h->last_rounds || iter >= max_iter || unsynced == MAXEV) {
+            HIPCHK(hipMemcpyAsync(h->active_host, h->P.active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipStreamSynchronize(h->stream));
+            if (h->profiling) for (int e = 0; e < unsynced; ++e) {
+                float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, h->ev0[e], h->ev1[e]));
+                if (ms > 0.02f) { h->admm_ms += ms; h->admm_launches += 1; }     // (empty launches of finished batches are not counted)
+            }
+            unsynced = 0;
+            finished = *h->active_host == 0;
+        }
     }
+    h->last_rounds = std::max(1, rounds);
     HIPCHK(hipGetLastError());
     return MPCQP_OK;
 }
