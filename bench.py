@@ -102,6 +102,9 @@ def main():
     ap.add_argument('--batch', type=int, default=1024, help='instances per GPU')
     ap.add_argument('--eps', type=float, default=1e-3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--path', default='stepwise', choices=['stepwise', 'device_loop'],
+                    help='stepwise: update()/solve()/output() per step from the host (the reference call pattern); '
+                         'device_loop: the same K steps inside mpcqp_mpc_run (SURVEY 8f-1)')
     ap.add_argument('--workload', default='cfg3', choices=['cfg3', 'cfg5'],
                     help='cfg3: 1024 x (12,4,30) (headline); cfg5: 512 x (20,8,100), tight state box (SURVEY 8d)')
     args = ap.parse_args()
@@ -168,30 +171,64 @@ def main():
         if world > 1:
             sharding.gather_inputs(u, out=u_all)
 
-    for _ in range(args.warmup):
-        step()
-    prob.stats(reset=True)
-    prob.profile(enable=True, reset=True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(i)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    loop_ms = None
+    if args.path == 'stepwise':
+        for _ in range(args.warmup):
+            step()
+        prob.stats(reset=True)
+        prob.profile(enable=True, reset=True)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(i)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+    else:
+        # the disturbance sequence is synthetic input: generated before the timed region, resident in HBM
+        K = args.steps
+        w_warm = 0.01 * torch.randn((max(1, args.warmup), B, NX), dtype=f64, device=dev, generator=gen)
+        w_all = 0.01 * torch.randn((K, B, NX), dtype=f64, device=dev, generator=gen)
+        outs = (torch.empty((K + 1, B, NX), dtype=f64, device=dev), torch.empty((K, B, NU), dtype=f64, device=dev),
+                torch.empty((K, B), dtype=torch.int32, device=dev), torch.empty((K, B), dtype=torch.int32, device=dev))
+        if args.warmup:
+            prob.mpc_run(args.warmup, w=w_warm, out=tuple(o[:args.warmup + (1 if j == 0 else 0)].contiguous() for j, o in enumerate(outs)))
+        prob.stats(reset=True)
+        u_hist = torch.empty((world, K, B, NU), dtype=f64, device=dev) if world > 1 else None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e0.record(stream)
+        prob.mpc_run(K, w=w_all, out=outs)
+        e1.record(stream)
+        if world > 1:
+            dist.all_gather_into_tensor(u_hist, outs[1])          # every rank ends with all applied inputs
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        loop_ms = e0.elapsed_time(e1)
     if world > 1:
         t = torch.tensor([elapsed], dtype=f64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     iters, checks, refacts, solves = prob.stats()
-    admm_ms, admm_launches = prob.profile()
     infos = prob.infos()
     n_solved = sum(1 for i in infos if i.status == 1)
-    solve_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))     # whole mpcqp_solve span on the stream
+    if args.path == 'stepwise':
+        admm_ms, admm_launches = prob.profile()
+        solve_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))     # whole mpcqp_solve span on the stream
+        kname = 'k_admm<16,true,12,4>' if args.workload == 'cfg3' else 'k_admm<32,false,20,8>'
+    else:
+        # one launch of the fused loop kernel does everything; its ADMM iterations are the algorithmic bytes
+        admm_ms, admm_launches = loop_ms, 1
+        solve_ms = loop_ms / args.steps
+        kname = 'k_mpc_run<16,true,12,4>' if args.workload == 'cfg3' else 'k_mpc_run<32,false,20,8>'
 
     if rank == 0:
         n, m, nnzL = prob.n, prob.m, prob.nnzL
@@ -212,14 +249,14 @@ def main():
             'dtype': 'f64', 'data': 'synthetic',
             'config': {'workload': '%s: %d random stable LTI MPC instances per GPU (nx=%d, nu=%d, Np=Nc=%d, n=%d, m=%d), '
                                    'warm-started receding horizon x+=Ad x+Bd u*+w' % ('cfg-3' if args.workload == 'cfg3' else 'cfg-5', B, NX, NU, NP, n, m),
-                       'batch_per_gpu': B, 'eps_abs': args.eps, 'eps_rel': args.eps,
+                       'batch_per_gpu': B, 'eps_abs': args.eps, 'eps_rel': args.eps, 'path': args.path,
                        'parallelism': 'instances sharded over %d GPU(s); RCCL scatter of data, all-gather of u*' % world},
             'mean_admm_iters': iters / max(1, solves),
             'solved_fraction_last_step': n_solved / B,
             'refactorizations_per_solve': refacts / max(1, solves),
             'roofline': {'bound': 'hbm', 'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK, 'traffic': pmc_traffic(),
-                         'kernel': 'k_admm<16,true,12,4>' if args.workload == 'cfg3' else 'k_admm<32,false,20,8>', 'kernel_ms': admm_ms / max(1, admm_launches),
+                         'kernel': kname, 'kernel_ms': admm_ms / max(1, admm_launches),
                          'launches': admm_launches, 'algorithmic_bytes_per_launch': admm_bytes / max(1, admm_launches),
                          'algorithmic_bytes_per_iter_per_qp': b_it, 'nnzL': nnzL,
                          'all_kernels_algorithmic_GBps': total_bytes / args.steps / (solve_ms * 1e-3) / 1e9,

@@ -130,6 +130,21 @@ int mpcqp_solve(mpcqp_handle *h);
 int mpcqp_get_solution(mpcqp_handle *h, double *x, double *y, mpcqp_info *info);
 int mpcqp_get_u0(mpcqp_handle *h, double *u0);
 
+/* Device-side receding-horizon loop: K closed-loop steps of every instance without host round trips,
+ *     for k in range(nsteps):  u = K.output();  x = Ap x + Bp u + w[k];  K.update(x)       (solve included)
+ * i.e. the caller loop of examples/example_point_mass.py:88-101 / pyMPC/mpc.py:688-692 with a linear plant.
+ * Needs a solved handle (mpcqp_setup + mpcqp_solve).  output() follows mpc.py:271-336: the first input of the
+ * last solution if its status is 'solved', else u_failure (= uref).  The reference xref stays as last uploaded.
+ *   w           [nsteps][batch][nx] additive disturbance, or NULL
+ *   Ap, Bp      [batch][nx*nx], [batch][nx*nu] plant matrices, or NULL (plant = the controller's Ad, Bd)
+ *   x_traj      [nsteps+1][batch][nx] states x_0..x_K (x_0 = the state of the last update/setup), or NULL
+ *   u_traj      [nsteps][batch][nu] applied inputs, or NULL
+ *   status_traj, iter_traj  [nsteps][batch] status / ADMM iterations of the solve after step k's update, or NULL
+ * Host or device pointers.  Returns when the run is complete; afterwards the handle holds the solution for x_K
+ * (mpcqp_get_solution / mpcqp_get_u0 work as after mpcqp_solve). */
+int mpcqp_mpc_run(mpcqp_handle *h, int nsteps, const double *w, const double *Ap, const double *Bp,
+                  double *x_traj, double *u_traj, int32_t *status_traj, int32_t *iter_traj);
+
 /* Cumulative work counters since creation / last reset: out4 = { ADMM iterations, residual
  * evaluations, refactorizations, instance-solves } summed over the batch (synchronises). */
 int mpcqp_get_stats(mpcqp_handle *h, uint64_t *out4, int reset);

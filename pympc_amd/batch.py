@@ -95,6 +95,17 @@ class BatchMPCController:
         self.prob.solve_async()
         self._u_last = None
 
+    def run(self, nsteps, w=None, Ap=None, Bp=None):
+        """``nsteps`` closed-loop steps on the device, equivalent to
+        ``for k in range(nsteps): u = K.output(); x = Ap @ x + Bp @ u + w[k]; K.update(x)``
+        (the loop of examples/example_point_mass.py:88-101 with a linear plant; default plant = (Ad, Bd)).
+        Returns ``dict(x=[nsteps+1,B,nx], u=[nsteps,B,nu], status=[nsteps,B] (OSQP status values), iter=[nsteps,B])``."""
+        xt, ut, st, it = self.prob.mpc_run(nsteps, w=w, Ap=Ap, Bp=Bp)
+        self.x0_rh = xt[-1].copy()
+        self.uminus1_rh = ut[-1].copy()
+        self._u_last = None
+        return dict(x=xt, u=ut, status=st, iter=it)
+
     def status(self):
         """Per-instance OSQP status strings of the last solve."""
         infos = self.prob.infos()

@@ -54,6 +54,8 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 // ------------------------------------------------------------------------------------------------
 // Layout of one instance
 // ------------------------------------------------------------------------------------------------
+constexpr int MAXEV = 8;          // rounds that may be in flight between two host syncs
+
 struct Lay {
     int nx, nu, Np, Nc, N, nb, n, m, n_x, n_u, ou, oe, rs, ri, rdu;
     int NB;                       // padded stage block size (16 or 32)
@@ -83,7 +85,7 @@ struct Ptrs {
     double *Dt, *Et;              // Ruiz temporaries
     int *ctype;
     int *done;                    // per instance: finished in this solve
-    int *active;                  // [1] instances still running after the last k_check
+    int *active;                  // [MAXEV] instances still running after the k_check of each round in flight
     unsigned long long *stats;    // [0] ADMM iterations, [1] residual evaluations, [2] refactorizations, [3] instance-solves
     mpcqp_info *info;
     long long fsz;                // factor doubles per instance
@@ -363,7 +365,13 @@ __device__ __forceinline__ double kkt_sub_entry(const Ctx &c, const double *om, 
 // ------------------------------------------------------------------------------------------------
 // Optimisation barriers: values the compiler would otherwise hoist out of the ADMM iteration loop (loop-invariant
 // loads and address arithmetic of the sweeps) and keep live across ALL phases, pushing the kernel into scratch spills.
-template <class T> __device__ __forceinline__ T *opaque_ptr(T *p) { asm volatile("" : "+s"(p)); return p; }
+template <class T> __device__ __forceinline__ T *opaque_ptr(T *p) {      // workgroup-uniform pointer, pinned to scalar registers
+    unsigned long long v = (unsigned long long)p;
+    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    p = (T *)(((unsigned long long)hi << 32) | lo);
+    asm volatile("" : "+s"(p));
+    return p;
+}
 __device__ __forceinline__ int opaque_lane(int v) { asm volatile("" : "+v"(v)); return v; }
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -1087,13 +1095,11 @@ __global__ __launch_bounds__(NT) void k_setup(Lay L, Ptrs P, mpcqp_settings S_) 
 // ------------------------------------------------------------------------------------------------
 enum { COLD_CHECK = 1, COLD_RHO = 2, COLD_FINAL = 4, COLD_PLAIN = 8 };
 
+// (the bodies are device functions so that the fused receding-horizon kernel k_mpc_run can reuse them verbatim)
 template <int NB>
-__global__ __launch_bounds__(NT) void k_begin(Lay L, Ptrs P, mpcqp_settings S_, int plain) {
-    extern __shared__ __attribute__((aligned(16))) double sh[];
-    double *p = sh; Smem S; smem_common(L, P, p, S);
+__device__ __forceinline__ void begin_body(const Lay &L, const Ptrs &P, const mpcqp_settings &S_, Smem &S, int plain) {
     const int b = blockIdx.x, tid = threadIdx.x;
     const double *model = P.model + (size_t)b * L.model_sz, *step = P.step + (size_t)b * L.step_sz;
-    load_common(L, model, step, S);
     Ctx c{L, S.hot, model};
     build_q(c, step, S.Qv);
     double *gx = P.x + (size_t)b * L.n, *gz = P.z + (size_t)b * L.m, *gy = P.y + (size_t)b * L.m;
@@ -1122,13 +1128,18 @@ __global__ __launch_bounds__(NT) void k_begin(Lay L, Ptrs P, mpcqp_settings S_, 
 }
 
 template <int NB>
-__global__ __launch_bounds__(NT) void k_check(Lay L, Ptrs P, mpcqp_settings S_, int iter, int mode) {
-    const int b = blockIdx.x, tid = threadIdx.x;
-    if (P.done[b]) return;
+__global__ __launch_bounds__(NT) void k_begin(Lay L, Ptrs P, mpcqp_settings S_, int plain) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     double *p = sh; Smem S; smem_common(L, P, p, S);
-    const double *model = P.model + (size_t)b * L.model_sz, *step = P.step + (size_t)b * L.step_sz;
-    load_common(L, model, step, S);
+    load_common(L, P.model + (size_t)blockIdx.x * L.model_sz, P.step + (size_t)blockIdx.x * L.step_sz, S);
+    begin_body<NB>(L, P, S_, S, plain);
+}
+
+// Returns 1 (to every thread) if the instance has terminated.
+template <int NB>
+__device__ __forceinline__ int check_body(const Lay &L, const Ptrs &P, const mpcqp_settings &S_, Smem &S, int iter, int mode, int *active_slot) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const double *model = P.model + (size_t)b * L.model_sz;
     Ctx c{L, S.hot, model};
     double *gx = P.x + (size_t)b * L.n, *gz = P.z + (size_t)b * L.m, *gy = P.y + (size_t)b * L.m;
     const double *X = gx, *Z = gz, *Y = gy;
@@ -1271,9 +1282,19 @@ __global__ __launch_bounds__(NT) void k_check(Lay L, Ptrs P, mpcqp_settings S_, 
             atomicAdd(&P.stats[2], (unsigned long long)inf.rho_updates); atomicAdd(&P.stats[3], 1ULL);
             inf.reserved = 0;
             P.done[b] = 1;
-        } else atomicAdd(P.active, 1);
+        } else if (active_slot) atomicAdd(active_slot, 1);
         P.info[b] = inf;
     }
+    return term;
+}
+
+template <int NB>
+__global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_check(Lay L, Ptrs P, mpcqp_settings S_, int iter, int mode, int slot) {
+    if (P.done[blockIdx.x]) return;
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    double *p = sh; Smem S; smem_common(L, P, p, S);
+    load_common(L, P.model + (size_t)blockIdx.x * L.model_sz, P.step + (size_t)blockIdx.x * L.step_sz, S);
+    check_body<NB>(L, P, S_, S, iter, mode, P.active + slot);
 }
 
 // ---- hot-loop pieces.  NXT/NUT: compile-time nx/nu (0 = take them from the layout at run time).
@@ -1407,32 +1428,24 @@ __device__ __forceinline__ void hot_update(const Lay &L, const double *hot, cons
     __syncthreads();
 }
 
-// The hot kernel: `iters` ADMM iterations of every instance that is not finished yet.
+// `iters` ADMM iterations of this workgroup's instance.  Expects the hot model prefix and the step data in LDS
+// (load_common) and, with LDSSTATE, X/Z/Y carved behind the common area.
 template <int NB, bool LDSSTATE, int NXT, int NUT, bool BORDER>
-__global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_admm(Lay L, HotPtrs P, double alpha, int iters) {
+__device__ __forceinline__ void admm_body(const Lay &L, const HotPtrs &P, Smem &S, double *X, double *Z, double *Y, double alpha, int iters) {
     const int b = blockIdx.x, tid = threadIdx.x;
-    if (P.done[b]) return;
-    extern __shared__ __attribute__((aligned(16))) double sh[];
-    double *p = sh; Smem S; smem_common(L, P, p, S);
-    const double *model = P.model + (size_t)b * L.model_sz, *step = P.step + (size_t)b * L.step_sz;
     double *gx = P.x + (size_t)b * L.n, *gz = P.z + (size_t)b * L.m, *gy = P.y + (size_t)b * L.m;
-    // small-problem mode (LDSSTATE): the iterate x, z, y lives in LDS for the whole round
-    double *X, *Z, *Y;
-    if (LDSSTATE) { X = carve(p, L.n); Z = carve(p, L.m); Y = carve(p, L.m); }
-    else { X = gx; Z = gz; Y = gy; }
-    load_common(L, model, step, S);
     double *W = S.T, *Tc = S.T + L.m;
-    if (LDSSTATE) {
+    if (LDSSTATE) {          // small-problem mode: the iterate x, z, y lives in LDS for the whole round
         for (int j = tid; j < L.n; j += NT) X[j] = gx[j];
         for (int r = tid; r < L.m; r += NT) { Z[r] = gz[r]; Y[r] = gy[r]; }
-    }
+    } else { X = gx; Z = gz; Y = gy; }
     __syncthreads();
     cgdouble *gom = (cgdouble *)(P.omega + (size_t)b * L.m), *gsv = (cgdouble *)(P.s + (size_t)b * L.n), *gqv = (cgdouble *)S.Qv;
     gdouble *dxg = (gdouble *)(P.dx + (size_t)b * L.n), *dyg = (gdouble *)(P.dy + (size_t)b * L.m);
     const double *F = P.F + (size_t)b * P.fsz;
     const double cc = P.c[b];
     for (int it = 1; it <= iters; ++it) {
-        const bool keep_delta = it == iters;         // the increments feed the infeasibility certificates of k_check
+        const bool keep_delta = it == iters;         // the increments feed the infeasibility certificates of the check
 #ifndef MPCQP_ABL_NOPAR
         hot_rhs<NB, NXT, NUT>(L, S.hot, gom, gsv, gqv, cc, X, Z, Y, W, Tc);
 #endif
@@ -1452,6 +1465,151 @@ __global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_admm(Lay L, HotPtrs 
         for (int j = tid; j < L.n; j += NT) gx[j] = X[j];
         for (int r = tid; r < L.m; r += NT) { gz[r] = Z[r]; gy[r] = Y[r]; }
     }
+}
+
+// The hot kernel: `iters` ADMM iterations of every instance that is not finished yet.
+template <int NB, bool LDSSTATE, int NXT, int NUT, bool BORDER>
+__global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_admm(Lay L, HotPtrs P, double alpha, int iters) {
+    if (P.done[blockIdx.x]) return;
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    double *p = sh; Smem S; smem_common(L, P, p, S);
+    double *X = nullptr, *Z = nullptr, *Y = nullptr;
+    if (LDSSTATE) { X = carve(p, L.n); Z = carve(p, L.m); Y = carve(p, L.m); }
+    load_common(L, P.model + (size_t)blockIdx.x * L.model_sz, P.step + (size_t)blockIdx.x * L.step_sz, S);
+    admm_body<NB, LDSSTATE, NXT, NUT, BORDER>(L, P, S, X, Z, Y, alpha, iters);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Device-side receding-horizon loop (the caller pattern of examples/example_point_mass.py:88-101 and
+// pyMPC/mpc.py:688-692):   for k in range(K):  u = K.output();  x = Ap x + Bp u + w_k;  K.update(x)
+// One workgroup walks its own instance through all K steps -- output (mpc.py:271-336, u_failure = uref unless
+// 'solved'), plant, QP refresh (mpc.py:386-454), warm-started solve -- with no host round trip and, unlike the
+// per-step API, no batch-wide barrier per round: an instance that needs 50 iterations does not hold up one that
+// needs 25.  The phase bodies are the ones of k_begin / k_admm / k_check.
+// ------------------------------------------------------------------------------------------------
+struct RunArgs {
+    int nsteps, max_iter, chk, rho_every;
+    const double *w;              // [nsteps][batch][nx] additive plant disturbance, or null
+    const double *Ap, *Bp;        // [batch][nx*nx], [batch][nx*nu] plant matrices, or null (plant = model Ad, Bd)
+    double *x_traj;               // [nsteps+1][batch][nx]
+    double *u_traj;               // [nsteps][batch][nu]
+    int *status_traj, *iter_traj; // [nsteps][batch]: outcome of the solve that follows step k's update
+    int batch;
+};
+
+__host__ __device__ inline int next_stop(int iter, int max_iter, int chk, int rho_every) {
+    int nxt = max_iter;
+    if (chk) { int v = (iter / chk + 1) * chk; nxt = v < nxt ? v : nxt; }
+    if (rho_every) { int v = (iter / rho_every + 1) * rho_every; nxt = v < nxt ? v : nxt; }
+    return nxt;
+}
+__host__ __device__ inline int stop_mode(int iter, int max_iter, int chk, int rho_every, bool plain) {
+    int mode = plain ? COLD_PLAIN : 0;
+    if (chk && iter % chk == 0) mode |= COLD_CHECK;
+    if (rho_every && iter % rho_every == 0) mode |= COLD_RHO;
+    if (iter == max_iter && !plain) mode |= COLD_FINAL;
+    return mode;
+}
+
+// The three phases are separate (non-inlined) functions so that each gets a register allocation of its own --
+// inlined into one body, the cold code's live ranges pushed spill reloads into the ADMM sweep.  They take no
+// pointer arguments: everything is re-read from the kernel-argument segment, which is uniform, constant memory
+// (scalar loads), instead of travelling through the vector-register calling convention.
+struct RunKArgs { Lay L; Ptrs P; mpcqp_settings S; RunArgs R; };
+static_assert(sizeof(RunKArgs) % 8 == 0, "hidden kernel arguments start right behind RunKArgs");
+typedef const __attribute__((address_space(4))) RunKArgs *ckargs;
+// (In a non-kernel function the kernarg segment pointer itself is not available, the implicit-argument pointer is:
+//  the hidden arguments follow the explicit ones, here the single RunKArgs struct, at the next 8-byte boundary.)
+__device__ __forceinline__ const RunKArgs &run_kargs() {
+    typedef const __attribute__((address_space(4))) char *cbytes;
+    return *(const RunKArgs *)(ckargs)((cbytes)__builtin_amdgcn_implicitarg_ptr() - ((sizeof(RunKArgs) + 7) & ~size_t(7)));
+}
+
+struct RunSmem { Smem S; double *X, *Z, *Y; };
+template <bool LDSSTATE>
+__device__ __forceinline__ RunSmem run_smem(const Lay &L, const Ptrs &P) {
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    RunSmem r; double *p = sh; smem_common(L, P, p, r.S);
+    r.X = r.Z = r.Y = nullptr;
+    if (LDSSTATE) { r.X = carve(p, L.n); r.Z = carve(p, L.m); r.Y = carve(p, L.m); }
+    return r;
+}
+
+template <int NB, bool LDSSTATE, int NXT, int NUT, bool BORDER>
+__device__ __noinline__ void run_admm_phase(int iters) {
+    const RunKArgs &A = run_kargs();
+    const Lay &L = A.L; const Ptrs &P = A.P;
+    RunSmem r = run_smem<LDSSTATE>(L, P);
+    HotPtrs hp; hp.model = P.model; hp.step = P.step; hp.omega = P.omega; hp.s = P.s; hp.qv = P.qv; hp.F = P.F; hp.c = P.c; hp.G = P.G;
+    hp.Bb = P.Bb; hp.Zb = P.Zb; hp.Sig = P.Sig; hp.x = P.x; hp.z = P.z; hp.y = P.y; hp.dx = P.dx; hp.dy = P.dy; hp.done = P.done; hp.fsz = P.fsz;
+    admm_body<NB, LDSSTATE, NXT, NUT, BORDER>(L, hp, r.S, r.X, r.Z, r.Y, A.S.alpha, __builtin_amdgcn_readfirstlane(iters));
+}
+
+template <int NB, bool LDSSTATE>
+__device__ __noinline__ void run_begin_phase() {
+    const RunKArgs &A = run_kargs();
+    RunSmem r = run_smem<LDSSTATE>(A.L, A.P);
+    begin_body<NB>(A.L, A.P, A.S, r.S, 0);
+}
+
+template <int NB, bool LDSSTATE>
+__device__ __noinline__ int run_check_phase(int iter, int mode) {
+    const RunKArgs &A = run_kargs();
+    RunSmem r = run_smem<LDSSTATE>(A.L, A.P);
+    return check_body<NB>(A.L, A.P, A.S, r.S, __builtin_amdgcn_readfirstlane(iter), __builtin_amdgcn_readfirstlane(mode), nullptr);
+}
+
+template <int NB, bool LDSSTATE, int NXT, int NUT, bool BORDER>
+__global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_mpc_run(RunKArgs A_) {
+    const RunKArgs &A = run_kargs();
+    const Lay &L = A.L; const Ptrs &P = A.P; const RunArgs &R = A.R;
+    RunSmem rs = run_smem<LDSSTATE>(L, P);
+    Smem &S = rs.S;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    double *step = P.step + (size_t)b * L.step_sz;
+    load_common(L, P.model + (size_t)b * L.model_sz, step, S);
+    const int nx = L.nx, nu = L.nu;
+    for (int k = 0; k < R.nsteps; ++k) {
+        // ---- output(): first input of the current solution, or u_failure
+        const int status = P.info[b].status;
+        double *un = S.tv, *xn = S.tv + nu;              // (nx + nu <= 32 < 64)
+        if (tid < nu) un[tid] = status == MPCQP_SOLVED ? P.xo[(size_t)b * L.n + L.ou + tid] : S.hot[L.ouref + tid];
+        __syncthreads();
+        // ---- plant step
+        if (tid < nx) {
+            const double *Ap = R.Ap ? R.Ap + (size_t)b * nx * nx : S.hot + L.oAd;
+            const double *Bp = R.Bp ? R.Bp + (size_t)b * nx * nu : S.hot + L.oBd;
+            double v = R.w ? R.w[((size_t)k * R.batch + b) * nx + tid] : 0.0;
+            double acc = 0.0;
+            for (int j = 0; j < nx; ++j) acc += Ap[tid * nx + j] * S.x0s[j];
+            for (int j = 0; j < nu; ++j) acc += Bp[tid * nu + j] * un[j];
+            xn[tid] = acc + v;
+            R.x_traj[((size_t)k * R.batch + b) * nx + tid] = S.x0s[tid];
+        }
+        if (tid < nu) R.u_traj[((size_t)k * R.batch + b) * nu + tid] = un[tid];
+        __syncthreads();
+        // ---- update(x): new initial state and previous input (mpc.py:338-364)
+        if (tid < nx) { S.x0s[tid] = xn[tid]; step[tid] = xn[tid]; }
+        if (tid < nu) { S.um1s[tid] = un[tid]; step[nx + tid] = un[tid]; }
+        __syncthreads();
+        run_begin_phase<NB, LDSSTATE>();
+        __syncthreads();
+        int iter = 0, term = 0;
+        while (!term) {
+            const int nxt = next_stop(iter, R.max_iter, R.chk, R.rho_every);
+            run_admm_phase<NB, LDSSTATE, NXT, NUT, BORDER>(nxt - iter);
+            iter = nxt;
+            __syncthreads();
+            term = run_check_phase<NB, LDSSTATE>(iter, stop_mode(iter, R.max_iter, R.chk, R.rho_every, false));
+            __syncthreads();
+        }
+        if (tid == 0) {
+            R.status_traj[(size_t)k * R.batch + b] = P.info[b].status;
+            R.iter_traj[(size_t)k * R.batch + b] = iter;
+        }
+        __syncthreads();
+    }
+    if (tid < nx) R.x_traj[((size_t)R.nsteps * R.batch + b) * nx + tid] = S.x0s[tid];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1493,8 +1651,6 @@ __global__ void k_gather_u0(Lay L, const double *xo, double *u0, int batch) {
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-constexpr int MAXEV = 8;          // rounds that may be in flight between two host syncs
-
 struct mpcqp_handle {
     int device, batch;
     Lay L;
@@ -1506,6 +1662,7 @@ struct mpcqp_handle {
     int last_rounds;              // rounds the previous solve needed (that many are enqueued without a host sync)
     std::vector<void *> allocs;
     double *u0_dev;
+    void *run_buf; size_t run_bytes;     // staging of mpcqp_mpc_run (disturbances, plant, trajectories)
     int *active_host;             // pinned
     bool profiling;
     hipEvent_t ev0[8], ev1[8];
@@ -1587,13 +1744,13 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     if (device < 0 || device >= ndev) return fail(MPCQP_ERR_ARG, "mpcqp_create: bad device index");
     HIPCHK(hipSetDevice(device));
     mpcqp_handle *h = new mpcqp_handle();
-    h->device = device; h->batch = batch; h->is_setup = false; h->u0_dev = nullptr;
+    h->device = device; h->batch = batch; h->is_setup = false; h->u0_dev = nullptr; h->run_buf = nullptr; h->run_bytes = 0;
     h->active_host = nullptr; h->profiling = false; h->admm_ms = 0.0; h->admm_launches = 0;
     h->L = make_layout(nx, nu, Np, Nc);
     if (s) h->S = *s; else mpcqp_default_settings(&h->S);
     HIPCHK(hipStreamCreate(&h->stream));
     h->own_stream = true;
-    HIPCHK(hipHostMalloc((void **)&h->active_host, sizeof(int)));
+    HIPCHK(hipHostMalloc((void **)&h->active_host, MAXEV * sizeof(int)));
     for (int e = 0; e < MAXEV; ++e) { HIPCHK(hipEventCreate(&h->ev0[e])); HIPCHK(hipEventCreate(&h->ev1[e])); }
     const Lay &L = h->L;
     Ptrs &P = h->P; memset(&P, 0, sizeof(P));
@@ -1612,7 +1769,7 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     if (L.border) { rc |= dalloc(h, &P.Bb, B * (size_t)L.nu * L.N * L.NB); rc |= dalloc(h, &P.Zb, B * (size_t)L.nu * L.N * L.NB); rc |= dalloc(h, &P.Sig, B * (size_t)L.nu * L.nu); }
     rc |= dalloc(h, &P.Dt, B * L.n); rc |= dalloc(h, &P.Et, B * L.m);
     rc |= dalloc(h, &P.ctype, B * L.m); rc |= dalloc(h, &P.info, B); rc |= dalloc(h, &P.stats, 8);
-    rc |= dalloc(h, &P.done, B); rc |= dalloc(h, &P.active, 4);
+    rc |= dalloc(h, &P.done, B); rc |= dalloc(h, &P.active, MAXEV);
     rc |= dalloc(h, &h->u0_dev, B * L.nu);
     if (rc) { mpcqp_destroy(h); return MPCQP_ERR_HIP; }
     h->smem_setup = sizeof(double) * (size_t)smem_common_doubles(L);
@@ -1630,6 +1787,7 @@ extern "C" void mpcqp_destroy(mpcqp_handle *h) {
     hipSetDevice(h->device);
     hipStreamSynchronize(h->stream);
     for (void *p : h->allocs) hipFree(p);
+    if (h->run_buf) hipFree(h->run_buf);
     if (h->active_host) { hipHostFree(h->active_host); for (int e = 0; e < MAXEV; ++e) { hipEventDestroy(h->ev0[e]); hipEventDestroy(h->ev1[e]); } }
     if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;
@@ -1765,36 +1923,39 @@ static int launch_solve(mpcqp_handle *h, int plain_iters) {
     // Rounds are enqueued back to back; the host only looks at the "still running" counter after as many rounds as
     // the previous solve needed (kernels of finished instances exit at once, so an over-estimate costs two empty
     // launches, an under-estimate one extra round trip).
-    int iter = 0, rounds = 0, unsynced = 0;
+    int iter = 0, rounds = 0, unsynced = 0, needed = 0;
     bool finished = false;
     while (iter < max_iter && !finished) {
         int nxt = max_iter;
         if (chk) nxt = std::min(nxt, (iter / chk + 1) * chk);
         if (rho_every) nxt = std::min(nxt, (iter / rho_every + 1) * rho_every);
-        if (h->profiling) HIPCHK(hipEventRecord(h->ev0[unsynced % MAXEV], h->stream));
+        if (unsynced == 0) HIPCHK(hipMemsetAsync(h->P.active, 0, MAXEV * sizeof(int), h->stream));
+        if (h->profiling) HIPCHK(hipEventRecord(h->ev0[unsynced], h->stream));
         int rc = launch_admm(h, nxt - iter);
         if (rc) return rc;
-        if (h->profiling) HIPCHK(hipEventRecord(h->ev1[unsynced % MAXEV], h->stream));
+        if (h->profiling) HIPCHK(hipEventRecord(h->ev1[unsynced], h->stream));
         iter = nxt;
         int mode = plain ? COLD_PLAIN : 0;
         if (chk && iter % chk == 0) mode |= COLD_CHECK;
         if (rho_every && iter % rho_every == 0) mode |= COLD_RHO;
         if (iter == max_iter && !plain) mode |= COLD_FINAL;
-        HIPCHK(hipMemsetAsync(h->P.active, 0, sizeof(int), h->stream));
-        DISPATCH_NB(L.NB, { hipLaunchKernelGGL(k_check<NB>, dim3(h->batch), dim3(NT), h->smem_setup, h->stream, h->L, h->P, h->S, iter, mode); });
+        DISPATCH_NB(L.NB, { hipLaunchKernelGGL(k_check<NB>, dim3(h->batch), dim3(NT), h->smem_setup, h->stream, h->L, h->P, h->S, iter, mode, unsynced); });
         ++rounds; ++unsynced;
         if (rounds >= h->last_rounds || iter >= max_iter || unsynced == MAXEV) {
-            HIPCHK(hipMemcpyAsync(h->active_host, h->P.active, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+            HIPCHK(hipMemcpyAsync(h->active_host, h->P.active, MAXEV * sizeof(int), hipMemcpyDeviceToHost, h->stream));
             HIPCHK(hipStreamSynchronize(h->stream));
-            if (h->profiling) for (int e = 0; e < unsynced; ++e) {
-                float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, h->ev0[e], h->ev1[e]));
-                if (ms > 0.02f) { h->admm_ms += ms; h->admm_launches += 1; }     // (empty launches of finished batches are not counted)
+            for (int e = 0; e < unsynced && !finished; ++e) {
+                if (h->profiling) {
+                    float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, h->ev0[e], h->ev1[e]));
+                    h->admm_ms += ms; h->admm_launches += 1;
+                }
+                ++needed;
+                finished = h->active_host[e] == 0;            // later rounds of this group were empty launches
             }
             unsynced = 0;
-            finished = *h->active_host == 0;
         }
     }
-    h->last_rounds = std::max(1, rounds);
+    h->last_rounds = std::max(1, needed);
     HIPCHK(hipGetLastError());
     return MPCQP_OK;
 }
@@ -1809,6 +1970,62 @@ static int get(mpcqp_handle *h, void *dst, const void *src, size_t bytes) {
     if (!dst) return 0;
     HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, h->stream));
     return 0;
+}
+
+template <int NB, bool LDSS, int NXT, int NUT, bool BORDER>
+static int launch_run_t(mpcqp_handle *h, const RunArgs &R) {
+    if (set_smem(k_mpc_run<NB, LDSS, NXT, NUT, BORDER>, h->smem_solve)) return MPCQP_ERR_HIP;
+    RunKArgs A; A.L = h->L; A.P = h->P; A.S = h->S; A.R = R;
+    hipLaunchKernelGGL((k_mpc_run<NB, LDSS, NXT, NUT, BORDER>), dim3(h->batch), dim3(NT), h->smem_solve, h->stream, A);
+    return 0;
+}
+template <int NB, bool LDSS>
+static int launch_run_generic(mpcqp_handle *h, const RunArgs &R) {
+    return h->L.border ? launch_run_t<NB, LDSS, 0, 0, true>(h, R) : launch_run_t<NB, LDSS, 0, 0, false>(h, R);
+}
+
+extern "C" int mpcqp_mpc_run(mpcqp_handle *h, int nsteps, const double *w, const double *Ap, const double *Bp,
+                             double *x_traj, double *u_traj, int32_t *status_traj, int32_t *iter_traj) {
+    if (!h || nsteps < 1) return fail(MPCQP_ERR_ARG, "mpcqp_mpc_run: bad argument");
+    if (!h->is_setup) return fail(MPCQP_ERR_STATE, "mpcqp_mpc_run before mpcqp_setup");
+    if ((Ap == nullptr) != (Bp == nullptr)) return fail(MPCQP_ERR_ARG, "mpcqp_mpc_run: give both Ap and Bp or neither");
+    HIPCHK(hipSetDevice(h->device));
+    const Lay &L = h->L; const mpcqp_settings &S = h->S;
+    const size_t B = (size_t)h->batch, K = (size_t)nsteps;
+    // one staging block: [w | Ap | Bp | x_traj | u_traj | status | iter]
+    const size_t nw = w ? K * B * L.nx : 0, nA = Ap ? B * L.nx * L.nx : 0, nBp = Bp ? B * L.nx * L.nu : 0;
+    const size_t nxt = (K + 1) * B * L.nx, nut = K * B * L.nu, nst = K * B;
+    const size_t bytes = sizeof(double) * (nw + nA + nBp + nxt + nut) + sizeof(int) * 2 * nst;
+    if (bytes > h->run_bytes) {
+        HIPCHK(hipStreamSynchronize(h->stream));
+        if (h->run_buf) hipFree(h->run_buf);
+        h->run_buf = nullptr; h->run_bytes = 0;
+        HIPCHK(hipMalloc(&h->run_buf, bytes));
+        h->run_bytes = bytes;
+    }
+    double *d = (double *)h->run_buf;
+    double *dw = d; d += nw; double *dA = d; d += nA; double *dB = d; d += nBp;
+    double *dx = d; d += nxt; double *du = d; d += nut;
+    int *dst = (int *)d, *dit = dst + nst;
+    if (w) HIPCHK(hipMemcpyAsync(dw, w, sizeof(double) * nw, hipMemcpyDefault, h->stream));
+    if (Ap) { HIPCHK(hipMemcpyAsync(dA, Ap, sizeof(double) * nA, hipMemcpyDefault, h->stream));
+              HIPCHK(hipMemcpyAsync(dB, Bp, sizeof(double) * nBp, hipMemcpyDefault, h->stream)); }
+    RunArgs R;
+    R.nsteps = nsteps; R.max_iter = S.max_iter; R.chk = S.check_termination;
+    R.rho_every = S.adaptive_rho ? (S.adaptive_rho_interval ? S.adaptive_rho_interval : (R.chk ? 4 * R.chk : 100)) : 0;
+    R.w = w ? dw : nullptr; R.Ap = Ap ? dA : nullptr; R.Bp = Bp ? dB : nullptr;
+    R.x_traj = dx; R.u_traj = du; R.status_traj = dst; R.iter_traj = dit; R.batch = h->batch;
+    int rc;
+    if (L.NB == 16 && h->lds_state && L.nx == 12 && L.nu == 4 && !L.border) rc = launch_run_t<16, true, 12, 4, false>(h, R);
+    else if (L.NB == 32 && !h->lds_state && L.nx == 20 && L.nu == 8 && !L.border) rc = launch_run_t<32, false, 20, 8, false>(h, R);
+    else if (L.NB == 16) rc = h->lds_state ? launch_run_generic<16, true>(h, R) : launch_run_generic<16, false>(h, R);
+    else rc = h->lds_state ? launch_run_generic<32, true>(h, R) : launch_run_generic<32, false>(h, R);
+    if (rc) return rc;
+    HIPCHK(hipGetLastError());
+    if (get(h, x_traj, dx, sizeof(double) * nxt) || get(h, u_traj, du, sizeof(double) * nut) ||
+        get(h, status_traj, dst, sizeof(int) * nst) || get(h, iter_traj, dit, sizeof(int) * nst)) return MPCQP_ERR_HIP;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MPCQP_OK;
 }
 
 extern "C" int mpcqp_get_solution(mpcqp_handle *h, double *x, double *y, mpcqp_info *info) {

@@ -182,6 +182,24 @@ class BatchProblem:
     def synchronize(self):
         _lib.check(self._L.mpcqp_synchronize(self._h), 'mpcqp_synchronize')
 
+    def mpc_run(self, nsteps, w=None, Ap=None, Bp=None, out=None):
+        """Device-side receding-horizon loop (mpcqp_mpc_run): ``nsteps`` closed-loop steps
+        ``u = output(); x = Ap x + Bp u + w[k]; update(x)`` of every instance without host round trips.
+
+        ``w`` [nsteps, batch, nx] (numpy or torch device tensor) or None; ``Ap``/``Bp`` default to the controller model.
+        Returns ``(x_traj [nsteps+1,B,nx], u_traj [nsteps,B,nu], status [nsteps,B] int32, iters [nsteps,B] int32)``
+        as numpy arrays, or fills the four arrays/tensors given in ``out``."""
+        K, B, nx, nu = int(nsteps), self.batch, self.nx, self.nu
+        wa = _prep(w, (K, B, nx), 'w') if w is not None else None
+        Aa = _prep(Ap, (B, nx, nx), 'Ap') if Ap is not None else None
+        Ba = _prep(Bp, (B, nx, nu), 'Bp') if Bp is not None else None
+        if out is None:
+            out = (np.empty((K + 1, B, nx)), np.empty((K, B, nu)), np.empty((K, B), dtype=np.int32), np.empty((K, B), dtype=np.int32))
+        xt, ut, st, it = out
+        _lib.check(self._L.mpcqp_mpc_run(self._h, K, _ptr(wa), _ptr(Aa), _ptr(Ba), _ptr(xt), _ptr(ut), _ptr(st), _ptr(it)),
+                   'mpcqp_mpc_run')
+        return xt, ut, st, it
+
     def solution(self, want_y=True):
         x = np.empty((self.batch, self.n))
         y = np.empty((self.batch, self.m)) if want_y else None

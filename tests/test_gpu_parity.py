@@ -282,3 +282,73 @@ def test_device_resident_inputs_match_host_inputs():
         pd.update(t(x), u_dev)
     it, chk, ref, sol = pd.stats()
     assert sol == 4 * B and it >= 25 * sol and chk >= sol
+
+
+def _stacked_batch(kws, **kw):
+    from pympc_amd import BatchMPCController
+    stack = lambda k: np.stack([np.asarray(d[k], dtype=float) for d in kws])
+    k0 = kws[0]
+    args = dict(Np=k0['Np'], Nc=k0.get('Nc'), x0=stack('x0'), xref=stack('xref'), uref=stack('uref'), uminus1=stack('uminus1'),
+                Qx=stack('Qx'), QxN=stack('QxN'), Qu=stack('Qu'), QDu=stack('QDu'), xmin=stack('xmin'), xmax=stack('xmax'),
+                umin=stack('umin'), umax=stack('umax'), Dumin=stack('Dumin'), Dumax=stack('Dumax'),
+                eps_feas=np.array([[d.get('eps_feas', 1e6)] for d in kws]))
+    args.update(kw)
+    return BatchMPCController(stack('Ad'), stack('Bd'), **args)
+
+
+@pytest.mark.parametrize('case', ['random_12_4_30', 'cart_pole', 'quadcopter_nc', 'random_20_8_12'])
+def test_device_loop_matches_stepwise_api(case):
+    """mpcqp_mpc_run (update -> solve -> output -> plant on the device for K steps) against the same
+    closed loop driven step by step through update()/output(): identical inputs, statuses and iteration counts."""
+    from pympc_amd import fixtures
+    K_STEPS = 12
+    if case == 'random_12_4_30':
+        kws = [fixtures.random_lti(300 + i) for i in range(7)]
+    elif case == 'random_20_8_12':
+        kws = [fixtures.random_lti(40 + i, nx=20, nu=8, Np=12, xbox=1.0) for i in range(3)]
+    else:
+        kws = []
+        for i in range(4):
+            kw = dict(fixtures.NAMED[case]())
+            kw['x0'] = np.asarray(kw['x0'], dtype=float) + 0.01 * i
+            kws.append(kw)
+    B, nx = len(kws), kws[0]['Ad'].shape[0]
+    rng = np.random.default_rng(5)
+    w = 0.01 * rng.standard_normal((K_STEPS, B, nx))
+    Kd = _stacked_batch(kws); Kd.setup()
+    Ks = _stacked_batch(kws); Ks.setup()
+    tr = Kd.run(K_STEPS, w=w)
+    assert np.array_equal(tr['x'][0], Ks.x0_rh)
+    for k in range(K_STEPS):
+        u = Ks.output()
+        assert np.array_equal(u, tr['u'][k]), k
+        xn = np.einsum('bij,bj->bi', Ks.Ad, tr['x'][k]) + np.einsum('bij,bj->bi', Ks.Bd, u) + w[k]
+        assert np.allclose(xn, tr['x'][k + 1], rtol=1e-13, atol=1e-14)
+        Ks.update(tr['x'][k + 1])                      # the device's own x_{k+1}: no plant rounding differences
+        infos = Ks.prob.infos()
+        assert [i.status for i in infos] == list(tr['status'][k]), k
+        assert [i.iter for i in infos] == list(tr['iter'][k]), k
+    # the handle is left exactly where the stepwise controller is
+    assert np.array_equal(Kd.output(), Ks.output())
+    xs_d, ys_d, _ = Kd.prob.solution(); xs_s, ys_s, _ = Ks.prob.solution()
+    assert np.array_equal(xs_d, xs_s) and np.array_equal(ys_d, ys_s)
+
+
+def test_device_loop_custom_plant_and_failure_fallback():
+    """Plant matrices different from the model, and output()'s u_failure branch (mpc.py:271-336) inside the loop:
+    with max_iter below the first termination check no solve ends 'solved' -> u = uref."""
+    from pympc_amd import fixtures
+    kws = [fixtures.random_lti(400 + i) for i in range(3)]
+    for kw in kws:
+        kw['uref'] = np.array([0.05, -0.02, 0.01, 0.03])
+    Ap = np.stack([kw['Ad'] * 0.9 for kw in kws]); Bp = np.stack([kw['Bd'] * 1.1 for kw in kws])
+    K = _stacked_batch(kws); K.setup()
+    tr = K.run(5, Ap=Ap, Bp=Bp)
+    for k in range(5):
+        xn = np.einsum('bij,bj->bi', Ap, tr['x'][k]) + np.einsum('bij,bj->bi', Bp, tr['u'][k])
+        assert np.allclose(xn, tr['x'][k + 1], rtol=1e-13, atol=1e-14)
+    assert (tr['status'] == 1).all()
+    Kf = _stacked_batch(kws, max_iter=10); Kf.setup()
+    trf = Kf.run(3)
+    assert np.isin(trf['status'], (-2, 2)).all() and (trf['iter'] == 10).all()     # max-iter / solved inaccurate: not 'solved'
+    assert np.array_equal(trf['u'], np.broadcast_to(np.stack([kw['uref'] for kw in kws]), trf['u'].shape))
