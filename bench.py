@@ -15,6 +15,7 @@ Rank 0 prints ONE JSON line.  With N > 1 the instances are sharded over ranks (w
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -82,14 +83,14 @@ def cpu_baseline(seconds_budget=20.0, inst=400, steps=100, eps=1e-3):
                        'mean %.1f ADMM iterations/solve, %.1f s of CPU work)' % (done, steps, iters / max(1, n_solve), t_solve))
 
 
-def pmc_traffic():
-    """HBM bytes per k_admm launch from the rocprofv3 PMC passes of this same command (FETCH_SIZE and WRITE_SIZE
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes of this same command (FETCH_SIZE and WRITE_SIZE
     collected in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); counters cannot
     be collected from inside the process, so the committed summary of the last profiled run is reported."""
     path = os.path.join(ROOT, 'profiles', 'pmc_hbm_traffic.json')
     try:
         with open(path) as f:
-            return json.load(f)['k_admm']['hbm_bytes_per_launch']
+            return json.load(f)[kernel]['hbm_bytes_per_launch']
     except Exception:
         return None
 
@@ -102,7 +103,8 @@ def main():
     ap.add_argument('--batch', type=int, default=1024, help='instances per GPU')
     ap.add_argument('--eps', type=float, default=1e-3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--path', default='stepwise', choices=['stepwise', 'device_loop'],
+    ap.add_argument('--no-other-path', action='store_true', help='skip the secondary measurement of the other path')
+    ap.add_argument('--path', default='device_loop', choices=['stepwise', 'device_loop'],
                     help='stepwise: update()/solve()/output() per step from the host (the reference call pattern); '
                          'device_loop: the same K steps inside mpcqp_mpc_run (SURVEY 8f-1)')
     ap.add_argument('--workload', default='cfg3', choices=['cfg3', 'cfg5'],
@@ -154,90 +156,94 @@ def main():
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     u_all = torch.empty((world * B, NU), dtype=f64, device=dev) if world > 1 else None
-    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
 
-    def step(i=None):
-        nonlocal x
-        w = 0.01 * torch.randn((B, NX), dtype=f64, device=dev, generator=gen)
-        x = torch.baddbmm(w.unsqueeze(2), Ad, x.unsqueeze(2)).add_(torch.bmm(Bd, u.unsqueeze(2))).squeeze(2)
-        prob.update(x, u)
-        if i is not None:
-            ev0[i].record(stream)
-        prob.solve_async()
-        if i is not None:
-            ev1[i].record(stream)
-        prob.u0(out=u)
-        if world > 1:
-            sharding.gather_inputs(u, out=u_all)
-
-    loop_ms = None
-    if args.path == 'stepwise':
-        for _ in range(args.warmup):
-            step()
+    def timed(run_warm, run_timed):
+        """W untimed steps, then the timed K steps between barrier + synchronize; returns max-over-ranks seconds
+        and the device-side accounting of the timed region."""
+        run_warm()
         prob.stats(reset=True)
         prob.profile(enable=True, reset=True)
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(i)
+        run_timed()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-    else:
-        # the disturbance sequence is synthetic input: generated before the timed region, resident in HBM
-        K = args.steps
-        w_warm = 0.01 * torch.randn((max(1, args.warmup), B, NX), dtype=f64, device=dev, generator=gen)
-        w_all = 0.01 * torch.randn((K, B, NX), dtype=f64, device=dev, generator=gen)
-        outs = (torch.empty((K + 1, B, NX), dtype=f64, device=dev), torch.empty((K, B, NU), dtype=f64, device=dev),
-                torch.empty((K, B), dtype=torch.int32, device=dev), torch.empty((K, B), dtype=torch.int32, device=dev))
-        if args.warmup:
-            prob.mpc_run(args.warmup, w=w_warm, out=tuple(o[:args.warmup + (1 if j == 0 else 0)].contiguous() for j, o in enumerate(outs)))
-        prob.stats(reset=True)
-        u_hist = torch.empty((world, K, B, NU), dtype=f64, device=dev) if world > 1 else None
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        e0.record(stream)
-        prob.mpc_run(K, w=w_all, out=outs)
-        e1.record(stream)
-        if world > 1:
-            dist.all_gather_into_tensor(u_hist, outs[1])          # every rank ends with all applied inputs
-            dist.barrier()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0
-        loop_ms = e0.elapsed_time(e1)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=f64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+            t = torch.tensor([elapsed], dtype=f64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        iters, checks, refacts, solves = prob.stats()
+        run_ms, launches = prob.profile(enable=False)
+        return dict(elapsed=elapsed, iters=iters, checks=checks, refacts=refacts, solves=solves, run_ms=run_ms, launches=launches)
 
-    iters, checks, refacts, solves = prob.stats()
+    def measure_stepwise(steps, warmup):
+        """The reference's call pattern: per step the host calls update(), solve(), output() (one kernel launch per
+        solve); plant and disturbance are torch ops on the same stream; with N > 1 u* is all-gathered every step."""
+        nonlocal x
+
+        def step():
+            nonlocal x
+            w = 0.01 * torch.randn((B, NX), dtype=f64, device=dev, generator=gen)
+            x = torch.baddbmm(w.unsqueeze(2), Ad, x.unsqueeze(2)).add_(torch.bmm(Bd, u.unsqueeze(2))).squeeze(2)
+            prob.update(x, u)
+            prob.solve_async()
+            prob.u0(out=u)
+            if world > 1:
+                sharding.gather_inputs(u, out=u_all)
+
+        return timed(lambda: [step() for _ in range(warmup)], lambda: [step() for _ in range(steps)])
+
+    def measure_device_loop(steps, warmup):
+        """The same closed loop inside mpcqp_mpc_run: launches of `chunk` steps each, so that every
+        launch (warm-up and timed) does the same work; the disturbance sequence is synthetic input generated before
+        the timed region; with N > 1 the applied inputs of a chunk are all-gathered after it."""
+        nonlocal x
+        chunk = math.gcd(steps, warmup) if warmup > 0 else steps
+        while chunk > 25 and chunk % 2 == 0:
+            chunk //= 2
+        w_all = 0.01 * torch.randn((warmup + steps, B, NX), dtype=f64, device=dev, generator=gen)
+        outs = (torch.empty((chunk + 1, B, NX), dtype=f64, device=dev), torch.empty((chunk, B, NU), dtype=f64, device=dev),
+                torch.empty((chunk, B), dtype=torch.int32, device=dev), torch.empty((chunk, B), dtype=torch.int32, device=dev))
+        u_hist = torch.empty((world, chunk, B, NU), dtype=f64, device=dev) if world > 1 else None
+
+        def run(first, count):
+            for c in range(first, first + count, chunk):
+                prob.mpc_run(chunk, w=w_all[c:c + chunk], out=outs)
+                if world > 1:
+                    dist.all_gather_into_tensor(u_hist, outs[1])
+
+        r = timed(lambda: run(0, warmup), lambda: run(warmup, steps))
+        x = outs[0][-1].clone()
+        u.copy_(outs[1][-1])
+        r['chunk'] = chunk
+        return r
+
+    measure = {'stepwise': measure_stepwise, 'device_loop': measure_device_loop}
+    res = measure[args.path](args.steps, args.warmup)
+    elapsed, iters, checks, refacts, solves = res['elapsed'], res['iters'], res['checks'], res['refacts'], res['solves']
+    admm_ms, admm_launches = res['run_ms'], res['launches']
     infos = prob.infos()
     n_solved = sum(1 for i in infos if i.status == 1)
-    if args.path == 'stepwise':
-        admm_ms, admm_launches = prob.profile()
-        solve_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))     # whole mpcqp_solve span on the stream
-        kname = 'k_admm<16,true,12,4>' if args.workload == 'cfg3' else 'k_admm<32,false,20,8>'
-    else:
-        # one launch of the fused loop kernel does everything; its ADMM iterations are the algorithmic bytes
-        admm_ms, admm_launches = loop_ms, 1
-        solve_ms = loop_ms / args.steps
-        kname = 'k_mpc_run<16,true,12,4>' if args.workload == 'cfg3' else 'k_mpc_run<32,false,20,8>'
+    other = None
+    if not args.no_other_path:
+        oname = 'stepwise' if args.path == 'device_loop' else 'device_loop'
+        o = measure[oname](args.steps, args.warmup)
+        other = {'path': oname, 'value': B * world * args.steps / o['elapsed'], 'ms_per_step': 1e3 * o['elapsed'] / args.steps,
+                 'mean_admm_iters': o['iters'] / max(1, o['solves'])}
+    kname = ('k_mpc_run<16,true,12,4,false,%s>' if args.workload == 'cfg3' else 'k_mpc_run<32,false,20,8,false,%s>') % ('true' if args.path == 'device_loop' else 'false')
 
     if rank == 0:
         n, m, nnzL = prob.n, prob.m, prob.nnzL
         nnz_triuP = (NP + 1) * NX * 2 + NP * NU + (NP - 1) * NU     # diagonal weights: diag + upper QDu coupling
         nnzA = (NP + 1) * NX + NP * NX * NX + NP * NX * NU + 2 * (NP + 1) * NX + NP * NU + NU + 2 * NP * NU - 1
         total_bytes, b_it = algorithmic_bytes(n, m, nnzL, iters, checks, solves, nnz_triuP, nnzA)
-        # dominant kernel k_admm: it performs the ADMM iterations (b_it each); residual evaluations and the
-        # per-solve I/O belong to k_check / k_begin.  HIP events bracket every k_admm launch on its stream.
-        admm_bytes = iters * b_it
+        # the one kernel of the path, k_mpc_run, does everything (QP refresh, ADMM iterations, residual checks); its
+        # algorithmic bytes are SURVEY 8(d)'s total.  HIP events bracket every launch on its stream (mpcqp_profile).
+        admm_bytes = total_bytes
         achieved = admm_bytes / (admm_ms * 1e-3)
         out = {
             'metric': 'QP-solves/sec (MPC steps/sec) at nx=%d nu=%d Np=%d' % (NX, NU, NP),
@@ -255,12 +261,12 @@ def main():
             'solved_fraction_last_step': n_solved / B,
             'refactorizations_per_solve': refacts / max(1, solves),
             'roofline': {'bound': 'hbm', 'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK, 'traffic': pmc_traffic(),
+                         'frac': achieved / HBM_PEAK, 'traffic': pmc_traffic(kname) if res.get('chunk', 1) == 10 or args.path == 'stepwise' else None,
                          'kernel': kname, 'kernel_ms': admm_ms / max(1, admm_launches),
                          'launches': admm_launches, 'algorithmic_bytes_per_launch': admm_bytes / max(1, admm_launches),
                          'algorithmic_bytes_per_iter_per_qp': b_it, 'nnzL': nnzL,
-                         'all_kernels_algorithmic_GBps': total_bytes / args.steps / (solve_ms * 1e-3) / 1e9,
-                         'solve_ms': solve_ms},
+                         'steps_per_launch': res.get('chunk', 1)},
+            'other_path': other,
         }
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(eps=args.eps)

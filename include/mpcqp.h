@@ -120,9 +120,10 @@ int mpcqp_warm_start(mpcqp_handle *h, const double *x, const double *y);
 /* Change tolerances / iteration limits after setup (osqp.update_settings). */
 int mpcqp_update_settings(mpcqp_handle *h, const mpcqp_settings *s);
 
-/* One ADMM solve of every instance.  Work is issued on the handle's stream; the call returns when the
- * solve is complete (termination is decided on the device every check_termination iterations and the
- * host only reads back how many instances are still running). */
+/* One ADMM solve of every instance: a single kernel launch on the handle's stream (asynchronous -- the
+ * mpcqp_get_* calls and mpcqp_synchronize wait for it).  Every instance iterates until ITS termination test
+ * passes (checked on the device every check_termination iterations); there is no host loop and no batch-wide
+ * barrier between rounds. */
 int mpcqp_solve(mpcqp_handle *h);
 
 /* Results of the last solve (synchronises).  x [batch][n], y [batch][m], info [batch];
@@ -149,9 +150,10 @@ int mpcqp_mpc_run(mpcqp_handle *h, int nsteps, const double *w, const double *Ap
  * evaluations, refactorizations, instance-solves } summed over the batch (synchronises). */
 int mpcqp_get_stats(mpcqp_handle *h, uint64_t *out4, int reset);
 
-/* Timing of the hot kernel (k_admm), measured with HIP events on the handle's stream: enable = 1/0 to
- * switch, -1 to leave unchanged; returns accumulated milliseconds and launch count, optionally resets. */
-int mpcqp_profile(mpcqp_handle *h, int enable, double *admm_ms, int64_t *admm_launches, int reset);
+/* Timing of the solve kernel (k_mpc_run: mpcqp_solve / mpcqp_iterate / mpcqp_mpc_run launches), measured with
+ * HIP events on the handle's stream: enable = 1/0 to switch, -1 to leave unchanged; returns accumulated
+ * milliseconds and launch count (synchronises on the pending launches), optionally resets. */
+int mpcqp_profile(mpcqp_handle *h, int enable, double *run_ms, int64_t *run_launches, int reset);
 
 /* Problem sizes: n, m of one instance, bytes of the KKT factor per instance, and nnz(L). */
 int mpcqp_get_dims(mpcqp_handle *h, int *n, int *m, int64_t *factor_doubles, int64_t *nnzL);

@@ -23,6 +23,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <algorithm>
+#include <cstdio>
 #include <string>
 #include <vector>
 
@@ -32,12 +33,9 @@
 #define NT 256                 // threads per workgroup (one workgroup = one MPC instance)
 #endif
 #define NWAVES (NT / 64)
-// Linear-system scheme for NB = 16: 0 = three factor blocks per stage (forward | S^-1 | backward), separate S^-1 phase;
-// 1 = only S^-1 stored, off-diagonal blocks applied matrix-free (kkt_core_sinv).  See DESIGN.md section 5 for the numbers.
-#ifndef MPCQP_SINV_ONLY
-#define MPCQP_SINV_ONLY 0
+#ifndef MPCQP_PRIO
+#define MPCQP_PRIO 0
 #endif
-#define SINV16(NB) (MPCQP_SINV_ONLY && (NB) == 16)
 #define QP_INFTY 1e30
 #define MIN_SCALING 1e-4
 #define MAX_SCALING 1e4
@@ -54,7 +52,7 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 // ------------------------------------------------------------------------------------------------
 // Layout of one instance
 // ------------------------------------------------------------------------------------------------
-constexpr int MAXEV = 8;          // rounds that may be in flight between two host syncs
+constexpr int MAXEV = 64;         // profiling: launches whose HIP events may be pending
 
 struct Lay {
     int nx, nu, Np, Nc, N, nb, n, m, n_x, n_u, ou, oe, rs, ri, rdu;
@@ -68,7 +66,7 @@ struct Lay {
     int oQx, oQxN, oQu, oQDu, model_sz;
     int step_sz;                  // [x0 | um1 | xref(N*nx)]
     int xref_rows;                // 1 or N
-    int fstage;                   // doubles per factor stage: NB*NB (S^-1 only, NB = 16) or 3*NB*NB
+    int fstage;                   // doubles per factor stage: 2*NB*NB  [forward matrix | S^-1]
     int tsz;                      // LDS work vector length: max(m, 4*NB*NB)
 };
 
@@ -79,13 +77,10 @@ struct Ptrs {
     double *x, *z, *y;            // iterate (unscaled units)
     double *xo, *yo;              // reported solution
     double *dx, *dy;              // last primal / dual increments (infeasibility certificates)
-    double *G;                    // [2*256] per instance (NB = 16): fragments of G = [[Ad,Bd],[0,c QDu']] and of G'
     double *Bb, *Zb, *Sig;        // border (Nc < Np): K[:,ubar] and T^-1 K[:,ubar] in padded layout [nu][N*NB], Schur inverse [nu*nu]
     double *qv;                   // linear cost of the x,u variables [n_x+n_u] (rebuilt by every kernel prologue)
     double *Dt, *Et;              // Ruiz temporaries
     int *ctype;
-    int *done;                    // per instance: finished in this solve
-    int *active;                  // [MAXEV] instances still running after the k_check of each round in flight
     unsigned long long *stats;    // [0] ADMM iterations, [1] residual evaluations, [2] refactorizations, [3] instance-solves
     mpcqp_info *info;
     long long fsz;                // factor doubles per instance
@@ -93,9 +88,8 @@ struct Ptrs {
 
 // The hot kernel gets only the pointers it uses (fewer scalar registers -> no SGPR spills into vector lanes).
 struct HotPtrs {
-    const double *model, *step, *omega, *s, *qv, *F, *c, *G, *Bb, *Zb, *Sig;
+    const double *model, *step, *omega, *s, *qv, *F, *c, *Bb, *Zb, *Sig;
     double *x, *z, *y, *dx, *dy;
-    const int *done;
     long long fsz;
 };
 
@@ -361,7 +355,8 @@ __device__ __forceinline__ double kkt_sub_entry(const Ctx &c, const double *om, 
 // 16-lane row by 4, 8, 12 lanes: DPP row_ror.  So a stage vector is ONE double per lane, stage outputs feed the next
 // stage through three DPP rotations and no LDS traffic, and a lane's four fragment values (one per step) are
 // contiguous: fragment element (r, c) -> lane 16(c&3) + 4(r>>2) + (r&3), step ((c>>2) - (r>>2)) & 3.
-// Per stage k:  [ forward matrix | S_k^-1 | backward matrix ]   (3 NB^2 doubles, 32 B per lane per block).
+// Per stage k:  [ forward matrix | S_k^-1 ]   (2 NB^2 doubles, 32 B per lane per block); the back substitution
+// applies the forward matrix of the neighbouring stage TRANSPOSED from the same fragments (frag_matvec_T).
 // ------------------------------------------------------------------------------------------------
 // Optimisation barriers: values the compiler would otherwise hoist out of the ADMM iteration loop (loop-invariant
 // loads and address arithmetic of the sweeps) and keep live across ALL phases, pushing the kernel into scratch spills.
@@ -395,13 +390,14 @@ __device__ __forceinline__ int frag_pos(int r, int cidx) {
 //   top    k < mid:  Mh_k = K_{k,k-1} Sn_{k-1},   S_k = K_kk - Mh_k K_{k,k-1}'
 //   bottom k > mid:  Mt_k = K_{k,k+1} Sn_{k+1},   S_k = K_kk - Mt_k K_{k,k+1}'        (K_{k,k+1} = K_{k+1,k}')
 //   middle        :  S_mid = K_mm - Mh_mid K_{mid,mid-1}' - Mt_mid K_{mid,mid+1}'
-// Per-stage factor slots (fragments, see above):   slot 0: forward matrix   slot 1: S_k^-1   slot 2: backward matrix
-//   top:    slot0 = -Mh_k        slot2 = -Mh_{k+1}'     bottom: slot0 = -Mt_k       slot2 = -Mt_{k-1}'
-//   middle: slot0 = -Mh_mid      slot2 = -Mt_mid  (its second forward matrix; the middle has no backward one)
+// Per-stage factor slots (fragments, see above):   slot 0: forward matrix   slot 1: S_k^-1
+//   top:    slot0 = -Mh_k        bottom: slot0 = -Mt_k        middle: slot0 = -Mh_mid, and its second forward matrix
+//   -Mt_mid in slot 0 of stage 0 (which has none of its own).  Back substitution: x_k += slot0(k+1)' x_{k+1} in the
+//   top half, x_k += slot0(k-1)' x_{k-1} in the bottom half (-Mt_mid' for k = mid+1).
 // W: LDS workspace of 6*NB*NB doubles.  Returns (uniformly) 0, or 1 if a pivot was not positive.
-struct BorderPtrs { double *Bb, *Zb, *Sig, *red, *G; };
+struct BorderPtrs { double *Bb, *Zb, *Sig, *red; };
 
-template <int NB> __device__ void border_factor(const Ctx &, const double *, const double *, double, const double *, double *, double *, double *, double *, double *, double *, const double *);
+template <int NB> __device__ void border_factor(const Ctx &, const double *, const double *, double, const double *, double *, double *, double *, double *, double *, double *);
 
 template <int NB>
 __device__ int factor_all(const Ctx &c, const double *om, const double *sv, double cc, double *F, double *W, int *iflag, BorderPtrs bp) {
@@ -425,18 +421,15 @@ __device__ int factor_all(const Ctx &c, const double *om, const double *sv, doub
             Mh[e] = acc;
         }
         __syncthreads();
-        const int fwd_slot = (k == mid && !up) ? 2 : 0;         // the middle keeps its second forward matrix in slot 2
-        const int nb = up ? k - 1 : k + 1;
+        const int fwd_stage = (k == mid && !up) ? 0 : k;
         for (int e = tid; e < NB * NB; e += NT) {              // S -= Mh * Ks'
             int a = e / NB, b = e % NB;
             double acc = 0.0;
             for (int l = 0; l < NB; ++l) acc += Mh[a * NB + l] * Ks[b * NB + l];
             S[e] -= acc;
-            if constexpr (!SINV16(NB)) {                        // (the S^-1-only scheme applies the off-diagonal blocks matrix-free)
-                double mv = -Mh[e];
-                F[(size_t)k * L.fstage + fwd_slot * NB * NB + frag_pos<NB>(a, b)] = mv;      // forward matrix of stage k
-                F[(size_t)nb * L.fstage + 2 * NB * NB + frag_pos<NB>(b, a)] = mv;            // its transpose: backward matrix of the neighbour
-            }
+            // forward matrix of stage k (the backward sweep applies the same fragment transposed); the middle stage's
+            // second forward matrix lives in the otherwise unused slot 0 of stage 0
+            F[(size_t)fwd_stage * L.fstage + frag_pos<NB>(a, b)] = -Mh[e];
         }
         __syncthreads();
     };
@@ -445,7 +438,7 @@ __device__ int factor_all(const Ctx &c, const double *om, const double *sv, doub
         for (int e = tid; e < NB * NB; e += NT) {
             S[e] = kkt_diag_entry(c, om, sv, cc, k, e / NB, e % NB);
             Li[e] = 0.0;
-            if (!SINV16(NB) && !use_up && !use_down) F[(size_t)k * L.fstage + e] = 0.0;      // end stages have no forward matrix
+            if (k == N - 1) F[(size_t)k * L.fstage + e] = 0.0;      // the last stage has no forward matrix (stage 0's slot holds the middle's second one)
         }
         if (use_up) eliminate_neighbour(k, true, SnA);
         if (use_down) eliminate_neighbour(k, false, SnB);
@@ -480,24 +473,14 @@ __device__ int factor_all(const Ctx &c, const double *om, const double *sv, doub
             double acc = 0.0;
             for (int l = max(a, b); l < NB; ++l) acc += Li[l * NB + a] * Li[l * NB + b];
             SnOut[e] = acc;
-            F[(size_t)k * L.fstage + (SINV16(NB) ? 0 : NB * NB) + frag_pos<NB>(a, b)] = acc;
+            F[(size_t)k * L.fstage + NB * NB + frag_pos<NB>(a, b)] = acc;
         }
     };
     for (int k = 0; k < mid; ++k) stage(k, k > 0, false, SnA);
     for (int k = N - 1; k > mid; --k) stage(k, false, k < N - 1, SnB);
     stage(mid, true, true, SnA);
-    if constexpr (SINV16(NB)) {      // G = [[Ad, Bd], [0, c QDu']] and G' as fragments
-        for (int e = tid; e < NB * NB; e += NT) {
-            const int r = e / NB, q = e % NB;
-            double g = 0.0;
-            if (r < L.nx) g = q < L.nx ? c.Ad()[r * L.nx + q] : (q < L.nb ? c.Bd()[r * L.nu + (q - L.nx)] : 0.0);
-            else if (r < L.nb && q >= L.nx && q < L.nb) g = cc * c.QDu()[(q - L.nx) * L.nu + (r - L.nx)];
-            bp.G[frag_pos<NB>(r, q)] = g;
-            bp.G[256 + frag_pos<NB>(q, r)] = g;
-        }
-    }
     __syncthreads();
-    if (L.border) border_factor<NB>(c, om, sv, cc, F, bp.Bb, bp.Zb, bp.Sig, W, W + L.m, bp.red, bp.G);
+    if (L.border) border_factor<NB>(c, om, sv, cc, F, bp.Bb, bp.Zb, bp.Sig, W, W + L.m, bp.red);
     return *iflag;
 }
 
@@ -566,9 +549,50 @@ __device__ __forceinline__ void frag_load_sinv(const double *Fm, int lane, d4 *A
 #define frag_load_sinv frag_load
 #endif
 
+// The TRANSPOSED product from the same fragments:  out[bj] += sum_bi A(bi,bj)' * in[bi].
+// The backward substitution needs Mh' where the forward elimination needed Mh; the MFMA always contracts over the
+// index that sits in the 16-lane-row position of the operand layout (the column of the stored block), so the
+// transposed product is done on the vector ALU instead -- and the factor stream loses its third block per stage:
+//   xl        lane (k,b,j) <- element 4b+j of `in`            (one cross-lane permute of the stage vector)
+//   p_s = a[s] * xl                                            = M[4b+j][4((b+s)&3)+k] * in[4b+j]
+//   t   = p_0 + rot_3(p_1) + rot_2(p_2) + rot_1(p_3)           block (b-s, b) contributes to output block b
+//   out += sum over the four lanes j of t                      (two DPP quad steps), again replicated over j
+__device__ __forceinline__ double lane_permute(double x, int byte_addr) {
+    const long long xi = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_ds_bpermute(byte_addr, (int)xi), hi = __builtin_amdgcn_ds_bpermute(byte_addr, (int)(xi >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double x) {
+    const long long xi = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)xi, CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(xi >> 32), CTRL, 0xF, 0xF, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ int transpose_lane_addr(int lane) { return 4 * (16 * (lane & 3) + (lane & 12) + (lane >> 4)); }
+template <int NB>
+__device__ __forceinline__ void frag_matvec_T(const d4 *A, const double *in, double *out, int perm_addr) {
+    constexpr int NBLK = NB / 16;
+#pragma unroll
+    for (int bi = 0; bi < NBLK; ++bi) {
+        const double xl = lane_permute(in[bi], perm_addr);
+#pragma unroll
+        for (int bj = 0; bj < NBLK; ++bj) {
+            const d4 a = A[bi * NBLK + bj];
+            double t = (a[0] * xl + rot_blocks<3>(a[1] * xl)) + (rot_blocks<2>(a[2] * xl) + rot_blocks<1>(a[3] * xl));
+            t += dpp_move<0xB1>(t);                            // quad_perm [1,0,3,2]
+            t += dpp_move<0x4E>(t);                            // quad_perm [2,3,0,1]
+            out[bj] += t;
+        }
+    }
+}
+
 template <int NB> struct SweepCfg {
     static constexpr int NF = (NB / 16) * (NB / 16);
-    static constexpr int DEPTH = 4;                            // factor stages kept in flight in registers (even)
+#ifndef MPCQP_DEPTH
+#define MPCQP_DEPTH 4
+#endif
+    static constexpr int DEPTH = MPCQP_DEPTH;                  // factor stages kept in flight in registers (even)
 };
 
 // The sweeping waves are dependent MFMA chains: two of them on one SIMD share its matrix pipe and slow each other
@@ -584,38 +608,54 @@ __device__ __forceinline__ int logical_wave() {
 }
 
 // Sequential sweep over `nsteps` stages by ONE wave: for i = 1..nsteps, k = first + dir*i:
-//     Tc[k] <- Tc[k] + Frag(slot, k) * Tc[k - dir]        (Frag holds the negated factor block)
-// The factor fragments of the next DEPTH stages are prefetched into a register ring; the running vector
-// ping-pongs between two register sets (no copies between MFMAs).
-template <int NB>
-__device__ __forceinline__ void chain_sweep(const int first, const int dir, const int nsteps, const int slot,
-                                            const int fstage, const double *F, double *Tc) {
+//     forward elimination (TRANSPOSED = false):  Tc[k] <- Tc[k] + Fwd(k)        * Tc[k - dir]
+//     back substitution   (TRANSPOSED = true) :  Tc[k] <- Tc[k] + Fwd(k - dir)' * Tc[k - dir]
+// (Fwd(k) = slot 0 of stage k holds the negated factor block; `first_stage` >= 0 names the stage whose slot replaces
+// Fwd(first) -- the middle stage's second forward matrix.)  The factor fragments of the next DEPTH stages are prefetched into a
+// register ring; the running vector ping-pongs between two register sets (no copies between MFMAs).
+template <int NB, bool TRANSPOSED>
+__device__ __forceinline__ void chain_sweep(const int first, const int dir, const int nsteps,
+                                            const int fstage, const double *F, const int first_stage, double *Tc) {
     constexpr int NBLK = NB / 16, NF = SweepCfg<NB>::NF, DEPTH = SweepCfg<NB>::DEPTH;
     const int lane = opaque_lane(threadIdx.x & 63);
     double *tb = Tc + vec_lane_offset(lane);
     const bool writer = vec_lane_writer(lane);
-    const double *Fs = F + (size_t)slot * NB * NB;
+    const int perm_addr = transpose_lane_addr(lane);
     auto stage_of = [&](int i) { return first + dir * i; };
+    auto frag_of = [&](int i) {                                // (offsets, not pointer selects)
+        int st = TRANSPOSED ? stage_of(i - 1) : stage_of(i);
+        if (TRANSPOSED && i == 1 && first_stage >= 0) st = first_stage;
+        return F + (size_t)st * fstage;
+    };
+    // The group loop below is branch-free on purpose: with conditionals around the refills the compiler can no longer
+    // count the loads in flight across the back edge and falls back to s_waitcnt vmcnt(0) -- the whole memory latency
+    // once per group.  Refills past the end re-read the last stage (clamped index), the tail group runs separately.
+    auto frag_clamped = [&](int i) { return frag_of(i < nsteps ? i : nsteps); };
     d4 ring[DEPTH][NF];
+    if (nsteps < 1) return;
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d)
-        if (1 + d <= nsteps) frag_load<NB>(Fs + (size_t)stage_of(1 + d) * fstage, lane, ring[d]);
+    for (int d = 0; d < DEPTH; ++d) frag_load<NB>(frag_clamped(1 + d), lane, ring[d]);
     double va[NBLK], vb[NBLK];
     vec_load<NB>(tb, first, va);
-    for (int i0 = 1; i0 <= nsteps; i0 += DEPTH) {
+    auto stage_step = [&](int i, int d) {
+        const int k = stage_of(i);
+        double *src = (d & 1) ? vb : va, *dst = (d & 1) ? va : vb;
+        vec_load<NB>(tb, k, dst);
+        if (TRANSPOSED) frag_matvec_T<NB>(ring[d], src, dst, perm_addr);
+        else frag_matvec<NB>(ring[d], src, dst);
+        vec_store<NB>(tb, k, dst, writer);
+    };
+    int i0 = 1;
+    for (; i0 + DEPTH - 1 <= nsteps; i0 += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
-            const int i = i0 + d;
-            if (i <= nsteps) {
-                const int k = stage_of(i);
-                double *src = (d & 1) ? vb : va, *dst = (d & 1) ? va : vb;
-                vec_load<NB>(tb, k, dst);
-                frag_matvec<NB>(ring[d], src, dst);
-                vec_store<NB>(tb, k, dst, writer);
-                if (i + DEPTH <= nsteps) frag_load<NB>(Fs + (size_t)stage_of(i + DEPTH) * fstage, lane, ring[d]);
-            }
+            stage_step(i0 + d, d);
+            frag_load<NB>(frag_clamped(i0 + d + DEPTH), lane, ring[d]);
         }
     }
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (i0 + d <= nsteps) stage_step(i0 + d, d);
 }
 
 // w_k = S_k^-1 yh_k for all stages (independent MFMA groups, dealt to the four waves).  Wave 0 first finishes the
@@ -642,7 +682,7 @@ __device__ __forceinline__ void sinv_apply(const int N, const int mid, const int
         d4 A0[NF], A2[NF], Am[NF];
         double up[NBLK], dn[NBLK], acc[NBLK];
         frag_load<NB>(F + (size_t)mid * fstage, lane, A0);
-        frag_load<NB>(F + (size_t)mid * fstage + 2 * NB * NB, lane, A2);
+        frag_load<NB>(F, lane, A2);                             // the middle's second forward matrix (kept in stage 0's slot)
         frag_load_sinv<NB>(Fs + (size_t)mid * fstage, lane, Am);
         vec_load<NB>(tb, mid, acc);
         vec_load<NB>(tb, mid - 1, up);
@@ -677,150 +717,38 @@ __device__ __forceinline__ void sinv_apply(const int N, const int mid, const int
 }
 
 // What the linear-system core needs to know about one instance.
-struct CoreArgs { int N, fstage, nx, nu, nb, NcT, rdu; const double *F, *om, *G; };
-__device__ __forceinline__ CoreArgs core_args(const Lay &L, const double *F, const double *om, const double *G) {
-    CoreArgs a; a.N = L.N; a.fstage = L.fstage; a.nx = L.nx; a.nu = L.nu; a.nb = L.nb; a.NcT = L.NcT; a.rdu = L.rdu;
-    a.F = F; a.om = om; a.G = G; return a;
+struct CoreArgs { int N, fstage; const double *F; };
+__device__ __forceinline__ CoreArgs core_args(const Lay &L, const double *F) {
+    CoreArgs a; a.N = L.N; a.fstage = L.fstage; a.F = F; return a;
 }
 
-// ---- scheme for NB = 32: forward matrix | S^-1 | backward matrix per stage, separate S^-1 phase ---------------
+// Twisted solve: forward elimination of the two half-chains (waves 0, 1), S^-1 of every stage (all waves; wave 0
+// closes the elimination at the middle first), back substitution outwards with the transposed forward matrices.
+#ifdef MPCQP_RUN_TIMING
+__device__ unsigned long long g_ticks[16];
+#define TICK(i) { unsigned long long t_ = wall_clock64(); if (threadIdx.x == 0) atomicAdd(&g_ticks[i], t_ - ttick); ttick = t_; }
+#define TICK_START unsigned long long ttick = wall_clock64();
+#else
+#define TICK(i)
+#define TICK_START
+#endif
+
 template <int NB>
-__device__ __forceinline__ void kkt_core_3slot(const CoreArgs &a, double *Tc) {
+__device__ __forceinline__ void kkt_core_sweeps(const CoreArgs &a, double *Tc) {
     const int N = a.N, fstage = a.fstage, mid = N / 2, wv = logical_wave();
     const double *F = a.F;
-    if (wv == 0) chain_sweep<NB>(0, +1, mid - 1, 0, fstage, F, Tc);                  // stages 1 .. mid-1
-    else if (wv == 1) chain_sweep<NB>(N - 1, -1, N - 2 - mid, 0, fstage, F, Tc);     // stages N-2 .. mid+1
+    TICK_START
+    if (wv == 0) chain_sweep<NB, false>(0, +1, mid - 1, fstage, F, -1, Tc);               // stages 1 .. mid-1
+    else if (wv == 1) chain_sweep<NB, false>(N - 1, -1, N - 2 - mid, fstage, F, -1, Tc);  // stages N-2 .. mid+1
     __syncthreads();
+    TICK(1)
     sinv_apply<NB>(N, mid, fstage, F, Tc);
     __syncthreads();
-    if (wv == 0) chain_sweep<NB>(mid, -1, mid, 2, fstage, F, Tc);                    // stages mid-1 .. 0
-    else if (wv == 1) chain_sweep<NB>(mid, +1, N - 1 - mid, 2, fstage, F, Tc);       // stages mid+1 .. N-1
-}
-
-// ---- scheme for NB = 16: ONLY S_k^-1 is stored and streamed (a third of the bytes) --------------------------------
-// The off-diagonal blocks are applied matrix-free.  With the constant block G = [[Ad, Bd], [0, c QDu']] (fragments
-// of G and G' stay in registers for the whole kernel), om_s = omega of the dynamics rows of stage s and
-// wd_s = omega of the Delta-u row that couples u_s[nu-1] with u_{s+1}[0] (mpc.py:570):
-//     -K_{k,k-1} v   = mask_k . ( om_k . (G v) )   + e_{nx}      wd_{k-1} v[nx+nu-1]          ("PA", neighbour above)
-//     -K_{k,k+1} v   = mask_k . ( G' (om_{k+1} . v) ) + e_{nx+nu-1} wd_k   v[nx]               ("PB", neighbour below)
-// (om acts on the x rows only, mask_k clears the u rows of stages that carry no input).  Twisted solve:
-//     forward   w_k = S_k^-1 ( b_k - K_{k,nbr} w_nbr )          top half with PA, bottom half with PB
-//     middle    x_m = S_m^-1 ( b_m - K_{m,m-1} w_{m-1} - K_{m,m+1} w_{m+1} )
-//     backward  x_k = w_k - S_k^-1 K_{k,nbr} x_nbr               top half with PB, bottom half with PA
-// i.e. per stage eight dependent 4x4x4 MFMAs and no separate S^-1 phase.
-struct SinvLane {                 // per-lane constants of the operand layout
-    int e; bool isx, isu; int src_pa, src_pb;      // own element; lanes holding elements nx+nu-1 / nx
-};
-__device__ __forceinline__ SinvLane sinv_lane(const CoreArgs &a, int lane) {
-    SinvLane q; q.e = vec_lane_offset(lane); q.isx = q.e < a.nx; q.isu = q.e >= a.nx && q.e < a.nb;
-    const int ea = a.nx + a.nu - 1, eb = a.nx;
-    q.src_pa = 16 * (ea & 3) + 4 * (ea >> 2); q.src_pb = 16 * (eb & 3) + 4 * (eb >> 2);
-    return q;
-}
-__device__ __forceinline__ double lane_bcast(double x, int src) {
-    const long long xi = __builtin_bit_cast(long long, x);
-    const int lo = __builtin_amdgcn_readlane((int)xi, src), hi = __builtin_amdgcn_readlane((int)(xi >> 32), src);
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
-}
-// t = -K_{k,nbr} v   (up: nbr = k-1, else nbr = k+1); sc = om of stage max(k,nbr) on x lanes (1 elsewhere), wd as above
-__device__ __forceinline__ double offdiag_apply(const CoreArgs &a, const SinvLane &q, const d4 &Gf, const d4 &GTf,
-                                                bool up, int k, double v, double sc, double wd) {
-    const double msk = (q.isx || (q.isu && k < a.NcT)) ? 1.0 : 0.0;
-    double t = 0.0;
-    if (up) {
-        d4 A[1] = {Gf}; double in[1] = {v}, out[1] = {0.0};
-        frag_matvec<16>(A, in, out);
-        t = msk * (sc * out[0]);
-        const double src = lane_bcast(v, q.src_pa);
-        if (q.e == a.nx) t += wd * src;
-    } else {
-        d4 A[1] = {GTf}; double in[1] = {sc * v}, out[1] = {0.0};
-        frag_matvec<16>(A, in, out);
-        t = msk * out[0];
-        const double src = lane_bcast(v, q.src_pb);
-        if (q.e == a.nx + a.nu - 1) t += wd * src;
-    }
-    return t;
-}
-
-struct SinvStep { d4 S; double sc, wd; };           // what one step streams: S_k^-1 fragment, om lanes, coupling weight
-__device__ __forceinline__ void sinv_step_load(const CoreArgs &a, const SinvLane &q, int lane, int k, int nbr, SinvStep &st) {
-    st.S = *(cgd4 *)(a.F + (size_t)k * a.fstage + lane * 4);
-    const int hi = max(k, nbr), lo = min(k, nbr);
-    const double o = ((cgdouble *)a.om)[hi * a.nx + (q.isx ? q.e : 0)];
-    st.sc = q.isx ? o : 1.0;
-    const int lc = min(lo, max(a.NcT - 2, 0));      // (clamped: the row only exists for lo <= NcT-2)
-    const double w = ((cgdouble *)a.om)[a.rdu + a.nu + lc * a.nu + a.nu - 1];
-    st.wd = (hi < a.NcT) ? w : 0.0;                 // the coupling row exists only between two stages that carry inputs
-}
-
-// One half-chain: stages first+dir, first+2dir, ... (nsteps of them).  FWD: w_k = S_k^-1 (b_k + t_k), first stage gets
-// w_first = S^-1 b_first;  BWD: x_k = w_k + S_k^-1 t_k, starting from x_first already in Tc.
-template <bool FWD>
-__device__ __forceinline__ void half_sweep(const CoreArgs &a, double *Tc, const d4 &Gf, const d4 &GTf,
-                                           const int first, const int dir, const int nsteps) {
-    constexpr int DEPTH = SweepCfg<16>::DEPTH;
-    const int lane = opaque_lane(threadIdx.x & 63);
-    const SinvLane q = sinv_lane(a, lane);
-    double *tb = Tc + q.e;
-    const bool writer = vec_lane_writer(lane);
-    const bool up = dir > 0;                                   // neighbour k - dir lies above (smaller index) iff dir > 0
-    SinvStep ring[DEPTH];
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d)
-        if (1 + d <= nsteps) sinv_step_load(a, q, lane, first + dir * (1 + d), first + dir * d, ring[d]);
-    double run;
-    if (FWD) {
-        const d4 S0 = *(cgd4 *)(a.F + (size_t)first * a.fstage + lane * 4);
-        d4 A[1] = {S0}; double in[1] = {tb[first * 16]}, out[1] = {0.0};
-        frag_matvec<16>(A, in, out);
-        run = out[0];
-        if (writer) tb[first * 16] = run;
-    } else {
-        run = tb[first * 16];
-    }
-    for (int i0 = 1; i0 <= nsteps; i0 += DEPTH) {
-#pragma unroll
-        for (int d = 0; d < DEPTH; ++d) {
-            const int i = i0 + d;
-            if (i <= nsteps) {
-                const int k = first + dir * i;
-                const double own = tb[k * 16];                 // b_k (FWD) or w_k (BWD)
-                const double t = offdiag_apply(a, q, Gf, GTf, up, k, run, ring[d].sc, ring[d].wd);
-                d4 A[1] = {ring[d].S};
-                double in[1], out[1];
-                if (FWD) { in[0] = own + t; out[0] = 0.0; } else { in[0] = t; out[0] = own; }
-                frag_matvec<16>(A, in, out);
-                run = out[0];
-                if (writer) tb[k * 16] = run;
-                if (i + DEPTH <= nsteps) sinv_step_load(a, q, lane, first + dir * (i + DEPTH), first + dir * (i + DEPTH - 1), ring[d]);
-            }
-        }
-    }
-}
-
-__device__ __forceinline__ void kkt_core_sinv(const CoreArgs &a, double *Tc) {
-    const int N = a.N, mid = N / 2, wv = logical_wave(), lane = opaque_lane(threadIdx.x & 63);
-    d4 Gf = d4{0.0, 0.0, 0.0, 0.0}, GTf = Gf;
-    if (wv < 2) { Gf = *(cgd4 *)(a.G + lane * 4); GTf = *(cgd4 *)(a.G + 256 + lane * 4); }
-    if (wv == 0) half_sweep<true>(a, Tc, Gf, GTf, 0, +1, mid - 1);                 // w_0 .. w_{mid-1}
-    else if (wv == 1) half_sweep<true>(a, Tc, Gf, GTf, N - 1, -1, N - 2 - mid);     // w_{N-1} .. w_{mid+1}
+    TICK(2)
+    if (wv == 0) chain_sweep<NB, true>(mid, -1, mid, fstage, F, -1, Tc);                  // stages mid-1 .. 0
+    else if (wv == 1) chain_sweep<NB, true>(mid, +1, N - 1 - mid, fstage, F, 0, Tc);           // stages mid+1 .. N-1
     __syncthreads();
-    if (wv == 0) {                                                                  // the middle stage sees both halves
-        const SinvLane q = sinv_lane(a, lane);
-        double *tb = Tc + q.e;
-        SinvStep su, sd;
-        sinv_step_load(a, q, lane, mid, mid - 1, su);
-        sinv_step_load(a, q, lane, mid, mid + 1, sd);
-        const double tu = offdiag_apply(a, q, Gf, GTf, true, mid, tb[(mid - 1) * 16], su.sc, su.wd);
-        const double td = offdiag_apply(a, q, Gf, GTf, false, mid, tb[(mid + 1) * 16], sd.sc, sd.wd);
-        d4 A[1] = {su.S}; double in[1] = {tb[mid * 16] + tu + td}, out[1] = {0.0};
-        frag_matvec<16>(A, in, out);
-        if (vec_lane_writer(lane)) tb[mid * 16] = out[0];
-    }
-    __syncthreads();
-    if (wv == 0) half_sweep<false>(a, Tc, Gf, GTf, mid, -1, mid);                   // x_{mid-1} .. x_0
-    else if (wv == 1) half_sweep<false>(a, Tc, Gf, GTf, mid, +1, N - 1 - mid);      // x_{mid+1} .. x_{N-1}
+    TICK(3)
 }
 
 // Tc <- K_xu^-1 Tc (eps already eliminated).  All threads call; barriers inside.  Waves 0 and 1 sweep the two
@@ -830,7 +758,7 @@ __device__ __forceinline__ void kkt_core_sinv(const CoreArgs &a, double *Tc) {
 template <int NB>
 __device__ __forceinline__ void kkt_core(const CoreArgs &a, double *Tc) {
 #ifndef MPCQP_ABL_NOCHAIN
-    if constexpr (SINV16(NB)) kkt_core_sinv(a, Tc); else kkt_core_3slot<NB>(a, Tc);
+    kkt_core_sweeps<NB>(a, Tc);
 #endif
     __syncthreads();
 }
@@ -863,7 +791,7 @@ __device__ __forceinline__ int padded_var(const Lay &L, int k, int a) {
 
 template <int NB>
 __device__ void border_factor(const Ctx &c, const double *om, const double *sv, double cc, const double *F,
-                              double *Bb, double *Zb, double *Sig, double *W, double *Tc, double *red, const double *G) {
+                              double *Bb, double *Zb, double *Sig, double *W, double *Tc, double *red) {
     const Lay &L = c.L;
     const int tid = threadIdx.x, nu = L.nu, NP = L.N * NB;
     const int ub0 = L.ou + (L.Nc - 1) * L.nu;
@@ -875,7 +803,7 @@ __device__ void border_factor(const Ctx &c, const double *om, const double *sv, 
     for (int j = 0; j < nu; ++j) {                         // Z_j = T^-1 B_j
         for (int idx = tid; idx < NP; idx += NT) Tc[idx] = Bb[(size_t)j * NP + idx];
         __syncthreads();
-        kkt_core<NB>(core_args(L, F, om, G), Tc);
+        kkt_core<NB>(core_args(L, F), Tc);
         for (int idx = tid; idx < NP; idx += NT) Zb[(size_t)j * NP + idx] = Tc[idx];
         __syncthreads();
     }
@@ -954,7 +882,7 @@ __device__ void kkt_solve(const Ctx &c, const double *om, const double *sv, doub
     }
     __syncthreads();
     if (L.border) border_pre<NB>(L, bp.Bb, bp.Zb, bp.Sig, Tc, ubar, bp.red);
-    kkt_core<NB>(core_args(L, F, om, bp.G), Tc);
+    kkt_core<NB>(core_args(L, F), Tc);
     if (L.border) border_post(L, NB, Tc, ubar);
     for (int idx = threadIdx.x; idx < L.N * NB; idx += NT) {
         int k = idx / NB, a = idx % NB;
@@ -979,7 +907,7 @@ __device__ __forceinline__ int row_type(double E, double lo, double hi) {
 __device__ __forceinline__ double row_rho(int type, double rho) { return type < 0 ? RHO_MIN : (type > 0 ? RHO_EQ_OVER_RHO_INEQ * rho : rho); }
 
 __device__ __forceinline__ BorderPtrs border_ptrs(const Lay &L, const Ptrs &P, double *red) {
-    BorderPtrs bp; bp.red = red; bp.G = P.G + (size_t)blockIdx.x * 512;
+    BorderPtrs bp; bp.red = red;
     const size_t npb = (size_t)L.nu * L.N * L.NB;
     bp.Bb = L.border ? P.Bb + blockIdx.x * npb : nullptr;
     bp.Zb = L.border ? P.Zb + blockIdx.x * npb : nullptr;
@@ -1086,12 +1014,10 @@ __global__ __launch_bounds__(NT) void k_setup(Lay L, Ptrs P, mpcqp_settings S_) 
 }
 
 // ------------------------------------------------------------------------------------------------
-// The solve is three kernels driven by a short host loop (mpcqp_solve):
-//   k_begin  once per solve : q refresh from (x0, u_{-1}, xref), constraint types, per-solve bookkeeping
-//   k_admm   per round      : check_termination ADMM iterations -- the hot kernel, nothing else in it
-//   k_check  per round      : residuals, termination, infeasibility certificates, rho adaptation + refactor
-// Separate kernels give the hot loop a register allocation of its own (as one fused kernel the cold code
-// pushed it into scratch spills, and a spill reload inside the sweep stalls on vmcnt(0)).
+// A solve has three phases (bodies below; k_mpc_run strings them together per instance):
+//   begin  once per solve : q refresh from (x0, u_{-1}, xref), constraint types, per-solve bookkeeping
+//   admm   per round      : check_termination ADMM iterations -- the hot loop, nothing else in it
+//   check  per round      : residuals, termination, infeasibility certificates, rho adaptation + refactor
 // ------------------------------------------------------------------------------------------------
 enum { COLD_CHECK = 1, COLD_RHO = 2, COLD_FINAL = 4, COLD_PLAIN = 8 };
 
@@ -1123,21 +1049,13 @@ __device__ __forceinline__ void begin_body(const Lay &L, const Ptrs &P, const mp
     if (tid == 0) {
         mpcqp_info inf; inf.status = MPCQP_UNSOLVED; inf.iter = 0; inf.rho_updates = 0; inf.reserved = 0;
         inf.obj_val = 0.0; inf.pri_res = 0.0; inf.dua_res = 0.0; inf.rho = rho;
-        P.info[b] = inf; P.done[b] = 0;
+        P.info[b] = inf;
     }
-}
-
-template <int NB>
-__global__ __launch_bounds__(NT) void k_begin(Lay L, Ptrs P, mpcqp_settings S_, int plain) {
-    extern __shared__ __attribute__((aligned(16))) double sh[];
-    double *p = sh; Smem S; smem_common(L, P, p, S);
-    load_common(L, P.model + (size_t)blockIdx.x * L.model_sz, P.step + (size_t)blockIdx.x * L.step_sz, S);
-    begin_body<NB>(L, P, S_, S, plain);
 }
 
 // Returns 1 (to every thread) if the instance has terminated.
 template <int NB>
-__device__ __forceinline__ int check_body(const Lay &L, const Ptrs &P, const mpcqp_settings &S_, Smem &S, int iter, int mode, int *active_slot) {
+__device__ __forceinline__ int check_body(const Lay &L, const Ptrs &P, const mpcqp_settings &S_, Smem &S, int iter, int mode) {
     const int b = blockIdx.x, tid = threadIdx.x;
     const double *model = P.model + (size_t)b * L.model_sz;
     Ctx c{L, S.hot, model};
@@ -1281,20 +1199,10 @@ __device__ __forceinline__ int check_body(const Lay &L, const Ptrs &P, const mpc
             atomicAdd(&P.stats[0], (unsigned long long)iter); atomicAdd(&P.stats[1], (unsigned long long)inf.reserved);
             atomicAdd(&P.stats[2], (unsigned long long)inf.rho_updates); atomicAdd(&P.stats[3], 1ULL);
             inf.reserved = 0;
-            P.done[b] = 1;
-        } else if (active_slot) atomicAdd(active_slot, 1);
+        }
         P.info[b] = inf;
     }
     return term;
-}
-
-template <int NB>
-__global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_check(Lay L, Ptrs P, mpcqp_settings S_, int iter, int mode, int slot) {
-    if (P.done[blockIdx.x]) return;
-    extern __shared__ __attribute__((aligned(16))) double sh[];
-    double *p = sh; Smem S; smem_common(L, P, p, S);
-    load_common(L, P.model + (size_t)blockIdx.x * L.model_sz, P.step + (size_t)blockIdx.x * L.step_sz, S);
-    check_body<NB>(L, P, S_, S, iter, mode, P.active + slot);
 }
 
 // ---- hot-loop pieces.  NXT/NUT: compile-time nx/nu (0 = take them from the layout at run time).
@@ -1307,12 +1215,22 @@ template <int NUT> __device__ __forceinline__ int divu(const Lay &L, int v) { re
 //   W = omega z - c y                       (rows, flat)
 //   rhs = s x - c q + A' W                  (variables)
 //   te = rhs_eps / kappa -> W[soft row]     Tc[k][a] = rhs_x - omega_soft te  |  rhs_u  |  0 (padding)
+#ifdef MPCQP_ABL_NOGLOBVEC      // ablation: no global vector reads in the parallel phases (timing only, results meaningless)
+#define GV(p, i) (1.0 + 1e-3 * (double)((i) & 7))
+#else
+#define GV(p, i) p[i]
+#endif
+#ifdef MPCQP_ABL_NODIV
+#define DIVIDE(a, b) ((a) * (b))
+#else
+#define DIVIDE(a, b) ((a) / (b))
+#endif
 template <int NB, int NXT, int NUT>
 __device__ __forceinline__ void hot_rhs(const Lay &L, const double *hot, cgdouble *om, cgdouble *sv, cgdouble *qv, double cc,
                                         const double *X, const double *Z, const double *Y, double *W, double *Tc) {
     const int tid = threadIdx.x;
     const int nx = hx<NXT>(L), nu = hu<NUT>(L);
-    for (int r = tid; r < L.m; r += NT) W[r] = om[r] * Z[r] - cc * Y[r];
+    for (int r = tid; r < L.m; r += NT) W[r] = GV(om, r) * Z[r] - cc * Y[r];
     __syncthreads();
     const double *Ad = hot + L.oAd, *Bd = hot + L.oBd;
     const double cef = cc * hot[L.oeps];
@@ -1321,7 +1239,7 @@ __device__ __forceinline__ void hot_rhs(const Lay &L, const double *hot, cgdoubl
         double v = 0.0;
         if (a < nx) {
             const int e = k * nx + a;
-            double rx = sv[e] * X[e] - cc * qv[e] - W[e];
+            double rx = GV(sv, e) * X[e] - cc * GV(qv, e) - W[e];
             if (k < L.Np) {
                 const double *w1 = W + (k + 1) * nx;
 #pragma unroll
@@ -1329,13 +1247,13 @@ __device__ __forceinline__ void hot_rhs(const Lay &L, const double *hot, cgdoubl
                 if (!NXT) for (int r = 0; r < nx; ++r) rx += Ad[r * nx + a] * w1[r];
             }
             const double wsoft = W[L.rs + e];
-            const double ws = om[L.rs + e];
-            const double te = (sv[L.oe + e] * X[L.oe + e] + wsoft) / (cef + sv[L.oe + e] + ws);
+            const double ws = GV(om, L.rs + e);
+            const double te = DIVIDE(GV(sv, L.oe + e) * X[L.oe + e] + wsoft, cef + GV(sv, L.oe + e) + ws);
             W[L.rs + e] = te;                      // only this thread ever reads W[soft row e]
             v = rx + wsoft - ws * te;
         } else if (a < nx + nu && k < L.Nc) {
             const int jj = a - nx, cu = k * nu + jj;
-            double ru = sv[L.ou + cu] * X[L.ou + cu] - cc * qv[L.n_x + cu] + W[L.ri + cu] - W[L.rdu + nu + cu];
+            double ru = GV(sv, L.ou + cu) * X[L.ou + cu] - cc * GV(qv, L.n_x + cu) + W[L.ri + cu] - W[L.rdu + nu + cu];
             if (k == 0) ru += W[L.rdu + jj];
             if (cu > 0) ru += W[L.rdu + nu + cu - 1];
             const int s_end = (k == L.Nc - 1) ? L.Np : k + 1;
@@ -1363,9 +1281,9 @@ __device__ __forceinline__ void hot_update(const Lay &L, const double *hot, cons
     // eps_t = te - (omega_soft / kappa) x_t ; x update for the x and eps variables
     for (int e = tid; e < L.n_x; e += NT) {
         const int k = divx<NXT>(L, e), i = e - k * nx;
-        const double ws = om[L.rs + e];
+        const double ws = GV(om, L.rs + e);
         const double xt = Tc[k * NB + i];
-        const double et = W[L.rs + e] - (ws / (cef + sv[L.oe + e] + ws)) * xt;
+        const double et = W[L.rs + e] - DIVIDE(ws, cef + GV(sv, L.oe + e) + ws) * xt;
         W[L.rs + e] = et;
         const double xo = X[e], eo = X[L.oe + e];
         const double xn = alpha * xt + (1.0 - alpha) * xo, en = alpha * et + (1.0 - alpha) * eo;
@@ -1418,9 +1336,9 @@ __device__ __forceinline__ void hot_update(const Lay &L, const double *hot, cons
         lo = lo < -QP_INFTY ? -QP_INFTY : lo;
         hi = hi > QP_INFTY ? QP_INFTY : hi;
         const double zr = alpha * zt + (1.0 - alpha) * zv;
-        const double w = om[r];
-        const double zn = fmin(fmax(zr + cc * yv / w, lo), hi);
-        const double dy = (w / cc) * (zr - zn);
+        const double w = GV(om, r);
+        const double zn = fmin(fmax(zr + DIVIDE(cc * yv, w), lo), hi);
+        const double dy = DIVIDE(w, cc) * (zr - zn);
         yv += dy; zv = zn;
         if (keep_delta) dyg[r] = dy;
     };
@@ -1446,37 +1364,28 @@ __device__ __forceinline__ void admm_body(const Lay &L, const HotPtrs &P, Smem &
     const double cc = P.c[b];
     for (int it = 1; it <= iters; ++it) {
         const bool keep_delta = it == iters;         // the increments feed the infeasibility certificates of the check
+        TICK_START
 #ifndef MPCQP_ABL_NOPAR
         hot_rhs<NB, NXT, NUT>(L, S.hot, gom, gsv, gqv, cc, X, Z, Y, W, Tc);
 #endif
+        TICK(0)
         BorderPtrs bp; bp.red = S.red;
         if (BORDER) {
             const size_t npb = (size_t)L.nu * L.N * L.NB;
             bp.Bb = (double *)P.Bb + blockIdx.x * npb; bp.Zb = (double *)P.Zb + blockIdx.x * npb; bp.Sig = (double *)P.Sig + (size_t)blockIdx.x * L.nu * L.nu;
         }
         if (BORDER) border_pre<NB>(L, bp.Bb, bp.Zb, bp.Sig, Tc, S.tv, S.red);
-        kkt_core<NB>(core_args(L, opaque_ptr(F), opaque_ptr((const double *)gom), opaque_ptr(P.G + (size_t)b * 512)), Tc);
+        kkt_core<NB>(core_args(L, opaque_ptr(F)), Tc);
         if (BORDER) border_post(L, NB, Tc, S.tv);
 #ifndef MPCQP_ABL_NOPAR
         hot_update<NB, NXT, NUT>(L, S.hot, S.x0s, S.um1s, gom, gsv, cc, alpha, X, Z, Y, W, Tc, keep_delta, dxg, dyg);
 #endif
+        TICK(4)
     }
     if (LDSSTATE) {
         for (int j = tid; j < L.n; j += NT) gx[j] = X[j];
         for (int r = tid; r < L.m; r += NT) { gz[r] = Z[r]; gy[r] = Y[r]; }
     }
-}
-
-// The hot kernel: `iters` ADMM iterations of every instance that is not finished yet.
-template <int NB, bool LDSSTATE, int NXT, int NUT, bool BORDER>
-__global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_admm(Lay L, HotPtrs P, double alpha, int iters) {
-    if (P.done[blockIdx.x]) return;
-    extern __shared__ __attribute__((aligned(16))) double sh[];
-    double *p = sh; Smem S; smem_common(L, P, p, S);
-    double *X = nullptr, *Z = nullptr, *Y = nullptr;
-    if (LDSSTATE) { X = carve(p, L.n); Z = carve(p, L.m); Y = carve(p, L.m); }
-    load_common(L, P.model + (size_t)blockIdx.x * L.model_sz, P.step + (size_t)blockIdx.x * L.step_sz, S);
-    admm_body<NB, LDSSTATE, NXT, NUT, BORDER>(L, P, S, X, Z, Y, alpha, iters);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1485,10 +1394,13 @@ __global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_admm(Lay L, HotPtrs 
 // One workgroup walks its own instance through all K steps -- output (mpc.py:271-336, u_failure = uref unless
 // 'solved'), plant, QP refresh (mpc.py:386-454), warm-started solve -- with no host round trip and, unlike the
 // per-step API, no batch-wide barrier per round: an instance that needs 50 iterations does not hold up one that
-// needs 25.  The phase bodies are the ones of k_begin / k_admm / k_check.
+// needs 25.  The same kernel with nsteps = 0 is
+// mpcqp_solve: begin, rounds of { admm, check } until this instance terminates -- no host loop, no batch barrier.
 // ------------------------------------------------------------------------------------------------
 struct RunArgs {
-    int nsteps, max_iter, chk, rho_every;
+    int nsteps;                   // closed-loop steps (LOOP kernels); 0 = one solve of the current data (mpcqp_solve)
+    int plain;                    // run exactly max_iter iterations, no termination test / rho adaptation (mpcqp_iterate)
+    int max_iter, chk, rho_every;
     const double *w;              // [nsteps][batch][nx] additive plant disturbance, or null
     const double *Ap, *Bp;        // [batch][nx*nx], [batch][nx*nu] plant matrices, or null (plant = model Ad, Bd)
     double *x_traj;               // [nsteps+1][batch][nx]
@@ -1540,26 +1452,26 @@ __device__ __noinline__ void run_admm_phase(int iters) {
     const RunKArgs &A = run_kargs();
     const Lay &L = A.L; const Ptrs &P = A.P;
     RunSmem r = run_smem<LDSSTATE>(L, P);
-    HotPtrs hp; hp.model = P.model; hp.step = P.step; hp.omega = P.omega; hp.s = P.s; hp.qv = P.qv; hp.F = P.F; hp.c = P.c; hp.G = P.G;
-    hp.Bb = P.Bb; hp.Zb = P.Zb; hp.Sig = P.Sig; hp.x = P.x; hp.z = P.z; hp.y = P.y; hp.dx = P.dx; hp.dy = P.dy; hp.done = P.done; hp.fsz = P.fsz;
+    HotPtrs hp; hp.model = P.model; hp.step = P.step; hp.omega = P.omega; hp.s = P.s; hp.qv = P.qv; hp.F = P.F; hp.c = P.c;
+    hp.Bb = P.Bb; hp.Zb = P.Zb; hp.Sig = P.Sig; hp.x = P.x; hp.z = P.z; hp.y = P.y; hp.dx = P.dx; hp.dy = P.dy; hp.fsz = P.fsz;
     admm_body<NB, LDSSTATE, NXT, NUT, BORDER>(L, hp, r.S, r.X, r.Z, r.Y, A.S.alpha, __builtin_amdgcn_readfirstlane(iters));
 }
 
 template <int NB, bool LDSSTATE>
-__device__ __noinline__ void run_begin_phase() {
+__device__ __noinline__ void run_begin_phase(int plain) {
     const RunKArgs &A = run_kargs();
     RunSmem r = run_smem<LDSSTATE>(A.L, A.P);
-    begin_body<NB>(A.L, A.P, A.S, r.S, 0);
+    begin_body<NB>(A.L, A.P, A.S, r.S, __builtin_amdgcn_readfirstlane(plain));
 }
 
 template <int NB, bool LDSSTATE>
 __device__ __noinline__ int run_check_phase(int iter, int mode) {
     const RunKArgs &A = run_kargs();
     RunSmem r = run_smem<LDSSTATE>(A.L, A.P);
-    return check_body<NB>(A.L, A.P, A.S, r.S, __builtin_amdgcn_readfirstlane(iter), __builtin_amdgcn_readfirstlane(mode), nullptr);
+    return check_body<NB>(A.L, A.P, A.S, r.S, __builtin_amdgcn_readfirstlane(iter), __builtin_amdgcn_readfirstlane(mode));
 }
 
-template <int NB, bool LDSSTATE, int NXT, int NUT, bool BORDER>
+template <int NB, bool LDSSTATE, int NXT, int NUT, bool BORDER, bool LOOP>
 __global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_mpc_run(RunKArgs A_) {
     const RunKArgs &A = run_kargs();
     const Lay &L = A.L; const Ptrs &P = A.P; const RunArgs &R = A.R;
@@ -1569,47 +1481,59 @@ __global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_mpc_run(RunKArgs A_)
     double *step = P.step + (size_t)b * L.step_sz;
     load_common(L, P.model + (size_t)b * L.model_sz, step, S);
     const int nx = L.nx, nu = L.nu;
-    for (int k = 0; k < R.nsteps; ++k) {
-        // ---- output(): first input of the current solution, or u_failure
-        const int status = P.info[b].status;
-        double *un = S.tv, *xn = S.tv + nu;              // (nx + nu <= 32 < 64)
-        if (tid < nu) un[tid] = status == MPCQP_SOLVED ? P.xo[(size_t)b * L.n + L.ou + tid] : S.hot[L.ouref + tid];
-        __syncthreads();
-        // ---- plant step
-        if (tid < nx) {
-            const double *Ap = R.Ap ? R.Ap + (size_t)b * nx * nx : S.hot + L.oAd;
-            const double *Bp = R.Bp ? R.Bp + (size_t)b * nx * nu : S.hot + L.oBd;
-            double v = R.w ? R.w[((size_t)k * R.batch + b) * nx + tid] : 0.0;
-            double acc = 0.0;
-            for (int j = 0; j < nx; ++j) acc += Ap[tid * nx + j] * S.x0s[j];
-            for (int j = 0; j < nu; ++j) acc += Bp[tid * nu + j] * un[j];
-            xn[tid] = acc + v;
-            R.x_traj[((size_t)k * R.batch + b) * nx + tid] = S.x0s[tid];
+    const int nrun = LOOP ? R.nsteps : 1;        // LOOP = false: one solve of the current data (mpcqp_solve)
+    for (int k = 0; k < nrun; ++k) {
+        if (LOOP) {
+            // ---- output(): first input of the current solution, or u_failure
+            const int status = P.info[b].status;
+            double *un = S.tv, *xn = S.tv + nu;              // (nx + nu <= 32 < 64)
+            if (tid < nu) un[tid] = status == MPCQP_SOLVED ? P.xo[(size_t)b * L.n + L.ou + tid] : S.hot[L.ouref + tid];
+            __syncthreads();
+            // ---- plant step
+            if (tid < nx) {
+                const double *Ap = R.Ap ? R.Ap + (size_t)b * nx * nx : S.hot + L.oAd;
+                const double *Bp = R.Bp ? R.Bp + (size_t)b * nx * nu : S.hot + L.oBd;
+                double v = R.w ? R.w[((size_t)k * R.batch + b) * nx + tid] : 0.0;
+                double acc = 0.0;
+                for (int j = 0; j < nx; ++j) acc += Ap[tid * nx + j] * S.x0s[j];
+                for (int j = 0; j < nu; ++j) acc += Bp[tid * nu + j] * un[j];
+                xn[tid] = acc + v;
+                R.x_traj[((size_t)k * R.batch + b) * nx + tid] = S.x0s[tid];
+            }
+            if (tid < nu) R.u_traj[((size_t)k * R.batch + b) * nu + tid] = un[tid];
+            __syncthreads();
+            // ---- update(x): new initial state and previous input (mpc.py:338-364)
+            if (tid < nx) { S.x0s[tid] = xn[tid]; step[tid] = xn[tid]; }
+            if (tid < nu) { S.um1s[tid] = un[tid]; step[nx + tid] = un[tid]; }
+            __syncthreads();
         }
-        if (tid < nu) R.u_traj[((size_t)k * R.batch + b) * nu + tid] = un[tid];
+#ifdef MPCQP_RUN_TIMING
+#define PHASE_CLOCK(i) { unsigned long long t_ = wall_clock64(); if (tid == 0) atomicAdd(&P.stats[4 + (i)], t_ - tphase); tphase = t_; }
+        unsigned long long tphase = wall_clock64();
+#else
+#define PHASE_CLOCK(i)
+#endif
+        run_begin_phase<NB, LDSSTATE>(R.plain);
         __syncthreads();
-        // ---- update(x): new initial state and previous input (mpc.py:338-364)
-        if (tid < nx) { S.x0s[tid] = xn[tid]; step[tid] = xn[tid]; }
-        if (tid < nu) { S.um1s[tid] = un[tid]; step[nx + tid] = un[tid]; }
-        __syncthreads();
-        run_begin_phase<NB, LDSSTATE>();
-        __syncthreads();
+        PHASE_CLOCK(0)
         int iter = 0, term = 0;
         while (!term) {
             const int nxt = next_stop(iter, R.max_iter, R.chk, R.rho_every);
             run_admm_phase<NB, LDSSTATE, NXT, NUT, BORDER>(nxt - iter);
             iter = nxt;
             __syncthreads();
-            term = run_check_phase<NB, LDSSTATE>(iter, stop_mode(iter, R.max_iter, R.chk, R.rho_every, false));
+            PHASE_CLOCK(1)
+            term = run_check_phase<NB, LDSSTATE>(iter, stop_mode(iter, R.max_iter, R.chk, R.rho_every, R.plain != 0));
             __syncthreads();
+            PHASE_CLOCK(2)
         }
-        if (tid == 0) {
+        if (LOOP && tid == 0) {
             R.status_traj[(size_t)k * R.batch + b] = P.info[b].status;
             R.iter_traj[(size_t)k * R.batch + b] = iter;
         }
         __syncthreads();
     }
-    if (tid < nx) R.x_traj[((size_t)R.nsteps * R.batch + b) * nx + tid] = S.x0s[tid];
+    if (LOOP && tid < nx) R.x_traj[((size_t)R.nsteps * R.batch + b) * nx + tid] = S.x0s[tid];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1659,15 +1583,15 @@ struct mpcqp_handle {
     hipStream_t stream;
     bool own_stream, is_setup, lds_state;
     size_t smem_setup, smem_solve;
-    int last_rounds;              // rounds the previous solve needed (that many are enqueued without a host sync)
     std::vector<void *> allocs;
     double *u0_dev;
     void *run_buf; size_t run_bytes;     // staging of mpcqp_mpc_run (disturbances, plant, trajectories)
-    int *active_host;             // pinned
     bool profiling;
-    hipEvent_t ev0[8], ev1[8];
-    double admm_ms;
-    long long admm_launches;
+    hipEvent_t ev0[MAXEV], ev1[MAXEV];   // ring of event pairs around the solve-kernel launches
+    long long ev_count;
+    double run_ms;
+    long long run_launches;
+    bool have_events;
 };
 
 extern "C" void mpcqp_default_settings(mpcqp_settings *s) {
@@ -1721,7 +1645,7 @@ static Lay make_layout(int nx, int nu, int Np, int Nc) {
     L.model_sz = o;
     L.step_sz = nx + nu + L.N * nx;
     L.xref_rows = 1;
-    L.fstage = (SINV16(L.NB) ? 1 : 3) * L.NB * L.NB;
+    L.fstage = 2 * L.NB * L.NB;
     L.tsz = (L.m + L.N * L.NB) > 6 * L.NB * L.NB ? (L.m + L.N * L.NB) : 6 * L.NB * L.NB;   // [W (m) | Tc (N*NB)] or factor workspace
     return L;
 }
@@ -1745,13 +1669,13 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     HIPCHK(hipSetDevice(device));
     mpcqp_handle *h = new mpcqp_handle();
     h->device = device; h->batch = batch; h->is_setup = false; h->u0_dev = nullptr; h->run_buf = nullptr; h->run_bytes = 0;
-    h->active_host = nullptr; h->profiling = false; h->admm_ms = 0.0; h->admm_launches = 0;
+    h->profiling = false; h->run_ms = 0.0; h->run_launches = 0; h->ev_count = 0; h->have_events = false;
     h->L = make_layout(nx, nu, Np, Nc);
     if (s) h->S = *s; else mpcqp_default_settings(&h->S);
     HIPCHK(hipStreamCreate(&h->stream));
     h->own_stream = true;
-    HIPCHK(hipHostMalloc((void **)&h->active_host, MAXEV * sizeof(int)));
     for (int e = 0; e < MAXEV; ++e) { HIPCHK(hipEventCreate(&h->ev0[e])); HIPCHK(hipEventCreate(&h->ev1[e])); }
+    h->have_events = true;
     const Lay &L = h->L;
     Ptrs &P = h->P; memset(&P, 0, sizeof(P));
     size_t B = (size_t)batch;
@@ -1765,18 +1689,15 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     rc |= dalloc(h, &P.xo, B * L.n); rc |= dalloc(h, &P.yo, B * L.m);
     rc |= dalloc(h, &P.dx, B * L.n); rc |= dalloc(h, &P.dy, B * L.m);
     rc |= dalloc(h, &P.qv, B * (size_t)(L.n_x + L.n_u));
-    rc |= dalloc(h, &P.G, B * 512);
     if (L.border) { rc |= dalloc(h, &P.Bb, B * (size_t)L.nu * L.N * L.NB); rc |= dalloc(h, &P.Zb, B * (size_t)L.nu * L.N * L.NB); rc |= dalloc(h, &P.Sig, B * (size_t)L.nu * L.nu); }
     rc |= dalloc(h, &P.Dt, B * L.n); rc |= dalloc(h, &P.Et, B * L.m);
     rc |= dalloc(h, &P.ctype, B * L.m); rc |= dalloc(h, &P.info, B); rc |= dalloc(h, &P.stats, 8);
-    rc |= dalloc(h, &P.done, B); rc |= dalloc(h, &P.active, MAXEV);
-    rc |= dalloc(h, &h->u0_dev, B * L.nu);
+        rc |= dalloc(h, &h->u0_dev, B * L.nu);
     if (rc) { mpcqp_destroy(h); return MPCQP_ERR_HIP; }
     h->smem_setup = sizeof(double) * (size_t)smem_common_doubles(L);
     size_t with_state = h->smem_setup + sizeof(double) * (size_t)(L.n + 2 * L.m);
     h->lds_state = with_state <= 40 * 1024;      // four workgroups per CU; larger problems keep the iterate in L2/HBM   // small problems: x in LDS, z/y in registers; else iterate in L2/HBM
     h->smem_solve = h->lds_state ? with_state : h->smem_setup;
-    h->last_rounds = 1;
     if (h->smem_solve > 160 * 1024) { mpcqp_destroy(h); return fail(MPCQP_ERR_UNSUPPORTED, "problem too large for one workgroup's LDS"); }
     *out = h;
     return MPCQP_OK;
@@ -1788,7 +1709,7 @@ extern "C" void mpcqp_destroy(mpcqp_handle *h) {
     hipStreamSynchronize(h->stream);
     for (void *p : h->allocs) hipFree(p);
     if (h->run_buf) hipFree(h->run_buf);
-    if (h->active_host) { hipHostFree(h->active_host); for (int e = 0; e < MAXEV; ++e) { hipEventDestroy(h->ev0[e]); hipEventDestroy(h->ev1[e]); } }
+    if (h->have_events) for (int e = 0; e < MAXEV; ++e) { hipEventDestroy(h->ev0[e]); hipEventDestroy(h->ev1[e]); }
     if (h->own_stream) hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1880,84 +1801,67 @@ extern "C" int mpcqp_update_settings(mpcqp_handle *h, const mpcqp_settings *s) {
 }
 
 template <int NB, bool LDSS, int NXT, int NUT, bool BORDER>
-static int launch_admm_t(mpcqp_handle *h, int iters) {
-    if (set_smem(k_admm<NB, LDSS, NXT, NUT, BORDER>, h->smem_solve)) return MPCQP_ERR_HIP;
-    const Ptrs &P = h->P;
-    HotPtrs hp; hp.model = P.model; hp.step = P.step; hp.omega = P.omega; hp.s = P.s; hp.qv = P.qv; hp.F = P.F; hp.c = P.c; hp.G = P.G;
-    hp.Bb = P.Bb; hp.Zb = P.Zb; hp.Sig = P.Sig; hp.x = P.x; hp.z = P.z; hp.y = P.y; hp.dx = P.dx; hp.dy = P.dy; hp.done = P.done; hp.fsz = P.fsz;
-    hipLaunchKernelGGL((k_admm<NB, LDSS, NXT, NUT, BORDER>), dim3(h->batch), dim3(NT), h->smem_solve, h->stream, h->L, hp, h->S.alpha, iters);
+static int launch_run_t(mpcqp_handle *h, const RunArgs &R) {
+    RunKArgs A; A.L = h->L; A.P = h->P; A.S = h->S; A.R = R;
+    if (R.nsteps > 0) {
+        if (set_smem(k_mpc_run<NB, LDSS, NXT, NUT, BORDER, true>, h->smem_solve)) return MPCQP_ERR_HIP;
+        hipLaunchKernelGGL((k_mpc_run<NB, LDSS, NXT, NUT, BORDER, true>), dim3(h->batch), dim3(NT), h->smem_solve, h->stream, A);
+    } else {
+        if (set_smem(k_mpc_run<NB, LDSS, NXT, NUT, BORDER, false>, h->smem_solve)) return MPCQP_ERR_HIP;
+        hipLaunchKernelGGL((k_mpc_run<NB, LDSS, NXT, NUT, BORDER, false>), dim3(h->batch), dim3(NT), h->smem_solve, h->stream, A);
+    }
     return 0;
 }
-
 template <int NB, bool LDSS>
-static int launch_admm_generic(mpcqp_handle *h, int iters) {
-    return h->L.border ? launch_admm_t<NB, LDSS, 0, 0, true>(h, iters) : launch_admm_t<NB, LDSS, 0, 0, false>(h, iters);
+static int launch_run_generic(mpcqp_handle *h, const RunArgs &R) {
+    return h->L.border ? launch_run_t<NB, LDSS, 0, 0, true>(h, R) : launch_run_t<NB, LDSS, 0, 0, false>(h, R);
 }
 
-static int launch_admm(mpcqp_handle *h, int iters) {
-    const Lay &L = h->L;
-    // specialisations with compile-time nx, nu for the BASELINE configurations; generic kernels otherwise
-    if (L.NB == 16 && h->lds_state && L.nx == 12 && L.nu == 4 && !L.border) return launch_admm_t<16, true, 12, 4, false>(h, iters);
-    if (L.NB == 32 && !h->lds_state && L.nx == 20 && L.nu == 8 && !L.border) return launch_admm_t<32, false, 20, 8, false>(h, iters);
-    if (L.NB == 16) return h->lds_state ? launch_admm_generic<16, true>(h, iters) : launch_admm_generic<16, false>(h, iters);
-    return h->lds_state ? launch_admm_generic<32, true>(h, iters) : launch_admm_generic<32, false>(h, iters);
+// One launch of the solve / closed-loop kernel on the handle's stream (asynchronous).  Specialisations with
+// compile-time nx, nu for the BASELINE configurations; generic kernels otherwise.
+static int launch_run(mpcqp_handle *h, RunArgs R, int plain_iters) {
+    const Lay &L = h->L; const mpcqp_settings &S = h->S;
+    R.plain = plain_iters > 0;
+    R.max_iter = R.plain ? plain_iters : S.max_iter;
+    R.chk = R.plain ? 0 : S.check_termination;
+    R.rho_every = (!R.plain && S.adaptive_rho) ? (S.adaptive_rho_interval ? S.adaptive_rho_interval : (R.chk ? 4 * R.chk : 100)) : 0;
+    R.batch = h->batch;
+    const int e = h->ev_count % MAXEV;
+    if (h->profiling) {
+        if (h->ev_count >= MAXEV) {                 // ring full: bank the oldest pair first
+            float ms = 0.f; HIPCHK(hipEventSynchronize(h->ev1[e])); HIPCHK(hipEventElapsedTime(&ms, h->ev0[e], h->ev1[e]));
+            h->run_ms += ms; h->run_launches += 1;
+        }
+        HIPCHK(hipEventRecord(h->ev0[e], h->stream));
+    }
+    int rc;
+    if (L.NB == 16 && h->lds_state && L.nx == 12 && L.nu == 4 && !L.border) rc = launch_run_t<16, true, 12, 4, false>(h, R);
+    else if (L.NB == 32 && !h->lds_state && L.nx == 20 && L.nu == 8 && !L.border) rc = launch_run_t<32, false, 20, 8, false>(h, R);
+    else if (L.NB == 16) rc = h->lds_state ? launch_run_generic<16, true>(h, R) : launch_run_generic<16, false>(h, R);
+    else rc = h->lds_state ? launch_run_generic<32, true>(h, R) : launch_run_generic<32, false>(h, R);
+    if (rc) return rc;
+    HIPCHK(hipGetLastError());
+    if (h->profiling) { HIPCHK(hipEventRecord(h->ev1[e], h->stream)); h->ev_count += 1; }
+    return MPCQP_OK;
 }
 
-// One solve of every instance: k_begin, then rounds of { k_admm (iterations up to the next termination /
-// rho-adaptation point), k_check } until no instance is left running.  Returns when the solve is complete.
+// Collect the pending event pairs (synchronises on them).
+static int drain_events(mpcqp_handle *h) {
+    const int pending = h->ev_count < MAXEV ? h->ev_count : MAXEV;
+    for (int i = 0; i < pending; ++i) {
+        const int e = (h->ev_count - pending + i) % MAXEV;
+        float ms = 0.f; HIPCHK(hipEventSynchronize(h->ev1[e])); HIPCHK(hipEventElapsedTime(&ms, h->ev0[e], h->ev1[e]));
+        h->run_ms += ms; h->run_launches += 1;
+    }
+    h->ev_count = 0;
+    return MPCQP_OK;
+}
+
 static int launch_solve(mpcqp_handle *h, int plain_iters) {
     if (!h->is_setup) return fail(MPCQP_ERR_STATE, "solve before mpcqp_setup");
     HIPCHK(hipSetDevice(h->device));
-    const Lay &L = h->L;
-    const mpcqp_settings &S = h->S;
-    const bool plain = plain_iters > 0;
-    DISPATCH_NB(L.NB, {
-        if (set_smem(k_begin<NB>, h->smem_setup)) return MPCQP_ERR_HIP;
-        if (set_smem(k_check<NB>, h->smem_setup)) return MPCQP_ERR_HIP;
-        hipLaunchKernelGGL(k_begin<NB>, dim3(h->batch), dim3(NT), h->smem_setup, h->stream, h->L, h->P, h->S, (int)plain);
-    });
-    const int max_iter = plain ? plain_iters : S.max_iter;
-    const int chk = plain ? 0 : S.check_termination;
-    int rho_every = 0;
-    if (!plain && S.adaptive_rho) rho_every = S.adaptive_rho_interval ? S.adaptive_rho_interval : (chk ? 4 * chk : 100);
-    // Rounds are enqueued back to back; the host only looks at the "still running" counter after as many rounds as
-    // the previous solve needed (kernels of finished instances exit at once, so an over-estimate costs two empty
-    // launches, an under-estimate one extra round trip).
-    int iter = 0, rounds = 0, unsynced = 0, needed = 0;
-    bool finished = false;
-    while (iter < max_iter && !finished) {
-        int nxt = max_iter;
-        if (chk) nxt = std::min(nxt, (iter / chk + 1) * chk);
-        if (rho_every) nxt = std::min(nxt, (iter / rho_every + 1) * rho_every);
-        if (unsynced == 0) HIPCHK(hipMemsetAsync(h->P.active, 0, MAXEV * sizeof(int), h->stream));
-        if (h->profiling) HIPCHK(hipEventRecord(h->ev0[unsynced], h->stream));
-        int rc = launch_admm(h, nxt - iter);
-        if (rc) return rc;
-        if (h->profiling) HIPCHK(hipEventRecord(h->ev1[unsynced], h->stream));
-        iter = nxt;
-        int mode = plain ? COLD_PLAIN : 0;
-        if (chk && iter % chk == 0) mode |= COLD_CHECK;
-        if (rho_every && iter % rho_every == 0) mode |= COLD_RHO;
-        if (iter == max_iter && !plain) mode |= COLD_FINAL;
-        DISPATCH_NB(L.NB, { hipLaunchKernelGGL(k_check<NB>, dim3(h->batch), dim3(NT), h->smem_setup, h->stream, h->L, h->P, h->S, iter, mode, unsynced); });
-        ++rounds; ++unsynced;
-        if (rounds >= h->last_rounds || iter >= max_iter || unsynced == MAXEV) {
-            HIPCHK(hipMemcpyAsync(h->active_host, h->P.active, MAXEV * sizeof(int), hipMemcpyDeviceToHost, h->stream));
-            HIPCHK(hipStreamSynchronize(h->stream));
-            for (int e = 0; e < unsynced && !finished; ++e) {
-                if (h->profiling) {
-                    float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, h->ev0[e], h->ev1[e]));
-                    h->admm_ms += ms; h->admm_launches += 1;
-                }
-                ++needed;
-                finished = h->active_host[e] == 0;            // later rounds of this group were empty launches
-            }
-            unsynced = 0;
-        }
-    }
-    h->last_rounds = std::max(1, needed);
-    HIPCHK(hipGetLastError());
-    return MPCQP_OK;
+    RunArgs R; memset(&R, 0, sizeof(R));
+    return launch_run(h, R, plain_iters);
 }
 
 extern "C" int mpcqp_solve(mpcqp_handle *h) { if (!h) return fail(MPCQP_ERR_ARG, "null handle"); return launch_solve(h, 0); }
@@ -1972,25 +1876,13 @@ static int get(mpcqp_handle *h, void *dst, const void *src, size_t bytes) {
     return 0;
 }
 
-template <int NB, bool LDSS, int NXT, int NUT, bool BORDER>
-static int launch_run_t(mpcqp_handle *h, const RunArgs &R) {
-    if (set_smem(k_mpc_run<NB, LDSS, NXT, NUT, BORDER>, h->smem_solve)) return MPCQP_ERR_HIP;
-    RunKArgs A; A.L = h->L; A.P = h->P; A.S = h->S; A.R = R;
-    hipLaunchKernelGGL((k_mpc_run<NB, LDSS, NXT, NUT, BORDER>), dim3(h->batch), dim3(NT), h->smem_solve, h->stream, A);
-    return 0;
-}
-template <int NB, bool LDSS>
-static int launch_run_generic(mpcqp_handle *h, const RunArgs &R) {
-    return h->L.border ? launch_run_t<NB, LDSS, 0, 0, true>(h, R) : launch_run_t<NB, LDSS, 0, 0, false>(h, R);
-}
-
 extern "C" int mpcqp_mpc_run(mpcqp_handle *h, int nsteps, const double *w, const double *Ap, const double *Bp,
                              double *x_traj, double *u_traj, int32_t *status_traj, int32_t *iter_traj) {
     if (!h || nsteps < 1) return fail(MPCQP_ERR_ARG, "mpcqp_mpc_run: bad argument");
     if (!h->is_setup) return fail(MPCQP_ERR_STATE, "mpcqp_mpc_run before mpcqp_setup");
     if ((Ap == nullptr) != (Bp == nullptr)) return fail(MPCQP_ERR_ARG, "mpcqp_mpc_run: give both Ap and Bp or neither");
     HIPCHK(hipSetDevice(h->device));
-    const Lay &L = h->L; const mpcqp_settings &S = h->S;
+    const Lay &L = h->L;
     const size_t B = (size_t)h->batch, K = (size_t)nsteps;
     // one staging block: [w | Ap | Bp | x_traj | u_traj | status | iter]
     const size_t nw = w ? K * B * L.nx : 0, nA = Ap ? B * L.nx * L.nx : 0, nBp = Bp ? B * L.nx * L.nu : 0;
@@ -2010,18 +1902,12 @@ extern "C" int mpcqp_mpc_run(mpcqp_handle *h, int nsteps, const double *w, const
     if (w) HIPCHK(hipMemcpyAsync(dw, w, sizeof(double) * nw, hipMemcpyDefault, h->stream));
     if (Ap) { HIPCHK(hipMemcpyAsync(dA, Ap, sizeof(double) * nA, hipMemcpyDefault, h->stream));
               HIPCHK(hipMemcpyAsync(dB, Bp, sizeof(double) * nBp, hipMemcpyDefault, h->stream)); }
-    RunArgs R;
-    R.nsteps = nsteps; R.max_iter = S.max_iter; R.chk = S.check_termination;
-    R.rho_every = S.adaptive_rho ? (S.adaptive_rho_interval ? S.adaptive_rho_interval : (R.chk ? 4 * R.chk : 100)) : 0;
+    RunArgs R; memset(&R, 0, sizeof(R));
+    R.nsteps = nsteps;
     R.w = w ? dw : nullptr; R.Ap = Ap ? dA : nullptr; R.Bp = Bp ? dB : nullptr;
-    R.x_traj = dx; R.u_traj = du; R.status_traj = dst; R.iter_traj = dit; R.batch = h->batch;
-    int rc;
-    if (L.NB == 16 && h->lds_state && L.nx == 12 && L.nu == 4 && !L.border) rc = launch_run_t<16, true, 12, 4, false>(h, R);
-    else if (L.NB == 32 && !h->lds_state && L.nx == 20 && L.nu == 8 && !L.border) rc = launch_run_t<32, false, 20, 8, false>(h, R);
-    else if (L.NB == 16) rc = h->lds_state ? launch_run_generic<16, true>(h, R) : launch_run_generic<16, false>(h, R);
-    else rc = h->lds_state ? launch_run_generic<32, true>(h, R) : launch_run_generic<32, false>(h, R);
+    R.x_traj = dx; R.u_traj = du; R.status_traj = dst; R.iter_traj = dit;
+    int rc = launch_run(h, R, 0);
     if (rc) return rc;
-    HIPCHK(hipGetLastError());
     if (get(h, x_traj, dx, sizeof(double) * nxt) || get(h, u_traj, du, sizeof(double) * nut) ||
         get(h, status_traj, dst, sizeof(int) * nst) || get(h, iter_traj, dit, sizeof(int) * nst)) return MPCQP_ERR_HIP;
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -2053,17 +1939,25 @@ extern "C" int mpcqp_get_stats(mpcqp_handle *h, uint64_t *out4, int reset) {
     if (!h || !out4) return fail(MPCQP_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->device));
     HIPCHK(hipMemcpyAsync(out4, h->P.stats, 4 * sizeof(uint64_t), hipMemcpyDefault, h->stream));
-    if (reset) HIPCHK(hipMemsetAsync(h->P.stats, 0, 4 * sizeof(uint64_t), h->stream));
+#ifdef MPCQP_RUN_TIMING
+    { uint64_t t[4]; hipMemcpy(t, h->P.stats + 4, sizeof(t), hipMemcpyDeviceToHost); fprintf(stderr, "phase wall-clock ticks: begin %llu admm %llu check %llu\n", (unsigned long long)t[0], (unsigned long long)t[1], (unsigned long long)t[2]);
+      unsigned long long g[16]; hipMemcpyFromSymbol(g, HIP_SYMBOL(g_ticks), sizeof(g)); unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_ticks), z, sizeof(z));
+      fprintf(stderr, "iteration ticks: rhs %llu fwd %llu sinv %llu bwd %llu (kkt tail in update) update %llu\n", g[0], g[1], g[2], g[3], g[4]); }
+#endif
+    if (reset) HIPCHK(hipMemsetAsync(h->P.stats, 0, 8 * sizeof(uint64_t), h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return MPCQP_OK;
 }
 
-extern "C" int mpcqp_profile(mpcqp_handle *h, int enable, double *admm_ms, int64_t *admm_launches, int reset) {
+extern "C" int mpcqp_profile(mpcqp_handle *h, int enable, double *run_ms, int64_t *run_launches, int reset) {
     if (!h) return fail(MPCQP_ERR_ARG, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    int rc = drain_events(h);
+    if (rc) return rc;
     if (enable >= 0) h->profiling = enable != 0;
-    if (admm_ms) *admm_ms = h->admm_ms;
-    if (admm_launches) *admm_launches = h->admm_launches;
-    if (reset) { h->admm_ms = 0.0; h->admm_launches = 0; }
+    if (run_ms) *run_ms = h->run_ms;
+    if (run_launches) *run_launches = h->run_launches;
+    if (reset) { h->run_ms = 0.0; h->run_launches = 0; }
     return MPCQP_OK;
 }
 

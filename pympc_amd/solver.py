@@ -226,7 +226,7 @@ class BatchProblem:
         return tuple(int(v) for v in out)
 
     def profile(self, enable=None, reset=False):
-        """(milliseconds, launches) of the hot kernel k_admm accumulated while profiling was enabled."""
+        """(milliseconds, launches) of the solve kernel k_mpc_run accumulated while profiling was enabled."""
         ms, nl = C.c_double(), C.c_int64()
         _lib.check(self._L.mpcqp_profile(self._h, -1 if enable is None else int(bool(enable)), C.byref(ms), C.byref(nl), int(bool(reset))), 'mpcqp_profile')
         return ms.value, nl.value

@@ -11,8 +11,8 @@ for path in sys.argv[1:]:
             a = agg[k]; a[0] += 1; a[1] += float(row['Counter_Value']); a[2] += int(row['End_Timestamp']) - int(row['Start_Timestamp'])
     for (name, ctr), (n, tot, ns) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:6]:
         kib = tot / n
-        line = '%-28s %-10s launches %4d  mean %12.1f KiB/launch  (x2 for wide reads: %10.1f MiB)  mean duration %8.1f us' % (
-            name[:28], ctr, n, kib, 2 * kib / 1024 if ctr == 'FETCH_SIZE' else kib / 1024, ns / n / 1e3)
+        line = '%-44s %-10s launches %4d  mean %12.1f KiB/launch  (x2 for wide reads: %10.1f MiB)  mean duration %8.1f us' % (
+            name[:44], ctr, n, kib, 2 * kib / 1024 if ctr == 'FETCH_SIZE' else kib / 1024, ns / n / 1e3)
         out.append(line)
 print('\n'.join(out))
 
@@ -21,7 +21,7 @@ res = {}
 for path in sys.argv[1:]:
     with open(path) as f:
         for row in csv.DictReader(f):
-            name = row['Kernel_Name'].split('<')[0].replace('void ', '').strip()
+            name = row['Kernel_Name'].split('(')[0].replace('void ', '').replace(' ', '').strip()     # full template signature
             if not name.startswith('k_'):
                 continue
             d = res.setdefault(name, {'FETCH_SIZE': [0, 0.0], 'WRITE_SIZE': [0, 0.0]})
