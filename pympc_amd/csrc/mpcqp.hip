@@ -1225,21 +1225,59 @@ template <int NUT> __device__ __forceinline__ int divu(const Lay &L, int v) { re
 #else
 #define DIVIDE(a, b) ((a) / (b))
 #endif
+// Small problems (REGV; m <= 4 NT rows and N NB <= 2 NT padded variables, the same condition as the LDS-resident
+// iterate): a thread always handles the same rows r = tid + NT j and the same padded variables idx = tid + NT j, and
+// what it needs of the iteration-invariant vectors omega, s, q stays in its registers for the whole round -- the
+// parallel phases then touch no global memory at all (ten dependent global-load latencies per iteration otherwise).
+struct HotRegs {
+    double om_r[4];                                  // omega of the thread's rows
+    double om_s[2], sv_s[2];                         // per padded variable (x part): omega of its soft row, s of its slack
+};
 template <int NB, int NXT, int NUT>
-__device__ __forceinline__ void hot_rhs(const Lay &L, const double *hot, cgdouble *om, cgdouble *sv, cgdouble *qv, double cc,
+__device__ __forceinline__ void load_hot_regs(const Lay &L, cgdouble *om, cgdouble *sv, cgdouble *qv, HotRegs &h) {
+    const int tid = threadIdx.x, nx = hx<NXT>(L), nu = hu<NUT>(L);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int r = tid + NT * j; h.om_r[j] = r < L.m ? om[r] : 1.0; }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int idx = tid + NT * j, k = idx / NB, a = idx % NB;
+        h.om_s[j] = 1.0; h.sv_s[j] = 0.0;
+        if (idx < L.N * NB) {
+            if (a < nx) { const int e = k * nx + a; h.om_s[j] = om[L.rs + e]; h.sv_s[j] = sv[L.oe + e]; }
+        }
+    }
+}
+
+template <int NB, int NXT, int NUT, bool REGV>
+__device__ __forceinline__ void hot_rhs(const Lay &L, const double *hot, cgdouble *om, cgdouble *sv, cgdouble *qv, const HotRegs &h, double cc,
                                         const double *X, const double *Z, const double *Y, double *W, double *Tc) {
-    const int tid = threadIdx.x;
+    const int tid = opaque_lane(threadIdx.x);        // (keeps the per-thread index arithmetic out of LICM's reach: hoisted, it spills)
     const int nx = hx<NXT>(L), nu = hu<NUT>(L);
-    for (int r = tid; r < L.m; r += NT) W[r] = GV(om, r) * Z[r] - cc * Y[r];
+    double sve[2] = {0.0, 0.0}, qve[2] = {0.0, 0.0};
+    if (REGV) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {                    // s and q of the thread's variables: in flight across the first barrier
+            const int idx = tid + NT * j, k = idx / NB, a = idx % NB;
+            if (idx < L.N * NB) {
+                if (a < nx) { sve[j] = sv[k * nx + a]; qve[j] = qv[k * nx + a]; }
+                else if (a < nx + nu && k < L.Nc) { sve[j] = sv[L.ou + k * nu + a - nx]; qve[j] = qv[L.n_x + k * nu + a - nx]; }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int r = tid + NT * j; if (r < L.m) W[r] = h.om_r[j] * Z[r] - cc * Y[r]; }
+    } else {
+        for (int r = tid; r < L.m; r += NT) W[r] = GV(om, r) * Z[r] - cc * Y[r];
+    }
     __syncthreads();
     const double *Ad = hot + L.oAd, *Bd = hot + L.oBd;
     const double cef = cc * hot[L.oeps];
-    for (int idx = tid; idx < L.N * NB; idx += NT) {
+    auto element = [&](int idx, double sve, double qve, double ws, double svs, bool have) {
         const int k = idx / NB, a = idx % NB;
         double v = 0.0;
         if (a < nx) {
             const int e = k * nx + a;
-            double rx = GV(sv, e) * X[e] - cc * GV(qv, e) - W[e];
+            if (!have) { sve = GV(sv, e); qve = GV(qv, e); ws = GV(om, L.rs + e); svs = GV(sv, L.oe + e); }
+            double rx = sve * X[e] - cc * qve - W[e];
             if (k < L.Np) {
                 const double *w1 = W + (k + 1) * nx;
 #pragma unroll
@@ -1247,13 +1285,13 @@ __device__ __forceinline__ void hot_rhs(const Lay &L, const double *hot, cgdoubl
                 if (!NXT) for (int r = 0; r < nx; ++r) rx += Ad[r * nx + a] * w1[r];
             }
             const double wsoft = W[L.rs + e];
-            const double ws = GV(om, L.rs + e);
-            const double te = DIVIDE(GV(sv, L.oe + e) * X[L.oe + e] + wsoft, cef + GV(sv, L.oe + e) + ws);
+            const double te = DIVIDE(svs * X[L.oe + e] + wsoft, cef + svs + ws);
             W[L.rs + e] = te;                      // only this thread ever reads W[soft row e]
             v = rx + wsoft - ws * te;
         } else if (a < nx + nu && k < L.Nc) {
             const int jj = a - nx, cu = k * nu + jj;
-            double ru = GV(sv, L.ou + cu) * X[L.ou + cu] - cc * GV(qv, L.n_x + cu) + W[L.ri + cu] - W[L.rdu + nu + cu];
+            if (!have) { sve = GV(sv, L.ou + cu); qve = GV(qv, L.n_x + cu); }
+            double ru = sve * X[L.ou + cu] - cc * qve + W[L.ri + cu] - W[L.rdu + nu + cu];
             if (k == 0) ru += W[L.rdu + jj];
             if (cu > 0) ru += W[L.rdu + nu + cu - 1];
             const int s_end = (k == L.Nc - 1) ? L.Np : k + 1;
@@ -1266,40 +1304,62 @@ __device__ __forceinline__ void hot_rhs(const Lay &L, const double *hot, cgdoubl
             v = ru;
         }
         Tc[idx] = v;
+    };
+    if (REGV) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { const int idx = tid + NT * j; if (idx < L.N * NB) element(idx, sve[j], qve[j], h.om_s[j], h.sv_s[j], true); }
+    } else {
+        for (int idx = tid; idx < L.N * NB; idx += NT) element(idx, 0.0, 0.0, 0.0, 0.0, false);
     }
     __syncthreads();
 }
 
 // Steps (4)-(6): slack back-substitution, zt = A xt, relaxation, projection on [l,u], dual update, x update.
-template <int NB, int NXT, int NUT>
+template <int NB, int NXT, int NUT, bool REGV>
 __device__ __forceinline__ void hot_update(const Lay &L, const double *hot, const double *x0s, const double *um1s,
-                                           cgdouble *om, cgdouble *sv, double cc, double alpha,
+                                           cgdouble *om, cgdouble *sv, const HotRegs &h, double cc, double alpha,
                                            double *X, double *Z, double *Y, double *W, const double *Tc, bool keep_delta, gdouble *dxg, gdouble *dyg) {
-    const int tid = threadIdx.x;
+    const int tid = opaque_lane(threadIdx.x);        // (keeps the per-thread index arithmetic out of LICM's reach: hoisted, it spills)
     const int nx = hx<NXT>(L), nu = hu<NUT>(L);
     const double cef = cc * hot[L.oeps];
     // eps_t = te - (omega_soft / kappa) x_t ; x update for the x and eps variables
-    for (int e = tid; e < L.n_x; e += NT) {
-        const int k = divx<NXT>(L, e), i = e - k * nx;
-        const double ws = GV(om, L.rs + e);
+    auto x_update = [&](int e, int k, int i, double ws, double svs) {
         const double xt = Tc[k * NB + i];
-        const double et = W[L.rs + e] - DIVIDE(ws, cef + GV(sv, L.oe + e) + ws) * xt;
+        const double et = W[L.rs + e] - DIVIDE(ws, cef + svs + ws) * xt;
         W[L.rs + e] = et;
         const double xo = X[e], eo = X[L.oe + e];
         const double xn = alpha * xt + (1.0 - alpha) * xo, en = alpha * et + (1.0 - alpha) * eo;
         X[e] = xn; X[L.oe + e] = en;
         if (keep_delta) { dxg[e] = xn - xo; dxg[L.oe + e] = en - eo; }
-    }
-    for (int cu = tid; cu < L.n_u; cu += NT) {
-        const int k = divu<NUT>(L, cu), jj = cu - k * nu;
+    };
+    auto u_update = [&](int cu, int k, int jj) {
         const double uo = X[L.ou + cu];
         const double un = alpha * Tc[k * NB + nx + jj] + (1.0 - alpha) * uo;
         X[L.ou + cu] = un;
         if (keep_delta) dxg[L.ou + cu] = un - uo;
+    };
+    if (REGV) {                                          // same padded-variable -> thread map as hot_rhs
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int idx = tid + NT * j, k = idx / NB, a = idx % NB;
+            if (idx < L.N * NB) {
+                if (a < nx) x_update(k * nx + a, k, a, h.om_s[j], h.sv_s[j]);
+                else if (a < nx + nu && k < L.Nc) u_update(k * nu + a - nx, k, a - nx);
+            }
+        }
+    } else {
+        for (int e = tid; e < L.n_x; e += NT) {
+            const int k = divx<NXT>(L, e), i = e - k * nx;
+            x_update(e, k, i, GV(om, L.rs + e), GV(sv, L.oe + e));
+        }
+        for (int cu = tid; cu < L.n_u; cu += NT) {
+            const int k = divu<NUT>(L, cu), jj = cu - k * nu;
+            u_update(cu, k, jj);
+        }
     }
     __syncthreads();
     const double *Ad = hot + L.oAd, *Bd = hot + L.oBd;
-    auto row_update = [&](int r, double &zv, double &yv) {
+    auto row_update = [&](int r, double w, double &zv, double &yv) {
         double zt, lo, hi;
         if (r < L.rs) {                                   // dynamics
             const int k = divx<NXT>(L, r), i = r - k * nx;
@@ -1336,13 +1396,20 @@ __device__ __forceinline__ void hot_update(const Lay &L, const double *hot, cons
         lo = lo < -QP_INFTY ? -QP_INFTY : lo;
         hi = hi > QP_INFTY ? QP_INFTY : hi;
         const double zr = alpha * zt + (1.0 - alpha) * zv;
-        const double w = GV(om, r);
         const double zn = fmin(fmax(zr + DIVIDE(cc * yv, w), lo), hi);
         const double dy = DIVIDE(w, cc) * (zr - zn);
         yv += dy; zv = zn;
         if (keep_delta) dyg[r] = dy;
     };
-    for (int r = tid; r < L.m; r += NT) { double zv = Z[r], yv = Y[r]; row_update(r, zv, yv); Z[r] = zv; Y[r] = yv; }
+    if (REGV) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = tid + NT * j;
+            if (r < L.m) { double zv = Z[r], yv = Y[r]; row_update(r, h.om_r[j], zv, yv); Z[r] = zv; Y[r] = yv; }
+        }
+    } else {
+        for (int r = tid; r < L.m; r += NT) { double zv = Z[r], yv = Y[r]; row_update(r, GV(om, r), zv, yv); Z[r] = zv; Y[r] = yv; }
+    }
     __syncthreads();
 }
 
@@ -1362,11 +1429,13 @@ __device__ __forceinline__ void admm_body(const Lay &L, const HotPtrs &P, Smem &
     gdouble *dxg = (gdouble *)(P.dx + (size_t)b * L.n), *dyg = (gdouble *)(P.dy + (size_t)b * L.m);
     const double *F = P.F + (size_t)b * P.fsz;
     const double cc = P.c[b];
+    HotRegs hr;
+    if (LDSSTATE) load_hot_regs<NB, NXT, NUT>(L, gom, gsv, gqv, hr);
     for (int it = 1; it <= iters; ++it) {
         const bool keep_delta = it == iters;         // the increments feed the infeasibility certificates of the check
         TICK_START
 #ifndef MPCQP_ABL_NOPAR
-        hot_rhs<NB, NXT, NUT>(L, S.hot, gom, gsv, gqv, cc, X, Z, Y, W, Tc);
+        hot_rhs<NB, NXT, NUT, LDSSTATE>(L, S.hot, gom, gsv, gqv, hr, cc, X, Z, Y, W, Tc);
 #endif
         TICK(0)
         BorderPtrs bp; bp.red = S.red;
@@ -1378,7 +1447,7 @@ __device__ __forceinline__ void admm_body(const Lay &L, const HotPtrs &P, Smem &
         kkt_core<NB>(core_args(L, opaque_ptr(F)), Tc);
         if (BORDER) border_post(L, NB, Tc, S.tv);
 #ifndef MPCQP_ABL_NOPAR
-        hot_update<NB, NXT, NUT>(L, S.hot, S.x0s, S.um1s, gom, gsv, cc, alpha, X, Z, Y, W, Tc, keep_delta, dxg, dyg);
+        hot_update<NB, NXT, NUT, LDSSTATE>(L, S.hot, S.x0s, S.um1s, gom, gsv, hr, cc, alpha, X, Z, Y, W, Tc, keep_delta, dxg, dyg);
 #endif
         TICK(4)
     }
@@ -1696,7 +1765,7 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     if (rc) { mpcqp_destroy(h); return MPCQP_ERR_HIP; }
     h->smem_setup = sizeof(double) * (size_t)smem_common_doubles(L);
     size_t with_state = h->smem_setup + sizeof(double) * (size_t)(L.n + 2 * L.m);
-    h->lds_state = with_state <= 40 * 1024;      // four workgroups per CU; larger problems keep the iterate in L2/HBM   // small problems: x in LDS, z/y in registers; else iterate in L2/HBM
+    h->lds_state = with_state <= 40 * 1024 && L.m <= 4 * NT && L.N * L.NB <= 2 * NT;      // four workgroups per CU; larger problems keep the iterate in L2/HBM   // small problems: x in LDS, z/y in registers; else iterate in L2/HBM
     h->smem_solve = h->lds_state ? with_state : h->smem_setup;
     if (h->smem_solve > 160 * 1024) { mpcqp_destroy(h); return fail(MPCQP_ERR_UNSUPPORTED, "problem too large for one workgroup's LDS"); }
     *out = h;
