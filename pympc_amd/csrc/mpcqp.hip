@@ -661,59 +661,80 @@ __device__ __forceinline__ void chain_sweep(const int first, const int dir, cons
 // w_k = S_k^-1 yh_k for all stages (independent MFMA groups, dealt to the four waves).  Wave 0 first finishes the
 // forward elimination at the middle stage: yh_mid = b_mid - Mh_mid yh_{mid-1} - Mt_mid yh_{mid+1}; it owns the three
 // stages around the middle (it reads yh_{mid-1}, yh_{mid+1}, so no other wave may overwrite them with w meanwhile).
-// The other N-3 stages are spread so that the four waves finish together (wave 0 takes every 7th of them on top of
-// its 3.5 stage-equivalents).  Fragments are fetched two stages at a time.
+// The other N-3 stages are spread so that the four waves finish together: wave 0 takes every 7th of them on top of
+// its 3.5 stage-equivalents, waves 1..3 the rest in turn.  The wave's t-th stage in closed form:
+static_assert(NWAVES == 4, "stage-to-wave map below assumes four waves");
+__device__ __forceinline__ int sinv_stage(int wv, int t, int N, int mid) {        // -1: the wave has no t-th stage
+    int j;                                                   // index among the stages outside {mid-1, mid, mid+1}
+    if (wv == 0) j = 7 * t; else { const int p = 3 * t + (wv - 1); j = p + p / 6 + 1; }
+    if (j >= N - 3) return -1;
+    return j < mid - 1 ? j : j + 3;
+}
+// The fragment loads are software-pipelined two stages ahead; the first pair (and wave 0's five fragments around the
+// middle) is requested BEFORE the barrier that ends the forward elimination (sinv_prefetch), so that waves 2 and 3,
+// idle during the sweeps, have their data long before they may start.
+template <int NB> struct SinvPre {
+    d4 P0[SweepCfg<NB>::NF], P1[SweepCfg<NB>::NF];          // the wave's first two stages
+    d4 A0[SweepCfg<NB>::NF], A2[SweepCfg<NB>::NF], Am[SweepCfg<NB>::NF], B0[SweepCfg<NB>::NF], B1[SweepCfg<NB>::NF];   // wave 0
+    int nt, klast;                                           // number of stages of this wave, the last one (clamp target)
+};
 template <int NB>
-__device__ __forceinline__ void sinv_apply(const int N, const int mid, const int fstage, const double *F, double *Tc) {
+__device__ __forceinline__ void sinv_prefetch(const int N, const int mid, const int fstage, const double *F, SinvPre<NB> &pre) {
+    const int lane = opaque_lane(threadIdx.x & 63), wv = logical_wave();
+    const double *Fs = F + NB * NB;
+    int nt = 0, klast = 0;
+    for (int t = 0; t < N; ++t) { const int k = sinv_stage(wv, t, N, mid); if (k < 0) break; klast = k; ++nt; }
+    pre.nt = nt; pre.klast = klast;
+    auto kc = [&](int t) { const int k = sinv_stage(wv, t, N, mid); return k < 0 ? klast : k; };
+    if (wv == 0) {
+        frag_load<NB>(F + (size_t)mid * fstage, lane, pre.A0);
+        frag_load<NB>(F, lane, pre.A2);                      // the middle's second forward matrix (kept in stage 0's slot)
+        frag_load_sinv<NB>(Fs + (size_t)mid * fstage, lane, pre.Am);
+        frag_load_sinv<NB>(Fs + (size_t)(mid - 1) * fstage, lane, pre.B0);
+        frag_load_sinv<NB>(Fs + (size_t)(mid + 1) * fstage, lane, pre.B1);
+    }
+    frag_load_sinv<NB>(Fs + (size_t)kc(0) * fstage, lane, pre.P0);
+    frag_load_sinv<NB>(Fs + (size_t)kc(1) * fstage, lane, pre.P1);
+}
+template <int NB>
+__device__ __forceinline__ void sinv_apply(const int N, const int mid, const int fstage, const double *F, double *Tc, SinvPre<NB> &pre) {
     constexpr int NBLK = NB / 16, NF = SweepCfg<NB>::NF;
     const int lane = opaque_lane(threadIdx.x & 63), wv = logical_wave();
     double *tb = Tc + vec_lane_offset(lane);
     const bool writer = vec_lane_writer(lane);
-    auto apply = [&](int k, const d4 *A) {
+    auto apply = [&](int k, const d4 *A, bool valid) {       // (invalid: a clamped repeat of the last stage -- computed, not stored)
         double in[NBLK], out[NBLK];
         vec_load<NB>(tb, k, in);
 #pragma unroll
         for (int b = 0; b < NBLK; ++b) out[b] = 0.0;
         frag_matvec<NB>(A, in, out);
-        vec_store<NB>(tb, k, out, writer);
+        vec_store<NB>(tb, k, out, writer && valid);
     };
     const double *Fs = F + NB * NB;
+    const int nt = pre.nt, klast = pre.klast;
+    auto kc = [&](int t) { const int k = sinv_stage(wv, t, N, mid); return k < 0 ? klast : k; };
     if (wv == 0) {
-        d4 A0[NF], A2[NF], Am[NF];
         double up[NBLK], dn[NBLK], acc[NBLK];
-        frag_load<NB>(F + (size_t)mid * fstage, lane, A0);
-        frag_load<NB>(F, lane, A2);                             // the middle's second forward matrix (kept in stage 0's slot)
-        frag_load_sinv<NB>(Fs + (size_t)mid * fstage, lane, Am);
         vec_load<NB>(tb, mid, acc);
         vec_load<NB>(tb, mid - 1, up);
         vec_load<NB>(tb, mid + 1, dn);
-        frag_matvec<NB>(A0, up, acc);
-        frag_matvec<NB>(A2, dn, acc);
+        frag_matvec<NB>(pre.A0, up, acc);
+        frag_matvec<NB>(pre.A2, dn, acc);
         vec_store<NB>(tb, mid, acc, writer);
-        d4 B0[NF], B1[NF];
-        frag_load_sinv<NB>(Fs + (size_t)(mid - 1) * fstage, lane, B0);
-        frag_load_sinv<NB>(Fs + (size_t)(mid + 1) * fstage, lane, B1);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        apply(mid, Am); apply(mid - 1, B0); apply(mid + 1, B1);
+        apply(mid, pre.Am, true); apply(mid - 1, pre.B0, true); apply(mid + 1, pre.B1, true);
     }
-    static_assert(NWAVES == 4, "stage-to-wave map below assumes four waves");
-    int pend = -1;                                           // pair up this wave's stages: two loads in flight
-    d4 P0[NF];
-    for (int j = 0; j < N - 3; ++j) {                        // j-th stage outside {mid-1, mid, mid+1}
-        const int owner = (j % 7 == 0) ? 0 : 1 + ((j - j / 7 - 1) % 3);
-        if (owner != wv) continue;
-        const int k = j < mid - 1 ? j : j + 3;
-        if (pend < 0) { frag_load_sinv<NB>(Fs + (size_t)k * fstage, lane, P0); pend = k; }
-        else {
-            d4 P1[NF];
-            frag_load_sinv<NB>(Fs + (size_t)k * fstage, lane, P1);
-            apply(pend, P0); apply(k, P1);
-            pend = -1;
-        }
+    d4 Q0[NF], Q1[NF];
+    for (int t = 0; t < nt; t += 4) {                        // branch-free body (exact vmcnt waits), see chain_sweep
+        frag_load_sinv<NB>(Fs + (size_t)kc(t + 2) * fstage, lane, Q0);
+        frag_load_sinv<NB>(Fs + (size_t)kc(t + 3) * fstage, lane, Q1);
+        apply(kc(t), pre.P0, true); apply(kc(t + 1), pre.P1, t + 1 < nt);
+        frag_load_sinv<NB>(Fs + (size_t)kc(t + 4) * fstage, lane, pre.P0);
+        frag_load_sinv<NB>(Fs + (size_t)kc(t + 5) * fstage, lane, pre.P1);
+        apply(kc(t + 2), Q0, t + 2 < nt); apply(kc(t + 3), Q1, t + 3 < nt);
     }
-    if (pend >= 0) apply(pend, P0);
 }
 
 // What the linear-system core needs to know about one instance.
@@ -740,9 +761,11 @@ __device__ __forceinline__ void kkt_core_sweeps(const CoreArgs &a, double *Tc) {
     TICK_START
     if (wv == 0) chain_sweep<NB, false>(0, +1, mid - 1, fstage, F, -1, Tc);               // stages 1 .. mid-1
     else if (wv == 1) chain_sweep<NB, false>(N - 1, -1, N - 2 - mid, fstage, F, -1, Tc);  // stages N-2 .. mid+1
+    SinvPre<NB> pre;
+    sinv_prefetch<NB>(N, mid, fstage, F, pre);
     __syncthreads();
     TICK(1)
-    sinv_apply<NB>(N, mid, fstage, F, Tc);
+    sinv_apply<NB>(N, mid, fstage, F, Tc, pre);
     __syncthreads();
     TICK(2)
     if (wv == 0) chain_sweep<NB, true>(mid, -1, mid, fstage, F, -1, Tc);                  // stages mid-1 .. 0
