@@ -1044,7 +1044,11 @@ __global__ __launch_bounds__(NT) void k_setup(Lay L, Ptrs P, mpcqp_settings S_) 
 // ------------------------------------------------------------------------------------------------
 enum { COLD_CHECK = 1, COLD_RHO = 2, COLD_FINAL = 4, COLD_PLAIN = 8 };
 
-// (the bodies are device functions so that the fused receding-horizon kernel k_mpc_run can reuse them verbatim)
+// Refactorization from inside a solve: a non-inlined function with a register allocation of its own (defined with the
+// other phases of k_mpc_run below), so that this rare, register-hungry path does not push the residual evaluation
+// and the per-solve prologue into scratch spills.
+template <int NB> __device__ void run_factor_phase();
+
 template <int NB>
 __device__ __forceinline__ void begin_body(const Lay &L, const Ptrs &P, const mpcqp_settings &S_, Smem &S, int plain) {
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -1068,7 +1072,7 @@ __device__ __forceinline__ void begin_body(const Lay &L, const Ptrs &P, const mp
         if (t != ctp[r]) { changed = 1; ctp[r] = t; om[r] = row_rho(t, rho) * E[r] * E[r]; }
     }
     changed = __syncthreads_or(changed);
-    if (changed) factor_all<NB>(c, om, sv, P.c[b], P.F + (size_t)b * P.fsz, S.T, S.iflag, border_ptrs(L, P, S.red));
+    if (changed) run_factor_phase<NB>();
     if (tid == 0) {
         mpcqp_info inf; inf.status = MPCQP_UNSOLVED; inf.iter = 0; inf.rho_updates = 0; inf.reserved = 0;
         inf.obj_val = 0.0; inf.pri_res = 0.0; inf.dua_res = 0.0; inf.rho = rho;
@@ -1200,7 +1204,7 @@ __device__ __forceinline__ int check_body(const Lay &L, const Ptrs &P, const mpc
                 rho = rn;
                 for (int r = tid; r < L.m; r += NT) om[r] = row_rho(ctp[r], rho) * E[r] * E[r];
                 __syncthreads();
-                factor_all<NB>(c, om, sv, cc, P.F + (size_t)b * P.fsz, S.T, S.iflag, border_ptrs(L, P, S.red));
+                run_factor_phase<NB>();
                 rho_upd = 1;
             }
         }
@@ -1537,6 +1541,17 @@ __device__ __forceinline__ RunSmem run_smem(const Lay &L, const Ptrs &P) {
     r.X = r.Z = r.Y = nullptr;
     if (LDSSTATE) { r.X = carve(p, L.n); r.Z = carve(p, L.m); r.Y = carve(p, L.m); }
     return r;
+}
+
+template <int NB>
+__device__ __noinline__ void run_factor_phase() {
+    const RunKArgs &A = run_kargs();
+    const Lay &L = A.L; const Ptrs &P = A.P;
+    RunSmem r = run_smem<false>(L, P);                       // (the common LDS area comes first in both layouts)
+    const int b = blockIdx.x;
+    Ctx c{L, r.S.hot, P.model + (size_t)b * L.model_sz};
+    factor_all<NB>(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], P.F + (size_t)b * P.fsz, r.S.T, r.S.iflag,
+                   border_ptrs(L, P, r.S.red));
 }
 
 template <int NB, bool LDSSTATE, int NXT, int NUT, bool BORDER>
