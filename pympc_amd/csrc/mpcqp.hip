@@ -1082,12 +1082,14 @@ __device__ __forceinline__ void begin_body(const Lay &L, const Ptrs &P, const mp
 
 // Returns 1 (to every thread) if the instance has terminated.
 template <int NB>
-__device__ __forceinline__ int check_body(const Lay &L, const Ptrs &P, const mpcqp_settings &S_, Smem &S, int iter, int mode) {
+__device__ __forceinline__ int check_body(const Lay &L, const Ptrs &P, const mpcqp_settings &S_, Smem &S, int iter, int mode,
+                                          const double *Xl, const double *Zl, const double *Yl) {
     const int b = blockIdx.x, tid = threadIdx.x;
     const double *model = P.model + (size_t)b * L.model_sz;
     Ctx c{L, S.hot, model};
     double *gx = P.x + (size_t)b * L.n, *gz = P.z + (size_t)b * L.m, *gy = P.y + (size_t)b * L.m;
-    const double *X = gx, *Z = gz, *Y = gy;
+    // the iterate: the LDS copy the last ADMM round left behind (small problems), else global memory
+    const double *X = Xl ? Xl : gx, *Z = Zl ? Zl : gz, *Y = Yl ? Yl : gy;
     double *om = P.omega + (size_t)b * L.m;
     const double *sv = P.s + (size_t)b * L.n;
     const double *D = P.D + (size_t)b * L.n, *E = P.E + (size_t)b * L.m;
@@ -1575,7 +1577,7 @@ template <int NB, bool LDSSTATE>
 __device__ __noinline__ int run_check_phase(int iter, int mode) {
     const RunKArgs &A = run_kargs();
     RunSmem r = run_smem<LDSSTATE>(A.L, A.P);
-    return check_body<NB>(A.L, A.P, A.S, r.S, __builtin_amdgcn_readfirstlane(iter), __builtin_amdgcn_readfirstlane(mode));
+    return check_body<NB>(A.L, A.P, A.S, r.S, __builtin_amdgcn_readfirstlane(iter), __builtin_amdgcn_readfirstlane(mode), r.X, r.Z, r.Y);
 }
 
 template <int NB, bool LDSSTATE, int NXT, int NUT, bool BORDER, bool LOOP>
