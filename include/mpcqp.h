@@ -146,6 +146,30 @@ int mpcqp_get_u0(mpcqp_handle *h, double *u0);
 int mpcqp_mpc_run(mpcqp_handle *h, int nsteps, const double *w, const double *Ap, const double *Bp,
                   double *x_traj, double *u_traj, int32_t *status_traj, int32_t *iter_traj);
 
+/* The same loop with everything optional spelled out (zero-initialise, then set what is used):
+ *  - a time-varying reference: the solve after step k uses xref_traj[k] (mpc.py:338-364 update(x, u, xref));
+ *  - output feedback: the controller does not see the plant state but the estimate of a LinearStateEstimator
+ *    (pyMPC/kalman.py:109-134; model = the controller's Ad, Bd), as in examples/example_inverted_pendulum_kalman.py:135-174:
+ *        y = C x + v[k];  u = K.output();  x = Ap x + Bp u + w[k];  KF.update(y);  KF.predict(u);  K.update(KF.x, u)
+ *    The estimate at step 0 is the state of the last update/setup; the true plant state is x_true (in/out). */
+typedef struct {
+    const double *w;            /* [nsteps][batch][nx] process disturbance, or NULL */
+    const double *Ap, *Bp;      /* [batch][nx*nx], [batch][nx*nu] plant, or NULL (the controller's Ad, Bd) */
+    const double *xref_traj;    /* [nsteps][batch][rows*nx], rows = xref_rows of the last upload (1 or Np+1), or NULL */
+    int32_t ny;                 /* > 0 switches output feedback on */
+    int32_t reserved;
+    const double *C;            /* [batch][ny*nx] */
+    const double *Lgain;        /* [batch][nx*ny] Kalman (filter) gain */
+    const double *v;            /* [nsteps][batch][ny] measurement noise, or NULL */
+    double *x_true;             /* [batch][nx] true plant state: in = at step 0, out = after the run */
+    double *x_traj;             /* [nsteps+1][batch][nx] plant states, or NULL */
+    double *xhat_traj;          /* [nsteps+1][batch][nx] estimates xhat[k|k-1] (output feedback only), or NULL */
+    double *y_traj;             /* [nsteps][batch][ny] measurements (output feedback only), or NULL */
+    double *u_traj;             /* [nsteps][batch][nu], or NULL */
+    int32_t *status_traj, *iter_traj;   /* [nsteps][batch], or NULL */
+} mpcqp_loop;
+int mpcqp_mpc_loop(mpcqp_handle *h, int nsteps, const mpcqp_loop *io);
+
 /* Cumulative work counters since creation / last reset: out4 = { ADMM iterations, residual
  * evaluations, refactorizations, instance-solves } summed over the batch (synchronises). */
 int mpcqp_get_stats(mpcqp_handle *h, uint64_t *out4, int reset);

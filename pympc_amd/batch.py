@@ -95,16 +95,32 @@ class BatchMPCController:
         self.prob.solve_async()
         self._u_last = None
 
-    def run(self, nsteps, w=None, Ap=None, Bp=None):
+    def run(self, nsteps, w=None, Ap=None, Bp=None, xref_traj=None, estimator=None):
         """``nsteps`` closed-loop steps on the device, equivalent to
-        ``for k in range(nsteps): u = K.output(); x = Ap @ x + Bp @ u + w[k]; K.update(x)``
-        (the loop of examples/example_point_mass.py:88-101 with a linear plant; default plant = (Ad, Bd)).
-        Returns ``dict(x=[nsteps+1,B,nx], u=[nsteps,B,nu], status=[nsteps,B] (OSQP status values), iter=[nsteps,B])``."""
-        xt, ut, st, it = self.prob.mpc_run(nsteps, w=w, Ap=Ap, Bp=Bp)
-        self.x0_rh = xt[-1].copy()
+        ``for k in range(nsteps): u = K.output(); x = Ap @ x + Bp @ u + w[k]; K.update(x, u, xref_traj[k])``
+        (the loop of examples/example_point_mass.py:88-101 with a linear plant; default plant = (Ad, Bd)), or, with
+        ``estimator = BatchLinearStateEstimator`` (pympc_amd.kalman), to the output-feedback loop of
+        examples/example_inverted_pendulum_kalman.py:135-174 -- the estimator object supplies C, L, the measurement noise
+        ``estimator.v`` [nsteps,B,ny] (optional) and the true plant state ``estimator.x_true`` [B,nx], advanced in place.
+        Returns ``dict(x=[nsteps+1,B,nx], u=[nsteps,B,nu], status=[nsteps,B] (OSQP status values), iter=[nsteps,B])``
+        plus ``xhat`` and ``y`` with an estimator."""
+        est = None
+        if estimator is not None:
+            est = dict(C=estimator.C, L=estimator.L, x_true=estimator.x_true, v=getattr(estimator, 'v', None))
+        out = self.prob.mpc_run(nsteps, w=w, Ap=Ap, Bp=Bp, xref_traj=xref_traj, estimator=est)
+        xt, ut, st, it = out[:4]
+        res = dict(x=xt, u=ut, status=st, iter=it)
+        if estimator is not None:
+            res['xhat'], res['y'] = out[4], out[5]
+            self.x0_rh = out[4][-1].copy()
+            estimator.x = out[4][-1].copy()
+        else:
+            self.x0_rh = xt[-1].copy()
+        if xref_traj is not None:
+            self.xref = np.asarray(xref_traj)[-1].reshape(self.B, -1)
         self.uminus1_rh = ut[-1].copy()
         self._u_last = None
-        return dict(x=xt, u=ut, status=st, iter=it)
+        return res
 
     def status(self):
         """Per-instance OSQP status strings of the last solve."""

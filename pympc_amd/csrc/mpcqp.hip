@@ -1501,7 +1501,14 @@ struct RunArgs {
     int max_iter, chk, rho_every;
     const double *w;              // [nsteps][batch][nx] additive plant disturbance, or null
     const double *Ap, *Bp;        // [batch][nx*nx], [batch][nx*nu] plant matrices, or null (plant = model Ad, Bd)
-    double *x_traj;               // [nsteps+1][batch][nx]
+    const double *xref_traj;      // [nsteps][batch][xref_blk] reference for the solve after step k, or null (unchanged)
+    int xref_blk;                 // xref_rows * nx
+    int ny;                       // > 0: output feedback through a LinearStateEstimator (pyMPC/kalman.py:109-134)
+    const double *C, *Lg, *v;     // [batch][ny*nx], [batch][nx*ny], [nsteps][batch][ny] (or null)
+    double *x_true;               // [batch][nx] true plant state (in/out) when the controller only sees the estimate
+    double *x_traj;               // [nsteps+1][batch][nx] plant states
+    double *xhat_traj;            // [nsteps+1][batch][nx] estimates xhat[k|k-1] handed to update() (estimator only)
+    double *y_traj;               // [nsteps][batch][ny] measurements (estimator only)
     double *u_traj;               // [nsteps][batch][nu]
     int *status_traj, *iter_traj; // [nsteps][batch]: outcome of the solve that follows step k's update
     int batch;
@@ -1593,27 +1600,57 @@ __global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_mpc_run(RunKArgs A_)
     const int nrun = LOOP ? R.nsteps : 1;        // LOOP = false: one solve of the current data (mpcqp_solve)
     for (int k = 0; k < nrun; ++k) {
         if (LOOP) {
+            // scratch in the (idle) work area: un | xn | xt | ym | inn | xu, 32 doubles each (nx + nu <= 32)
+            double *un = S.T, *xn = S.T + 32, *xt = S.T + 64, *ym = S.T + 96, *inn = S.T + 128, *xu = S.T + 160;
+            const size_t kb = (size_t)k * R.batch + b;
+            const int ny = R.ny;
             // ---- output(): first input of the current solution, or u_failure
             const int status = P.info[b].status;
-            double *un = S.tv, *xn = S.tv + nu;              // (nx + nu <= 32 < 64)
             if (tid < nu) un[tid] = status == MPCQP_SOLVED ? P.xo[(size_t)b * L.n + L.ou + tid] : S.hot[L.ouref + tid];
+            if (tid < nx) xt[tid] = ny ? R.x_true[(size_t)b * nx + tid] : S.x0s[tid];      // the plant state
             __syncthreads();
+            if (ny && tid < ny) {                            // measurement y = C x + v and innovation y - C xhat
+                const double *C = R.C + (size_t)b * ny * nx + (size_t)tid * nx;
+                double y = R.v ? R.v[kb * ny + tid] : 0.0, yh = 0.0;
+                for (int j = 0; j < nx; ++j) { y += C[j] * xt[j]; yh += C[j] * S.x0s[j]; }
+                ym[tid] = y; inn[tid] = y - yh;
+                if (R.y_traj) R.y_traj[kb * ny + tid] = y;
+            }
             // ---- plant step
             if (tid < nx) {
                 const double *Ap = R.Ap ? R.Ap + (size_t)b * nx * nx : S.hot + L.oAd;
                 const double *Bp = R.Bp ? R.Bp + (size_t)b * nx * nu : S.hot + L.oBd;
-                double v = R.w ? R.w[((size_t)k * R.batch + b) * nx + tid] : 0.0;
+                double v = R.w ? R.w[kb * nx + tid] : 0.0;
                 double acc = 0.0;
-                for (int j = 0; j < nx; ++j) acc += Ap[tid * nx + j] * S.x0s[j];
+                for (int j = 0; j < nx; ++j) acc += Ap[tid * nx + j] * xt[j];
                 for (int j = 0; j < nu; ++j) acc += Bp[tid * nu + j] * un[j];
                 xn[tid] = acc + v;
-                R.x_traj[((size_t)k * R.batch + b) * nx + tid] = S.x0s[tid];
+                R.x_traj[kb * nx + tid] = xt[tid];
+                if (ny) { R.x_true[(size_t)b * nx + tid] = xn[tid]; if (R.xhat_traj) R.xhat_traj[kb * nx + tid] = S.x0s[tid]; }
             }
-            if (tid < nu) R.u_traj[((size_t)k * R.batch + b) * nu + tid] = un[tid];
+            if (tid < nu) R.u_traj[kb * nu + tid] = un[tid];
             __syncthreads();
-            // ---- update(x): new initial state and previous input (mpc.py:338-364)
+            if (ny) {                                        // KF.update(y): xhat[k|k] = xhat[k|k-1] + L (y - yhat);  KF.predict(u)
+                if (tid < nx) {
+                    const double *Lg = R.Lg + (size_t)b * nx * ny + (size_t)tid * ny;
+                    double acc = S.x0s[tid];
+                    for (int j = 0; j < ny; ++j) acc += Lg[j] * inn[j];
+                    xu[tid] = acc;
+                }
+                __syncthreads();
+                if (tid < nx) {
+                    const double *Ad = S.hot + L.oAd, *Bd = S.hot + L.oBd;
+                    double acc = 0.0;
+                    for (int j = 0; j < nx; ++j) acc += Ad[tid * nx + j] * xu[j];
+                    for (int j = 0; j < nu; ++j) acc += Bd[tid * nu + j] * un[j];
+                    xn[tid] = acc;                           // xhat[k+1|k]: what the controller is updated with
+                }
+                __syncthreads();
+            }
+            // ---- update(x): new initial state, previous input (mpc.py:338-364) and, if given, reference
             if (tid < nx) { S.x0s[tid] = xn[tid]; step[tid] = xn[tid]; }
             if (tid < nu) { S.um1s[tid] = un[tid]; step[nx + tid] = un[tid]; }
+            if (R.xref_traj) for (int i = tid; i < R.xref_blk; i += NT) step[nx + nu + i] = R.xref_traj[kb * R.xref_blk + i];
             __syncthreads();
         }
 #ifdef MPCQP_RUN_TIMING
@@ -1642,7 +1679,11 @@ __global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_mpc_run(RunKArgs A_)
         }
         __syncthreads();
     }
-    if (LOOP && tid < nx) R.x_traj[((size_t)R.nsteps * R.batch + b) * nx + tid] = S.x0s[tid];
+    if (LOOP && tid < nx) {
+        const size_t e = ((size_t)R.nsteps * R.batch + b) * nx + tid;
+        R.x_traj[e] = R.ny ? R.x_true[(size_t)b * nx + tid] : S.x0s[tid];
+        if (R.ny && R.xhat_traj) R.xhat_traj[e] = S.x0s[tid];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1985,42 +2026,61 @@ static int get(mpcqp_handle *h, void *dst, const void *src, size_t bytes) {
     return 0;
 }
 
-extern "C" int mpcqp_mpc_run(mpcqp_handle *h, int nsteps, const double *w, const double *Ap, const double *Bp,
-                             double *x_traj, double *u_traj, int32_t *status_traj, int32_t *iter_traj) {
-    if (!h || nsteps < 1) return fail(MPCQP_ERR_ARG, "mpcqp_mpc_run: bad argument");
-    if (!h->is_setup) return fail(MPCQP_ERR_STATE, "mpcqp_mpc_run before mpcqp_setup");
-    if ((Ap == nullptr) != (Bp == nullptr)) return fail(MPCQP_ERR_ARG, "mpcqp_mpc_run: give both Ap and Bp or neither");
+extern "C" int mpcqp_mpc_loop(mpcqp_handle *h, int nsteps, const mpcqp_loop *io) {
+    if (!h || !io || nsteps < 1) return fail(MPCQP_ERR_ARG, "mpcqp_mpc_loop: bad argument");
+    if (!h->is_setup) return fail(MPCQP_ERR_STATE, "mpcqp_mpc_loop before mpcqp_setup");
+    if ((io->Ap == nullptr) != (io->Bp == nullptr)) return fail(MPCQP_ERR_ARG, "mpcqp_mpc_loop: give both Ap and Bp or neither");
+    const int ny = io->ny;
+    if (ny < 0 || ny > 32) return fail(MPCQP_ERR_ARG, "mpcqp_mpc_loop: ny must be in 0..32");
+    if (ny && (!io->C || !io->Lgain || !io->x_true)) return fail(MPCQP_ERR_ARG, "mpcqp_mpc_loop: output feedback needs C, Lgain and x_true");
     HIPCHK(hipSetDevice(h->device));
     const Lay &L = h->L;
-    const size_t B = (size_t)h->batch, K = (size_t)nsteps;
-    // one staging block: [w | Ap | Bp | x_traj | u_traj | status | iter]
-    const size_t nw = w ? K * B * L.nx : 0, nA = Ap ? B * L.nx * L.nx : 0, nBp = Bp ? B * L.nx * L.nu : 0;
-    const size_t nxt = (K + 1) * B * L.nx, nut = K * B * L.nu, nst = K * B;
-    const size_t bytes = sizeof(double) * (nw + nA + nBp + nxt + nut) + sizeof(int) * 2 * nst;
-    if (bytes > h->run_bytes) {
+    const size_t B = (size_t)h->batch, K = (size_t)nsteps, nx = L.nx, nu = L.nu;
+    const size_t xblk = (size_t)L.xref_rows * nx;
+    // one staging block on the device; inputs are copied in, outputs copied out (host or device pointers alike)
+    struct Part { const void *src; void *dst; size_t bytes; size_t off; };
+    Part parts[16]; int np = 0; size_t total = 0;
+    auto add = [&](const void *src, void *dst, size_t bytes) { parts[np] = Part{src, dst, bytes, total}; total += (bytes + 15) & ~size_t(15); return np++; };
+    const int iw = add(io->w, nullptr, io->w ? 8 * K * B * nx : 0);
+    const int iA = add(io->Ap, nullptr, io->Ap ? 8 * B * nx * nx : 0), iB = add(io->Bp, nullptr, io->Bp ? 8 * B * nx * nu : 0);
+    const int ir = add(io->xref_traj, nullptr, io->xref_traj ? 8 * K * B * xblk : 0);
+    const int iC = add(io->C, nullptr, ny ? 8 * B * ny * nx : 0), iL = add(io->Lgain, nullptr, ny ? 8 * B * nx * ny : 0);
+    const int iv = add(io->v, nullptr, (ny && io->v) ? 8 * K * B * ny : 0);
+    const int ixt = add(io->x_true, io->x_true, ny ? 8 * B * nx : 0);
+    const int ox = add(nullptr, io->x_traj, 8 * (K + 1) * B * nx), oxh = add(nullptr, io->xhat_traj, ny ? 8 * (K + 1) * B * nx : 0);
+    const int oy = add(nullptr, io->y_traj, ny ? 8 * K * B * ny : 0), ou = add(nullptr, io->u_traj, 8 * K * B * nu);
+    const int os = add(nullptr, io->status_traj, 4 * K * B), oi = add(nullptr, io->iter_traj, 4 * K * B);
+    if (total > h->run_bytes) {
         HIPCHK(hipStreamSynchronize(h->stream));
         if (h->run_buf) hipFree(h->run_buf);
         h->run_buf = nullptr; h->run_bytes = 0;
-        HIPCHK(hipMalloc(&h->run_buf, bytes));
-        h->run_bytes = bytes;
+        HIPCHK(hipMalloc(&h->run_buf, total));
+        h->run_bytes = total;
     }
-    double *d = (double *)h->run_buf;
-    double *dw = d; d += nw; double *dA = d; d += nA; double *dB = d; d += nBp;
-    double *dx = d; d += nxt; double *du = d; d += nut;
-    int *dst = (int *)d, *dit = dst + nst;
-    if (w) HIPCHK(hipMemcpyAsync(dw, w, sizeof(double) * nw, hipMemcpyDefault, h->stream));
-    if (Ap) { HIPCHK(hipMemcpyAsync(dA, Ap, sizeof(double) * nA, hipMemcpyDefault, h->stream));
-              HIPCHK(hipMemcpyAsync(dB, Bp, sizeof(double) * nBp, hipMemcpyDefault, h->stream)); }
+    char *base = (char *)h->run_buf;
+    auto dev = [&](int i) -> void * { return parts[i].bytes ? base + parts[i].off : nullptr; };
+    for (int i = 0; i < np; ++i)
+        if (parts[i].src && parts[i].bytes) HIPCHK(hipMemcpyAsync(dev(i), parts[i].src, parts[i].bytes, hipMemcpyDefault, h->stream));
     RunArgs R; memset(&R, 0, sizeof(R));
     R.nsteps = nsteps;
-    R.w = w ? dw : nullptr; R.Ap = Ap ? dA : nullptr; R.Bp = Bp ? dB : nullptr;
-    R.x_traj = dx; R.u_traj = du; R.status_traj = dst; R.iter_traj = dit;
+    R.w = (const double *)dev(iw); R.Ap = (const double *)dev(iA); R.Bp = (const double *)dev(iB);
+    R.xref_traj = (const double *)dev(ir); R.xref_blk = (int)xblk;
+    R.ny = ny; R.C = (const double *)dev(iC); R.Lg = (const double *)dev(iL); R.v = (const double *)dev(iv); R.x_true = (double *)dev(ixt);
+    R.x_traj = (double *)dev(ox); R.xhat_traj = (double *)dev(oxh); R.y_traj = (double *)dev(oy); R.u_traj = (double *)dev(ou);
+    R.status_traj = (int *)dev(os); R.iter_traj = (int *)dev(oi);
     int rc = launch_run(h, R, 0);
     if (rc) return rc;
-    if (get(h, x_traj, dx, sizeof(double) * nxt) || get(h, u_traj, du, sizeof(double) * nut) ||
-        get(h, status_traj, dst, sizeof(int) * nst) || get(h, iter_traj, dit, sizeof(int) * nst)) return MPCQP_ERR_HIP;
+    for (int i = 0; i < np; ++i)
+        if (parts[i].dst && parts[i].bytes && get(h, parts[i].dst, dev(i), parts[i].bytes)) return MPCQP_ERR_HIP;
     HIPCHK(hipStreamSynchronize(h->stream));
     return MPCQP_OK;
+}
+
+extern "C" int mpcqp_mpc_run(mpcqp_handle *h, int nsteps, const double *w, const double *Ap, const double *Bp,
+                             double *x_traj, double *u_traj, int32_t *status_traj, int32_t *iter_traj) {
+    mpcqp_loop io; memset(&io, 0, sizeof(io));
+    io.w = w; io.Ap = Ap; io.Bp = Bp; io.x_traj = x_traj; io.u_traj = u_traj; io.status_traj = status_traj; io.iter_traj = iter_traj;
+    return mpcqp_mpc_loop(h, nsteps, &io);
 }
 
 extern "C" int mpcqp_get_solution(mpcqp_handle *h, double *x, double *y, mpcqp_info *info) {

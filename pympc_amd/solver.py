@@ -182,23 +182,50 @@ class BatchProblem:
     def synchronize(self):
         _lib.check(self._L.mpcqp_synchronize(self._h), 'mpcqp_synchronize')
 
-    def mpc_run(self, nsteps, w=None, Ap=None, Bp=None, out=None):
-        """Device-side receding-horizon loop (mpcqp_mpc_run): ``nsteps`` closed-loop steps
+    def mpc_run(self, nsteps, w=None, Ap=None, Bp=None, out=None, xref_traj=None, estimator=None):
+        """Device-side receding-horizon loop (mpcqp_mpc_loop): ``nsteps`` closed-loop steps
         ``u = output(); x = Ap x + Bp u + w[k]; update(x)`` of every instance without host round trips.
 
-        ``w`` [nsteps, batch, nx] (numpy or torch device tensor) or None; ``Ap``/``Bp`` default to the controller model.
-        Returns ``(x_traj [nsteps+1,B,nx], u_traj [nsteps,B,nu], status [nsteps,B] int32, iters [nsteps,B] int32)``
-        as numpy arrays, or fills the four arrays/tensors given in ``out``."""
+        ``w`` [nsteps, batch, nx] (numpy or torch device tensor) or None; ``Ap``/``Bp`` default to the controller model;
+        ``xref_traj`` [nsteps, batch, rows*nx] gives the reference of the solve after step k (rows as last uploaded).
+        ``estimator = dict(C=[B,ny,nx], L=[B,nx,ny], x_true=[B,nx], v=[nsteps,B,ny] or None)`` switches output feedback on
+        (pyMPC/kalman.py:109-134): the controller is updated with the estimate, ``x_true`` is advanced in place.
+        Returns ``(x_traj [nsteps+1,B,nx], u_traj [nsteps,B,nu], status [nsteps,B] int32, iters [nsteps,B] int32)`` as
+        numpy arrays (plus ``xhat_traj, y_traj`` with an estimator), or fills the arrays/tensors given in ``out``."""
         K, B, nx, nu = int(nsteps), self.batch, self.nx, self.nu
-        wa = _prep(w, (K, B, nx), 'w') if w is not None else None
-        Aa = _prep(Ap, (B, nx, nx), 'Ap') if Ap is not None else None
-        Ba = _prep(Bp, (B, nx, nu), 'Bp') if Bp is not None else None
+        io = _lib.Loop()
+        keep = []
+
+        def inp(a, shape, name):
+            if a is None:
+                return None
+            a = _prep(a, shape, name); keep.append(a)
+            return _ptr(a)
+
+        io.w = inp(w, (K, B, nx), 'w'); io.Ap = inp(Ap, (B, nx, nx), 'Ap'); io.Bp = inp(Bp, (B, nx, nu), 'Bp')
+        if xref_traj is not None:
+            per = int(np.prod(tuple(xref_traj.shape)[2:])) if len(tuple(xref_traj.shape)) > 2 else 1
+            io.xref_traj = inp(xref_traj, (K, B, per), 'xref_traj')
+        ny = 0
+        if estimator is not None:
+            Cm = estimator['C']
+            ny = int(tuple(Cm.shape)[-2])
+            io.ny = ny
+            io.C = inp(Cm, (B, ny, nx), 'C'); io.Lgain = inp(estimator['L'], (B, nx, ny), 'L')
+            io.v = inp(estimator.get('v'), (K, B, ny), 'v')
+            xt = estimator['x_true']
+            if hasattr(xt, 'ctypes') and not (xt.dtype == np.float64 and xt.flags['C_CONTIGUOUS'] and xt.shape == (B, nx)):
+                raise ValueError('estimator["x_true"] must be a C-contiguous float64 [batch, nx] array (it is updated in place)')
+            keep.append(xt); io.x_true = _ptr(xt)
         if out is None:
-            out = (np.empty((K + 1, B, nx)), np.empty((K, B, nu)), np.empty((K, B), dtype=np.int32), np.empty((K, B), dtype=np.int32))
-        xt, ut, st, it = out
-        _lib.check(self._L.mpcqp_mpc_run(self._h, K, _ptr(wa), _ptr(Aa), _ptr(Ba), _ptr(xt), _ptr(ut), _ptr(st), _ptr(it)),
-                   'mpcqp_mpc_run')
-        return xt, ut, st, it
+            out = [np.empty((K + 1, B, nx)), np.empty((K, B, nu)), np.empty((K, B), dtype=np.int32), np.empty((K, B), dtype=np.int32)]
+            if ny:
+                out += [np.empty((K + 1, B, nx)), np.empty((K, B, ny))]
+        io.x_traj, io.u_traj, io.status_traj, io.iter_traj = (_ptr(o) for o in out[:4])
+        if ny and len(out) >= 6:
+            io.xhat_traj, io.y_traj = _ptr(out[4]), _ptr(out[5])
+        _lib.check(self._L.mpcqp_mpc_loop(self._h, K, C.byref(io)), 'mpcqp_mpc_loop')
+        return tuple(out)
 
     def solution(self, want_y=True):
         x = np.empty((self.batch, self.n))

@@ -352,3 +352,68 @@ def test_device_loop_custom_plant_and_failure_fallback():
     trf = Kf.run(3)
     assert np.isin(trf['status'], (-2, 2)).all() and (trf['iter'] == 10).all()     # max-iter / solved inaccurate: not 'solved'
     assert np.array_equal(trf['u'], np.broadcast_to(np.stack([kw['uref'] for kw in kws]), trf['u'].shape))
+
+
+def test_device_loop_time_varying_reference():
+    """xref_traj inside the device loop == update(x, u, xref_k) step by step (mpc.py:338-364), 1-row and (Np+1)-row xref."""
+    from pympc_amd import fixtures
+    K_STEPS = 6
+    rng = np.random.default_rng(9)
+    for rows_full in (False, True):
+        kws = [fixtures.random_lti(500 + i) for i in range(3)]
+        B, nx, Np = len(kws), 12, 30
+        if rows_full:
+            for kw in kws:
+                kw['xref'] = np.tile(kw['xref'], (Np + 1, 1))
+        per = (Np + 1) * nx if rows_full else nx
+        xr = 0.1 * rng.standard_normal((K_STEPS, B, per))
+        Kd = _stacked_batch(kws); Kd.setup()
+        Ks = _stacked_batch(kws); Ks.setup()
+        tr = Kd.run(K_STEPS, xref_traj=xr)
+        for k in range(K_STEPS):
+            u = Ks.output()
+            assert np.array_equal(u, tr['u'][k]), (rows_full, k)
+            Ks.update(tr['x'][k + 1], xref=xr[k].reshape((B, Np + 1, nx) if rows_full else (B, nx)))
+            assert [i.iter for i in Ks.prob.infos()] == list(tr['iter'][k])
+        assert np.array_equal(Kd.output(), Ks.output())
+
+
+def test_device_loop_output_feedback_matches_reference_style_loop():
+    """Output feedback inside the device loop (LinearStateEstimator, pyMPC/kalman.py:109-134) against the loop of
+    examples/example_inverted_pendulum_kalman.py:135-174 driven from the host: numpy estimator + stepwise controller."""
+    from pympc_amd import fixtures
+    from pympc_amd.kalman import kalman_design_simple, BatchLinearStateEstimator
+    K_STEPS = 10
+    kws = []
+    for i in range(3):
+        kw = dict(fixtures.cart_pole())
+        kw['x0'] = np.asarray(kw['x0'], dtype=float) * (1.0 + 0.1 * i)
+        kws.append(kw)
+    B, nx, nu = len(kws), 4, 1
+    Ad, Bd = kws[0]['Ad'], kws[0]['Bd']
+    Cd = np.array([[1.0, 0, 0, 0], [0, 0, 1.0, 0]])            # position and angle are measured
+    L, _, _ = kalman_design_simple(Ad, Bd, Cd, np.zeros((2, 1)), np.diag([0.1, 10, 0.1, 10]), 0.01 * np.eye(2), type='filter')
+    rng = np.random.default_rng(3)
+    v = 0.01 * rng.standard_normal((K_STEPS, B, 2))
+    w = 0.001 * rng.standard_normal((K_STEPS, B, nx))
+    x_true0 = np.stack([kw['x0'] * 1.05 for kw in kws])         # the controller starts from a wrong estimate
+    st = lambda M: np.stack([M] * B)
+    est = BatchLinearStateEstimator(np.stack([kw['x0'] for kw in kws]), st(Ad), st(Bd), st(Cd), st(L), x_true=x_true0.copy(), v=v)
+    Kd = _stacked_batch(kws); Kd.setup()
+    tr = Kd.run(K_STEPS, w=w, estimator=est)
+    # host replica: numpy estimator, stepwise controller
+    Ks = _stacked_batch(kws); Ks.setup()
+    KF = BatchLinearStateEstimator(np.stack([kw['x0'] for kw in kws]), st(Ad), st(Bd), st(Cd), st(L))
+    x = x_true0.copy()
+    for k in range(K_STEPS):
+        y = np.einsum('bij,bj->bi', st(Cd), x) + v[k]
+        u = Ks.output()
+        assert np.array_equal(u, tr['u'][k]), k
+        assert np.allclose(x, tr['x'][k], rtol=1e-12, atol=1e-14) and np.allclose(y, tr['y'][k], rtol=1e-12, atol=1e-14)
+        assert np.allclose(KF.x, tr['xhat'][k], rtol=1e-12, atol=1e-14)
+        x = np.einsum('bij,bj->bi', st(Ad), x) + np.einsum('bij,bj->bi', st(Bd), u) + w[k]
+        KF.update(y); KF.predict(u)
+        assert np.allclose(KF.x, tr['xhat'][k + 1], rtol=1e-11, atol=1e-13)
+        x = tr['x'][k + 1]; KF.x = tr['xhat'][k + 1].copy(); KF.y = np.einsum('bij,bj->bi', st(Cd), KF.x)   # no rounding drift
+        Ks.update(tr['xhat'][k + 1])
+    assert np.array_equal(est.x_true, tr['x'][-1]) and np.array_equal(Kd.x0_rh, tr['xhat'][-1])
