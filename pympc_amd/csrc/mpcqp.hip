@@ -33,9 +33,6 @@
 #define NT 256                 // threads per workgroup (one workgroup = one MPC instance)
 #endif
 #define NWAVES (NT / 64)
-#ifndef MPCQP_PRIO
-#define MPCQP_PRIO 0
-#endif
 #define QP_INFTY 1e30
 #define MIN_SCALING 1e-4
 #define MAX_SCALING 1e4
@@ -1241,26 +1238,17 @@ template <int NXT> __device__ __forceinline__ int divx(const Lay &L, int v) { re
 template <int NUT> __device__ __forceinline__ int divu(const Lay &L, int v) { return NUT ? v / NUT : idiv(v, L.rnu); }
 
 // Steps (1)-(2) of the ADMM iteration with the slack elimination fused in:
-//   W = omega z - c y                       (rows, flat)
+//   W = omega z - c y                       (rows, flat; left behind by hot_rows_w / the previous hot_update)
 //   rhs = s x - c q + A' W                  (variables)
 //   te = rhs_eps / kappa -> W[soft row]     Tc[k][a] = rhs_x - omega_soft te  |  rhs_u  |  0 (padding)
-#ifdef MPCQP_ABL_NOGLOBVEC      // ablation: no global vector reads in the parallel phases (timing only, results meaningless)
-#define GV(p, i) (1.0 + 1e-3 * (double)((i) & 7))
-#else
-#define GV(p, i) p[i]
-#endif
-#ifdef MPCQP_ABL_NODIV
-#define DIVIDE(a, b) ((a) * (b))
-#else
-#define DIVIDE(a, b) ((a) / (b))
-#endif
 // Small problems (REGV; m <= 4 NT rows and N NB <= 2 NT padded variables, the same condition as the LDS-resident
 // iterate): a thread always handles the same rows r = tid + NT j and the same padded variables idx = tid + NT j, and
 // what it needs of the iteration-invariant vectors omega, s, q stays in its registers for the whole round -- the
 // parallel phases then touch no global memory at all (ten dependent global-load latencies per iteration otherwise).
 struct HotRegs {
     double om_r[4];                                  // omega of the thread's rows
-    double om_s[2], sv_s[2];                         // per padded variable (x part): omega of its soft row, s of its slack
+    double sv_e[2], qv_e[2];                         // per padded variable: its s and its linear cost q
+    double om_s[2], sv_s[2];                         // (x part only) omega of its soft row, s of its slack
 };
 template <int NB, int NXT, int NUT>
 __device__ __forceinline__ void load_hot_regs(const Lay &L, cgdouble *om, cgdouble *sv, cgdouble *qv, HotRegs &h) {
@@ -1270,11 +1258,25 @@ __device__ __forceinline__ void load_hot_regs(const Lay &L, cgdouble *om, cgdoub
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int idx = tid + NT * j, k = idx / NB, a = idx % NB;
-        h.om_s[j] = 1.0; h.sv_s[j] = 0.0;
+        h.sv_e[j] = 0.0; h.qv_e[j] = 0.0; h.om_s[j] = 1.0; h.sv_s[j] = 0.0;
         if (idx < L.N * NB) {
-            if (a < nx) { const int e = k * nx + a; h.om_s[j] = om[L.rs + e]; h.sv_s[j] = sv[L.oe + e]; }
+            if (a < nx) { const int e = k * nx + a; h.sv_e[j] = sv[e]; h.qv_e[j] = qv[e]; h.om_s[j] = om[L.rs + e]; h.sv_s[j] = sv[L.oe + e]; }
+            else if (a < nx + nu && k < L.Nc) { const int cu = k * nu + a - nx; h.sv_e[j] = sv[L.ou + cu]; h.qv_e[j] = qv[L.n_x + cu]; }
         }
     }
+}
+
+// W = omega z - c y for the first iteration of a round (afterwards hot_update leaves it behind: a thread owns its rows).
+template <bool REGV>
+__device__ __forceinline__ void hot_rows_w(const Lay &L, cgdouble *om, const HotRegs &h, double cc, const double *Z, const double *Y, double *W) {
+    const int tid = opaque_lane(threadIdx.x);
+    if (REGV) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int r = tid + NT * j; if (r < L.m) W[r] = h.om_r[j] * Z[r] - cc * Y[r]; }
+    } else {
+        for (int r = tid; r < L.m; r += NT) W[r] = om[r] * Z[r] - cc * Y[r];
+    }
+    __syncthreads();
 }
 
 template <int NB, int NXT, int NUT, bool REGV>
@@ -1282,22 +1284,6 @@ __device__ __forceinline__ void hot_rhs(const Lay &L, const double *hot, cgdoubl
                                         const double *X, const double *Z, const double *Y, double *W, double *Tc) {
     const int tid = opaque_lane(threadIdx.x);        // (keeps the per-thread index arithmetic out of LICM's reach: hoisted, it spills)
     const int nx = hx<NXT>(L), nu = hu<NUT>(L);
-    double sve[2] = {0.0, 0.0}, qve[2] = {0.0, 0.0};
-    if (REGV) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {                    // s and q of the thread's variables: in flight across the first barrier
-            const int idx = tid + NT * j, k = idx / NB, a = idx % NB;
-            if (idx < L.N * NB) {
-                if (a < nx) { sve[j] = sv[k * nx + a]; qve[j] = qv[k * nx + a]; }
-                else if (a < nx + nu && k < L.Nc) { sve[j] = sv[L.ou + k * nu + a - nx]; qve[j] = qv[L.n_x + k * nu + a - nx]; }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const int r = tid + NT * j; if (r < L.m) W[r] = h.om_r[j] * Z[r] - cc * Y[r]; }
-    } else {
-        for (int r = tid; r < L.m; r += NT) W[r] = GV(om, r) * Z[r] - cc * Y[r];
-    }
-    __syncthreads();
     const double *Ad = hot + L.oAd, *Bd = hot + L.oBd;
     const double cef = cc * hot[L.oeps];
     auto element = [&](int idx, double sve, double qve, double ws, double svs, bool have) {
@@ -1305,7 +1291,7 @@ __device__ __forceinline__ void hot_rhs(const Lay &L, const double *hot, cgdoubl
         double v = 0.0;
         if (a < nx) {
             const int e = k * nx + a;
-            if (!have) { sve = GV(sv, e); qve = GV(qv, e); ws = GV(om, L.rs + e); svs = GV(sv, L.oe + e); }
+            if (!have) { sve = sv[e]; qve = qv[e]; ws = om[L.rs + e]; svs = sv[L.oe + e]; }
             double rx = sve * X[e] - cc * qve - W[e];
             if (k < L.Np) {
                 const double *w1 = W + (k + 1) * nx;
@@ -1314,12 +1300,12 @@ __device__ __forceinline__ void hot_rhs(const Lay &L, const double *hot, cgdoubl
                 if (!NXT) for (int r = 0; r < nx; ++r) rx += Ad[r * nx + a] * w1[r];
             }
             const double wsoft = W[L.rs + e];
-            const double te = DIVIDE(svs * X[L.oe + e] + wsoft, cef + svs + ws);
+            const double te = (svs * X[L.oe + e] + wsoft) / (cef + svs + ws);
             W[L.rs + e] = te;                      // only this thread ever reads W[soft row e]
             v = rx + wsoft - ws * te;
         } else if (a < nx + nu && k < L.Nc) {
             const int jj = a - nx, cu = k * nu + jj;
-            if (!have) { sve = GV(sv, L.ou + cu); qve = GV(qv, L.n_x + cu); }
+            if (!have) { sve = sv[L.ou + cu]; qve = qv[L.n_x + cu]; }
             double ru = sve * X[L.ou + cu] - cc * qve + W[L.ri + cu] - W[L.rdu + nu + cu];
             if (k == 0) ru += W[L.rdu + jj];
             if (cu > 0) ru += W[L.rdu + nu + cu - 1];
@@ -1336,7 +1322,7 @@ __device__ __forceinline__ void hot_rhs(const Lay &L, const double *hot, cgdoubl
     };
     if (REGV) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { const int idx = tid + NT * j; if (idx < L.N * NB) element(idx, sve[j], qve[j], h.om_s[j], h.sv_s[j], true); }
+        for (int j = 0; j < 2; ++j) { const int idx = tid + NT * j; if (idx < L.N * NB) element(idx, h.sv_e[j], h.qv_e[j], h.om_s[j], h.sv_s[j], true); }
     } else {
         for (int idx = tid; idx < L.N * NB; idx += NT) element(idx, 0.0, 0.0, 0.0, 0.0, false);
     }
@@ -1354,7 +1340,7 @@ __device__ __forceinline__ void hot_update(const Lay &L, const double *hot, cons
     // eps_t = te - (omega_soft / kappa) x_t ; x update for the x and eps variables
     auto x_update = [&](int e, int k, int i, double ws, double svs) {
         const double xt = Tc[k * NB + i];
-        const double et = W[L.rs + e] - DIVIDE(ws, cef + svs + ws) * xt;
+        const double et = W[L.rs + e] - (ws / (cef + svs + ws)) * xt;
         W[L.rs + e] = et;
         const double xo = X[e], eo = X[L.oe + e];
         const double xn = alpha * xt + (1.0 - alpha) * xo, en = alpha * et + (1.0 - alpha) * eo;
@@ -1379,7 +1365,7 @@ __device__ __forceinline__ void hot_update(const Lay &L, const double *hot, cons
     } else {
         for (int e = tid; e < L.n_x; e += NT) {
             const int k = divx<NXT>(L, e), i = e - k * nx;
-            x_update(e, k, i, GV(om, L.rs + e), GV(sv, L.oe + e));
+            x_update(e, k, i, om[L.rs + e], sv[L.oe + e]);
         }
         for (int cu = tid; cu < L.n_u; cu += NT) {
             const int k = divu<NUT>(L, cu), jj = cu - k * nu;
@@ -1425,8 +1411,8 @@ __device__ __forceinline__ void hot_update(const Lay &L, const double *hot, cons
         lo = lo < -QP_INFTY ? -QP_INFTY : lo;
         hi = hi > QP_INFTY ? QP_INFTY : hi;
         const double zr = alpha * zt + (1.0 - alpha) * zv;
-        const double zn = fmin(fmax(zr + DIVIDE(cc * yv, w), lo), hi);
-        const double dy = DIVIDE(w, cc) * (zr - zn);
+        const double zn = fmin(fmax(zr + cc * yv / w, lo), hi);
+        const double dy = (w / cc) * (zr - zn);
         yv += dy; zv = zn;
         if (keep_delta) dyg[r] = dy;
     };
@@ -1434,10 +1420,10 @@ __device__ __forceinline__ void hot_update(const Lay &L, const double *hot, cons
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int r = tid + NT * j;
-            if (r < L.m) { double zv = Z[r], yv = Y[r]; row_update(r, h.om_r[j], zv, yv); Z[r] = zv; Y[r] = yv; }
+            if (r < L.m) { double zv = Z[r], yv = Y[r]; row_update(r, h.om_r[j], zv, yv); Z[r] = zv; Y[r] = yv; W[r] = h.om_r[j] * zv - cc * yv; }
         }
     } else {
-        for (int r = tid; r < L.m; r += NT) { double zv = Z[r], yv = Y[r]; row_update(r, GV(om, r), zv, yv); Z[r] = zv; Y[r] = yv; }
+        for (int r = tid; r < L.m; r += NT) { double zv = Z[r], yv = Y[r]; const double w = om[r]; row_update(r, w, zv, yv); Z[r] = zv; Y[r] = yv; W[r] = w * zv - cc * yv; }
     }
     __syncthreads();
 }
@@ -1460,6 +1446,9 @@ __device__ __forceinline__ void admm_body(const Lay &L, const HotPtrs &P, Smem &
     const double cc = P.c[b];
     HotRegs hr;
     if (LDSSTATE) load_hot_regs<NB, NXT, NUT>(L, gom, gsv, gqv, hr);
+#ifndef MPCQP_ABL_NOPAR
+    hot_rows_w<LDSSTATE>(L, gom, hr, cc, Z, Y, W);
+#endif
     for (int it = 1; it <= iters; ++it) {
         const bool keep_delta = it == iters;         // the increments feed the infeasibility certificates of the check
         TICK_START
