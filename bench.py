@@ -87,9 +87,9 @@ def pmc_traffic(path, kernel):
     """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes of this same command (FETCH_SIZE and WRITE_SIZE
     collected in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950); counters cannot
     be collected from inside the process, so the committed summary of the last profiled run is reported."""
-    path = os.path.join(ROOT, 'profiles', 'pmc_hbm_traffic.json')
+    fname = os.path.join(ROOT, 'profiles', 'pmc_hbm_traffic.json')
     try:
-        with open(path) as f:
+        with open(fname) as f:
             return json.load(f)[path][kernel]['hbm_bytes_per_launch']
     except Exception:
         return None
