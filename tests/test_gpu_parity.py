@@ -417,3 +417,39 @@ def test_device_loop_output_feedback_matches_reference_style_loop():
         x = tr['x'][k + 1]; KF.x = tr['xhat'][k + 1].copy(); KF.y = np.einsum('bij,bj->bi', st(Cd), KF.x)   # no rounding drift
         Ks.update(tr['xhat'][k + 1])
     assert np.array_equal(est.x_true, tr['x'][-1]) and np.array_equal(Kd.x0_rh, tr['xhat'][-1])
+
+
+@pytest.mark.parametrize('dims', [(1, 1, 2, 2), (2, 1, 3, 1), (3, 2, 5, 5), (13, 3, 6, 6), (12, 5, 4, 2), (24, 8, 4, 4), (20, 12, 3, 3),
+                                  (4, 1, 150, 75), (2, 2, 64, 64)])
+def test_boundary_dimensions_match_oracle(dims):
+    """Shapes at the edges of the device code paths: smallest problem (nx=nu=1, Np=2), nx+nu = 16/17 (block size switch),
+    nx+nu = 32 (largest supported), Nc = 1, long horizons with Nc < Np (the reference's Kalman example uses Np=150, Nc=75),
+    LDS-resident and global-memory iterate.  u* against the oracle at tight tolerance, plus one warm step."""
+    from pympc_amd import fixtures
+    nx, nu, Np, Nc = dims
+    kw = dict(fixtures.random_lti(900 + nx * 7 + nu, nx=nx, nu=nu, Np=Np, xbox=3.0))
+    kw['x0'] = 0.3 * kw['x0']
+    if Nc != Np:
+        kw['Nc'] = Nc
+    kw.update(eps_abs=1e-9, eps_rel=1e-9)
+    K = _gpu_controller(kw, max_iter=200000); Ko = _oracle_controller(kw, max_iter=200000)
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        K.setup(); Ko.setup()
+    (u, info), (uo, infoo) = K.output(return_u_seq=True, return_x_seq=True), Ko.output(return_u_seq=True, return_x_seq=True)
+    scale = max(1e-3, np.abs(infoo['u_seq']).max())
+    assert np.abs(info['u_seq'] - infoo['u_seq']).max() <= 1e-6 * scale
+    assert np.abs(info['x_seq'] - infoo['x_seq']).max() <= 1e-6 * max(1e-3, np.abs(infoo['x_seq']).max())
+    x = kw['Ad'] @ kw['x0'] + kw['Bd'] @ uo
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        K.update(x, uo); Ko.update(x, uo)
+    assert np.abs(K.output() - Ko.output()).max() <= 1e-6 * scale
+
+
+def test_unsupported_dimensions_fail_loudly():
+    from pympc_amd import fixtures
+    kw = dict(fixtures.random_lti(1, nx=25, nu=8, Np=3))
+    K = _gpu_controller(kw)
+    with pytest.raises(NotImplementedError):
+        K.setup()
