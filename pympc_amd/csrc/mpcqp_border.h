@@ -1,0 +1,137 @@
+// mpcqp_border.h -- part of libmpcqp_hip (included by mpcqp.hip, one translation unit).
+// Control horizon Nc < Np: bordered (Schur complement) correction; generic KKT solve for the tests.
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// Control horizon Nc < Np (mpc.py:513-517,540-543): the last input ub = u_{Nc-1} is held to the end of the
+// horizon, so it couples to every later stage and K is block tridiagonal plus a border:
+//     K = [ T  B ; B' C ],   T = K without ub (stage Nc-1 keeps only x),   B = K[:, ub],   C = K[ub, ub].
+// With Z = T^-1 B and Sigma = C - B'Z (computed at factor time):  ub = Sigma^-1 (r2 - Z' r1),  y = T^-1 (r1 - B ub).
+// B and C are taken entry by entry from the matrix-free operators (K = cP + diag(s) + A' diag(omega) A).
+// ------------------------------------------------------------------------------------------------
+__device__ double kkt_entry_generic(const Ctx &c, const double *om, const double *sv, double cc, int v, int w) {
+    double acc = 0.0;
+    P_row(c, v, [&](double co, int idx) { if (idx == w) acc += cc * co; });
+    if (v == w) acc += sv[v];
+    AT_row(c, v, [&](double cot, int r) {
+        double arw = 0.0;
+        A_row(c, r, [&](double co, int idx) { if (idx == w) arw += co; });
+        acc += cot * om[r] * arw;
+    });
+    return acc;
+}
+
+// flat variable index of padded slot (k, a), or -1 for padding / the border input
+__device__ __forceinline__ int padded_var(const Lay &L, int k, int a) {
+    if (a < L.nx) return k * L.nx + a;
+    if (a < L.nb && k < L.NcT) return L.ou + k * L.nu + (a - L.nx);
+    return -1;
+}
+
+template <int NB>
+__device__ void border_factor(const Ctx &c, const double *om, const double *sv, double cc, const double *F,
+                              double *Bb, double *Zb, double *Sig, double *W, double *Tc, double *red) {
+    const Lay &L = c.L;
+    const int tid = threadIdx.x, nu = L.nu, NP = L.N * NB;
+    const int ub0 = L.ou + (L.Nc - 1) * L.nu;
+    for (int idx = tid; idx < NP; idx += NT) {
+        const int v = padded_var(L, idx / NB, idx % NB);
+        for (int j = 0; j < nu; ++j) Bb[(size_t)j * NP + idx] = (v >= 0) ? kkt_entry_generic(c, om, sv, cc, v, ub0 + j) : 0.0;
+    }
+    __syncthreads();
+    for (int j = 0; j < nu; ++j) {                         // Z_j = T^-1 B_j
+        for (int idx = tid; idx < NP; idx += NT) Tc[idx] = Bb[(size_t)j * NP + idx];
+        __syncthreads();
+        kkt_core<NB>(core_args(L, F), Tc);
+        for (int idx = tid; idx < NP; idx += NT) Zb[(size_t)j * NP + idx] = Tc[idx];
+        __syncthreads();
+    }
+    // Sigma = C - B'Z, inverted by Gauss-Jordan (SPD, nu x nu) by one thread
+    double *Sg = W;                                        // nu*nu doubles (W, the row work vector, is free here)
+    for (int e = 0; e < nu * nu; ++e) {
+        const int i = e / nu, j = e % nu;
+        double vsum[1] = {0.0}, vmax[1] = {0.0};
+        for (int idx = tid; idx < NP; idx += NT) vsum[0] += Bb[(size_t)i * NP + idx] * Zb[(size_t)j * NP + idx];
+        block_reduce<1, 1>(vmax, vsum, red);
+        if (tid == 0) Sg[e] = kkt_entry_generic(c, om, sv, cc, ub0 + i, ub0 + j) - vsum[0];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        double *Iv = W + nu * nu;                          // scratch for the inverse
+        for (int e = 0; e < nu * nu; ++e) Iv[e] = (e / nu == e % nu) ? 1.0 : 0.0;
+        for (int p = 0; p < nu; ++p) {
+            double d = 1.0 / Sg[p * nu + p];
+            for (int j = 0; j < nu; ++j) { Sg[p * nu + j] *= d; Iv[p * nu + j] *= d; }
+            for (int i = 0; i < nu; ++i) if (i != p) {
+                double f = Sg[i * nu + p];
+                for (int j = 0; j < nu; ++j) { Sg[i * nu + j] -= f * Sg[p * nu + j]; Iv[i * nu + j] -= f * Iv[p * nu + j]; }
+            }
+        }
+        for (int e = 0; e < nu * nu; ++e) Sig[e] = Iv[e];
+    }
+    __syncthreads();
+}
+
+// Before the tridiagonal solve: Tc holds r1 in the padded slots and r2 in the (otherwise padding) u slots of stage
+// Nc-1.  Computes ub, leaves it in ubar[] (LDS, nu doubles) and replaces r1 by r1 - B ub.
+template <int NB>
+__device__ void border_pre(const Lay &L, const double *Bb, const double *Zb, const double *Sig, double *Tc, double *ubar, double *red) {
+    const int tid = threadIdx.x, nu = L.nu, NP = L.N * NB;
+    const int slot = (L.Nc - 1) * NB + L.nx;
+    for (int j = 0; j < nu; ++j) {
+        double vsum[1] = {0.0}, vmax[1] = {0.0};
+        for (int idx = tid; idx < NP; idx += NT) vsum[0] += Zb[(size_t)j * NP + idx] * Tc[idx];     // Z is zero in the r2 slots
+        block_reduce<1, 1>(vmax, vsum, red);
+        if (tid == 0) ubar[nu + j] = Tc[slot + j] - vsum[0];
+        __syncthreads();
+    }
+    if (tid < nu) { double a = 0.0; for (int j = 0; j < nu; ++j) a += Sig[tid * nu + j] * ubar[nu + j]; ubar[tid] = a; }
+    __syncthreads();
+    for (int idx = tid; idx < NP; idx += NT) {
+        double a = Tc[idx];
+        for (int j = 0; j < nu; ++j) a -= Bb[(size_t)j * NP + idx] * ubar[j];
+        Tc[idx] = a;
+    }
+    if (tid < nu) Tc[slot + tid] = 0.0;
+    __syncthreads();
+}
+__device__ __forceinline__ void border_post(const Lay &L, int NB, double *Tc, const double *ubar) {
+    if ((int)threadIdx.x < L.nu) Tc[(L.Nc - 1) * NB + L.nx + threadIdx.x] = ubar[threadIdx.x];
+    __syncthreads();
+}
+
+// Generic front end (verification kernel): flat rhs (global) -> flat solution `out` (global, n doubles).
+// Tc: LDS, N*NB doubles.
+template <int NB>
+__device__ void kkt_solve(const Ctx &c, const double *om, const double *sv, double cc, const double *F,
+                          const double *rg, double *Tc, double *out, BorderPtrs bp, double *ubar) {
+    const Lay &L = c.L;
+    const double cef = cc * c.eps_feas();
+    for (int idx = threadIdx.x; idx < L.N * NB; idx += NT) {
+        int k = idx / NB, a = idx % NB;
+        double v = 0.0;
+        if (a < L.nx) {
+            int e = k * L.nx + a;
+            double ws = om[L.rs + e];
+            double te = rg[L.oe + e] / (cef + sv[L.oe + e] + ws);
+            out[L.oe + e] = te;
+            v = rg[e] - ws * te;
+        } else if (a < L.nb && k < L.Nc) v = rg[L.ou + k * L.nu + (a - L.nx)];
+        Tc[idx] = v;
+    }
+    __syncthreads();
+    if (L.border) border_pre<NB>(L, bp.Bb, bp.Zb, bp.Sig, Tc, ubar, bp.red);
+    kkt_core<NB>(core_args(L, F), Tc);
+    if (L.border) border_post(L, NB, Tc, ubar);
+    for (int idx = threadIdx.x; idx < L.N * NB; idx += NT) {
+        int k = idx / NB, a = idx % NB;
+        if (a < L.nx) {
+            int e = k * L.nx + a;
+            double ws = om[L.rs + e];
+            double xe = Tc[idx];
+            out[e] = xe;
+            out[L.oe + e] -= (ws / (cef + sv[L.oe + e] + ws)) * xe;
+        } else if (a < L.nb && k < L.Nc) out[L.ou + k * L.nu + (a - L.nx)] = Tc[idx];
+    }
+    __syncthreads();
+}

@@ -1,0 +1,148 @@
+// mpcqp_factor.h -- part of libmpcqp_hip (included by mpcqp.hip, one translation unit).
+// Twisted block LDL' factorization of the reduced KKT matrix into FP64-MFMA operand fragments.
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// Block LDL' of the block-tridiagonal K (stage blocks NB x NB, NB = 16 or 32):
+//      S_0 = K_00,   Mh_k = K_{k,k-1} S_{k-1}^-1,   S_k = K_kk - Mh_k K_{k,k-1}'
+// Solve K x = b:    yh_0 = b_0,  yh_k = b_k - Mh_k yh_{k-1};   w_k = S_k^-1 yh_k;
+//                   x_{N-1} = w_{N-1},  x_k = w_k - Mh_{k+1}' x_{k+1}.
+// The factor is stored in the operand order of the matrix-core instruction the sweeps use, v_mfma_f64_4x4x4_4b_f64
+// (four independent 4x4x4 products per instruction; 31 cycles dependent latency measured, against 83 for the
+// 16x16x4 shape, and a quarter of its pipe time).  Layouts probed on gfx950 (scripts/probe_mfma4.hip):
+//     A[blk][i][k] in lane 16k + 4blk + i,   B[blk][k][j] in lane 16k + 4blk + j,   D[blk][i][j] in lane 16i + 4blk + j.
+// A 16x16 block M times a 16-vector v, as 4x4 sub-blocks M_IJ: step s = 0..3 computes, in block slot b,
+// M_{b,(b+s)%4} * v_{(b+s)%4} (B operand = the sub-vector replicated over j) and accumulates y_b = sum_J M_bJ v_J.
+// The result y[4b+i] sits in lane 16i + 4b + j, which is exactly where step 0 of the NEXT product wants its B operand
+// (lane 16k + 4b + j holds v[4b+k]); steps 1..3 need the sub-vector of the neighbouring block slot, a rotation of each
+// 16-lane row by 4, 8, 12 lanes: DPP row_ror.  So a stage vector is ONE double per lane, stage outputs feed the next
+// stage through three DPP rotations and no LDS traffic, and a lane's four fragment values (one per step) are
+// contiguous: fragment element (r, c) -> lane 16(c&3) + 4(r>>2) + (r&3), step ((c>>2) - (r>>2)) & 3.
+// Per stage k:  [ forward matrix | S_k^-1 ]   (2 NB^2 doubles, 32 B per lane per block); the back substitution
+// applies the forward matrix of the neighbouring stage TRANSPOSED from the same fragments (frag_matvec_T).
+// ------------------------------------------------------------------------------------------------
+// Optimisation barriers: values the compiler would otherwise hoist out of the ADMM iteration loop (loop-invariant
+// loads and address arithmetic of the sweeps) and keep live across ALL phases, pushing the kernel into scratch spills.
+template <class T> __device__ __forceinline__ T *opaque_ptr(T *p) {      // workgroup-uniform pointer, pinned to scalar registers
+    unsigned long long v = (unsigned long long)p;
+    unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    p = (T *)(((unsigned long long)hi << 32) | lo);
+    asm volatile("" : "+s"(p));
+    return p;
+}
+__device__ __forceinline__ int opaque_lane(int v) { asm volatile("" : "+v"(v)); return v; }
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) double gdouble;     // explicit global address space: plain global_load/store,
+typedef __attribute__((address_space(1))) const double cgdouble;  // not flat_* (which also counts on lgkmcnt)
+typedef __attribute__((address_space(1))) const d4 cgd4;
+
+template <int NB>
+__device__ __forceinline__ int frag_pos(int r, int cidx) {
+    constexpr int NBLK = NB / 16;
+    const int bi = r >> 4, bj = cidx >> 4, rr = r & 15, cc = cidx & 15;
+    const int b = rr >> 2, i = rr & 3, J = cc >> 2, k = cc & 3;
+    const int sft = (J - b) & 3;                       // MFMA step in which 4x4 block (b, J) is used
+    const int lane = k * 16 + b * 4 + i;
+    return (bi * NBLK + bj) * 256 + lane * 4 + sft;
+}
+
+// TWISTED (two-sided) elimination: stages 0..mid-1 are eliminated top-down, stages N-1..mid+1 bottom-up, the
+// middle stage mid = N/2 last, so that two waves can sweep the two half-chains concurrently (half the
+// sequential depth).  With Sn = S^-1 of the neighbour eliminated just before,
+//   top    k < mid:  Mh_k = K_{k,k-1} Sn_{k-1},   S_k = K_kk - Mh_k K_{k,k-1}'
+//   bottom k > mid:  Mt_k = K_{k,k+1} Sn_{k+1},   S_k = K_kk - Mt_k K_{k,k+1}'        (K_{k,k+1} = K_{k+1,k}')
+//   middle        :  S_mid = K_mm - Mh_mid K_{mid,mid-1}' - Mt_mid K_{mid,mid+1}'
+// Per-stage factor slots (fragments, see above):   slot 0: forward matrix   slot 1: S_k^-1
+//   top:    slot0 = -Mh_k        bottom: slot0 = -Mt_k        middle: slot0 = -Mh_mid, and its second forward matrix
+//   -Mt_mid in slot 0 of stage 0 (which has none of its own).  Back substitution: x_k += slot0(k+1)' x_{k+1} in the
+//   top half, x_k += slot0(k-1)' x_{k-1} in the bottom half (-Mt_mid' for k = mid+1).
+// W: LDS workspace of 6*NB*NB doubles.  Returns (uniformly) 0, or 1 if a pivot was not positive.
+struct BorderPtrs { double *Bb, *Zb, *Sig, *red; };
+
+template <int NB> __device__ void border_factor(const Ctx &, const double *, const double *, double, const double *, double *, double *, double *, double *, double *, double *);
+
+template <int NB>
+__device__ int factor_all(const Ctx &c, const double *om, const double *sv, double cc, double *F, double *W, int *iflag, BorderPtrs bp) {
+    const Lay &L = c.L;
+    double *S = W, *Ks = W + NB * NB, *Mh = W + 2 * NB * NB, *SnA = W + 3 * NB * NB, *Li = W + 4 * NB * NB, *SnB = W + 5 * NB * NB;
+    const int tid = threadIdx.x;
+    const int N = L.N, mid = N / 2;
+    if (tid == 0) *iflag = 0;
+    // S -= (Ks Sn) Ks' for the neighbour on side `up` (true: k-1, false: k+1); stores the two fragment copies
+    auto eliminate_neighbour = [&](int k, bool up, const double *Sn) {
+        __syncthreads();
+        for (int e = tid; e < NB * NB; e += NT) {
+            int a = e / NB, b = e % NB;
+            Ks[e] = up ? kkt_sub_entry(c, om, cc, k - 1, a, b) : kkt_sub_entry(c, om, cc, k, b, a);
+        }
+        __syncthreads();
+        for (int e = tid; e < NB * NB; e += NT) {              // Mh = Ks * Sn
+            int a = e / NB, b = e % NB;
+            double acc = 0.0;
+            for (int l = 0; l < NB; ++l) acc += Ks[a * NB + l] * Sn[l * NB + b];
+            Mh[e] = acc;
+        }
+        __syncthreads();
+        const int fwd_stage = (k == mid && !up) ? 0 : k;
+        for (int e = tid; e < NB * NB; e += NT) {              // S -= Mh * Ks'
+            int a = e / NB, b = e % NB;
+            double acc = 0.0;
+            for (int l = 0; l < NB; ++l) acc += Mh[a * NB + l] * Ks[b * NB + l];
+            S[e] -= acc;
+            // forward matrix of stage k (the backward sweep applies the same fragment transposed); the middle stage's
+            // second forward matrix lives in the otherwise unused slot 0 of stage 0
+            F[(size_t)fwd_stage * L.fstage + frag_pos<NB>(a, b)] = -Mh[e];
+        }
+        __syncthreads();
+    };
+    auto stage = [&](int k, bool use_up, bool use_down, double *SnOut) {
+        __syncthreads();
+        for (int e = tid; e < NB * NB; e += NT) {
+            S[e] = kkt_diag_entry(c, om, sv, cc, k, e / NB, e % NB);
+            Li[e] = 0.0;
+            if (k == N - 1) F[(size_t)k * L.fstage + e] = 0.0;      // the last stage has no forward matrix (stage 0's slot holds the middle's second one)
+        }
+        if (use_up) eliminate_neighbour(k, true, SnA);
+        if (use_down) eliminate_neighbour(k, false, SnB);
+        __syncthreads();
+        // Cholesky of S (lower), right-looking
+        for (int j = 0; j < NB; ++j) {
+            double d = S[j * NB + j];
+            if (!(d > 0.0)) { if (tid == 0) *iflag = 1; d = 1e-300; }
+            d = sqrt(d);
+            __syncthreads();
+            for (int i = j + tid; i < NB; i += NT) S[i * NB + j] = (i == j) ? d : S[i * NB + j] / d;
+            __syncthreads();
+            const int rem = NB - 1 - j;
+            for (int e = tid; e < rem * rem; e += NT) {
+                int i = j + 1 + e / rem, l = j + 1 + e % rem;
+                if (l <= i) S[i * NB + l] -= S[i * NB + j] * S[l * NB + j];
+            }
+            __syncthreads();
+        }
+        if (tid < NB) {                                       // Li = L^-1, one thread per column
+            const int col = tid;
+            Li[col * NB + col] = 1.0 / S[col * NB + col];
+            for (int i = col + 1; i < NB; ++i) {
+                double acc = 0.0;
+                for (int l = col; l < i; ++l) acc += S[i * NB + l] * Li[l * NB + col];
+                Li[i * NB + col] = -acc / S[i * NB + i];
+            }
+        }
+        __syncthreads();
+        for (int e = tid; e < NB * NB; e += NT) {              // S^-1 = Li' Li
+            int a = e / NB, b = e % NB;
+            double acc = 0.0;
+            for (int l = max(a, b); l < NB; ++l) acc += Li[l * NB + a] * Li[l * NB + b];
+            SnOut[e] = acc;
+            F[(size_t)k * L.fstage + NB * NB + frag_pos<NB>(a, b)] = acc;
+        }
+    };
+    for (int k = 0; k < mid; ++k) stage(k, k > 0, false, SnA);
+    for (int k = N - 1; k > mid; --k) stage(k, false, k < N - 1, SnB);
+    stage(mid, true, true, SnA);
+    __syncthreads();
+    if (L.border) border_factor<NB>(c, om, sv, cc, F, bp.Bb, bp.Zb, bp.Sig, W, W + L.m, bp.red);
+    return *iflag;
+}

@@ -1,0 +1,239 @@
+// mpcqp_kernels.h -- part of libmpcqp_hip (included by mpcqp.hip, one translation unit).
+// The persistent solve / closed-loop kernel k_mpc_run and the verification kernels.
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// Device-side receding-horizon loop (the caller pattern of examples/example_point_mass.py:88-101 and
+// pyMPC/mpc.py:688-692):   for k in range(K):  u = K.output();  x = Ap x + Bp u + w_k;  K.update(x)
+// One workgroup walks its own instance through all K steps -- output (mpc.py:271-336, u_failure = uref unless
+// 'solved'), plant, QP refresh (mpc.py:386-454), warm-started solve -- with no host round trip and, unlike the
+// per-step API, no batch-wide barrier per round: an instance that needs 50 iterations does not hold up one that
+// needs 25.  The same kernel with nsteps = 0 is
+// mpcqp_solve: begin, rounds of { admm, check } until this instance terminates -- no host loop, no batch barrier.
+// ------------------------------------------------------------------------------------------------
+struct RunArgs {
+    int nsteps;                   // closed-loop steps (LOOP kernels); 0 = one solve of the current data (mpcqp_solve)
+    int plain;                    // run exactly max_iter iterations, no termination test / rho adaptation (mpcqp_iterate)
+    int max_iter, chk, rho_every;
+    const double *w;              // [nsteps][batch][nx] additive plant disturbance, or null
+    const double *Ap, *Bp;        // [batch][nx*nx], [batch][nx*nu] plant matrices, or null (plant = model Ad, Bd)
+    const double *xref_traj;      // [nsteps][batch][xref_blk] reference for the solve after step k, or null (unchanged)
+    int xref_blk;                 // xref_rows * nx
+    int ny;                       // > 0: output feedback through a LinearStateEstimator (pyMPC/kalman.py:109-134)
+    const double *C, *Lg, *v;     // [batch][ny*nx], [batch][nx*ny], [nsteps][batch][ny] (or null)
+    double *x_true;               // [batch][nx] true plant state (in/out) when the controller only sees the estimate
+    double *x_traj;               // [nsteps+1][batch][nx] plant states
+    double *xhat_traj;            // [nsteps+1][batch][nx] estimates xhat[k|k-1] handed to update() (estimator only)
+    double *y_traj;               // [nsteps][batch][ny] measurements (estimator only)
+    double *u_traj;               // [nsteps][batch][nu]
+    int *status_traj, *iter_traj; // [nsteps][batch]: outcome of the solve that follows step k's update
+    int batch;
+};
+
+__host__ __device__ inline int next_stop(int iter, int max_iter, int chk, int rho_every) {
+    int nxt = max_iter;
+    if (chk) { int v = (iter / chk + 1) * chk; nxt = v < nxt ? v : nxt; }
+    if (rho_every) { int v = (iter / rho_every + 1) * rho_every; nxt = v < nxt ? v : nxt; }
+    return nxt;
+}
+__host__ __device__ inline int stop_mode(int iter, int max_iter, int chk, int rho_every, bool plain) {
+    int mode = plain ? COLD_PLAIN : 0;
+    if (chk && iter % chk == 0) mode |= COLD_CHECK;
+    if (rho_every && iter % rho_every == 0) mode |= COLD_RHO;
+    if (iter == max_iter && !plain) mode |= COLD_FINAL;
+    return mode;
+}
+
+// The three phases are separate (non-inlined) functions so that each gets a register allocation of its own --
+// inlined into one body, the cold code's live ranges pushed spill reloads into the ADMM sweep.  They take no
+// pointer arguments: everything is re-read from the kernel-argument segment, which is uniform, constant memory
+// (scalar loads), instead of travelling through the vector-register calling convention.
+struct RunKArgs { Lay L; Ptrs P; mpcqp_settings S; RunArgs R; };
+static_assert(sizeof(RunKArgs) % 8 == 0, "hidden kernel arguments start right behind RunKArgs");
+typedef const __attribute__((address_space(4))) RunKArgs *ckargs;
+// (In a non-kernel function the kernarg segment pointer itself is not available, the implicit-argument pointer is:
+//  the hidden arguments follow the explicit ones, here the single RunKArgs struct, at the next 8-byte boundary.)
+__device__ __forceinline__ const RunKArgs &run_kargs() {
+    typedef const __attribute__((address_space(4))) char *cbytes;
+    return *(const RunKArgs *)(ckargs)((cbytes)__builtin_amdgcn_implicitarg_ptr() - ((sizeof(RunKArgs) + 7) & ~size_t(7)));
+}
+
+struct RunSmem { Smem S; double *X, *Z, *Y; };
+template <bool LDSSTATE>
+__device__ __forceinline__ RunSmem run_smem(const Lay &L, const Ptrs &P) {
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    RunSmem r; double *p = sh; smem_common(L, P, p, r.S);
+    r.X = r.Z = r.Y = nullptr;
+    if (LDSSTATE) { r.X = carve(p, L.n); r.Z = carve(p, L.m); r.Y = carve(p, L.m); }
+    return r;
+}
+
+template <int NB>
+__device__ __noinline__ void run_factor_phase() {
+    const RunKArgs &A = run_kargs();
+    const Lay &L = A.L; const Ptrs &P = A.P;
+    RunSmem r = run_smem<false>(L, P);                       // (the common LDS area comes first in both layouts)
+    const int b = blockIdx.x;
+    Ctx c{L, r.S.hot, P.model + (size_t)b * L.model_sz};
+    factor_all<NB>(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], P.F + (size_t)b * P.fsz, r.S.T, r.S.iflag,
+                   border_ptrs(L, P, r.S.red));
+}
+
+template <int NB, bool LDSSTATE, int NXT, int NUT, bool BORDER>
+__device__ __noinline__ void run_admm_phase(int iters) {
+    const RunKArgs &A = run_kargs();
+    const Lay &L = A.L; const Ptrs &P = A.P;
+    RunSmem r = run_smem<LDSSTATE>(L, P);
+    HotPtrs hp; hp.model = P.model; hp.step = P.step; hp.omega = P.omega; hp.s = P.s; hp.qv = P.qv; hp.F = P.F; hp.c = P.c;
+    hp.Bb = P.Bb; hp.Zb = P.Zb; hp.Sig = P.Sig; hp.x = P.x; hp.z = P.z; hp.y = P.y; hp.dx = P.dx; hp.dy = P.dy; hp.fsz = P.fsz;
+    admm_body<NB, LDSSTATE, NXT, NUT, BORDER>(L, hp, r.S, r.X, r.Z, r.Y, A.S.alpha, __builtin_amdgcn_readfirstlane(iters));
+}
+
+template <int NB, bool LDSSTATE>
+__device__ __noinline__ void run_begin_phase(int plain) {
+    const RunKArgs &A = run_kargs();
+    RunSmem r = run_smem<LDSSTATE>(A.L, A.P);
+    begin_body<NB>(A.L, A.P, A.S, r.S, __builtin_amdgcn_readfirstlane(plain));
+}
+
+template <int NB, bool LDSSTATE>
+__device__ __noinline__ int run_check_phase(int iter, int mode) {
+    const RunKArgs &A = run_kargs();
+    RunSmem r = run_smem<LDSSTATE>(A.L, A.P);
+    return check_body<NB>(A.L, A.P, A.S, r.S, __builtin_amdgcn_readfirstlane(iter), __builtin_amdgcn_readfirstlane(mode), r.X, r.Z, r.Y);
+}
+
+template <int NB, bool LDSSTATE, int NXT, int NUT, bool BORDER, bool LOOP>
+__global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_mpc_run(RunKArgs A_) {
+    const RunKArgs &A = run_kargs();
+    const Lay &L = A.L; const Ptrs &P = A.P; const RunArgs &R = A.R;
+    RunSmem rs = run_smem<LDSSTATE>(L, P);
+    Smem &S = rs.S;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    double *step = P.step + (size_t)b * L.step_sz;
+    load_common(L, P.model + (size_t)b * L.model_sz, step, S);
+    const int nx = L.nx, nu = L.nu;
+    const int nrun = LOOP ? R.nsteps : 1;        // LOOP = false: one solve of the current data (mpcqp_solve)
+    for (int k = 0; k < nrun; ++k) {
+        if (LOOP) {
+            // scratch in the (idle) work area: un | xn | xt | ym | inn | xu, 32 doubles each (nx + nu <= 32)
+            double *un = S.T, *xn = S.T + 32, *xt = S.T + 64, *ym = S.T + 96, *inn = S.T + 128, *xu = S.T + 160;
+            const size_t kb = (size_t)k * R.batch + b;
+            const int ny = R.ny;
+            // ---- output(): first input of the current solution, or u_failure
+            const int status = P.info[b].status;
+            if (tid < nu) un[tid] = status == MPCQP_SOLVED ? P.xo[(size_t)b * L.n + L.ou + tid] : S.hot[L.ouref + tid];
+            if (tid < nx) xt[tid] = ny ? R.x_true[(size_t)b * nx + tid] : S.x0s[tid];      // the plant state
+            __syncthreads();
+            if (ny && tid < ny) {                            // measurement y = C x + v and innovation y - C xhat
+                const double *C = R.C + (size_t)b * ny * nx + (size_t)tid * nx;
+                double y = R.v ? R.v[kb * ny + tid] : 0.0, yh = 0.0;
+                for (int j = 0; j < nx; ++j) { y += C[j] * xt[j]; yh += C[j] * S.x0s[j]; }
+                ym[tid] = y; inn[tid] = y - yh;
+                if (R.y_traj) R.y_traj[kb * ny + tid] = y;
+            }
+            // ---- plant step
+            if (tid < nx) {
+                const double *Ap = R.Ap ? R.Ap + (size_t)b * nx * nx : S.hot + L.oAd;
+                const double *Bp = R.Bp ? R.Bp + (size_t)b * nx * nu : S.hot + L.oBd;
+                double v = R.w ? R.w[kb * nx + tid] : 0.0;
+                double acc = 0.0;
+                for (int j = 0; j < nx; ++j) acc += Ap[tid * nx + j] * xt[j];
+                for (int j = 0; j < nu; ++j) acc += Bp[tid * nu + j] * un[j];
+                xn[tid] = acc + v;
+                R.x_traj[kb * nx + tid] = xt[tid];
+                if (ny) { R.x_true[(size_t)b * nx + tid] = xn[tid]; if (R.xhat_traj) R.xhat_traj[kb * nx + tid] = S.x0s[tid]; }
+            }
+            if (tid < nu) R.u_traj[kb * nu + tid] = un[tid];
+            __syncthreads();
+            if (ny) {                                        // KF.update(y): xhat[k|k] = xhat[k|k-1] + L (y - yhat);  KF.predict(u)
+                if (tid < nx) {
+                    const double *Lg = R.Lg + (size_t)b * nx * ny + (size_t)tid * ny;
+                    double acc = S.x0s[tid];
+                    for (int j = 0; j < ny; ++j) acc += Lg[j] * inn[j];
+                    xu[tid] = acc;
+                }
+                __syncthreads();
+                if (tid < nx) {
+                    const double *Ad = S.hot + L.oAd, *Bd = S.hot + L.oBd;
+                    double acc = 0.0;
+                    for (int j = 0; j < nx; ++j) acc += Ad[tid * nx + j] * xu[j];
+                    for (int j = 0; j < nu; ++j) acc += Bd[tid * nu + j] * un[j];
+                    xn[tid] = acc;                           // xhat[k+1|k]: what the controller is updated with
+                }
+                __syncthreads();
+            }
+            // ---- update(x): new initial state, previous input (mpc.py:338-364) and, if given, reference
+            if (tid < nx) { S.x0s[tid] = xn[tid]; step[tid] = xn[tid]; }
+            if (tid < nu) { S.um1s[tid] = un[tid]; step[nx + tid] = un[tid]; }
+            if (R.xref_traj) for (int i = tid; i < R.xref_blk; i += NT) step[nx + nu + i] = R.xref_traj[kb * R.xref_blk + i];
+            __syncthreads();
+        }
+#ifdef MPCQP_RUN_TIMING
+#define PHASE_CLOCK(i) { unsigned long long t_ = wall_clock64(); if (tid == 0) atomicAdd(&P.stats[4 + (i)], t_ - tphase); tphase = t_; }
+        unsigned long long tphase = wall_clock64();
+#else
+#define PHASE_CLOCK(i)
+#endif
+        run_begin_phase<NB, LDSSTATE>(R.plain);
+        __syncthreads();
+        PHASE_CLOCK(0)
+        int iter = 0, term = 0;
+        while (!term) {
+            const int nxt = next_stop(iter, R.max_iter, R.chk, R.rho_every);
+            run_admm_phase<NB, LDSSTATE, NXT, NUT, BORDER>(nxt - iter);
+            iter = nxt;
+            __syncthreads();
+            PHASE_CLOCK(1)
+            term = run_check_phase<NB, LDSSTATE>(iter, stop_mode(iter, R.max_iter, R.chk, R.rho_every, R.plain != 0));
+            __syncthreads();
+            PHASE_CLOCK(2)
+        }
+        if (LOOP && tid == 0) {
+            R.status_traj[(size_t)k * R.batch + b] = P.info[b].status;
+            R.iter_traj[(size_t)k * R.batch + b] = iter;
+        }
+        __syncthreads();
+    }
+    if (LOOP && tid < nx) {
+        const size_t e = ((size_t)R.nsteps * R.batch + b) * nx + tid;
+        R.x_traj[e] = R.ny ? R.x_true[(size_t)b * nx + tid] : S.x0s[tid];
+        if (R.ny && R.xhat_traj) R.xhat_traj[e] = S.x0s[tid];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// verification kernels
+// ------------------------------------------------------------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(NT) void k_export(Lay L, Ptrs P, double *Pd, double *Ad_, double *q, double *l, double *u) {
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    double *p = sh; Smem S; smem_common(L, P, p, S);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const double *model = P.model + (size_t)b * L.model_sz, *step = P.step + (size_t)b * L.step_sz;
+    load_common(L, model, step, S);
+    Ctx c{L, S.hot, model};
+    build_q(c, step, S.Qv);
+    __syncthreads();
+    if (Pd) { double *o = Pd + (size_t)b * L.n * L.n; for (int j = tid; j < L.n; j += NT) P_row(c, j, [&](double co, int idx) { o[(size_t)j * L.n + idx] = co; }); }
+    if (Ad_) { double *o = Ad_ + (size_t)b * L.m * L.n; for (int r = tid; r < L.m; r += NT) A_row(c, r, [&](double co, int idx) { o[(size_t)r * L.n + idx] = co; }); }
+    if (q) for (int j = tid; j < L.n; j += NT) q[(size_t)b * L.n + j] = (j < L.oe) ? S.Qv[j] : 0.0;
+    if (l && u) for (int r = tid; r < L.m; r += NT) { double lo, hi; row_bounds(c, S.x0s, S.um1s, r, lo, hi); l[(size_t)b * L.m + r] = lo; u[(size_t)b * L.m + r] = hi; }
+}
+
+template <int NB>
+__global__ __launch_bounds__(NT) void k_kkt_solve(Lay L, Ptrs P, const double *rhs, double *sol) {
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    double *p = sh; Smem S; smem_common(L, P, p, S);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const double *model = P.model + (size_t)b * L.model_sz, *step = P.step + (size_t)b * L.step_sz;
+    load_common(L, model, step, S);
+    Ctx c{L, S.hot, model};
+    kkt_solve<NB>(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], P.F + (size_t)b * P.fsz, rhs + (size_t)b * L.n, S.T + L.m, sol + (size_t)b * L.n, border_ptrs(L, P, S.red), S.tv);
+    (void)tid;
+}
+
+__global__ void k_gather_u0(Lay L, const double *xo, double *u0, int batch) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < batch * L.nu) { int b = i / L.nu, j = i - b * L.nu; u0[i] = xo[(size_t)b * L.n + L.ou + j]; }
+}

@@ -1,0 +1,65 @@
+// mpcqp_layout.h -- part of libmpcqp_hip (included by mpcqp.hip, one translation unit).
+// Instance layout, device pointer tables, visitor context.
+#pragma once
+
+// ------------------------------------------------------------------------------------------------
+// Layout of one instance
+// ------------------------------------------------------------------------------------------------
+constexpr int MAXEV = 64;         // profiling: launches whose HIP events may be pending
+
+struct Lay {
+    int nx, nu, Np, Nc, N, nb, n, m, n_x, n_u, ou, oe, rs, ri, rdu;
+    int NB;                       // padded stage block size (16 or 32)
+    int NcT;                      // stages 0..NcT-1 carry their input u_k inside the block-tridiagonal part
+    int border;                   // 1 if Nc < Np: the held last input u_{Nc-1} couples to every later stage and is
+                                  // handled as a bordered (Schur-complement) correction, see border_* below
+    float rnx, rnu;               // reciprocals for cheap index division
+    // model blob: hot prefix [Ad|Bd|xmin|xmax|umin|umax|Dumin|Dumax|uref|eps_feas] then [Qx|QxN|Qu|QDu]
+    int oAd, oBd, oxmin, oxmax, oumin, oumax, oDumin, oDumax, ouref, oeps, hot_sz;
+    int oQx, oQxN, oQu, oQDu, model_sz;
+    int step_sz;                  // [x0 | um1 | xref(N*nx)]
+    int xref_rows;                // 1 or N
+    int fstage;                   // doubles per factor stage: 2*NB*NB  [forward matrix | S^-1]
+    int tsz;                      // LDS work vector length: max(m, 4*NB*NB)
+};
+
+struct Ptrs {
+    double *model, *step;
+    double *D, *E, *c, *omega, *s, *rho;
+    double *F;
+    double *x, *z, *y;            // iterate (unscaled units)
+    double *xo, *yo;              // reported solution
+    double *dx, *dy;              // last primal / dual increments (infeasibility certificates)
+    double *Bb, *Zb, *Sig;        // border (Nc < Np): K[:,ubar] and T^-1 K[:,ubar] in padded layout [nu][N*NB], Schur inverse [nu*nu]
+    double *qv;                   // linear cost of the x,u variables [n_x+n_u] (rebuilt by every kernel prologue)
+    double *Dt, *Et;              // Ruiz temporaries
+    int *ctype;
+    unsigned long long *stats;    // [0] ADMM iterations, [1] residual evaluations, [2] refactorizations, [3] instance-solves
+    mpcqp_info *info;
+    long long fsz;                // factor doubles per instance
+};
+
+// The hot kernel gets only the pointers it uses (fewer scalar registers -> no SGPR spills into vector lanes).
+struct HotPtrs {
+    const double *model, *step, *omega, *s, *qv, *F, *c, *Bb, *Zb, *Sig;
+    double *x, *z, *y, *dx, *dy;
+    long long fsz;
+};
+
+__device__ __forceinline__ int idiv(int r, float rcp) { return __float2int_rd(((float)r + 0.5f) * rcp); }
+__device__ __forceinline__ double limit_scaling(double v) { v = v < MIN_SCALING ? 1.0 : v; return v > MAX_SCALING ? MAX_SCALING : v; }
+
+// Everything a row visitor needs.  `hot` points at the hot prefix of the model blob (LDS or global),
+// `Q` at the blob itself (global) for the weight matrices.
+struct Ctx {
+    Lay L;
+    const double *hot;
+    const double *blob;
+    __device__ __forceinline__ const double *Ad() const { return hot + L.oAd; }
+    __device__ __forceinline__ const double *Bd() const { return hot + L.oBd; }
+    __device__ __forceinline__ const double *Qx() const { return blob + L.oQx; }
+    __device__ __forceinline__ const double *QxN() const { return blob + L.oQxN; }
+    __device__ __forceinline__ const double *Qu() const { return blob + L.oQu; }
+    __device__ __forceinline__ const double *QDu() const { return blob + L.oQDu; }
+    __device__ __forceinline__ double eps_feas() const { return hot[L.oeps]; }
+};

@@ -1,0 +1,561 @@
+// mpcqp_phases.h -- part of libmpcqp_hip (included by mpcqp.hip, one translation unit).
+// Setup kernel and the phases of a solve: begin, check (OSQP termination / infeasibility / rho adaptation), ADMM iterations.
+#pragma once
+
+// rho vector -> metric.  Constraint types are decided on the SCALED bounds, as OSQP does.
+__device__ __forceinline__ int row_type(double E, double lo, double hi) {
+    double ls = E * lo, us = E * hi;
+    if (ls < -QP_INFTY * MIN_SCALING && us > QP_INFTY * MIN_SCALING) return -1;
+    if (us - ls < RHO_TOL) return 1;
+    return 0;
+}
+__device__ __forceinline__ double row_rho(int type, double rho) { return type < 0 ? RHO_MIN : (type > 0 ? RHO_EQ_OVER_RHO_INEQ * rho : rho); }
+
+__device__ __forceinline__ BorderPtrs border_ptrs(const Lay &L, const Ptrs &P, double *red) {
+    BorderPtrs bp; bp.red = red;
+    const size_t npb = (size_t)L.nu * L.N * L.NB;
+    bp.Bb = L.border ? P.Bb + blockIdx.x * npb : nullptr;
+    bp.Zb = L.border ? P.Zb + blockIdx.x * npb : nullptr;
+    bp.Sig = L.border ? P.Sig + (size_t)blockIdx.x * L.nu * L.nu : nullptr;
+    return bp;
+}
+
+// Shared prologue: stage the hot model prefix and the step data in LDS.
+struct Smem {
+    double *T, *Qv, *hot, *x0s, *um1s, *red, *tv;
+    int *iflag;
+};
+__device__ __forceinline__ double *carve(double *&p, int n) { double *r = p; p += n; return r; }
+template <class PT>
+__device__ void smem_common(const Lay &L, const PT &P, double *&p, Smem &S) {
+    S.T = carve(p, L.tsz);
+    S.Qv = (double *)P.qv + (size_t)blockIdx.x * (L.n_x + L.n_u);
+    S.hot = carve(p, L.hot_sz);
+    S.x0s = carve(p, L.nx);
+    S.um1s = carve(p, L.nu);
+    S.red = carve(p, 64);
+    S.tv = carve(p, 64);
+    S.iflag = (int *)carve(p, 2);
+}
+__host__ __device__ inline int smem_common_doubles(const Lay &L) { return L.tsz + L.hot_sz + L.nx + L.nu + 64 + 64 + 2; }
+
+__device__ void load_common(const Lay &L, const double *model, const double *step, Smem &S) {
+    for (int i = threadIdx.x; i < L.hot_sz; i += NT) S.hot[i] = model[i];
+    for (int i = threadIdx.x; i < L.nx; i += NT) S.x0s[i] = step[i];
+    for (int i = threadIdx.x; i < L.nu; i += NT) S.um1s[i] = step[L.nx + i];
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// setup kernel: Ruiz equilibration (OSQP, 10 passes), rho vector, metric, first factorization.
+// ------------------------------------------------------------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(NT) void k_setup(Lay L, Ptrs P, mpcqp_settings S_) {
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    double *p = sh; Smem S; smem_common(L, P, p, S);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const double *model = P.model + (size_t)b * L.model_sz, *step = P.step + (size_t)b * L.step_sz;
+    load_common(L, model, step, S);
+    Ctx c{L, S.hot, model};
+    build_q(c, step, S.Qv);
+    double *D = P.D + (size_t)b * L.n, *E = P.E + (size_t)b * L.m, *Dt = P.Dt + (size_t)b * L.n, *Et = P.Et + (size_t)b * L.m;
+    for (int j = tid; j < L.n; j += NT) D[j] = 1.0;
+    for (int r = tid; r < L.m; r += NT) E[r] = 1.0;
+    double cc = 1.0;
+    __syncthreads();
+    for (int it = 0; it < S_.scaling; ++it) {
+        for (int j = tid; j < L.n; j += NT) {
+            double pn = 0.0, an = 0.0;
+            P_row(c, j, [&](double co, int idx) { pn = fmax(pn, fabs(co) * D[idx]); });
+            AT_row(c, j, [&](double co, int row) { an = fmax(an, fabs(co) * E[row]); });
+            pn *= cc * D[j]; an *= D[j];
+            Dt[j] = 1.0 / sqrt(limit_scaling(fmax(pn, an)));
+        }
+        for (int r = tid; r < L.m; r += NT) {
+            double en = 0.0;
+            A_row(c, r, [&](double co, int idx) { en = fmax(en, fabs(co) * D[idx]); });
+            Et[r] = 1.0 / sqrt(limit_scaling(en * E[r]));
+        }
+        __syncthreads();
+        for (int j = tid; j < L.n; j += NT) D[j] *= Dt[j];
+        for (int r = tid; r < L.m; r += NT) E[r] *= Et[r];
+        __syncthreads();
+        double vmax[1] = {0.0}, vsum[1] = {0.0};
+        for (int j = tid; j < L.n; j += NT) {
+            double pn = 0.0;
+            P_row(c, j, [&](double co, int idx) { pn = fmax(pn, fabs(co) * D[idx]); });
+            vsum[0] += cc * D[j] * pn;
+            double qj = (j < L.oe) ? S.Qv[j] : 0.0;
+            vmax[0] = fmax(vmax[0], fabs(cc * D[j] * qj));
+        }
+        block_reduce<1, 1>(vmax, vsum, S.red);
+        double ct = vsum[0] / (double)L.n;
+        double qn = limit_scaling(vmax[0]);
+        ct = limit_scaling(fmax(ct, qn));
+        cc *= 1.0 / ct;
+    }
+    // rho vector / metric
+    double rho = S_.rho;
+    double *om = P.omega + (size_t)b * L.m, *sv = P.s + (size_t)b * L.n;
+    int *ct = P.ctype + (size_t)b * L.m;
+    for (int r = tid; r < L.m; r += NT) {
+        double lo, hi; row_bounds(c, S.x0s, S.um1s, r, lo, hi);
+        int t = row_type(E[r], lo, hi);
+        ct[r] = t;
+        om[r] = row_rho(t, rho) * E[r] * E[r];
+    }
+    for (int j = tid; j < L.n; j += NT) sv[j] = S_.sigma / (D[j] * D[j]);
+    if (tid == 0) { P.c[b] = cc; P.rho[b] = rho; }
+    __syncthreads();
+    int bad = factor_all<NB>(c, om, sv, cc, P.F + (size_t)b * P.fsz, S.T, S.iflag, border_ptrs(L, P, S.red));
+    // cold start
+    for (int j = tid; j < L.n; j += NT) { P.x[(size_t)b * L.n + j] = 0.0; P.xo[(size_t)b * L.n + j] = 0.0; }
+    for (int r = tid; r < L.m; r += NT) { P.z[(size_t)b * L.m + r] = 0.0; P.y[(size_t)b * L.m + r] = 0.0; P.yo[(size_t)b * L.m + r] = 0.0; }
+    if (tid == 0) {
+        mpcqp_info inf; inf.status = bad ? MPCQP_NON_CVX : MPCQP_UNSOLVED; inf.iter = 0; inf.rho_updates = 0; inf.reserved = 0;
+        inf.obj_val = 0; inf.pri_res = 0; inf.dua_res = 0; inf.rho = rho;
+        P.info[b] = inf;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// A solve has three phases (bodies below; k_mpc_run strings them together per instance):
+//   begin  once per solve : q refresh from (x0, u_{-1}, xref), constraint types, per-solve bookkeeping
+//   admm   per round      : check_termination ADMM iterations -- the hot loop, nothing else in it
+//   check  per round      : residuals, termination, infeasibility certificates, rho adaptation + refactor
+// ------------------------------------------------------------------------------------------------
+enum { COLD_CHECK = 1, COLD_RHO = 2, COLD_FINAL = 4, COLD_PLAIN = 8 };
+
+// Refactorization from inside a solve: a non-inlined function with a register allocation of its own (defined with the
+// other phases of k_mpc_run below), so that this rare, register-hungry path does not push the residual evaluation
+// and the per-solve prologue into scratch spills.
+template <int NB> __device__ void run_factor_phase();
+
+template <int NB>
+__device__ __forceinline__ void begin_body(const Lay &L, const Ptrs &P, const mpcqp_settings &S_, Smem &S, int plain) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const double *model = P.model + (size_t)b * L.model_sz, *step = P.step + (size_t)b * L.step_sz;
+    Ctx c{L, S.hot, model};
+    build_q(c, step, S.Qv);
+    double *gx = P.x + (size_t)b * L.n, *gz = P.z + (size_t)b * L.m, *gy = P.y + (size_t)b * L.m;
+    if (!(S_.warm_start || plain)) {
+        for (int j = tid; j < L.n; j += NT) gx[j] = 0.0;
+        for (int r = tid; r < L.m; r += NT) { gz[r] = 0.0; gy[r] = 0.0; }
+    }
+    // constraint types (bounds may have changed since the last factorization)
+    double *om = P.omega + (size_t)b * L.m;
+    const double *sv = P.s + (size_t)b * L.n, *E = P.E + (size_t)b * L.m;
+    int *ctp = P.ctype + (size_t)b * L.m;
+    const double rho = P.rho[b];
+    int changed = 0;
+    for (int r = tid; r < L.m; r += NT) {
+        double lo, hi; row_bounds(c, S.x0s, S.um1s, r, lo, hi);
+        int t = row_type(E[r], lo, hi);
+        if (t != ctp[r]) { changed = 1; ctp[r] = t; om[r] = row_rho(t, rho) * E[r] * E[r]; }
+    }
+    changed = __syncthreads_or(changed);
+    if (changed) run_factor_phase<NB>();
+    if (tid == 0) {
+        mpcqp_info inf; inf.status = MPCQP_UNSOLVED; inf.iter = 0; inf.rho_updates = 0; inf.reserved = 0;
+        inf.obj_val = 0.0; inf.pri_res = 0.0; inf.dua_res = 0.0; inf.rho = rho;
+        P.info[b] = inf;
+    }
+}
+
+// Returns 1 (to every thread) if the instance has terminated.
+template <int NB>
+__device__ __forceinline__ int check_body(const Lay &L, const Ptrs &P, const mpcqp_settings &S_, Smem &S, int iter, int mode,
+                                          const double *Xl, const double *Zl, const double *Yl) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const double *model = P.model + (size_t)b * L.model_sz;
+    Ctx c{L, S.hot, model};
+    double *gx = P.x + (size_t)b * L.n, *gz = P.z + (size_t)b * L.m, *gy = P.y + (size_t)b * L.m;
+    // the iterate: the LDS copy the last ADMM round left behind (small problems), else global memory
+    const double *X = Xl ? Xl : gx, *Z = Zl ? Zl : gz, *Y = Yl ? Yl : gy;
+    double *om = P.omega + (size_t)b * L.m;
+    const double *sv = P.s + (size_t)b * L.n;
+    const double *D = P.D + (size_t)b * L.n, *E = P.E + (size_t)b * L.m;
+    const double *dxg = P.dx + (size_t)b * L.n, *dyg = P.dy + (size_t)b * L.m;
+    const int *ctp = P.ctype + (size_t)b * L.m;
+    const double cc = P.c[b];
+    double rho = P.rho[b];
+    int status = MPCQP_UNSOLVED;
+    double obj_val, pri_res, dua_res;
+
+    // ---- OSQP update_info: objective, unscaled residuals, and the scaled norms the rho estimate needs
+    // vmax: 0 pri, 1 |Ax|, 2 |z|, 3 dua, 4 |Px|, 5 |A'y|, 6 |q|; scaled: 7 pri, 8 max(|EAx|,|Ez|), 9 dua, 10 max(|cD(..)|)
+    double nrm[11], vsum[1] = {0.0};
+#pragma unroll
+    for (int i = 0; i < 11; ++i) nrm[i] = 0.0;
+    for (int r = tid; r < L.m; r += NT) {
+        double ax = 0.0;
+        A_row(c, r, [&](double co, int idx) { ax += co * X[idx]; });
+        double z = Z[r], d = ax - z, e = E[r];
+        nrm[0] = fmax(nrm[0], fabs(d)); nrm[1] = fmax(nrm[1], fabs(ax)); nrm[2] = fmax(nrm[2], fabs(z));
+        nrm[7] = fmax(nrm[7], fabs(e * d)); nrm[8] = fmax(nrm[8], fmax(fabs(e * ax), fabs(e * z)));
+    }
+    for (int j = tid; j < L.n; j += NT) {
+        double px = 0.0, aty = 0.0;
+        P_row(c, j, [&](double co, int idx) { px += co * X[idx]; });
+        AT_row(c, j, [&](double co, int row) { aty += co * Y[row]; });
+        double qj = (j < L.oe) ? S.Qv[j] : 0.0, xj = X[j];
+        double d = px + qj + aty, cd = cc * D[j];
+        nrm[3] = fmax(nrm[3], fabs(d)); nrm[4] = fmax(nrm[4], fabs(px)); nrm[5] = fmax(nrm[5], fabs(aty)); nrm[6] = fmax(nrm[6], fabs(qj));
+        nrm[9] = fmax(nrm[9], fabs(cd * d));
+        nrm[10] = fmax(nrm[10], fmax(fabs(cd * qj), fmax(fabs(cd * aty), fabs(cd * px))));
+        vsum[0] += xj * (0.5 * px + qj);
+    }
+    block_reduce<11, 1>(nrm, vsum, S.red);
+    obj_val = vsum[0]; pri_res = nrm[0]; dua_res = nrm[3];
+
+    // ---- OSQP's infeasibility certificates (paper section 3.5) on the last increments, in unscaled terms
+    auto primal_infeasible = [&](double eps) -> bool {
+        // v = c * delta_y (= E * scaled delta_y), projected on the polar of the recession cone of [l,u]
+        double vmax[1] = {0.0}, vs[1] = {0.0};
+        for (int r = tid; r < L.m; r += NT) {
+            double lo, hi; row_bounds(c, S.x0s, S.um1s, r, lo, hi);
+            double e = E[r], v = cc * dyg[r];
+            if (e * hi > QP_INFTY * MIN_SCALING) { if (e * lo < -QP_INFTY * MIN_SCALING) v = 0.0; else v = fmin(v, 0.0); }
+            else if (e * lo < -QP_INFTY * MIN_SCALING) v = fmax(v, 0.0);
+            S.T[r] = v;
+            vmax[0] = fmax(vmax[0], fabs(v));
+            vs[0] += hi * fmax(v, 0.0) + lo * fmin(v, 0.0);
+        }
+        block_reduce<1, 1>(vmax, vs, S.red);
+        double nd = vmax[0];
+        if (!(nd > eps)) return false;
+        if (!(vs[0] < -eps * nd)) return false;
+        double amax[1] = {0.0}, dummy[1] = {0.0};
+        for (int j = tid; j < L.n; j += NT) {
+            double a = 0.0; AT_row(c, j, [&](double co, int row) { a += co * S.T[row]; });
+            amax[0] = fmax(amax[0], fabs(a));
+        }
+        block_reduce<1, 1>(amax, dummy, S.red);
+        return amax[0] < eps * nd;
+    };
+    auto dual_infeasible = [&](double eps) -> bool {
+        double vmax[1] = {0.0}, vs[1] = {0.0};
+        for (int j = tid; j < L.n; j += NT) {
+            double d = dxg[j];
+            vmax[0] = fmax(vmax[0], fabs(d));
+            vs[0] += ((j < L.oe) ? S.Qv[j] : 0.0) * d;
+        }
+        block_reduce<1, 1>(vmax, vs, S.red);
+        double nd = vmax[0];
+        if (!(nd > eps)) return false;
+        if (!(vs[0] < -eps * nd)) return false;
+        double pmax[1] = {0.0}, bad[1] = {0.0};
+        for (int j = tid; j < L.n; j += NT) {
+            double a = 0.0; P_row(c, j, [&](double co, int idx) { a += co * dxg[idx]; });
+            pmax[0] = fmax(pmax[0], fabs(a));
+        }
+        for (int r = tid; r < L.m; r += NT) {
+            double a = 0.0; A_row(c, r, [&](double co, int idx) { a += co * dxg[idx]; });
+            double lo, hi; row_bounds(c, S.x0s, S.um1s, r, lo, hi);
+            double e = E[r];
+            if ((e * hi < QP_INFTY * MIN_SCALING && a > eps * nd) || (e * lo > -QP_INFTY * MIN_SCALING && a < -eps * nd)) bad[0] = 1.0;
+        }
+        block_reduce<1, 1>(pmax, bad, S.red);
+        return (pmax[0] < eps * nd) && (bad[0] == 0.0);
+    };
+    auto check_termination = [&](bool approx) -> bool {
+        double ea = S_.eps_abs, er = S_.eps_rel, epi = S_.eps_prim_inf, edi = S_.eps_dual_inf;
+        if (pri_res > QP_INFTY || dua_res > QP_INFTY) { status = MPCQP_NON_CVX; obj_val = NAN; return true; }
+        if (approx) { ea *= 10; er *= 10; epi *= 10; edi *= 10; }
+        bool pc = pri_res < ea + er * fmax(nrm[2], nrm[1]);
+        bool dc = dua_res < ea + er * fmax(fmax(nrm[6], nrm[5]), nrm[4]);
+        bool pic = false, dic = false;
+        if (!pc) pic = primal_infeasible(epi);
+        if (!dc) dic = dual_infeasible(edi);
+        if (pc && dc) { status = approx ? MPCQP_SOLVED_INACCURATE : MPCQP_SOLVED; return true; }
+        if (pic) { status = approx ? MPCQP_PRIMAL_INFEASIBLE_INACCURATE : MPCQP_PRIMAL_INFEASIBLE; obj_val = QP_INFTY; return true; }
+        if (dic) { status = approx ? MPCQP_DUAL_INFEASIBLE_INACCURATE : MPCQP_DUAL_INFEASIBLE; obj_val = -QP_INFTY; return true; }
+        return false;
+    };
+
+    int term = 0, rho_upd = 0;
+    if (mode & COLD_PLAIN) { status = MPCQP_UNSOLVED; term = 1; }
+    else {
+        if (mode & COLD_CHECK) term = check_termination(false) ? 1 : 0;
+        if (!term && (mode & COLD_FINAL)) {             // iteration limit: OSQP retries with 10x looser tolerances
+            if (!check_termination(true)) status = MPCQP_MAX_ITER_REACHED;
+            term = 1;
+        }
+        if (!term && (mode & COLD_RHO)) {
+            double pri = nrm[7] / (nrm[8] + 1e-10), dua = nrm[9] / (nrm[10] + 1e-10);
+            double rn = fmin(fmax(rho * sqrt(pri / (dua + 1e-10)), RHO_MIN), RHO_MAX);
+            if (rn > rho * S_.adaptive_rho_tolerance || rn < rho / S_.adaptive_rho_tolerance) {
+                rho = rn;
+                for (int r = tid; r < L.m; r += NT) om[r] = row_rho(ctp[r], rho) * E[r] * E[r];
+                __syncthreads();
+                run_factor_phase<NB>();
+                rho_upd = 1;
+            }
+        }
+    }
+    __syncthreads();
+    if (term) {      // solution, and the iterate the next warm start begins from
+        const bool has_sol = !(status == MPCQP_PRIMAL_INFEASIBLE || status == MPCQP_PRIMAL_INFEASIBLE_INACCURATE ||
+                               status == MPCQP_DUAL_INFEASIBLE || status == MPCQP_DUAL_INFEASIBLE_INACCURATE || status == MPCQP_NON_CVX);
+        double *xo = P.xo + (size_t)b * L.n, *yo = P.yo + (size_t)b * L.m;
+        for (int j = tid; j < L.n; j += NT) { double v = gx[j]; xo[j] = has_sol ? v : NAN; if (!has_sol) gx[j] = 0.0; }
+        for (int r = tid; r < L.m; r += NT) { double v = gy[r]; yo[r] = has_sol ? v : NAN; if (!has_sol) { gy[r] = 0.0; gz[r] = 0.0; } }
+    }
+    if (tid == 0) {
+        mpcqp_info inf = P.info[b];
+        inf.status = status; inf.iter = iter; inf.rho_updates += rho_upd; inf.reserved += 1;
+        inf.obj_val = obj_val; inf.pri_res = pri_res; inf.dua_res = dua_res; inf.rho = rho;
+        P.rho[b] = rho;
+        if (term) {
+            atomicAdd(&P.stats[0], (unsigned long long)iter); atomicAdd(&P.stats[1], (unsigned long long)inf.reserved);
+            atomicAdd(&P.stats[2], (unsigned long long)inf.rho_updates); atomicAdd(&P.stats[3], 1ULL);
+            inf.reserved = 0;
+        }
+        P.info[b] = inf;
+    }
+    return term;
+}
+
+// ---- hot-loop pieces.  NXT/NUT: compile-time nx/nu (0 = take them from the layout at run time).
+template <int NXT> __device__ __forceinline__ int hx(const Lay &L) { return NXT ? NXT : L.nx; }
+template <int NUT> __device__ __forceinline__ int hu(const Lay &L) { return NUT ? NUT : L.nu; }
+template <int NXT> __device__ __forceinline__ int divx(const Lay &L, int v) { return NXT ? v / NXT : idiv(v, L.rnx); }
+template <int NUT> __device__ __forceinline__ int divu(const Lay &L, int v) { return NUT ? v / NUT : idiv(v, L.rnu); }
+
+// Steps (1)-(2) of the ADMM iteration with the slack elimination fused in:
+//   W = omega z - c y                       (rows, flat; left behind by hot_rows_w / the previous hot_update)
+//   rhs = s x - c q + A' W                  (variables)
+//   te = rhs_eps / kappa -> W[soft row]     Tc[k][a] = rhs_x - omega_soft te  |  rhs_u  |  0 (padding)
+// Small problems (REGV; m <= 4 NT rows and N NB <= 2 NT padded variables, the same condition as the LDS-resident
+// iterate): a thread always handles the same rows r = tid + NT j and the same padded variables idx = tid + NT j, and
+// what it needs of the iteration-invariant vectors omega, s, q stays in its registers for the whole round -- the
+// parallel phases then touch no global memory at all (ten dependent global-load latencies per iteration otherwise).
+struct HotRegs {
+    double om_r[4];                                  // omega of the thread's rows
+    double sv_e[2], qv_e[2];                         // per padded variable: its s and its linear cost q
+    double om_s[2], sv_s[2];                         // (x part only) omega of its soft row, s of its slack
+};
+template <int NB, int NXT, int NUT>
+__device__ __forceinline__ void load_hot_regs(const Lay &L, cgdouble *om, cgdouble *sv, cgdouble *qv, HotRegs &h) {
+    const int tid = threadIdx.x, nx = hx<NXT>(L), nu = hu<NUT>(L);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int r = tid + NT * j; h.om_r[j] = r < L.m ? om[r] : 1.0; }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int idx = tid + NT * j, k = idx / NB, a = idx % NB;
+        h.sv_e[j] = 0.0; h.qv_e[j] = 0.0; h.om_s[j] = 1.0; h.sv_s[j] = 0.0;
+        if (idx < L.N * NB) {
+            if (a < nx) { const int e = k * nx + a; h.sv_e[j] = sv[e]; h.qv_e[j] = qv[e]; h.om_s[j] = om[L.rs + e]; h.sv_s[j] = sv[L.oe + e]; }
+            else if (a < nx + nu && k < L.Nc) { const int cu = k * nu + a - nx; h.sv_e[j] = sv[L.ou + cu]; h.qv_e[j] = qv[L.n_x + cu]; }
+        }
+    }
+}
+
+// W = omega z - c y for the first iteration of a round (afterwards hot_update leaves it behind: a thread owns its rows).
+template <bool REGV>
+__device__ __forceinline__ void hot_rows_w(const Lay &L, cgdouble *om, const HotRegs &h, double cc, const double *Z, const double *Y, double *W) {
+    const int tid = opaque_lane(threadIdx.x);
+    if (REGV) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int r = tid + NT * j; if (r < L.m) W[r] = h.om_r[j] * Z[r] - cc * Y[r]; }
+    } else {
+        for (int r = tid; r < L.m; r += NT) W[r] = om[r] * Z[r] - cc * Y[r];
+    }
+    __syncthreads();
+}
+
+template <int NB, int NXT, int NUT, bool REGV>
+__device__ __forceinline__ void hot_rhs(const Lay &L, const double *hot, cgdouble *om, cgdouble *sv, cgdouble *qv, const HotRegs &h, double cc,
+                                        const double *X, const double *Z, const double *Y, double *W, double *Tc) {
+    const int tid = opaque_lane(threadIdx.x);        // (keeps the per-thread index arithmetic out of LICM's reach: hoisted, it spills)
+    const int nx = hx<NXT>(L), nu = hu<NUT>(L);
+    const double *Ad = hot + L.oAd, *Bd = hot + L.oBd;
+    const double cef = cc * hot[L.oeps];
+    auto element = [&](int idx, double sve, double qve, double ws, double svs, bool have) {
+        const int k = idx / NB, a = idx % NB;
+        double v = 0.0;
+        if (a < nx) {
+            const int e = k * nx + a;
+            if (!have) { sve = sv[e]; qve = qv[e]; ws = om[L.rs + e]; svs = sv[L.oe + e]; }
+            double rx = sve * X[e] - cc * qve - W[e];
+            if (k < L.Np) {
+                const double *w1 = W + (k + 1) * nx;
+#pragma unroll
+                for (int r = 0; r < (NXT ? NXT : 1); ++r) if (NXT) rx += Ad[r * nx + a] * w1[r];
+                if (!NXT) for (int r = 0; r < nx; ++r) rx += Ad[r * nx + a] * w1[r];
+            }
+            const double wsoft = W[L.rs + e];
+            const double te = (svs * X[L.oe + e] + wsoft) / (cef + svs + ws);
+            W[L.rs + e] = te;                      // only this thread ever reads W[soft row e]
+            v = rx + wsoft - ws * te;
+        } else if (a < nx + nu && k < L.Nc) {
+            const int jj = a - nx, cu = k * nu + jj;
+            if (!have) { sve = sv[L.ou + cu]; qve = qv[L.n_x + cu]; }
+            double ru = sve * X[L.ou + cu] - cc * qve + W[L.ri + cu] - W[L.rdu + nu + cu];
+            if (k == 0) ru += W[L.rdu + jj];
+            if (cu > 0) ru += W[L.rdu + nu + cu - 1];
+            const int s_end = (k == L.Nc - 1) ? L.Np : k + 1;
+            for (int s = k + 1; s <= s_end; ++s) {
+                const double *w1 = W + s * nx;
+#pragma unroll
+                for (int r = 0; r < (NXT ? NXT : 1); ++r) if (NXT) ru += Bd[r * nu + jj] * w1[r];
+                if (!NXT) for (int r = 0; r < nx; ++r) ru += Bd[r * nu + jj] * w1[r];
+            }
+            v = ru;
+        }
+        Tc[idx] = v;
+    };
+    if (REGV) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { const int idx = tid + NT * j; if (idx < L.N * NB) element(idx, h.sv_e[j], h.qv_e[j], h.om_s[j], h.sv_s[j], true); }
+    } else {
+        for (int idx = tid; idx < L.N * NB; idx += NT) element(idx, 0.0, 0.0, 0.0, 0.0, false);
+    }
+    __syncthreads();
+}
+
+// Steps (4)-(6): slack back-substitution, zt = A xt, relaxation, projection on [l,u], dual update, x update.
+template <int NB, int NXT, int NUT, bool REGV>
+__device__ __forceinline__ void hot_update(const Lay &L, const double *hot, const double *x0s, const double *um1s,
+                                           cgdouble *om, cgdouble *sv, const HotRegs &h, double cc, double alpha,
+                                           double *X, double *Z, double *Y, double *W, const double *Tc, bool keep_delta, gdouble *dxg, gdouble *dyg) {
+    const int tid = opaque_lane(threadIdx.x);        // (keeps the per-thread index arithmetic out of LICM's reach: hoisted, it spills)
+    const int nx = hx<NXT>(L), nu = hu<NUT>(L);
+    const double cef = cc * hot[L.oeps];
+    // eps_t = te - (omega_soft / kappa) x_t ; x update for the x and eps variables
+    auto x_update = [&](int e, int k, int i, double ws, double svs) {
+        const double xt = Tc[k * NB + i];
+        const double et = W[L.rs + e] - (ws / (cef + svs + ws)) * xt;
+        W[L.rs + e] = et;
+        const double xo = X[e], eo = X[L.oe + e];
+        const double xn = alpha * xt + (1.0 - alpha) * xo, en = alpha * et + (1.0 - alpha) * eo;
+        X[e] = xn; X[L.oe + e] = en;
+        if (keep_delta) { dxg[e] = xn - xo; dxg[L.oe + e] = en - eo; }
+    };
+    auto u_update = [&](int cu, int k, int jj) {
+        const double uo = X[L.ou + cu];
+        const double un = alpha * Tc[k * NB + nx + jj] + (1.0 - alpha) * uo;
+        X[L.ou + cu] = un;
+        if (keep_delta) dxg[L.ou + cu] = un - uo;
+    };
+    if (REGV) {                                          // same padded-variable -> thread map as hot_rhs
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int idx = tid + NT * j, k = idx / NB, a = idx % NB;
+            if (idx < L.N * NB) {
+                if (a < nx) x_update(k * nx + a, k, a, h.om_s[j], h.sv_s[j]);
+                else if (a < nx + nu && k < L.Nc) u_update(k * nu + a - nx, k, a - nx);
+            }
+        }
+    } else {
+        for (int e = tid; e < L.n_x; e += NT) {
+            const int k = divx<NXT>(L, e), i = e - k * nx;
+            x_update(e, k, i, om[L.rs + e], sv[L.oe + e]);
+        }
+        for (int cu = tid; cu < L.n_u; cu += NT) {
+            const int k = divu<NUT>(L, cu), jj = cu - k * nu;
+            u_update(cu, k, jj);
+        }
+    }
+    __syncthreads();
+    const double *Ad = hot + L.oAd, *Bd = hot + L.oBd;
+    auto row_update = [&](int r, double w, double &zv, double &yv) {
+        double zt, lo, hi;
+        if (r < L.rs) {                                   // dynamics
+            const int k = divx<NXT>(L, r), i = r - k * nx;
+            zt = -Tc[k * NB + i];
+            if (k > 0) {
+                const double *xp = Tc + (k - 1) * NB;
+                const double *up = Tc + min(k - 1, L.Nc - 1) * NB + nx;
+#pragma unroll
+                for (int j = 0; j < (NXT ? NXT : 1); ++j) if (NXT) zt += Ad[i * nx + j] * xp[j];
+                if (!NXT) for (int j = 0; j < nx; ++j) zt += Ad[i * nx + j] * xp[j];
+#pragma unroll
+                for (int j = 0; j < (NUT ? NUT : 1); ++j) if (NUT) zt += Bd[i * nu + j] * up[j];
+                if (!NUT) for (int j = 0; j < nu; ++j) zt += Bd[i * nu + j] * up[j];
+            }
+            lo = hi = (r < nx) ? -x0s[r] : 0.0;
+        } else if (r < L.ri) {                            // soft state box
+            const int e = r - L.rs, k = divx<NXT>(L, e), i = e - k * nx;
+            zt = Tc[k * NB + i] + W[r];
+            lo = hot[L.oxmin + i]; hi = hot[L.oxmax + i];
+        } else if (r < L.rdu) {                           // input box
+            const int cu = r - L.ri, k = divu<NUT>(L, cu), jj = cu - k * nu;
+            zt = Tc[k * NB + nx + jj];
+            lo = hot[L.oumin + jj]; hi = hot[L.oumax + jj];
+        } else {                                          // Delta-u rows
+            const int rr = r - L.rdu, kk = divu<NUT>(L, rr), jj = rr - kk * nu;
+            lo = hot[L.oDumin + jj]; hi = hot[L.oDumax + jj];
+            if (rr < nu) { zt = Tc[nx + rr]; lo += um1s[jj]; hi += um1s[jj]; }
+            else {
+                const int cu = rr - nu, k = kk - 1;       // cu = k*nu + jj
+                zt = -Tc[k * NB + nx + jj];
+                if (cu + 1 < L.n_u) zt += (jj + 1 < nu) ? Tc[k * NB + nx + jj + 1] : Tc[(k + 1) * NB + nx];
+            }
+        }
+        lo = lo < -QP_INFTY ? -QP_INFTY : lo;
+        hi = hi > QP_INFTY ? QP_INFTY : hi;
+        const double zr = alpha * zt + (1.0 - alpha) * zv;
+        const double zn = fmin(fmax(zr + cc * yv / w, lo), hi);
+        const double dy = (w / cc) * (zr - zn);
+        yv += dy; zv = zn;
+        if (keep_delta) dyg[r] = dy;
+    };
+    if (REGV) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = tid + NT * j;
+            if (r < L.m) { double zv = Z[r], yv = Y[r]; row_update(r, h.om_r[j], zv, yv); Z[r] = zv; Y[r] = yv; W[r] = h.om_r[j] * zv - cc * yv; }
+        }
+    } else {
+        for (int r = tid; r < L.m; r += NT) { double zv = Z[r], yv = Y[r]; const double w = om[r]; row_update(r, w, zv, yv); Z[r] = zv; Y[r] = yv; W[r] = w * zv - cc * yv; }
+    }
+    __syncthreads();
+}
+
+// `iters` ADMM iterations of this workgroup's instance.  Expects the hot model prefix and the step data in LDS
+// (load_common) and, with LDSSTATE, X/Z/Y carved behind the common area.
+template <int NB, bool LDSSTATE, int NXT, int NUT, bool BORDER>
+__device__ __forceinline__ void admm_body(const Lay &L, const HotPtrs &P, Smem &S, double *X, double *Z, double *Y, double alpha, int iters) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    double *gx = P.x + (size_t)b * L.n, *gz = P.z + (size_t)b * L.m, *gy = P.y + (size_t)b * L.m;
+    double *W = S.T, *Tc = S.T + L.m;
+    if (LDSSTATE) {          // small-problem mode: the iterate x, z, y lives in LDS for the whole round
+        for (int j = tid; j < L.n; j += NT) X[j] = gx[j];
+        for (int r = tid; r < L.m; r += NT) { Z[r] = gz[r]; Y[r] = gy[r]; }
+    } else { X = gx; Z = gz; Y = gy; }
+    __syncthreads();
+    cgdouble *gom = (cgdouble *)(P.omega + (size_t)b * L.m), *gsv = (cgdouble *)(P.s + (size_t)b * L.n), *gqv = (cgdouble *)S.Qv;
+    gdouble *dxg = (gdouble *)(P.dx + (size_t)b * L.n), *dyg = (gdouble *)(P.dy + (size_t)b * L.m);
+    const double *F = P.F + (size_t)b * P.fsz;
+    const double cc = P.c[b];
+    HotRegs hr;
+    if (LDSSTATE) load_hot_regs<NB, NXT, NUT>(L, gom, gsv, gqv, hr);
+#ifndef MPCQP_ABL_NOPAR
+    hot_rows_w<LDSSTATE>(L, gom, hr, cc, Z, Y, W);
+#endif
+    for (int it = 1; it <= iters; ++it) {
+        const bool keep_delta = it == iters;         // the increments feed the infeasibility certificates of the check
+        TICK_START
+#ifndef MPCQP_ABL_NOPAR
+        hot_rhs<NB, NXT, NUT, LDSSTATE>(L, S.hot, gom, gsv, gqv, hr, cc, X, Z, Y, W, Tc);
+#endif
+        TICK(0)
+        BorderPtrs bp; bp.red = S.red;
+        if (BORDER) {
+            const size_t npb = (size_t)L.nu * L.N * L.NB;
+            bp.Bb = (double *)P.Bb + blockIdx.x * npb; bp.Zb = (double *)P.Zb + blockIdx.x * npb; bp.Sig = (double *)P.Sig + (size_t)blockIdx.x * L.nu * L.nu;
+        }
+        if (BORDER) border_pre<NB>(L, bp.Bb, bp.Zb, bp.Sig, Tc, S.tv, S.red);
+        kkt_core<NB>(core_args(L, opaque_ptr(F)), Tc);
+        if (BORDER) border_post(L, NB, Tc, S.tv);
+#ifndef MPCQP_ABL_NOPAR
+        hot_update<NB, NXT, NUT, LDSSTATE>(L, S.hot, S.x0s, S.um1s, gom, gsv, hr, cc, alpha, X, Z, Y, W, Tc, keep_delta, dxg, dyg);
+#endif
+        TICK(4)
+    }
+    if (LDSSTATE) {
+        for (int j = tid; j < L.n; j += NT) gx[j] = X[j];
+        for (int r = tid; r < L.m; r += NT) { gz[r] = Z[r]; gy[r] = Y[r]; }
+    }
+}

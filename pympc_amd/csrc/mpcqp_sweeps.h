@@ -1,0 +1,305 @@
+// mpcqp_sweeps.h -- part of libmpcqp_hip (included by mpcqp.hip, one translation unit).
+// Triangular solves with the factor: MFMA stage sweeps, transposed VALU apply, pipelined S^-1 phase.
+#pragma once
+
+// The sweeps work on Tc: the x,u part of the right-hand side / solution in STAGE-MAJOR PADDED layout,
+// Tc[k*NB + a] = element a of stage k (a < nx: x_k[a]; nx <= a < nb: u_k[a-nx]; everything else is padding
+// and stays exactly zero because the factor is the identity there).  In the operand layout lane 16k + 4b + j
+// holds element 4b + k (+16 per block): one 8-byte LDS read per lane and block.
+template <int NB>
+__device__ __forceinline__ void vec_load(const double *tb, int k, double *v) {
+#pragma unroll
+    for (int bi = 0; bi < NB / 16; ++bi) v[bi] = tb[k * NB + bi * 16];
+}
+template <int NB>
+__device__ __forceinline__ void vec_store(double *tb, int k, const double *v, bool writer) {
+    if (writer) {
+#pragma unroll
+        for (int bi = 0; bi < NB / 16; ++bi) tb[k * NB + bi * 16] = v[bi];
+    }
+}
+// per-lane base of a stage vector in Tc: lane 16k + 4b + j holds element 4b + k
+__device__ __forceinline__ int vec_lane_offset(int lane) { return 4 * ((lane >> 2) & 3) + (lane >> 4); }
+__device__ __forceinline__ bool vec_lane_writer(int lane) { return (lane & 3) == 0; }
+
+// rotate every 16-lane row by 4*sft lanes: lane (k, b, j) receives the value of lane (k, (b+sft)%4, j)
+template <int SFT>
+__device__ __forceinline__ double rot_blocks(double x) {
+    if (SFT == 0) return x;
+    constexpr int CTRL = 0x120 | (16 - 4 * SFT);          // row_ror:n gives dst[i] = src[(i - n) mod 16]
+    const long long xi = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)xi, CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(xi >> 32), CTRL, 0xF, 0xF, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+
+// out[bi] += sum_bj A(bi,bj) * in[bj]   with A given as fragments (one d4 per block per lane)
+template <int NB>
+__device__ __forceinline__ void frag_matvec(const d4 *A, const double *in, double *out) {
+    constexpr int NBLK = NB / 16;
+#pragma unroll
+    for (int bj = 0; bj < NBLK; ++bj) {
+        const double r0 = in[bj], r1 = rot_blocks<1>(in[bj]), r2 = rot_blocks<2>(in[bj]), r3 = rot_blocks<3>(in[bj]);
+#pragma unroll
+        for (int bi = 0; bi < NBLK; ++bi) {
+            const d4 a = A[bi * NBLK + bj];
+            out[bi] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[0], r0, out[bi], 0, 0, 0);
+            out[bi] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[1], r1, out[bi], 0, 0, 0);
+            out[bi] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[2], r2, out[bi], 0, 0, 0);
+            out[bi] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[3], r3, out[bi], 0, 0, 0);
+        }
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ void frag_load(const double *Fm, int lane, d4 *A) {
+    constexpr int NBLK = NB / 16;
+#pragma unroll
+    for (int b = 0; b < NBLK * NBLK; ++b) A[b] = *(cgd4 *)(Fm + b * 256 + lane * 4);
+}
+#ifdef MPCQP_ABL_NOSINVLOAD
+template <int NB>
+__device__ __forceinline__ void frag_load_sinv(const double *Fm, int lane, d4 *A) {
+#pragma unroll
+    for (int b = 0; b < (NB / 16) * (NB / 16); ++b) A[b] = d4{1e-3 * lane, 1e-3, 2e-3, 3e-3};
+}
+#else
+#define frag_load_sinv frag_load
+#endif
+
+// The TRANSPOSED product from the same fragments:  out[bj] += sum_bi A(bi,bj)' * in[bi].
+// The backward substitution needs Mh' where the forward elimination needed Mh; the MFMA always contracts over the
+// index that sits in the 16-lane-row position of the operand layout (the column of the stored block), so the
+// transposed product is done on the vector ALU instead -- and the factor stream loses its third block per stage:
+//   xl        lane (k,b,j) <- element 4b+j of `in`            (one cross-lane permute of the stage vector)
+//   p_s = a[s] * xl                                            = M[4b+j][4((b+s)&3)+k] * in[4b+j]
+//   t   = p_0 + rot_3(p_1) + rot_2(p_2) + rot_1(p_3)           block (b-s, b) contributes to output block b
+//   out += sum over the four lanes j of t                      (two DPP quad steps), again replicated over j
+__device__ __forceinline__ double lane_permute(double x, int byte_addr) {
+    const long long xi = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_ds_bpermute(byte_addr, (int)xi), hi = __builtin_amdgcn_ds_bpermute(byte_addr, (int)(xi >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double x) {
+    const long long xi = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)xi, CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(xi >> 32), CTRL, 0xF, 0xF, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ int transpose_lane_addr(int lane) { return 4 * (16 * (lane & 3) + (lane & 12) + (lane >> 4)); }
+template <int NB>
+__device__ __forceinline__ void frag_matvec_T(const d4 *A, const double *in, double *out, int perm_addr) {
+    constexpr int NBLK = NB / 16;
+#pragma unroll
+    for (int bi = 0; bi < NBLK; ++bi) {
+        const double xl = lane_permute(in[bi], perm_addr);
+#pragma unroll
+        for (int bj = 0; bj < NBLK; ++bj) {
+            const d4 a = A[bi * NBLK + bj];
+            double t = (a[0] * xl + rot_blocks<3>(a[1] * xl)) + (rot_blocks<2>(a[2] * xl) + rot_blocks<1>(a[3] * xl));
+            t += dpp_move<0xB1>(t);                            // quad_perm [1,0,3,2]
+            t += dpp_move<0x4E>(t);                            // quad_perm [2,3,0,1]
+            out[bj] += t;
+        }
+    }
+}
+
+template <int NB> struct SweepCfg {
+    static constexpr int NF = (NB / 16) * (NB / 16);
+#ifndef MPCQP_DEPTH
+#define MPCQP_DEPTH 4
+#endif
+    static constexpr int DEPTH = MPCQP_DEPTH;                  // factor stages kept in flight in registers (even)
+};
+
+// The sweeping waves are dependent MFMA chains: two of them on one SIMD share its matrix pipe and slow each other
+// down.  Workgroups that are co-resident on a CU (dispatch order: block b -> XCD b%8, CU (b/8)%32) therefore rotate
+// which of their waves does what, so that the sweepers of the four co-resident workgroups spread over the four
+// SIMDs.  Purely a speed matter: any placement gives the same results.
+__device__ __forceinline__ int logical_wave() {
+#ifdef MPCQP_NO_WAVE_ROTATION
+    return threadIdx.x >> 6;
+#else
+    return ((threadIdx.x >> 6) - (blockIdx.x >> 8)) & (NWAVES - 1);
+#endif
+}
+
+// Sequential sweep over `nsteps` stages by ONE wave: for i = 1..nsteps, k = first + dir*i:
+//     forward elimination (TRANSPOSED = false):  Tc[k] <- Tc[k] + Fwd(k)        * Tc[k - dir]
+//     back substitution   (TRANSPOSED = true) :  Tc[k] <- Tc[k] + Fwd(k - dir)' * Tc[k - dir]
+// (Fwd(k) = slot 0 of stage k holds the negated factor block; `first_stage` >= 0 names the stage whose slot replaces
+// Fwd(first) -- the middle stage's second forward matrix.)  The factor fragments of the next DEPTH stages are prefetched into a
+// register ring; the running vector ping-pongs between two register sets (no copies between MFMAs).
+template <int NB, bool TRANSPOSED>
+__device__ __forceinline__ void chain_sweep(const int first, const int dir, const int nsteps,
+                                            const int fstage, const double *F, const int first_stage, double *Tc) {
+    constexpr int NBLK = NB / 16, NF = SweepCfg<NB>::NF, DEPTH = SweepCfg<NB>::DEPTH;
+    const int lane = opaque_lane(threadIdx.x & 63);
+    double *tb = Tc + vec_lane_offset(lane);
+    const bool writer = vec_lane_writer(lane);
+    const int perm_addr = transpose_lane_addr(lane);
+    auto stage_of = [&](int i) { return first + dir * i; };
+    auto frag_of = [&](int i) {                                // (offsets, not pointer selects)
+        int st = TRANSPOSED ? stage_of(i - 1) : stage_of(i);
+        if (TRANSPOSED && i == 1 && first_stage >= 0) st = first_stage;
+        return F + (size_t)st * fstage;
+    };
+    // The group loop below is branch-free on purpose: with conditionals around the refills the compiler can no longer
+    // count the loads in flight across the back edge and falls back to s_waitcnt vmcnt(0) -- the whole memory latency
+    // once per group.  Refills past the end re-read the last stage (clamped index), the tail group runs separately.
+    auto frag_clamped = [&](int i) { return frag_of(i < nsteps ? i : nsteps); };
+    d4 ring[DEPTH][NF];
+    if (nsteps < 1) return;
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) frag_load<NB>(frag_clamped(1 + d), lane, ring[d]);
+    double va[NBLK], vb[NBLK];
+    vec_load<NB>(tb, first, va);
+    auto stage_step = [&](int i, int d) {
+        const int k = stage_of(i);
+        double *src = (d & 1) ? vb : va, *dst = (d & 1) ? va : vb;
+        vec_load<NB>(tb, k, dst);
+        if (TRANSPOSED) frag_matvec_T<NB>(ring[d], src, dst, perm_addr);
+        else frag_matvec<NB>(ring[d], src, dst);
+        vec_store<NB>(tb, k, dst, writer);
+    };
+    int i0 = 1;
+    for (; i0 + DEPTH - 1 <= nsteps; i0 += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            stage_step(i0 + d, d);
+            frag_load<NB>(frag_clamped(i0 + d + DEPTH), lane, ring[d]);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (i0 + d <= nsteps) stage_step(i0 + d, d);
+}
+
+// w_k = S_k^-1 yh_k for all stages (independent MFMA groups, dealt to the four waves).  Wave 0 first finishes the
+// forward elimination at the middle stage: yh_mid = b_mid - Mh_mid yh_{mid-1} - Mt_mid yh_{mid+1}; it owns the three
+// stages around the middle (it reads yh_{mid-1}, yh_{mid+1}, so no other wave may overwrite them with w meanwhile).
+// The other N-3 stages are spread so that the four waves finish together: wave 0 takes every 7th of them on top of
+// its 3.5 stage-equivalents, waves 1..3 the rest in turn.  The wave's t-th stage in closed form:
+static_assert(NWAVES == 4, "stage-to-wave map below assumes four waves");
+__device__ __forceinline__ int sinv_stage(int wv, int t, int N, int mid) {        // -1: the wave has no t-th stage
+    int j;                                                   // index among the stages outside {mid-1, mid, mid+1}
+    if (wv == 0) j = 7 * t; else { const int p = 3 * t + (wv - 1); j = p + p / 6 + 1; }
+    if (j >= N - 3) return -1;
+    return j < mid - 1 ? j : j + 3;
+}
+// The fragment loads are software-pipelined two stages ahead; the first pair (and wave 0's five fragments around the
+// middle) is requested BEFORE the barrier that ends the forward elimination (sinv_prefetch), so that waves 2 and 3,
+// idle during the sweeps, have their data long before they may start.
+template <int NB> struct SinvPre {
+    d4 P0[SweepCfg<NB>::NF], P1[SweepCfg<NB>::NF];          // the wave's first two stages
+    d4 A0[SweepCfg<NB>::NF], A2[SweepCfg<NB>::NF], Am[SweepCfg<NB>::NF], B0[SweepCfg<NB>::NF], B1[SweepCfg<NB>::NF];   // wave 0
+    int nt, klast;                                           // number of stages of this wave, the last one (clamp target)
+};
+template <int NB>
+__device__ __forceinline__ void sinv_prefetch(const int N, const int mid, const int fstage, const double *F, SinvPre<NB> &pre) {
+    const int lane = opaque_lane(threadIdx.x & 63), wv = logical_wave();
+    const double *Fs = F + NB * NB;
+    int nt = 0, klast = 0;
+    for (int t = 0; t < N; ++t) { const int k = sinv_stage(wv, t, N, mid); if (k < 0) break; klast = k; ++nt; }
+    pre.nt = nt; pre.klast = klast;
+    auto kc = [&](int t) { const int k = sinv_stage(wv, t, N, mid); return k < 0 ? klast : k; };
+    if (wv == 0) {
+        frag_load<NB>(F + (size_t)mid * fstage, lane, pre.A0);
+        frag_load<NB>(F, lane, pre.A2);                      // the middle's second forward matrix (kept in stage 0's slot)
+        frag_load_sinv<NB>(Fs + (size_t)mid * fstage, lane, pre.Am);
+        frag_load_sinv<NB>(Fs + (size_t)(mid - 1) * fstage, lane, pre.B0);
+        frag_load_sinv<NB>(Fs + (size_t)(mid + 1) * fstage, lane, pre.B1);
+    }
+    frag_load_sinv<NB>(Fs + (size_t)kc(0) * fstage, lane, pre.P0);
+    frag_load_sinv<NB>(Fs + (size_t)kc(1) * fstage, lane, pre.P1);
+}
+template <int NB>
+__device__ __forceinline__ void sinv_apply(const int N, const int mid, const int fstage, const double *F, double *Tc, SinvPre<NB> &pre) {
+    constexpr int NBLK = NB / 16, NF = SweepCfg<NB>::NF;
+    const int lane = opaque_lane(threadIdx.x & 63), wv = logical_wave();
+    double *tb = Tc + vec_lane_offset(lane);
+    const bool writer = vec_lane_writer(lane);
+    auto apply = [&](int k, const d4 *A, bool valid) {       // (invalid: a clamped repeat of the last stage -- computed, not stored)
+        double in[NBLK], out[NBLK];
+        vec_load<NB>(tb, k, in);
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) out[b] = 0.0;
+        frag_matvec<NB>(A, in, out);
+        vec_store<NB>(tb, k, out, writer && valid);
+    };
+    const double *Fs = F + NB * NB;
+    const int nt = pre.nt, klast = pre.klast;
+    auto kc = [&](int t) { const int k = sinv_stage(wv, t, N, mid); return k < 0 ? klast : k; };
+    if (wv == 0) {
+        double up[NBLK], dn[NBLK], acc[NBLK];
+        vec_load<NB>(tb, mid, acc);
+        vec_load<NB>(tb, mid - 1, up);
+        vec_load<NB>(tb, mid + 1, dn);
+        frag_matvec<NB>(pre.A0, up, acc);
+        frag_matvec<NB>(pre.A2, dn, acc);
+        vec_store<NB>(tb, mid, acc, writer);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        apply(mid, pre.Am, true); apply(mid - 1, pre.B0, true); apply(mid + 1, pre.B1, true);
+    }
+    d4 Q0[NF], Q1[NF];
+    for (int t = 0; t < nt; t += 4) {                        // branch-free body (exact vmcnt waits), see chain_sweep
+        frag_load_sinv<NB>(Fs + (size_t)kc(t + 2) * fstage, lane, Q0);
+        frag_load_sinv<NB>(Fs + (size_t)kc(t + 3) * fstage, lane, Q1);
+        apply(kc(t), pre.P0, true); apply(kc(t + 1), pre.P1, t + 1 < nt);
+        frag_load_sinv<NB>(Fs + (size_t)kc(t + 4) * fstage, lane, pre.P0);
+        frag_load_sinv<NB>(Fs + (size_t)kc(t + 5) * fstage, lane, pre.P1);
+        apply(kc(t + 2), Q0, t + 2 < nt); apply(kc(t + 3), Q1, t + 3 < nt);
+    }
+}
+
+// What the linear-system core needs to know about one instance.
+struct CoreArgs { int N, fstage; const double *F; };
+__device__ __forceinline__ CoreArgs core_args(const Lay &L, const double *F) {
+    CoreArgs a; a.N = L.N; a.fstage = L.fstage; a.F = F; return a;
+}
+
+// Twisted solve: forward elimination of the two half-chains (waves 0, 1), S^-1 of every stage (all waves; wave 0
+// closes the elimination at the middle first), back substitution outwards with the transposed forward matrices.
+#ifdef MPCQP_RUN_TIMING
+__device__ unsigned long long g_ticks[16];
+#define TICK(i) { unsigned long long t_ = wall_clock64(); if (threadIdx.x == 0) atomicAdd(&g_ticks[i], t_ - ttick); ttick = t_; }
+#define TICK_START unsigned long long ttick = wall_clock64();
+#else
+#define TICK(i)
+#define TICK_START
+#endif
+
+template <int NB>
+__device__ __forceinline__ void kkt_core_sweeps(const CoreArgs &a, double *Tc) {
+    const int N = a.N, fstage = a.fstage, mid = N / 2, wv = logical_wave();
+    const double *F = a.F;
+    TICK_START
+    if (wv == 0) chain_sweep<NB, false>(0, +1, mid - 1, fstage, F, -1, Tc);               // stages 1 .. mid-1
+    else if (wv == 1) chain_sweep<NB, false>(N - 1, -1, N - 2 - mid, fstage, F, -1, Tc);  // stages N-2 .. mid+1
+    SinvPre<NB> pre;
+    sinv_prefetch<NB>(N, mid, fstage, F, pre);
+    __syncthreads();
+    TICK(1)
+    sinv_apply<NB>(N, mid, fstage, F, Tc, pre);
+    __syncthreads();
+    TICK(2)
+    if (wv == 0) chain_sweep<NB, true>(mid, -1, mid, fstage, F, -1, Tc);                  // stages mid-1 .. 0
+    else if (wv == 1) chain_sweep<NB, true>(mid, +1, N - 1 - mid, fstage, F, 0, Tc);           // stages mid+1 .. N-1
+    __syncthreads();
+    TICK(3)
+}
+
+// Tc <- K_xu^-1 Tc (eps already eliminated).  All threads call; barriers inside.  Waves 0 and 1 sweep the two
+// half-chains of the twisted factorization concurrently.  Tc must be seen by the compiler as an LDS pointer
+// (a pointer laundered through an integer becomes FLAT: flat LDS accesses count on vmcnt AND lgkmcnt and force a
+// full s_waitcnt vmcnt(0) -- draining the factor prefetch -- before every stage).
+template <int NB>
+__device__ __forceinline__ void kkt_core(const CoreArgs &a, double *Tc) {
+#ifndef MPCQP_ABL_NOCHAIN
+    kkt_core_sweeps<NB>(a, Tc);
+#endif
+    __syncthreads();
+}

@@ -5,7 +5,7 @@
 exactly as the reference hands it to its solver (pyMPC/mpc.py:456-608 for the full build,
 pyMPC/mpc.py:386-454 for the per-step q/l/u refresh).  This module exists so that the
 drop-in ``MPCController`` can expose the same public ``P, q, A, l, u`` attributes; the
-numbers the solver works on are built independently on the GPU by ``csrc/mpcqp.hip`` and
+numbers the solver works on are built independently on the GPU by ``csrc/mpcqp*.h`` and
 the two are compared in the tests.
 
 Layout facts reproduced bug-for-bug:
