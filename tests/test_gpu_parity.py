@@ -453,3 +453,46 @@ def test_unsupported_dimensions_fail_loudly():
     K = _gpu_controller(kw)
     with pytest.raises(NotImplementedError):
         K.setup()
+
+
+def test_device_loop_recovers_from_infeasible_step_like_stepwise():
+    """An instance whose first QP is primal infeasible (u_{-1} far outside what the input box and the Delta-u bounds allow):
+    'primal infeasible' -> output() falls back to u_failure = uref (mpc.py:271-336), the iterate is cold-started, and the
+    next step is feasible again -- identical inside the device loop and through the stepwise API."""
+    from pympc_amd import fixtures
+    kws = [fixtures.random_lti(600 + i) for i in range(4)]
+    kws[1]['uminus1'] = np.array([5.0, 0.0, 0.0, 0.0])        # needs u_0[0] in [4.5, 5.5] but u <= 1
+    kws[3]['uminus1'] = np.array([0.0, -7.0, 0.0, 0.0])
+    Kd = _stacked_batch(kws); Ks = _stacked_batch(kws)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        Kd.setup(); Ks.setup()
+        st0 = Ks.status()
+        assert st0[1] == 'primal infeasible' and st0[3] == 'primal infeasible' and st0[0] == 'solved' and st0[2] == 'solved'
+        tr = Kd.run(6)
+        for k in range(6):
+            u = Ks.output()
+            assert np.array_equal(u, tr['u'][k]), k
+            if k == 0:
+                assert np.array_equal(u[1], kws[1]['uref']) and np.array_equal(u[3], kws[3]['uref'])
+            Ks.update(tr['x'][k + 1])
+            infos = Ks.prob.infos()
+            assert [i.status for i in infos] == list(tr['status'][k]) and [i.iter for i in infos] == list(tr['iter'][k])
+        assert (tr['status'][1:] == 1).all()
+
+
+def test_device_loop_long_run_stays_bounded_and_solved():
+    """400 noisy closed-loop steps of 64 instances in four launches: every solve ends 'solved', states stay inside a
+    generous box, and chaining launches equals one long launch."""
+    from pympc_amd import fixtures
+    kws = [fixtures.random_lti(700 + i) for i in range(64)]
+    rng = np.random.default_rng(11)
+    w = 0.05 * rng.standard_normal((400, 64, 12))
+    Ka = _stacked_batch(kws); Ka.setup()
+    Kb = _stacked_batch(kws); Kb.setup()
+    ta = Ka.run(400, w=w)
+    parts = [Kb.run(100, w=w[100 * i:100 * (i + 1)]) for i in range(4)]
+    assert np.array_equal(ta['u'], np.concatenate([p['u'] for p in parts]))
+    assert np.array_equal(ta['x'][-1], parts[-1]['x'][-1])
+    assert (ta['status'] == 1).all()
+    assert np.isfinite(ta['x']).all() and np.abs(ta['x']).max() < 50 and np.abs(ta['u']).max() <= 1 + 1e-6
