@@ -16,6 +16,9 @@
  *   mpcqp_get_solution    res.x / res.y / res.info.*                    pyMPC/mpc.py:301-327
  *   mpcqp_get_u0          output(): res.x[(Np+1)nx : (Np+1)nx+nu]        pyMPC/mpc.py:301-304
  *   mpcqp_export_qp       the public attributes P,q,A,l,u               pyMPC/mpc.py:598-606
+ *   mpcqp_mpc_step        __controller_function__: update(x,u); output() pyMPC/mpc.py:377-384
+ *   mpcqp_mpc_run / _loop the caller loop  u = output(); plant; update() examples/example_point_mass.py:88-101,
+ *                         (+ LinearStateEstimator update/predict)        pyMPC/mpc.py:688-692, pyMPC/kalman.py:109-134
  *
  * The QP is the reference's sparse (non-condensed) formulation, bug-for-bug:
  *   w = [x_0..x_Np | u_0..u_{Nc-1} | eps_0..eps_Np],  n = 2(Np+1)nx + Nc nu
@@ -130,6 +133,13 @@ int mpcqp_solve(mpcqp_handle *h);
  * any pointer may be NULL.  u0 [batch][nu] is the first optimal input of each instance. */
 int mpcqp_get_solution(mpcqp_handle *h, double *x, double *y, mpcqp_info *info);
 int mpcqp_get_u0(mpcqp_handle *h, double *u0);
+
+/* One control step u = K(x, u_{-1}) (MPCController.__controller_function__, mpc.py:377-384): update(x0, uminus1, xref),
+ * warm-started solve, output() -- u_out [batch][nu] receives the first optimal input of every instance, or u_failure
+ * (= uref) where the status is not 'solved' (mpc.py:271-336).  Like output(), the call also makes u_out the u_{-1} of
+ * the next step, so uminus1 may be NULL from the second step on; xref may be NULL (unchanged).  Synchronises. */
+int mpcqp_mpc_step(mpcqp_handle *h, const double *x0, const double *uminus1, const double *xref, int xref_rows,
+                   double *u_out);
 
 /* Device-side receding-horizon loop: K closed-loop steps of every instance without host round trips,
  *     for k in range(nsteps):  u = K.output();  x = Ap x + Bp u + w[k];  K.update(x)       (solve included)

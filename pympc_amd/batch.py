@@ -95,6 +95,19 @@ class BatchMPCController:
         self.prob.solve_async()
         self._u_last = None
 
+    def step(self, x, u=None, xref=None):
+        """``u = K(x, u_{-1})``: ``update(x, u, xref)`` followed by ``output()`` in one library call
+        (MPCController.__controller_function__, mpc.py:377-384)."""
+        self.x0_rh = x
+        if u is not None:
+            self.uminus1_rh = u
+        if xref is not None:
+            self.xref = xref
+        uMPC = self.prob.mpc_step(x, u, xref)
+        self.uminus1_rh = uMPC
+        self._u_last = None
+        return uMPC
+
     def run(self, nsteps, w=None, Ap=None, Bp=None, xref_traj=None, estimator=None):
         """``nsteps`` closed-loop steps on the device, equivalent to
         ``for k in range(nsteps): u = K.output(); x = Ap @ x + Bp @ u + w[k]; K.update(x, u, xref_traj[k])``

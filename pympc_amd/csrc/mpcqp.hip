@@ -440,6 +440,21 @@ extern "C" int mpcqp_get_u0(mpcqp_handle *h, double *u0) {
     return MPCQP_OK;
 }
 
+extern "C" int mpcqp_mpc_step(mpcqp_handle *h, const double *x0, const double *uminus1, const double *xref, int xref_rows, double *u_out) {
+    if (!h || !x0 || !u_out) return fail(MPCQP_ERR_ARG, "mpcqp_mpc_step: null argument");
+    if (!h->is_setup) return fail(MPCQP_ERR_STATE, "mpcqp_mpc_step before mpcqp_setup");
+    HIPCHK(hipSetDevice(h->device));
+    int rc = step_upload(h, x0, uminus1, xref, xref_rows);
+    if (rc) return rc;
+    if ((rc = launch_solve(h, 0))) return rc;
+    const int tot = h->batch * h->L.nu;
+    hipLaunchKernelGGL(k_output_u, dim3((tot + 255) / 256), dim3(256), 0, h->stream, h->L, h->P, h->u0_dev, h->batch, 1);
+    HIPCHK(hipGetLastError());
+    if (get(h, u_out, h->u0_dev, sizeof(double) * (size_t)tot)) return MPCQP_ERR_HIP;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MPCQP_OK;
+}
+
 extern "C" int mpcqp_get_stats(mpcqp_handle *h, uint64_t *out4, int reset) {
     if (!h || !out4) return fail(MPCQP_ERR_ARG, "null argument");
     HIPCHK(hipSetDevice(h->device));

@@ -237,3 +237,15 @@ __global__ void k_gather_u0(Lay L, const double *xo, double *u0, int batch) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < batch * L.nu) { int b = i / L.nu, j = i - b * L.nu; u0[i] = xo[(size_t)b * L.n + L.ou + j]; }
 }
+
+// output() of mpc.py:271-336 for the whole batch: u = first input of the solution if the status is 'solved', else
+// u_failure (= uref); optionally also becomes u_{-1} of the next update (output() sets uminus1_rh).
+__global__ void k_output_u(Lay L, Ptrs P, double *u_out, int batch, int store_um1) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < batch * L.nu) {
+        const int b = i / L.nu, j = i - b * L.nu;
+        const double u = P.info[b].status == MPCQP_SOLVED ? P.xo[(size_t)b * L.n + L.ou + j] : P.model[(size_t)b * L.model_sz + L.ouref + j];
+        u_out[i] = u;
+        if (store_um1) P.step[(size_t)b * L.step_sz + L.nx + j] = u;
+    }
+}

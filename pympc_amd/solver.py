@@ -182,6 +182,20 @@ class BatchProblem:
     def synchronize(self):
         _lib.check(self._L.mpcqp_synchronize(self._h), 'mpcqp_synchronize')
 
+    def mpc_step(self, x0, uminus1=None, xref=None, out=None):
+        """One control step ``u = K(x, u_{-1})`` (mpcqp_mpc_step = update + warm solve + output with the u_failure rule)."""
+        B, nx, nu = self.batch, self.nx, self.nu
+        a = _prep(x0, (B, nx), 'x0')
+        b = _prep(uminus1, (B, nu), 'uminus1') if uminus1 is not None else None
+        c, rows = None, 1
+        if xref is not None:
+            rows = self._xref_rows(xref)
+            c = _prep(xref, (B, rows * nx), 'xref')
+        if out is None:
+            out = np.empty((B, nu))
+        _lib.check(self._L.mpcqp_mpc_step(self._h, _ptr(a), _ptr(b), _ptr(c), rows, _ptr(out)), 'mpcqp_mpc_step')
+        return out
+
     def mpc_run(self, nsteps, w=None, Ap=None, Bp=None, out=None, xref_traj=None, estimator=None):
         """Device-side receding-horizon loop (mpcqp_mpc_loop): ``nsteps`` closed-loop steps
         ``u = output(); x = Ap x + Bp u + w[k]; update(x)`` of every instance without host round trips.

@@ -496,3 +496,24 @@ def test_device_loop_long_run_stays_bounded_and_solved():
     assert np.array_equal(ta['x'][-1], parts[-1]['x'][-1])
     assert (ta['status'] == 1).all()
     assert np.isfinite(ta['x']).all() and np.abs(ta['x']).max() < 50 and np.abs(ta['u']).max() <= 1 + 1e-6
+
+
+def test_mpc_step_equals_update_then_output():
+    """mpcqp_mpc_step (u = K(x, u_{-1}), mpc.py:377-384) against update() + output(), including the implicit u_{-1} hand-over
+    and the u_failure fallback."""
+    from pympc_amd import fixtures
+    kws = [fixtures.random_lti(800 + i) for i in range(5)]
+    Ka = _stacked_batch(kws); Ka.setup()
+    Kb = _stacked_batch(kws); Kb.setup()
+    x = Ka.x0_rh.copy()
+    rng = np.random.default_rng(2)
+    ua, ub = Ka.output(), Kb.output()
+    assert np.array_equal(ua, ub)
+    for k in range(5):
+        x = np.einsum('bij,bj->bi', Ka.Ad, x) + np.einsum('bij,bj->bi', Ka.Bd, ua) + 0.01 * rng.standard_normal(x.shape)
+        Ka.update(x); ua = Ka.output()
+        ub = Kb.step(x, ub if k == 0 else None)            # u_{-1} handed over by the previous step from k = 1 on
+        assert np.array_equal(ua, ub), k
+    Kf = _stacked_batch(kws, max_iter=10); Kf.setup()
+    uf = Kf.step(x)
+    assert np.array_equal(uf, Kf.uref)                     # not 'solved' after 10 iterations -> u_failure
