@@ -1,0 +1,59 @@
+"""Closed-loop golden trajectories produced by the REFERENCE's controller class (tests/golden/make_traj.py): our host
+class, driven through the same caller loop with the CPU oracle as its solver, must visit the same states and apply
+the same inputs -- QP refresh, warm starts, u_{-1} bookkeeping and output() over whole runs (mpc.py:271-364,386-454)."""
+import warnings
+
+import numpy as np
+import pytest
+
+from util import traj_names, load_traj, cart_pole_plant
+
+
+def _closed_loop(K, kw, g, plant, feed_golden_states, tol):
+    pattern = str(g['pattern'])
+    xs, us = g['x'], g['u']
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        K.setup()
+        x, u = np.array(kw['x0'], dtype=float), np.array(kw['uminus1'], dtype=float)
+        for k in range(len(us)):
+            if pattern == 'update_output':
+                K.update(x, u)
+                u = K.output()
+            else:
+                u = K.output()
+            scale = max(1e-3, np.abs(us).max())
+            assert np.abs(u - us[k]).max() <= tol * scale, (k, u, us[k])
+            x = xs[k + 1] if feed_golden_states else plant(x, u)
+            assert np.abs(x - xs[k + 1]).max() <= tol * max(1e-3, np.abs(xs).max()), k
+            if pattern != 'update_output':
+                K.update(x)
+
+
+@pytest.mark.parametrize('name', traj_names())
+def test_host_class_with_oracle_reproduces_reference_closed_loop(name):
+    from pympc_amd import MPCController, fixtures
+    from oracle.osqp_oracle import OSQP
+    g = load_traj(name)
+    kw = dict(fixtures.NAMED[str(g['fixture'])]())
+    kw.update(eps_abs=float(g['eps']), eps_rel=float(g['eps']))
+    K = MPCController(**kw)
+    K.prob = OSQP()
+    K.solver_settings = dict(max_iter=400000)
+    Ad, Bd = kw['Ad'], kw['Bd']
+    plant = cart_pole_plant if name == 'cart_pole' else (lambda x, u: Ad @ x + Bd @ u)
+    _closed_loop(K, kw, g, plant, feed_golden_states=False, tol=1e-8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', traj_names())
+def test_gpu_controller_follows_reference_closed_loop(name):
+    """The drop-in class on the GPU (eps 1e-9) along the reference's trajectory: every applied input within 1e-6 (relative
+    to the input range) of the reference controller's -- the north-star criterion, step after step."""
+    from pympc_amd import MPCController, fixtures
+    g = load_traj(name)
+    kw = dict(fixtures.NAMED[str(g['fixture'])]())
+    kw.update(eps_abs=1e-9, eps_rel=1e-9)
+    K = MPCController(**kw)
+    K.solver_settings = dict(max_iter=400000)
+    _closed_loop(K, kw, g, None, feed_golden_states=True, tol=1e-6)

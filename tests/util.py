@@ -54,3 +54,26 @@ def kkt_certificate(P, q, A, l, u, x, y):
         cu = np.where(np.isfinite(u), yp * (u - Ax), np.where(yp > 1e-9 * ysc, np.inf, 0.0)).max()
         cl = np.where(np.isfinite(l), -ym * (Ax - l), np.where(ym < -1e-9 * ysc, np.inf, 0.0)).max()
     return stat, pv, max(cu, cl) / ysc
+
+
+# ---- closed-loop golden trajectories (tests/golden/make_traj.py) ------------------------------------------------------
+def traj_names():
+    import glob
+    return sorted(os.path.basename(p)[5:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, 'traj_*.npz')))
+
+
+def load_traj(name):
+    return np.load(os.path.join(GOLDEN_DIR, 'traj_%s.npz' % name), allow_pickle=False)
+
+
+def cart_pole_plant(x, u, Ts=50e-3):
+    """Nonlinear cart-pole + forward Euler, the plant of examples/example_inverted_pendulum.py:10-17,92-103
+    (same restatement as in tests/golden/make_traj.py)."""
+    M, m, b, ftheta, l, g = 0.5, 0.2, 0.1, 0.1, 0.3, 9.81
+    F, v, theta, omega = float(u[0]), x[1], x[2], x[3]
+    der = np.zeros(4)
+    der[0] = v
+    der[1] = (m * l * np.sin(theta) * omega ** 2 - m * g * np.sin(theta) * np.cos(theta) + m * ftheta * np.cos(theta) * omega + F - b * v) / (M + m * (1 - np.cos(theta) ** 2))
+    der[2] = omega
+    der[3] = ((M + m) * (g * np.sin(theta) - ftheta * omega) - m * l * omega ** 2 * np.sin(theta) * np.cos(theta) - (F - b * v) * np.cos(theta)) / (l * (M + m * (1 - np.cos(theta) ** 2)))
+    return x + der * Ts
