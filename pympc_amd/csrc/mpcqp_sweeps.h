@@ -255,6 +255,57 @@ __device__ __forceinline__ void sinv_apply(const int N, const int mid, const int
     }
 }
 
+// The same phase for 32 x 32 stages (four fragments = 32 VGPRs per stage): two fragment buffers in all -- the current
+// stage and the next one in flight -- instead of the seven of the pipelined version, which does not fit the register file.
+template <int NB>
+__device__ __forceinline__ void sinv_apply_lean(const int N, const int mid, const int fstage, const double *F, double *Tc) {
+    constexpr int NBLK = NB / 16, NF = SweepCfg<NB>::NF;
+    const int lane = opaque_lane(threadIdx.x & 63), wv = logical_wave();
+    double *tb = Tc + vec_lane_offset(lane);
+    const bool writer = vec_lane_writer(lane);
+    auto apply = [&](int k, const d4 *A) {
+        double in[NBLK], out[NBLK];
+        vec_load<NB>(tb, k, in);
+#pragma unroll
+        for (int b = 0; b < NBLK; ++b) out[b] = 0.0;
+        frag_matvec<NB>(A, in, out);
+        vec_store<NB>(tb, k, out, writer);
+    };
+    const double *Fs = F + NB * NB;
+    d4 A[NF], B[NF];
+    if (wv == 0) {
+        double up[NBLK], dn[NBLK], acc[NBLK];
+        frag_load<NB>(F + (size_t)mid * fstage, lane, A);
+        frag_load<NB>(F, lane, B);                            // the middle's second forward matrix (kept in stage 0's slot)
+        vec_load<NB>(tb, mid, acc);
+        vec_load<NB>(tb, mid - 1, up);
+        vec_load<NB>(tb, mid + 1, dn);
+        frag_matvec<NB>(A, up, acc);
+        frag_load_sinv<NB>(Fs + (size_t)mid * fstage, lane, A);
+        frag_matvec<NB>(B, dn, acc);
+        frag_load_sinv<NB>(Fs + (size_t)(mid - 1) * fstage, lane, B);
+        vec_store<NB>(tb, mid, acc, writer);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        apply(mid, A);
+        frag_load_sinv<NB>(Fs + (size_t)(mid + 1) * fstage, lane, A);
+        apply(mid - 1, B);
+        apply(mid + 1, A);
+    }
+    int k = sinv_stage(wv, 0, N, mid);
+    if (k >= 0) frag_load_sinv<NB>(Fs + (size_t)k * fstage, lane, A);
+    for (int t = 0; k >= 0; t += 2) {                         // A holds stage t; B is filled with stage t+1 while A is applied
+        const int k1 = sinv_stage(wv, t + 1, N, mid);
+        if (k1 >= 0) frag_load_sinv<NB>(Fs + (size_t)k1 * fstage, lane, B);
+        apply(k, A);
+        if (k1 < 0) break;
+        k = sinv_stage(wv, t + 2, N, mid);
+        if (k >= 0) frag_load_sinv<NB>(Fs + (size_t)k * fstage, lane, A);
+        apply(k1, B);
+    }
+}
+
 // What the linear-system core needs to know about one instance.
 struct CoreArgs { int N, fstage; const double *F; };
 __device__ __forceinline__ CoreArgs core_args(const Lay &L, const double *F) {
@@ -279,11 +330,17 @@ __device__ __forceinline__ void kkt_core_sweeps(const CoreArgs &a, double *Tc) {
     TICK_START
     if (wv == 0) chain_sweep<NB, false>(0, +1, mid - 1, fstage, F, -1, Tc);               // stages 1 .. mid-1
     else if (wv == 1) chain_sweep<NB, false>(N - 1, -1, N - 2 - mid, fstage, F, -1, Tc);  // stages N-2 .. mid+1
-    SinvPre<NB> pre;
-    sinv_prefetch<NB>(N, mid, fstage, F, pre);
-    __syncthreads();
-    TICK(1)
-    sinv_apply<NB>(N, mid, fstage, F, Tc, pre);
+    if constexpr (NB <= 16) {
+        SinvPre<NB> pre;
+        sinv_prefetch<NB>(N, mid, fstage, F, pre);
+        __syncthreads();
+        TICK(1)
+        sinv_apply<NB>(N, mid, fstage, F, Tc, pre);
+    } else {
+        __syncthreads();
+        TICK(1)
+        sinv_apply_lean<NB>(N, mid, fstage, F, Tc);
+    }
     __syncthreads();
     TICK(2)
     if (wv == 0) chain_sweep<NB, true>(mid, -1, mid, fstage, F, -1, Tc);                  // stages mid-1 .. 0
