@@ -131,7 +131,7 @@ static Lay make_layout(int nx, int nu, int Np, int Nc) {
     L.model_sz = o;
     L.step_sz = nx + nu + L.N * nx;
     L.xref_rows = 1;
-    L.fstage = 2 * L.NB * L.NB;
+    L.fstage = L.NB * L.NB + (L.NB == 16 ? SinvFmt<16>::DOUBLES : SinvFmt<32>::DOUBLES);
     L.tsz = (L.m + L.N * L.NB) > 6 * L.NB * L.NB ? (L.m + L.N * L.NB) : 6 * L.NB * L.NB;   // [W (m) | Tc (N*NB)] or factor workspace
     return L;
 }

@@ -37,6 +37,18 @@ typedef __attribute__((address_space(1))) double gdouble;     // explicit global
 typedef __attribute__((address_space(1))) const double cgdouble;  // not flat_* (which also counts on lgkmcnt)
 typedef __attribute__((address_space(1))) const d4 cgd4;
 
+// Storage format of the S^-1 slot (explained next to its reader, frag_load_sinv / sym_expand in mpcqp_sweeps.h).
+#ifndef MPCQP_SYM_SINV
+#define MPCQP_SYM_SINV 1
+#endif
+template <int NB> struct SinvFmt { static constexpr bool SYM = MPCQP_SYM_SINV && NB == 16; static constexpr int DOUBLES = SYM ? 164 : NB * NB; };
+typedef double d4u __attribute__((ext_vector_type(4), aligned(8)));
+typedef __attribute__((address_space(1))) const d4u cgd4u;
+__host__ __device__ inline int sym_cum(int R) { return 16 * R - 2 * R * (R - 1); }
+__device__ __forceinline__ int sym_pos(int r, int c) {       // (r, c) with c>>2 >= r>>2
+    const int R = r >> 2;
+    return 40 * (c & 3) + sym_cum(R) + (r & 3) * (4 - R) + ((c >> 2) - R);
+}
 template <int NB>
 __device__ __forceinline__ int frag_pos(int r, int cidx) {
     constexpr int NBLK = NB / 16;
@@ -136,7 +148,8 @@ __device__ int factor_all(const Ctx &c, const double *om, const double *sv, doub
             double acc = 0.0;
             for (int l = max(a, b); l < NB; ++l) acc += Li[l * NB + a] * Li[l * NB + b];
             SnOut[e] = acc;
-            F[(size_t)k * L.fstage + NB * NB + frag_pos<NB>(a, b)] = acc;
+            if constexpr (SinvFmt<NB>::SYM) { if ((b >> 2) >= (a >> 2)) F[(size_t)k * L.fstage + NB * NB + sym_pos(a, b)] = acc; }
+            else F[(size_t)k * L.fstage + NB * NB + frag_pos<NB>(a, b)] = acc;
         }
     };
     for (int k = 0; k < mid; ++k) stage(k, k > 0, false, SnA);

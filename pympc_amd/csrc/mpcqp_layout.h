@@ -19,7 +19,7 @@ struct Lay {
     int oQx, oQxN, oQu, oQDu, model_sz;
     int step_sz;                  // [x0 | um1 | xref(N*nx)]
     int xref_rows;                // 1 or N
-    int fstage;                   // doubles per factor stage: 2*NB*NB  [forward matrix | S^-1]
+    int fstage;                   // doubles per factor stage: [forward matrix NB*NB | S^-1 (NB = 16: packed upper blocks, 164)]
     int tsz;                      // LDS work vector length: max(m, 4*NB*NB)
 };
 

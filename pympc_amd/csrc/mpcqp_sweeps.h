@@ -57,15 +57,36 @@ __device__ __forceinline__ void frag_load(const double *Fm, int lane, d4 *A) {
 #pragma unroll
     for (int b = 0; b < NBLK * NBLK; ++b) A[b] = *(cgd4 *)(Fm + b * 256 + lane * 4);
 }
-#ifdef MPCQP_ABL_NOSINVLOAD
+__device__ __forceinline__ double lane_permute(double x, int byte_addr);
+
+// S_k^-1 is symmetric.  For 16 x 16 stages only the 4x4 blocks on and above the block diagonal are stored -- 160 of 256
+// doubles, packed per operand-layout lane: a lane of block row R owns its 4-R values (steps 0..3-R) back to back,
+//     offset(lane = 16k + 4R + i) = 40 k + cum(R) + i (4-R),   cum = 0, 16, 28, 36      (+4 doubles of slack per fragment)
+// A lane loads a 4-double window at its offset (the tail of the window belongs to the next lane and is discarded) and
+// sym_expand rebuilds the missing steps from the transposed block: step s of block row R with R+s >= 4 is block
+// (R, R+s-4) = block (R+s-4, R)', i.e. step 4-s of lane 16 i + 4 (R+s-4) + k -- three cross-lane permutes.
+// The MFMA mat-vec then runs on the full fragment as before; a quarter fewer bytes per S^-1 read.
 template <int NB>
 __device__ __forceinline__ void frag_load_sinv(const double *Fm, int lane, d4 *A) {
-#pragma unroll
-    for (int b = 0; b < (NB / 16) * (NB / 16); ++b) A[b] = d4{1e-3 * lane, 1e-3, 2e-3, 3e-3};
+    if constexpr (SinvFmt<NB>::SYM) {
+        const int R = (lane >> 2) & 3;
+        const d4u w = *(cgd4u *)(Fm + 40 * (lane >> 4) + sym_cum(R) + (lane & 3) * (4 - R));
+        A[0] = d4{w[0], w[1], w[2], w[3]};
+    } else {
+        frag_load<NB>(Fm, lane, A);
+    }
 }
-#else
-#define frag_load_sinv frag_load
-#endif
+template <int NB>
+__device__ __forceinline__ void sym_expand(d4 *A, int lane) {
+    if constexpr (SinvFmt<NB>::SYM) {
+        const int R = (lane >> 2) & 3, k = lane >> 4, i = lane & 3;
+        const d4 w = A[0];
+        const double t1 = lane_permute(w[3], 4 * (16 * i + 4 * ((R + 1) & 3) + k));
+        const double t2 = lane_permute(w[2], 4 * (16 * i + 4 * ((R + 2) & 3) + k));
+        const double t3 = lane_permute(w[1], 4 * (16 * i + 4 * ((R + 3) & 3) + k));
+        A[0] = d4{w[0], R + 1 >= 4 ? t1 : w[1], R + 2 >= 4 ? t2 : w[2], R + 3 >= 4 ? t3 : w[3]};
+    }
+}
 
 // The TRANSPOSED product from the same fragments:  out[bj] += sum_bi A(bi,bj)' * in[bi].
 // The backward substitution needs Mh' where the forward elimination needed Mh; the MFMA always contracts over the
@@ -225,7 +246,11 @@ __device__ __forceinline__ void sinv_apply(const int N, const int mid, const int
         vec_load<NB>(tb, k, in);
 #pragma unroll
         for (int b = 0; b < NBLK; ++b) out[b] = 0.0;
-        frag_matvec<NB>(A, in, out);
+        d4 Af[NF];
+#pragma unroll
+        for (int b = 0; b < NF; ++b) Af[b] = A[b];
+        sym_expand<NB>(Af, lane);
+        frag_matvec<NB>(Af, in, out);
         vec_store<NB>(tb, k, out, writer && valid);
     };
     const double *Fs = F + NB * NB;
