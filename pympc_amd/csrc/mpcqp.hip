@@ -28,6 +28,7 @@
 #include <string.h>
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -61,6 +62,8 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+constexpr int BALANCE_EVERY = 16;  // stepwise API: solves between two rebuilds of the workgroup -> instance map
+
 struct mpcqp_handle {
     int device, batch;
     Lay L;
@@ -71,6 +74,9 @@ struct mpcqp_handle {
     size_t smem_setup, smem_solve;
     std::vector<void *> allocs;
     double *u0_dev;
+    int *perm_dev;                // [batch] workgroup -> instance map (P.perm points here once a map has been built)
+    std::vector<double> work_ema; // per instance: smoothed ADMM iterations per balancing interval (host)
+    int ncu, solves_since_balance, auto_balance;
     void *run_buf; size_t run_bytes;     // staging of mpcqp_mpc_run (disturbances, plant, trajectories)
     bool profiling;
     hipEvent_t ev0[MAXEV], ev1[MAXEV];   // ring of event pairs around the solve-kernel launches
@@ -154,7 +160,7 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     if (device < 0 || device >= ndev) return fail(MPCQP_ERR_ARG, "mpcqp_create: bad device index");
     HIPCHK(hipSetDevice(device));
     mpcqp_handle *h = new mpcqp_handle();
-    h->device = device; h->batch = batch; h->is_setup = false; h->u0_dev = nullptr; h->run_buf = nullptr; h->run_bytes = 0;
+    h->device = device; h->batch = batch; h->is_setup = false; h->u0_dev = nullptr; h->run_buf = nullptr; h->run_bytes = 0; h->perm_dev = nullptr; h->solves_since_balance = 0; h->auto_balance = 1; h->ncu = 0;
     h->profiling = false; h->run_ms = 0.0; h->run_launches = 0; h->ev_count = 0; h->have_events = false;
     h->L = make_layout(nx, nu, Np, Nc);
     if (s) h->S = *s; else mpcqp_default_settings(&h->S);
@@ -179,6 +185,9 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     rc |= dalloc(h, &P.Dt, B * L.n); rc |= dalloc(h, &P.Et, B * L.m);
     rc |= dalloc(h, &P.ctype, B * L.m); rc |= dalloc(h, &P.info, B); rc |= dalloc(h, &P.stats, 8);
         rc |= dalloc(h, &h->u0_dev, B * L.nu);
+    rc |= dalloc(h, &P.work, B); rc |= dalloc(h, &h->perm_dev, B);
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->ncu = prop.multiProcessorCount; }
+    if (const char *e = getenv("MPCQP_BALANCE")) h->auto_balance = atoi(e) != 0;      // development switch
     if (rc) { mpcqp_destroy(h); return MPCQP_ERR_HIP; }
     h->smem_setup = sizeof(double) * (size_t)smem_common_doubles(L);
     size_t with_state = h->smem_setup + sizeof(double) * (size_t)(L.n + 2 * L.m);
@@ -303,6 +312,40 @@ static int launch_run_generic(mpcqp_handle *h, const RunArgs &R) {
     return h->L.border ? launch_run_t<NB, LDSS, 0, 0, true>(h, R) : launch_run_t<NB, LDSS, 0, 0, false>(h, R);
 }
 
+// Load balancing across CUs.  All workgroups of a launch are resident at once (a few per CU) and an instance keeps its
+// character -- one that needs two ADMM rounds per solve mostly keeps needing them -- so CUs that happen to host several
+// slow instances finish last and set the launch time.  Every now and then the per-instance iteration counts are read
+// back, smoothed, and the workgroup -> instance map is rebuilt: instances sorted by expected work, dealt to the CUs in
+// snake order (blocks b, b + #CU, b + 2 #CU, ... share a CU: dispatch is round-robin over XCDs and CUs), so that every CU
+// gets a similar total.  Pure scheduling: which workgroup handles which instance never changes a result.
+// Must be called with the stream idle.
+static int rebalance(mpcqp_handle *h) {
+    const int B = h->batch, ncu = h->ncu;
+    h->solves_since_balance = 0;
+    if (!h->auto_balance || ncu <= 0 || B <= ncu) return MPCQP_OK;
+    std::vector<unsigned> work(B);
+    HIPCHK(hipMemcpy(work.data(), h->P.work, sizeof(unsigned) * (size_t)B, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemsetAsync(h->P.work, 0, sizeof(unsigned) * (size_t)B, h->stream));
+    if (h->work_ema.empty()) h->work_ema.assign(B, 0.0);
+    bool any = false;
+    const double decay = 0.75;                             // (anything from 0.5 to 0.95 measured the same)
+    for (int i = 0; i < B; ++i) { h->work_ema[i] = decay * h->work_ema[i] + (double)work[i]; any |= work[i] != 0; }
+    if (!any) return MPCQP_OK;
+    std::vector<int> order(B), perm(B);
+    for (int i = 0; i < B; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return h->work_ema[a] > h->work_ema[b]; });
+    const int full_rows = B / ncu;
+    for (int j = 0; j < B; ++j) {
+        const int row = j / ncu, pos = j % ncu;
+        const bool reversed = (row & 1) && row < full_rows;            // a partial last row keeps forward order
+        perm[row * ncu + (reversed ? ncu - 1 - pos : pos)] = order[j];
+    }
+    HIPCHK(hipMemcpyAsync(h->perm_dev, perm.data(), sizeof(int) * (size_t)B, hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));                          // (perm is a stack-lifetime host buffer)
+    h->P.perm = h->perm_dev;
+    return MPCQP_OK;
+}
+
 // One launch of the solve / closed-loop kernel on the handle's stream (asynchronous).  Specialisations with
 // compile-time nx, nu for the BASELINE configurations; generic kernels otherwise.
 static int launch_run(mpcqp_handle *h, RunArgs R, int plain_iters) {
@@ -312,6 +355,7 @@ static int launch_run(mpcqp_handle *h, RunArgs R, int plain_iters) {
     R.chk = R.plain ? 0 : S.check_termination;
     R.rho_every = (!R.plain && S.adaptive_rho) ? (S.adaptive_rho_interval ? S.adaptive_rho_interval : (R.chk ? 4 * R.chk : 100)) : 0;
     R.batch = h->batch;
+    h->solves_since_balance += R.nsteps > 0 ? R.nsteps : 1;
     const int e = h->ev_count % MAXEV;
     if (h->profiling) {
         if (h->ev_count >= MAXEV) {                 // ring full: bank the oldest pair first
@@ -409,7 +453,7 @@ extern "C" int mpcqp_mpc_loop(mpcqp_handle *h, int nsteps, const mpcqp_loop *io)
     for (int i = 0; i < np; ++i)
         if (parts[i].dst && parts[i].bytes && get(h, parts[i].dst, dev(i), parts[i].bytes)) return MPCQP_ERR_HIP;
     HIPCHK(hipStreamSynchronize(h->stream));
-    return MPCQP_OK;
+    return rebalance(h);
 }
 
 extern "C" int mpcqp_mpc_run(mpcqp_handle *h, int nsteps, const double *w, const double *Ap, const double *Bp,
@@ -437,7 +481,7 @@ extern "C" int mpcqp_get_u0(mpcqp_handle *h, double *u0) {
     HIPCHK(hipGetLastError());
     if (get(h, u0, h->u0_dev, sizeof(double) * (size_t)tot)) return MPCQP_ERR_HIP;
     HIPCHK(hipStreamSynchronize(h->stream));
-    return MPCQP_OK;
+    return h->solves_since_balance >= BALANCE_EVERY ? rebalance(h) : MPCQP_OK;
 }
 
 extern "C" int mpcqp_mpc_step(mpcqp_handle *h, const double *x0, const double *uminus1, const double *xref, int xref_rows, double *u_out) {
@@ -452,7 +496,7 @@ extern "C" int mpcqp_mpc_step(mpcqp_handle *h, const double *x0, const double *u
     HIPCHK(hipGetLastError());
     if (get(h, u_out, h->u0_dev, sizeof(double) * (size_t)tot)) return MPCQP_ERR_HIP;
     HIPCHK(hipStreamSynchronize(h->stream));
-    return MPCQP_OK;
+    return h->solves_since_balance >= BALANCE_EVERY ? rebalance(h) : MPCQP_OK;
 }
 
 extern "C" int mpcqp_get_stats(mpcqp_handle *h, uint64_t *out4, int reset) {

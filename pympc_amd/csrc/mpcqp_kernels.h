@@ -73,7 +73,7 @@ __device__ __noinline__ void run_factor_phase() {
     const RunKArgs &A = run_kargs();
     const Lay &L = A.L; const Ptrs &P = A.P;
     RunSmem r = run_smem<false>(L, P);                       // (the common LDS area comes first in both layouts)
-    const int b = blockIdx.x;
+    const int b = inst_of(P.perm);
     Ctx c{L, r.S.hot, P.model + (size_t)b * L.model_sz};
     factor_all<NB>(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], P.F + (size_t)b * P.fsz, r.S.T, r.S.iflag,
                    border_ptrs(L, P, r.S.red));
@@ -85,7 +85,7 @@ __device__ __noinline__ void run_admm_phase(int iters) {
     const Lay &L = A.L; const Ptrs &P = A.P;
     RunSmem r = run_smem<LDSSTATE>(L, P);
     HotPtrs hp; hp.model = P.model; hp.step = P.step; hp.omega = P.omega; hp.s = P.s; hp.qv = P.qv; hp.F = P.F; hp.c = P.c;
-    hp.Bb = P.Bb; hp.Zb = P.Zb; hp.Sig = P.Sig; hp.x = P.x; hp.z = P.z; hp.y = P.y; hp.dx = P.dx; hp.dy = P.dy; hp.fsz = P.fsz;
+    hp.Bb = P.Bb; hp.Zb = P.Zb; hp.Sig = P.Sig; hp.x = P.x; hp.z = P.z; hp.y = P.y; hp.dx = P.dx; hp.dy = P.dy; hp.perm = P.perm; hp.fsz = P.fsz;
     admm_body<NB, LDSSTATE, NXT, NUT, BORDER>(L, hp, r.S, r.X, r.Z, r.Y, A.S.alpha, __builtin_amdgcn_readfirstlane(iters));
 }
 
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_mpc_run(RunKArgs A_)
     const Lay &L = A.L; const Ptrs &P = A.P; const RunArgs &R = A.R;
     RunSmem rs = run_smem<LDSSTATE>(L, P);
     Smem &S = rs.S;
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = inst_of(P.perm), tid = threadIdx.x;
     double *step = P.step + (size_t)b * L.step_sz;
     load_common(L, P.model + (size_t)b * L.model_sz, step, S);
     const int nx = L.nx, nu = L.nu;
@@ -209,7 +209,7 @@ template <int NB>
 __global__ __launch_bounds__(NT) void k_export(Lay L, Ptrs P, double *Pd, double *Ad_, double *q, double *l, double *u) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     double *p = sh; Smem S; smem_common(L, P, p, S);
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = inst_of(P.perm), tid = threadIdx.x;
     const double *model = P.model + (size_t)b * L.model_sz, *step = P.step + (size_t)b * L.step_sz;
     load_common(L, model, step, S);
     Ctx c{L, S.hot, model};
@@ -225,7 +225,7 @@ template <int NB>
 __global__ __launch_bounds__(NT) void k_kkt_solve(Lay L, Ptrs P, const double *rhs, double *sol) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     double *p = sh; Smem S; smem_common(L, P, p, S);
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = inst_of(P.perm), tid = threadIdx.x;
     const double *model = P.model + (size_t)b * L.model_sz, *step = P.step + (size_t)b * L.step_sz;
     load_common(L, model, step, S);
     Ctx c{L, S.hot, model};

@@ -36,6 +36,8 @@ struct Ptrs {
     int *ctype;
     unsigned long long *stats;    // [0] ADMM iterations, [1] residual evaluations, [2] refactorizations, [3] instance-solves
     mpcqp_info *info;
+    const int *perm;              // workgroup -> instance map (load balancing, see rebalance() in mpcqp.hip), or null = identity
+    unsigned *work;               // per instance: ADMM iterations since the map was last rebuilt
     long long fsz;                // factor doubles per instance
 };
 
@@ -43,8 +45,13 @@ struct Ptrs {
 struct HotPtrs {
     const double *model, *step, *omega, *s, *qv, *F, *c, *Bb, *Zb, *Sig;
     double *x, *z, *y, *dx, *dy;
+    const int *perm;
     long long fsz;
 };
+
+// The instance this workgroup works on.  (Which workgroup handles which instance never changes a result; the map
+// only decides which instances share a CU.)
+__device__ __forceinline__ int inst_of(const int *perm) { return perm ? perm[blockIdx.x] : (int)blockIdx.x; }
 
 __device__ __forceinline__ int idiv(int r, float rcp) { return __float2int_rd(((float)r + 0.5f) * rcp); }
 __device__ __forceinline__ double limit_scaling(double v) { v = v < MIN_SCALING ? 1.0 : v; return v > MAX_SCALING ? MAX_SCALING : v; }

@@ -14,9 +14,10 @@ __device__ __forceinline__ double row_rho(int type, double rho) { return type < 
 __device__ __forceinline__ BorderPtrs border_ptrs(const Lay &L, const Ptrs &P, double *red) {
     BorderPtrs bp; bp.red = red;
     const size_t npb = (size_t)L.nu * L.N * L.NB;
-    bp.Bb = L.border ? P.Bb + blockIdx.x * npb : nullptr;
-    bp.Zb = L.border ? P.Zb + blockIdx.x * npb : nullptr;
-    bp.Sig = L.border ? P.Sig + (size_t)blockIdx.x * L.nu * L.nu : nullptr;
+    const int b = inst_of(P.perm);
+    bp.Bb = L.border ? P.Bb + b * npb : nullptr;
+    bp.Zb = L.border ? P.Zb + b * npb : nullptr;
+    bp.Sig = L.border ? P.Sig + (size_t)b * L.nu * L.nu : nullptr;
     return bp;
 }
 
@@ -29,7 +30,7 @@ __device__ __forceinline__ double *carve(double *&p, int n) { double *r = p; p +
 template <class PT>
 __device__ void smem_common(const Lay &L, const PT &P, double *&p, Smem &S) {
     S.T = carve(p, L.tsz);
-    S.Qv = (double *)P.qv + (size_t)blockIdx.x * (L.n_x + L.n_u);
+    S.Qv = (double *)P.qv + (size_t)inst_of(P.perm) * (L.n_x + L.n_u);
     S.hot = carve(p, L.hot_sz);
     S.x0s = carve(p, L.nx);
     S.um1s = carve(p, L.nu);
@@ -53,7 +54,7 @@ template <int NB>
 __global__ __launch_bounds__(NT) void k_setup(Lay L, Ptrs P, mpcqp_settings S_) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     double *p = sh; Smem S; smem_common(L, P, p, S);
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = inst_of(P.perm), tid = threadIdx.x;
     const double *model = P.model + (size_t)b * L.model_sz, *step = P.step + (size_t)b * L.step_sz;
     load_common(L, model, step, S);
     Ctx c{L, S.hot, model};
@@ -133,7 +134,7 @@ template <int NB> __device__ void run_factor_phase();
 
 template <int NB>
 __device__ __forceinline__ void begin_body(const Lay &L, const Ptrs &P, const mpcqp_settings &S_, Smem &S, int plain) {
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = inst_of(P.perm), tid = threadIdx.x;
     const double *model = P.model + (size_t)b * L.model_sz, *step = P.step + (size_t)b * L.step_sz;
     Ctx c{L, S.hot, model};
     build_q(c, step, S.Qv);
@@ -166,7 +167,7 @@ __device__ __forceinline__ void begin_body(const Lay &L, const Ptrs &P, const mp
 template <int NB>
 __device__ __forceinline__ int check_body(const Lay &L, const Ptrs &P, const mpcqp_settings &S_, Smem &S, int iter, int mode,
                                           const double *Xl, const double *Zl, const double *Yl) {
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = inst_of(P.perm), tid = threadIdx.x;
     const double *model = P.model + (size_t)b * L.model_sz;
     Ctx c{L, S.hot, model};
     double *gx = P.x + (size_t)b * L.n, *gz = P.z + (size_t)b * L.m, *gy = P.y + (size_t)b * L.m;
@@ -309,6 +310,7 @@ __device__ __forceinline__ int check_body(const Lay &L, const Ptrs &P, const mpc
         if (term) {
             atomicAdd(&P.stats[0], (unsigned long long)iter); atomicAdd(&P.stats[1], (unsigned long long)inf.reserved);
             atomicAdd(&P.stats[2], (unsigned long long)inf.rho_updates); atomicAdd(&P.stats[3], 1ULL);
+            P.work[b] += (unsigned)iter;
             inf.reserved = 0;
         }
         P.info[b] = inf;
@@ -517,7 +519,7 @@ __device__ __forceinline__ void hot_update(const Lay &L, const double *hot, cons
 // (load_common) and, with LDSSTATE, X/Z/Y carved behind the common area.
 template <int NB, bool LDSSTATE, int NXT, int NUT, bool BORDER>
 __device__ __forceinline__ void admm_body(const Lay &L, const HotPtrs &P, Smem &S, double *X, double *Z, double *Y, double alpha, int iters) {
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = inst_of(P.perm), tid = threadIdx.x;
     double *gx = P.x + (size_t)b * L.n, *gz = P.z + (size_t)b * L.m, *gy = P.y + (size_t)b * L.m;
     double *W = S.T, *Tc = S.T + L.m;
     if (LDSSTATE) {          // small-problem mode: the iterate x, z, y lives in LDS for the whole round
@@ -544,7 +546,7 @@ __device__ __forceinline__ void admm_body(const Lay &L, const HotPtrs &P, Smem &
         BorderPtrs bp; bp.red = S.red;
         if (BORDER) {
             const size_t npb = (size_t)L.nu * L.N * L.NB;
-            bp.Bb = (double *)P.Bb + blockIdx.x * npb; bp.Zb = (double *)P.Zb + blockIdx.x * npb; bp.Sig = (double *)P.Sig + (size_t)blockIdx.x * L.nu * L.nu;
+            bp.Bb = (double *)P.Bb + b * npb; bp.Zb = (double *)P.Zb + b * npb; bp.Sig = (double *)P.Sig + (size_t)b * L.nu * L.nu;
         }
         if (BORDER) border_pre<NB>(L, bp.Bb, bp.Zb, bp.Sig, Tc, S.tv, S.red);
         kkt_core<NB>(core_args(L, opaque_ptr(F)), Tc);

@@ -517,3 +517,28 @@ def test_mpc_step_equals_update_then_output():
     Kf = _stacked_batch(kws, max_iter=10); Kf.setup()
     uf = Kf.step(x)
     assert np.array_equal(uf, Kf.uref)                     # not 'solved' after 10 iterations -> u_failure
+
+
+def test_load_balancing_map_never_changes_results(monkeypatch):
+    """The workgroup -> instance map (rebuilt from the observed iteration counts) is pure scheduling: a batch larger than
+    the number of CUs gives bit-identical trajectories, statuses and iteration counts with and without it, through the
+    device loop and through the stepwise API."""
+    from pympc_amd import fixtures
+    B = 300                                              # > 256 CUs: the map becomes a real permutation
+    kws = [fixtures.random_lti(1000 + i) for i in range(B)]
+    rng = np.random.default_rng(4)
+    w = 0.02 * rng.standard_normal((30, B, 12))
+    out = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('MPCQP_BALANCE', flag)
+        K = _stacked_batch(kws); K.setup()
+        parts = [K.run(10, w=w[10 * i:10 * (i + 1)]) for i in range(3)]       # the map is rebuilt after every launch
+        x = parts[-1]['x'][-1]
+        us = []
+        for k in range(20):                              # stepwise: rebuilt every 16 solves
+            u = K.output(); us.append(u)
+            x = np.einsum('bij,bj->bi', K.Ad, x) + np.einsum('bij,bj->bi', K.Bd, u)
+            K.update(x)
+        out[flag] = (np.concatenate([p['u'] for p in parts]), np.concatenate([p['iter'] for p in parts]), np.array(us), K.prob.solution()[0])
+    for a, b in zip(out['1'], out['0']):
+        assert np.array_equal(a, b)
