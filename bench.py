@@ -7,7 +7,7 @@ Workload (BASELINE.json configs[2]): 1024 seed-pinned random
 systems nx=12, nu=4, Np=30 per GPU, reference-default tolerances (eps_abs=eps_rel=1e-3,
 pyMPC/mpc.py:80), synthetic data, FP64, all inputs resident in HBM when the timed region starts.
 
-    python bench.py --gpus 1 --steps 50 --warmup 10
+    python bench.py --gpus 1 --steps 100 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line.  With N > 1 the instances are sharded over ranks (weak scaling:
@@ -79,8 +79,8 @@ def pmc_traffic(path, kernel):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=100, help='timed MPC steps (SURVEY 8d cfg-3: 100-step receding horizon)')
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--batch', type=int, default=1024, help='instances per GPU')
     ap.add_argument('--eps', type=float, default=1e-3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -226,7 +226,7 @@ def main():
         # algorithmic bytes are SURVEY 8(d)'s total.  HIP events bracket every launch on its stream (mpcqp_profile).
         admm_bytes = total_bytes
         achieved = admm_bytes / (admm_ms * 1e-3)
-        traffic = pmc_traffic(args.path, kname) if B == 1024 and args.workload == 'cfg3' and res.get('chunk', 10) == 10 else None
+        traffic = pmc_traffic(args.path, kname) if B == 1024 and args.workload == 'cfg3' and res.get('chunk', 20) == 20 else None
         out = {
             'metric': 'QP-solves/sec (MPC steps/sec) at nx=%d nu=%d Np=%d' % (NX, NU, NP),
             'value': B * world * args.steps / elapsed,
