@@ -74,6 +74,7 @@ struct mpcqp_handle {
     size_t smem_setup, smem_solve;
     std::vector<void *> allocs;
     double *u0_dev;
+    int *pending_dev, *npending_dev;   // two-launch solve: instances that need more than the first round
     int *perm_dev;                // [batch] workgroup -> instance map (P.perm points here once a map has been built)
     std::vector<double> work_ema; // per instance: smoothed ADMM iterations per balancing interval (host)
     int ncu, solves_since_balance, auto_balance;
@@ -186,6 +187,7 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     rc |= dalloc(h, &P.ctype, B * L.m); rc |= dalloc(h, &P.info, B); rc |= dalloc(h, &P.stats, 8);
         rc |= dalloc(h, &h->u0_dev, B * L.nu);
     rc |= dalloc(h, &P.work, B); rc |= dalloc(h, &h->perm_dev, B);
+    rc |= dalloc(h, &h->pending_dev, B); rc |= dalloc(h, &h->npending_dev, 4);
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->ncu = prop.multiProcessorCount; }
     if (const char *e = getenv("MPCQP_BALANCE")) h->auto_balance = atoi(e) != 0;      // development switch
     if (rc) { mpcqp_destroy(h); return MPCQP_ERR_HIP; }
@@ -387,11 +389,29 @@ static int drain_events(mpcqp_handle *h) {
     return MPCQP_OK;
 }
 
+// One solve of every instance.  Batches larger than the number of CUs are solved in two launches: begin + first ADMM
+// round + check for everybody, then the instances that are not finished (typically 40 %) are continued by a second launch
+// whose workgroup -> instance map is the list the first one compiled -- the dispatcher spreads them evenly over the CUs,
+// whereas staying put would leave some CUs with four running workgroups and others with none (the launch would last as
+// long as two fully contended rounds).  Both launches are asynchronous; no host round trip in between.
 static int launch_solve(mpcqp_handle *h, int plain_iters) {
     if (!h->is_setup) return fail(MPCQP_ERR_STATE, "solve before mpcqp_setup");
     HIPCHK(hipSetDevice(h->device));
     RunArgs R; memset(&R, 0, sizeof(R));
-    return launch_run(h, R, plain_iters);
+    const bool split = plain_iters == 0 && h->auto_balance && h->ncu > 0 && h->batch > h->ncu;
+    if (!split) return launch_run(h, R, plain_iters);
+    R.pending = h->pending_dev; R.npending = h->npending_dev;
+    HIPCHK(hipMemsetAsync(h->npending_dev, 0, sizeof(int), h->stream));
+    R.part = 1;
+    int rc = launch_run(h, R, 0);
+    if (rc) return rc;
+    R.part = 2;
+    const int *perm = h->P.perm;
+    h->P.perm = h->pending_dev;                     // the follow-up launch walks the pending list
+    h->solves_since_balance -= 1;                   // (one solve, two launches)
+    rc = launch_run(h, R, 0);
+    h->P.perm = perm;
+    return rc;
 }
 
 extern "C" int mpcqp_solve(mpcqp_handle *h) { if (!h) return fail(MPCQP_ERR_ARG, "null handle"); return launch_solve(h, 0); }

@@ -14,6 +14,11 @@
 struct RunArgs {
     int nsteps;                   // closed-loop steps (LOOP kernels); 0 = one solve of the current data (mpcqp_solve)
     int plain;                    // run exactly max_iter iterations, no termination test / rho adaptation (mpcqp_iterate)
+    int part;                     // LOOP = false only.  0: the whole solve.  1: begin + first round; instances that are not
+                                  // finished are appended to `pending`.  2: continue the `pending` instances to the end
+                                  // (the launch that follows part 1: its workgroup -> instance map IS the pending list, so
+                                  // the unfinished instances spread evenly over the CUs instead of staying where they were)
+    int *pending, *npending;      // [batch] instance list and its length (device)
     int max_iter, chk, rho_every;
     const double *w;              // [nsteps][batch][nx] additive plant disturbance, or null
     const double *Ap, *Bp;        // [batch][nx*nx], [batch][nx*nu] plant matrices, or null (plant = model Ad, Bd)
@@ -107,6 +112,7 @@ template <int NB, bool LDSSTATE, int NXT, int NUT, bool BORDER, bool LOOP>
 __global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_mpc_run(RunKArgs A_) {
     const RunKArgs &A = run_kargs();
     const Lay &L = A.L; const Ptrs &P = A.P; const RunArgs &R = A.R;
+    if (!LOOP && R.part == 2 && (int)blockIdx.x >= *R.npending) return;
     RunSmem rs = run_smem<LDSSTATE>(L, P);
     Smem &S = rs.S;
     const int b = inst_of(P.perm), tid = threadIdx.x;
@@ -175,10 +181,11 @@ __global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_mpc_run(RunKArgs A_)
 #else
 #define PHASE_CLOCK(i)
 #endif
-        run_begin_phase<NB, LDSSTATE>(R.plain);
+        int iter = 0, term = 0;
+        if (!LOOP && R.part == 2) iter = P.info[b].iter;      // resumed: the first round and its check are done
+        else run_begin_phase<NB, LDSSTATE>(R.plain);
         __syncthreads();
         PHASE_CLOCK(0)
-        int iter = 0, term = 0;
         while (!term) {
             const int nxt = next_stop(iter, R.max_iter, R.chk, R.rho_every);
             run_admm_phase<NB, LDSSTATE, NXT, NUT, BORDER>(nxt - iter);
@@ -188,6 +195,10 @@ __global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_mpc_run(RunKArgs A_)
             term = run_check_phase<NB, LDSSTATE>(iter, stop_mode(iter, R.max_iter, R.chk, R.rho_every, R.plain != 0));
             __syncthreads();
             PHASE_CLOCK(2)
+            if (!LOOP && R.part == 1 && !term) {              // hand the instance over to the follow-up launch
+                if (tid == 0) R.pending[atomicAdd(R.npending, 1)] = b;
+                break;
+            }
         }
         if (LOOP && tid == 0) {
             R.status_traj[(size_t)k * R.batch + b] = P.info[b].status;
