@@ -130,7 +130,8 @@ int mpcqp_update_settings(mpcqp_handle *h, const mpcqp_settings *s);
 int mpcqp_solve(mpcqp_handle *h);
 
 /* Results of the last solve (synchronises).  x [batch][n], y [batch][m], info [batch];
- * any pointer may be NULL.  u0 [batch][nu] is the first optimal input of each instance. */
+ * any pointer may be NULL.  u0 [batch][nu] is the first optimal input of each instance; with a DEVICE destination
+ * mpcqp_get_u0 / mpcqp_mpc_step are stream-ordered and return without waiting. */
 int mpcqp_get_solution(mpcqp_handle *h, double *x, double *y, mpcqp_info *info);
 int mpcqp_get_u0(mpcqp_handle *h, double *u0);
 

@@ -420,6 +420,13 @@ extern "C" int mpcqp_iterate(mpcqp_handle *h, int iters) {
     return launch_solve(h, iters);
 }
 
+// true if p points to device memory (results copied there are stream-ordered: the call need not wait for them)
+static bool is_device_ptr(const void *p) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return attr.type == hipMemoryTypeDevice;
+}
+
 static int get(mpcqp_handle *h, void *dst, const void *src, size_t bytes) {
     if (!dst) return 0;
     HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, h->stream));
@@ -500,8 +507,10 @@ extern "C" int mpcqp_get_u0(mpcqp_handle *h, double *u0) {
     hipLaunchKernelGGL(k_gather_u0, dim3((tot + 255) / 256), dim3(256), 0, h->stream, h->L, h->P.xo, h->u0_dev, h->batch);
     HIPCHK(hipGetLastError());
     if (get(h, u0, h->u0_dev, sizeof(double) * (size_t)tot)) return MPCQP_ERR_HIP;
+    const bool due = h->solves_since_balance >= BALANCE_EVERY;
+    if (!due && is_device_ptr(u0)) return MPCQP_OK;           // device destination: stream-ordered, no need to wait
     HIPCHK(hipStreamSynchronize(h->stream));
-    return h->solves_since_balance >= BALANCE_EVERY ? rebalance(h) : MPCQP_OK;
+    return due ? rebalance(h) : MPCQP_OK;
 }
 
 extern "C" int mpcqp_mpc_step(mpcqp_handle *h, const double *x0, const double *uminus1, const double *xref, int xref_rows, double *u_out) {
@@ -515,8 +524,10 @@ extern "C" int mpcqp_mpc_step(mpcqp_handle *h, const double *x0, const double *u
     hipLaunchKernelGGL(k_output_u, dim3((tot + 255) / 256), dim3(256), 0, h->stream, h->L, h->P, h->u0_dev, h->batch, 1);
     HIPCHK(hipGetLastError());
     if (get(h, u_out, h->u0_dev, sizeof(double) * (size_t)tot)) return MPCQP_ERR_HIP;
+    const bool due = h->solves_since_balance >= BALANCE_EVERY;
+    if (!due && is_device_ptr(u_out)) return MPCQP_OK;
     HIPCHK(hipStreamSynchronize(h->stream));
-    return h->solves_since_balance >= BALANCE_EVERY ? rebalance(h) : MPCQP_OK;
+    return due ? rebalance(h) : MPCQP_OK;
 }
 
 extern "C" int mpcqp_get_stats(mpcqp_handle *h, uint64_t *out4, int reset) {
