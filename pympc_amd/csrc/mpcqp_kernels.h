@@ -79,7 +79,7 @@ __device__ __noinline__ void run_factor_phase() {
     const Lay &L = A.L; const Ptrs &P = A.P;
     RunSmem r = run_smem<false>(L, P);                       // (the common LDS area comes first in both layouts)
     const int b = inst_of(P.perm);
-    Ctx c{L, r.S.hot, P.model + (size_t)b * L.model_sz};
+    Ctx c{L, r.S.hot, P.model + (size_t)b * L.model_sz + L.hot_sz};
     factor_all<NB>(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], P.F + (size_t)b * P.fsz, r.S.T, r.S.iflag,
                    border_ptrs(L, P, r.S.red));
 }
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(NT) void k_export(Lay L, Ptrs P, double *Pd, double
     const int b = inst_of(P.perm), tid = threadIdx.x;
     const double *model = P.model + (size_t)b * L.model_sz, *step = P.step + (size_t)b * L.step_sz;
     load_common(L, model, step, S);
-    Ctx c{L, S.hot, model};
+    Ctx c{L, S.hot, model + L.hot_sz};
     build_q(c, step, S.Qv);
     __syncthreads();
     if (Pd) { double *o = Pd + (size_t)b * L.n * L.n; for (int j = tid; j < L.n; j += NT) P_row(c, j, [&](double co, int idx) { o[(size_t)j * L.n + idx] = co; }); }
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(NT) void k_kkt_solve(Lay L, Ptrs P, const double *r
     const int b = inst_of(P.perm), tid = threadIdx.x;
     const double *model = P.model + (size_t)b * L.model_sz, *step = P.step + (size_t)b * L.step_sz;
     load_common(L, model, step, S);
-    Ctx c{L, S.hot, model};
+    Ctx c{L, S.hot, model + L.hot_sz};
     kkt_solve<NB>(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], P.F + (size_t)b * P.fsz, rhs + (size_t)b * L.n, S.T + L.m, sol + (size_t)b * L.n, border_ptrs(L, P, S.red), S.tv);
     (void)tid;
 }

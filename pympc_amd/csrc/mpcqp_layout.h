@@ -61,12 +61,12 @@ __device__ __forceinline__ double limit_scaling(double v) { v = v < MIN_SCALING 
 struct Ctx {
     Lay L;
     const double *hot;
-    const double *blob;
+    const double *wts;            // the weight matrices [Qx|QxN|Qu|QDu] (global model blob + hot_sz, or a copy in LDS)
     __device__ __forceinline__ const double *Ad() const { return hot + L.oAd; }
     __device__ __forceinline__ const double *Bd() const { return hot + L.oBd; }
-    __device__ __forceinline__ const double *Qx() const { return blob + L.oQx; }
-    __device__ __forceinline__ const double *QxN() const { return blob + L.oQxN; }
-    __device__ __forceinline__ const double *Qu() const { return blob + L.oQu; }
-    __device__ __forceinline__ const double *QDu() const { return blob + L.oQDu; }
+    __device__ __forceinline__ const double *Qx() const { return wts + (L.oQx - L.hot_sz); }
+    __device__ __forceinline__ const double *QxN() const { return wts + (L.oQxN - L.hot_sz); }
+    __device__ __forceinline__ const double *Qu() const { return wts + (L.oQu - L.hot_sz); }
+    __device__ __forceinline__ const double *QDu() const { return wts + (L.oQDu - L.hot_sz); }
     __device__ __forceinline__ double eps_feas() const { return hot[L.oeps]; }
 };

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(NT) void k_setup(Lay L, Ptrs P, mpcqp_settings S_) 
     const int b = inst_of(P.perm), tid = threadIdx.x;
     const double *model = P.model + (size_t)b * L.model_sz, *step = P.step + (size_t)b * L.step_sz;
     load_common(L, model, step, S);
-    Ctx c{L, S.hot, model};
+    Ctx c{L, S.hot, model + L.hot_sz};
     build_q(c, step, S.Qv);
     double *D = P.D + (size_t)b * L.n, *E = P.E + (size_t)b * L.m, *Dt = P.Dt + (size_t)b * L.n, *Et = P.Et + (size_t)b * L.m;
     for (int j = tid; j < L.n; j += NT) D[j] = 1.0;
@@ -136,7 +136,7 @@ template <int NB>
 __device__ __forceinline__ void begin_body(const Lay &L, const Ptrs &P, const mpcqp_settings &S_, Smem &S, int plain) {
     const int b = inst_of(P.perm), tid = threadIdx.x;
     const double *model = P.model + (size_t)b * L.model_sz, *step = P.step + (size_t)b * L.step_sz;
-    Ctx c{L, S.hot, model};
+    Ctx c{L, S.hot, model + L.hot_sz};
     build_q(c, step, S.Qv);
     double *gx = P.x + (size_t)b * L.n, *gz = P.z + (size_t)b * L.m, *gy = P.y + (size_t)b * L.m;
     if (!(S_.warm_start || plain)) {
@@ -169,7 +169,16 @@ __device__ __forceinline__ int check_body(const Lay &L, const Ptrs &P, const mpc
                                           const double *Xl, const double *Zl, const double *Yl) {
     const int b = inst_of(P.perm), tid = threadIdx.x;
     const double *model = P.model + (size_t)b * L.model_sz;
-    Ctx c{L, S.hot, model};
+    // the weight matrices (read entry by entry by P_row) go to the idle Tc area of the work vector if they fit
+    const int nweights = L.model_sz - L.hot_sz;
+    const double *wts = model + L.hot_sz;
+    if (nweights <= L.tsz - L.m) {
+        double *wq = S.T + L.m;
+        for (int i = tid; i < nweights; i += NT) wq[i] = model[L.hot_sz + i];
+        __syncthreads();
+        wts = wq;
+    }
+    Ctx c{L, S.hot, wts};
     double *gx = P.x + (size_t)b * L.n, *gz = P.z + (size_t)b * L.m, *gy = P.y + (size_t)b * L.m;
     // the iterate: the LDS copy the last ADMM round left behind (small problems), else global memory
     const double *X = Xl ? Xl : gx, *Z = Zl ? Zl : gz, *Y = Yl ? Yl : gy;
