@@ -10,6 +10,13 @@ pyMPC/mpc.py:80), synthetic data, FP64, all inputs resident in HBM when the time
     python bench.py --gpus 1 --steps 100 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Two ways through the same library, both measured, `--path` chooses which one is `value` (the other is `other_path`):
+  device_loop (default): the K steps run inside mpcqp_mpc_loop launches (output -> plant -> update -> solve per
+                         instance on the device), launches of gcd(K, W) steps each so that warm-up and
+                         timed launches are the same kernel doing the same work;
+  stepwise             : the reference's call pattern, update()/solve()/output() per step from the host.
+Both give bit-identical trajectories (tests/test_gpu_parity.py::test_device_loop_*).
+
 Rank 0 prints ONE JSON line.  With N > 1 the instances are sharded over ranks (weak scaling:
 1024 per GPU); RCCL is used only to scatter the problem data from rank 0 and to all-gather u*.
 """
