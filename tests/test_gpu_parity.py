@@ -542,3 +542,60 @@ def test_load_balancing_map_never_changes_results(monkeypatch):
         out[flag] = (np.concatenate([p['u'] for p in parts]), np.concatenate([p['iter'] for p in parts]), np.array(us), K.prob.solution()[0])
     for a, b in zip(out['1'], out['0']):
         assert np.array_equal(a, b)
+
+
+def _random_case(seed):
+    """A seeded random controller: dimensions, horizon split, bound pattern (finite / one-sided / absent), weights
+    (including semidefinite ones) and reference shape are all drawn."""
+    from pympc_amd import fixtures
+    rng = np.random.default_rng(7000 + seed)
+    nx = int(rng.integers(1, 14)); nu = int(rng.integers(1, 6))
+    Np = int(rng.integers(2, 26)); Nc = int(rng.integers(1, Np + 1)) if rng.random() < 0.5 else Np
+    kw = dict(fixtures.random_lti(9000 + seed, nx=nx, nu=nu, Np=Np, xbox=4.0))
+    kw['x0'] = 0.5 * kw['x0']
+    if Nc != Np:
+        kw['Nc'] = Nc
+    inf = np.inf
+    def pattern(lo, hi):
+        lo, hi = lo.copy(), hi.copy()
+        for i in range(lo.size):
+            t = rng.random()
+            if t < 0.2: lo[i] = -inf
+            elif t < 0.4: hi[i] = inf
+            elif t < 0.5: lo[i], hi[i] = -inf, inf
+        return lo, hi
+    kw['xmin'], kw['xmax'] = pattern(kw['xmin'], kw['xmax'])
+    kw['Dumin'], kw['Dumax'] = pattern(kw['Dumin'], kw['Dumax'])
+    if rng.random() < 0.3:
+        kw['umin'], kw['umax'] = pattern(kw['umin'], kw['umax'])
+    w = rng.random()
+    if w < 0.25: kw['QDu'] = np.zeros((nu, nu))                       # Qu > 0 keeps the optimum unique
+    elif w < 0.5: kw['Qu'] = np.zeros((nu, nu))                       # QDu > 0 does
+    G = rng.standard_normal((nx, nx)); kw['Qx'] = G @ G.T / nx        # dense PSD state weight
+    if rng.random() < 0.5: kw['QxN'] = 3.0 * kw['Qx']
+    if rng.random() < 0.3: kw['xref'] = 0.2 * rng.standard_normal((Np + 1, nx))
+    else: kw['xref'] = 0.2 * rng.standard_normal(nx)
+    kw['uref'] = 0.1 * rng.standard_normal(nu)
+    kw['uminus1'] = 0.1 * rng.standard_normal(nu)
+    kw['eps_feas'] = float(10.0 ** rng.integers(2, 7))
+    return kw
+
+
+@pytest.mark.parametrize('seed', range(24))
+def test_randomised_controllers_match_oracle(seed):
+    """Seeded random controllers (shapes, Nc < Np, one-sided and absent bounds, semidefinite weights, 1-D / 2-D references):
+    cold solve and one warm step against the oracle at tight tolerance; statuses must agree too."""
+    kw = _random_case(seed)
+    kw.update(eps_abs=1e-9, eps_rel=1e-9)
+    K = _gpu_controller(kw, max_iter=400000); Ko = _oracle_controller(kw, max_iter=400000)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        K.setup(); Ko.setup()
+        assert K.res.info.status == Ko.res.info.status
+        (u, info), (uo, infoo) = K.output(return_u_seq=True), Ko.output(return_u_seq=True)
+        scale = max(1e-3, np.abs(infoo['u_seq']).max())
+        assert np.abs(info['u_seq'] - infoo['u_seq']).max() <= 2e-6 * scale
+        x = kw['Ad'] @ kw['x0'] + kw['Bd'] @ uo
+        K.update(x, uo); Ko.update(x, uo)
+        assert K.res.info.status == Ko.res.info.status
+        assert np.abs(K.output() - Ko.output()).max() <= 2e-6 * scale
