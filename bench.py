@@ -222,6 +222,16 @@ def main():
         o = measure[oname](args.steps, args.warmup)
         other = {'path': oname, 'value': B * world * args.steps / o['elapsed'], 'ms_per_step': 1e3 * o['elapsed'] / args.steps,
                  'mean_admm_iters': o['iters'] / max(1, o['solves'])}
+    parity = None
+    if not args.no_other_path and args.eps > 1e-8:
+        # the same loop at the parity setting eps = 1e-9 (the tolerance the u* comparison is made at)
+        prob.update_settings(eps_abs=1e-9, eps_rel=1e-9)
+        pr = measure[args.path](args.steps, args.warmup)
+        pinf = prob.infos()
+        parity = {'eps_abs': 1e-9, 'eps_rel': 1e-9, 'path': args.path, 'value': B * world * args.steps / pr['elapsed'],
+                  'ms_per_step': 1e3 * pr['elapsed'] / args.steps, 'mean_admm_iters': pr['iters'] / max(1, pr['solves']),
+                  'solved_fraction_last_step': sum(1 for i in pinf if i.status == 1) / B}
+        prob.update_settings(eps_abs=args.eps, eps_rel=args.eps)
     kname = ('k_mpc_run<16,true,12,4,false,%s>' if args.workload == 'cfg3' else 'k_mpc_run<32,false,20,8,false,%s>') % ('true' if args.path == 'device_loop' else 'false')
 
     if rank == 0:
@@ -260,6 +270,7 @@ def main():
                          'algorithmic_bytes_per_iter_per_qp': b_it, 'nnzL': nnzL,
                          'steps_per_launch': res.get('chunk', 1)},
             'other_path': other,
+            'parity_setting': parity,
         }
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(eps=args.eps)
