@@ -20,7 +20,9 @@
  * oracle instead: (1) it consumes P,q,A,l,u that are bit-identical to what the reference builds
  * (tests/golden/qp_*.npz, captured from the imported reference); (2) every optimum it returns at
  * tight tolerance is certified solver-independently by KKT conditions and cross-checked with the
- * HiGHS QP solver bundled in scipy (tests/test_oracle.py, tests/golden/make_optimum.py).
+ * HiGHS QP solver bundled in scipy (tests/test_oracle.py, tests/golden/make_optimum.py); (3) plugged
+ * into the REFERENCE's own controller class as its `osqp`, it produces the closed-loop golden trajectories
+ * of tests/golden/make_traj.py (traj_*.npz), which the product is tested against.
  * `adaptive_rho_interval=0` (OSQP: derived from wall-clock setup time, hence not reproducible)
  * is resolved deterministically to 4*check_termination, OSQP's own rule for builds without timers.
  *
