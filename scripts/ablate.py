@@ -5,12 +5,14 @@ import numpy as np, torch
 import bench
 from pympc_amd.solver import BatchProblem
 B = int(os.environ.get('B', 1024)); iters = int(os.environ.get('ITERS', 100))
+NX, NU, NP = (int(os.environ.get(k, v)) for k, v in (('NX', 12), ('NU', 4), ('NP', 30)))
+bench.NX, bench.NU, bench.NP = NX, NU, NP
 d = bench.make_instances(0, B)
-prob = BatchProblem(B, 12, 4, 30)
+prob = BatchProblem(B, NX, NU, NP)
 eye = lambda k, s: np.broadcast_to(s * np.eye(k), (B, k, k))
 ones = lambda k, s: np.full((B, k), s)
-prob.setup(d['Ad'], d['Bd'], eye(12, 1.0), eye(12, 1.0), eye(4, .1), eye(4, .1), ones(12, -10.), ones(12, 10.), ones(4, -1.), ones(4, 1.),
-           ones(4, -.5), ones(4, .5), ones(4, 0.), np.full((B, 1), 1e6), d['x0'], ones(4, 0.), np.zeros((B, 12)))
+prob.setup(d['Ad'], d['Bd'], eye(NX, 1.0), eye(NX, 1.0), eye(NU, .1), eye(NU, .1), ones(NX, -10.), ones(NX, 10.), ones(NU, -1.), ones(NU, 1.),
+           ones(NU, -.5), ones(NU, .5), ones(NU, 0.), np.full((B, 1), 1e6), d['x0'], ones(NU, 0.), np.zeros((B, NX)))
 prob.iterate(10)
 ts = []
 for _ in range(5):
