@@ -140,14 +140,12 @@ class MPCController:
 
         self.res = None
         self.P = None
-        self.q = None
+        self._q = self._l = self._u = self._J_CNST = None
+        self._stale = False           # q, l, u, J_CNST not yet refreshed after the last update() (device solver only)
         self.A = None
-        self.l = None
-        self.u = None
         self.P_X = None
         self.x0_rh = None
         self.uminus1_rh = None
-        self.J_CNST = None
 
     # ------------------------------------------------------------------------------------
     def _model_data(self):
@@ -237,9 +235,27 @@ class MPCController:
         return self.output()
 
     # ------------------------------------------------------------------------------------
+    # q, l, u, J_CNST are public attributes of the reference (mpc.py:598-606).  The device solver rebuilds them itself from
+    # (x0, u_{-1}, xref), so after update() the host copies are refreshed only when somebody reads them.
+    def _fresh(self):
+        if self._stale:
+            self._stale = False
+            self._q, self._J_CNST = qp_build.refresh_vectors(self)
+
+    q = property(lambda self: (self._fresh(), self._q)[1], lambda self, v: setattr(self, '_q', v))
+    l = property(lambda self: (self._fresh(), self._l)[1], lambda self, v: setattr(self, '_l', v))
+    u = property(lambda self: (self._fresh(), self._u)[1], lambda self, v: setattr(self, '_u', v))
+    J_CNST = property(lambda self: (self._fresh(), self._J_CNST)[1], lambda self, v: setattr(self, '_J_CNST', v))
+
     def _update_QP_matrices_(self):
-        self.q, self.J_CNST = qp_build.refresh_vectors(self)
-        self.prob.update(l=self.l, u=self.u, q=self.q, mpc_step=self._step_data())
+        from .solver import DeviceProblem
+        if isinstance(self.prob, DeviceProblem):
+            self._stale = True                    # refreshed on first read
+            self.prob.update(mpc_step=self._step_data())
+        else:                                     # a solver that wants the vectors (the oracle in the tests)
+            self._stale = False
+            self.q, self.J_CNST = qp_build.refresh_vectors(self)
+            self.prob.update(l=self.l, u=self.u, q=self.q, mpc_step=self._step_data())
 
     def _compute_QP_matrices_(self):
         self.P, self.q, self.A, self.l, self.u, self.P_X, self.J_CNST = qp_build.build_qp(self)
