@@ -196,13 +196,13 @@ def main():
         w_all = 0.01 * torch.randn((warmup + steps, B, NX), dtype=f64, device=dev, generator=gen)
         outs = (torch.empty((chunk + 1, B, NX), dtype=f64, device=dev), torch.empty((chunk, B, NU), dtype=f64, device=dev),
                 torch.empty((chunk, B), dtype=torch.int32, device=dev), torch.empty((chunk, B), dtype=torch.int32, device=dev))
-        u_hist = torch.empty((world, chunk, B, NU), dtype=f64, device=dev) if world > 1 else None
+        u_hist = torch.empty((world * chunk, B, NU), dtype=f64, device=dev) if world > 1 else None
 
         def run(first, count):
             for c in range(first, first + count, chunk):
                 prob.mpc_run(chunk, w=w_all[c:c + chunk], out=outs)
                 if world > 1:
-                    dist.all_gather_into_tensor(u_hist, outs[1])
+                    sharding.gather_trajectory(outs[1], out=u_hist)
 
         r = timed(lambda: run(0, warmup), lambda: run(warmup, steps))
         x = outs[0][-1].clone()

@@ -3,7 +3,8 @@
 The instances are independent (no coupling, no reduction -- SURVEY.md section 8e): rank r owns the contiguous block
 [r*B, (r+1)*B).  Collectives (RCCL on GPUs, gloo in the CPU tests) are used only where the path has a real exchange:
   * ``scatter_instances``: the problem data (Ad, Bd, x0, ...) is generated on rank 0 and scattered once, at setup;
-  * ``gather_inputs``:     the first optimal inputs u* of every shard are all-gathered after each solve.
+  * ``gather_inputs``:     the first optimal inputs u* of every shard are all-gathered after each solve;
+  * ``gather_trajectory``: the applied inputs of a whole device-loop launch are all-gathered at once.
 One process per GPU, launched by torch.distributed.run; world_size 1 degenerates to plain copies.
 """
 import torch
@@ -49,3 +50,17 @@ def gather_inputs(u_local, out=None):
         out = torch.empty((ws * u_local.shape[0],) + tuple(u_local.shape[1:]), dtype=u_local.dtype, device=u_local.device)
     dist.all_gather_into_tensor(out, u_local.contiguous())
     return out
+
+
+def gather_trajectory(u_traj, out=None):
+    """All-gather a [steps, per_rank, nu] input trajectory of every rank into [world, steps, per_rank, nu]
+    (device loop: one exchange per launch instead of one per step).  ``out``, if given, is [world*steps, per_rank, nu]
+    (the concatenated form every backend accepts); the returned tensor is a view of it."""
+    rank, ws = world()
+    if ws == 1:
+        return u_traj.unsqueeze(0)
+    steps = u_traj.shape[0]
+    if out is None:
+        out = torch.empty((ws * steps,) + tuple(u_traj.shape[1:]), dtype=u_traj.dtype, device=u_traj.device)
+    dist.all_gather_into_tensor(out, u_traj.contiguous())
+    return out.view((ws, steps) + tuple(u_traj.shape[1:]))

@@ -50,6 +50,10 @@ def _worker(rank, world_size, port, per, q):
     assert (lo, hi) == (rank * per, (rank + 1) * per)
     u = _solve_shard(loc['Ad'], loc['Bd'], loc['x0'])
     u_all = sharding.gather_inputs(u)
+    traj = torch.stack([u + 10.0 * k for k in range(4)])              # [steps, per, nu]: a device-loop launch's inputs
+    tr_all = sharding.gather_trajectory(traj)
+    assert tuple(tr_all.shape) == (world_size, 4, per, 3)
+    assert torch.equal(tr_all[rank], traj) and torch.equal(tr_all[:, 0].reshape(-1, 3), u_all)
     if rank == 0:
         q.put(u_all.numpy())
     dist.barrier()
