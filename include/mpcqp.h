@@ -166,9 +166,10 @@ int mpcqp_mpc_run(mpcqp_handle *h, int nsteps, const double *w, const double *Ap
 typedef struct {
     const double *w;            /* [nsteps][batch][nx] process disturbance, or NULL */
     const double *Ap, *Bp;      /* [batch][nx*nx], [batch][nx*nu] plant, or NULL (the controller's Ad, Bd) */
-    const double *xref_traj;    /* [nsteps][batch][rows*nx], rows = xref_rows of the last upload (1 or Np+1), or NULL */
+    const double *xref_traj;    /* [nsteps][batch][xref_rows*nx], or NULL */
     int32_t ny;                 /* > 0 switches output feedback on */
-    int32_t reserved;
+    int32_t xref_rows;          /* rows of one xref_traj entry: 1 or Np+1 (like mpcqp_update: the reference shape may change,
+                                   mpc.py:414-424); 0 = the shape of the last upload.  Anything else: MPCQP_ERR_ARG */
     const double *C;            /* [batch][ny*nx] */
     const double *Lgain;        /* [batch][nx*ny] Kalman (filter) gain */
     const double *v;            /* [nsteps][batch][ny] measurement noise, or NULL */

@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get('MPCQP_LIB') or os.path.join(_HERE, 'libmpcqp_hip.so')   # MPCQP_LIB: ablation builds only
+LIB_PATH = os.path.join(_HERE, 'libmpcqp_hip.so')     # the in-tree build, nothing else (no environment override)
 
 # every symbol declared in include/mpcqp.h
 SYMBOLS = [
@@ -45,7 +45,7 @@ class Model(C.Structure):
 class Loop(C.Structure):
     """mpcqp_loop (include/mpcqp.h): optional inputs/outputs of the device-side closed loop."""
     _fields_ = [('w', C.c_void_p), ('Ap', C.c_void_p), ('Bp', C.c_void_p), ('xref_traj', C.c_void_p),
-                ('ny', C.c_int32), ('reserved', C.c_int32),
+                ('ny', C.c_int32), ('xref_rows', C.c_int32),
                 ('C', C.c_void_p), ('Lgain', C.c_void_p), ('v', C.c_void_p), ('x_true', C.c_void_p),
                 ('x_traj', C.c_void_p), ('xhat_traj', C.c_void_p), ('y_traj', C.c_void_p), ('u_traj', C.c_void_p),
                 ('status_traj', C.c_void_p), ('iter_traj', C.c_void_p)]

@@ -67,6 +67,9 @@ class BatchMPCController:
         self.x0_rh = None
         self._u_last = None
         self._status = None
+        # does the device copy of u_{-1} equal self.uminus1_rh?  output() moves the host value on (mpc.py:330) without
+        # touching the device; setup()/update() upload it, step()/run() leave the applied input on the device themselves
+        self._um1_on_device = False
 
     def setup(self, solve=True):
         self.x0_rh = self.x0.copy()
@@ -78,6 +81,7 @@ class BatchMPCController:
         self.prob.setup(self.Ad, self.Bd, self.Qx, self.QxN, self.Qu, self.QDu, self.xmin, self.xmax,
                         self.umin, self.umax, self.Dumin, self.Dumax, self.uref, self.eps_feas,
                         self.x0_rh, self.uminus1_rh, self.xref)
+        self._um1_on_device = True
         if solve:
             self.solve()
 
@@ -88,6 +92,7 @@ class BatchMPCController:
         if xref is not None:
             self.xref = xref
         self.prob.update(self.x0_rh, self.uminus1_rh, xref)
+        self._um1_on_device = True
         if solve:
             self.solve()
 
@@ -103,8 +108,11 @@ class BatchMPCController:
             self.uminus1_rh = u
         if xref is not None:
             self.xref = xref
+        if u is None and not self._um1_on_device:
+            u = self.uminus1_rh                   # update(x, u=None) uses the input of the last output() (mpc.py:330,357-359)
         uMPC = self.prob.mpc_step(x, u, xref)
         self.uminus1_rh = uMPC
+        self._um1_on_device = True                # mpcqp_mpc_step stored it as the next u_{-1}
         self._u_last = None
         return uMPC
 
@@ -132,6 +140,7 @@ class BatchMPCController:
         if xref_traj is not None:
             self.xref = np.asarray(xref_traj)[-1].reshape(self.B, -1)
         self.uminus1_rh = ut[-1].copy()
+        self._um1_on_device = True
         self._u_last = None
         return res
 
@@ -167,4 +176,5 @@ class BatchMPCController:
         if return_obj_val:
             info['obj_val'] = np.array([i.obj_val for i in infos])
         self.uminus1_rh = uMPC
+        self._um1_on_device = False
         return uMPC if len(info) == 0 else (uMPC, info)

@@ -240,7 +240,14 @@ class MPCController:
     def _fresh(self):
         if self._stale:
             self._stale = False
-            self._q, self._J_CNST = qp_build.refresh_vectors(self)
+            # the QP that was handed to the solver: built from the values update() saw, not from what x0_rh /
+            # uminus1_rh / xref have become since (output() moves uminus1_rh on, callers may reuse their x array)
+            live = self.x0_rh, self.uminus1_rh, self.xref
+            self.x0_rh, self.uminus1_rh, self.xref = self._snap
+            try:
+                self._q, self._J_CNST = qp_build.refresh_vectors(self)
+            finally:
+                self.x0_rh, self.uminus1_rh, self.xref = live
 
     q = property(lambda self: (self._fresh(), self._q)[1], lambda self, v: setattr(self, '_q', v))
     l = property(lambda self: (self._fresh(), self._l)[1], lambda self, v: setattr(self, '_l', v))
@@ -250,7 +257,8 @@ class MPCController:
     def _update_QP_matrices_(self):
         from .solver import DeviceProblem
         if isinstance(self.prob, DeviceProblem):
-            self._stale = True                    # refreshed on first read
+            self._stale = True                    # refreshed on first read, from a snapshot of this call's inputs
+            self._snap = (np.array(self.x0_rh, dtype=float), np.array(self.uminus1_rh, dtype=float), np.array(self.xref, dtype=float))
             self.prob.update(mpc_step=self._step_data())
         else:                                     # a solver that wants the vectors (the oracle in the tests)
             self._stale = False

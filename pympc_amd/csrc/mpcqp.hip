@@ -84,7 +84,8 @@ struct mpcqp_handle {
     long long ev_count;
     double run_ms;
     long long run_launches;
-    bool have_events;
+    int nevents;                         // event pairs created so far (a partially built handle is destroyed cleanly)
+    bool warm_x_pending;                 // mpcqp_warm_start replaced x: the next solve starts from z = A x (osqp_warm_start)
 };
 
 extern "C" void mpcqp_default_settings(mpcqp_settings *s) {
@@ -162,13 +163,19 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     HIPCHK(hipSetDevice(device));
     mpcqp_handle *h = new mpcqp_handle();
     h->device = device; h->batch = batch; h->is_setup = false; h->u0_dev = nullptr; h->run_buf = nullptr; h->run_bytes = 0; h->perm_dev = nullptr; h->solves_since_balance = 0; h->auto_balance = 1; h->ncu = 0;
-    h->profiling = false; h->run_ms = 0.0; h->run_launches = 0; h->ev_count = 0; h->have_events = false;
+    h->profiling = false; h->run_ms = 0.0; h->run_launches = 0; h->ev_count = 0; h->nevents = 0; h->stream = nullptr; h->own_stream = false;
+    h->warm_x_pending = false;
     h->L = make_layout(nx, nu, Np, Nc);
     if (s) h->S = *s; else mpcqp_default_settings(&h->S);
-    HIPCHK(hipStreamCreate(&h->stream));
+    // (every failure from here on releases what has been created so far: mpcqp_destroy copes with a partial handle)
+    auto hip_fail = [&](hipError_t e, const char *what) { std::string msg = std::string(what) + ": " + hipGetErrorString(e); mpcqp_destroy(h); return fail(MPCQP_ERR_HIP, msg); };
+    { hipError_t e = hipStreamCreate(&h->stream); if (e != hipSuccess) { h->stream = nullptr; return hip_fail(e, "hipStreamCreate"); } }
     h->own_stream = true;
-    for (int e = 0; e < MAXEV; ++e) { HIPCHK(hipEventCreate(&h->ev0[e])); HIPCHK(hipEventCreate(&h->ev1[e])); }
-    h->have_events = true;
+    for (int i = 0; i < MAXEV; ++i) {
+        hipError_t e = hipEventCreate(&h->ev0[i]); if (e != hipSuccess) return hip_fail(e, "hipEventCreate");
+        e = hipEventCreate(&h->ev1[i]); if (e != hipSuccess) { hipEventDestroy(h->ev0[i]); return hip_fail(e, "hipEventCreate"); }
+        h->nevents = i + 1;
+    }
     const Lay &L = h->L;
     Ptrs &P = h->P; memset(&P, 0, sizeof(P));
     size_t B = (size_t)batch;
@@ -190,7 +197,7 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     rc |= dalloc(h, &h->pending_dev, B); rc |= dalloc(h, &h->npending_dev, 4);
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->ncu = prop.multiProcessorCount; }
     if (const char *e = getenv("MPCQP_BALANCE")) h->auto_balance = atoi(e) != 0;      // development switch
-    if (rc) { mpcqp_destroy(h); return MPCQP_ERR_HIP; }
+    if (rc) { std::string msg = g_err; mpcqp_destroy(h); return fail(MPCQP_ERR_HIP, msg); }
     h->smem_setup = sizeof(double) * (size_t)smem_common_doubles(L);
     size_t with_state = h->smem_setup + sizeof(double) * (size_t)(L.n + 2 * L.m);
     h->lds_state = with_state <= 40 * 1024 && L.m <= 4 * NT && L.N * L.NB <= 2 * NT;      // four workgroups per CU; larger problems keep the iterate in L2/HBM   // small problems: x in LDS, z/y in registers; else iterate in L2/HBM
@@ -203,11 +210,11 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
 extern "C" void mpcqp_destroy(mpcqp_handle *h) {
     if (!h) return;
     hipSetDevice(h->device);
-    hipStreamSynchronize(h->stream);
+    if (h->stream) hipStreamSynchronize(h->stream);
     for (void *p : h->allocs) hipFree(p);
     if (h->run_buf) hipFree(h->run_buf);
-    if (h->have_events) for (int e = 0; e < MAXEV; ++e) { hipEventDestroy(h->ev0[e]); hipEventDestroy(h->ev1[e]); }
-    if (h->own_stream) hipStreamDestroy(h->stream);
+    for (int e = 0; e < h->nevents; ++e) { hipEventDestroy(h->ev0[e]); hipEventDestroy(h->ev1[e]); }
+    if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
 }
 
@@ -226,6 +233,15 @@ extern "C" int mpcqp_synchronize(mpcqp_handle *h) {
     HIPCHK(hipStreamSynchronize(h->stream));
     return MPCQP_OK;
 }
+
+// Device scratch of one call: freed when the call returns, on every path.
+struct Scratch {
+    std::vector<void *> ptrs;
+    ~Scratch() { for (void *p : ptrs) hipFree(p); }
+    template <class T> hipError_t get(T **out, size_t count) {
+        void *q = nullptr; hipError_t e = hipMalloc(&q, count * sizeof(T)); if (e == hipSuccess) { ptrs.push_back(q); *out = (T *)q; } return e;
+    }
+};
 
 // strided upload: src [batch][w] -> dst [batch][stride] at column offset off
 static int put(mpcqp_handle *h, double *dst, int stride, int off, const double *src, int w) {
@@ -354,6 +370,8 @@ static int rebalance(mpcqp_handle *h) {
 static int launch_run(mpcqp_handle *h, RunArgs R, int plain_iters) {
     const Lay &L = h->L; const mpcqp_settings &S = h->S;
     R.plain = plain_iters > 0;
+    R.warm_x = (h->warm_x_pending && R.part != 2) ? 1 : 0;
+    if (R.part != 1) h->warm_x_pending = false;          // (a two-launch solve begins in its first launch only)
     R.max_iter = R.plain ? plain_iters : S.max_iter;
     R.chk = R.plain ? 0 : S.check_termination;
     R.rho_every = (!R.plain && S.adaptive_rho) ? (S.adaptive_rho_interval ? S.adaptive_rho_interval : (R.chk ? 4 * R.chk : 100)) : 0;
@@ -441,7 +459,10 @@ extern "C" int mpcqp_mpc_loop(mpcqp_handle *h, int nsteps, const mpcqp_loop *io)
     const int ny = io->ny;
     if (ny < 0 || ny > 32) return fail(MPCQP_ERR_ARG, "mpcqp_mpc_loop: ny must be in 0..32");
     if (ny && (!io->C || !io->Lgain || !io->x_true)) return fail(MPCQP_ERR_ARG, "mpcqp_mpc_loop: output feedback needs C, Lgain and x_true");
+    if (io->xref_traj && io->xref_rows != 0 && io->xref_rows != 1 && io->xref_rows != h->L.N)
+        return fail(MPCQP_ERR_ARG, "mpcqp_mpc_loop: xref_rows must be 0 (as last uploaded), 1 or Np+1");
     HIPCHK(hipSetDevice(h->device));
+    if (io->xref_traj && io->xref_rows) h->L.xref_rows = io->xref_rows;     // update(x, u, xref_k) with this reference shape
     const Lay &L = h->L;
     const size_t B = (size_t)h->batch, K = (size_t)nsteps, nx = L.nx, nu = L.nu;
     const size_t xblk = (size_t)L.xref_rows * nx;
@@ -579,7 +600,7 @@ extern "C" int mpcqp_warm_start(mpcqp_handle *h, const double *x, const double *
     if (!h->is_setup) return fail(MPCQP_ERR_STATE, "warm_start before setup");
     HIPCHK(hipSetDevice(h->device));
     size_t B = (size_t)h->batch;
-    if (x) { HIPCHK(hipMemcpyAsync(h->P.x, x, B * h->L.n * sizeof(double), hipMemcpyDefault, h->stream)); }
+    if (x) { HIPCHK(hipMemcpyAsync(h->P.x, x, B * h->L.n * sizeof(double), hipMemcpyDefault, h->stream)); h->warm_x_pending = true; }
     if (y) { HIPCHK(hipMemcpyAsync(h->P.y, y, B * h->L.m * sizeof(double), hipMemcpyDefault, h->stream)); }
     return MPCQP_OK;
 }
@@ -590,10 +611,11 @@ extern "C" int mpcqp_export_qp(mpcqp_handle *h, double *Pm, double *Am, double *
     HIPCHK(hipSetDevice(h->device));
     const Lay &L = h->L; size_t B = (size_t)h->batch;
     double *dP = nullptr, *dA = nullptr, *dq = nullptr, *dl = nullptr, *du = nullptr;
-    if (Pm) { HIPCHK(hipMalloc((void **)&dP, B * L.n * L.n * sizeof(double))); HIPCHK(hipMemsetAsync(dP, 0, B * L.n * L.n * sizeof(double), h->stream)); }
-    if (Am) { HIPCHK(hipMalloc((void **)&dA, B * L.m * L.n * sizeof(double))); HIPCHK(hipMemsetAsync(dA, 0, B * L.m * L.n * sizeof(double), h->stream)); }
-    if (q) HIPCHK(hipMalloc((void **)&dq, B * L.n * sizeof(double)));
-    if (l && u) { HIPCHK(hipMalloc((void **)&dl, B * L.m * sizeof(double))); HIPCHK(hipMalloc((void **)&du, B * L.m * sizeof(double))); }
+    Scratch sc;
+    if (Pm) { HIPCHK(sc.get(&dP, B * L.n * L.n)); HIPCHK(hipMemsetAsync(dP, 0, B * L.n * L.n * sizeof(double), h->stream)); }
+    if (Am) { HIPCHK(sc.get(&dA, B * L.m * L.n)); HIPCHK(hipMemsetAsync(dA, 0, B * L.m * L.n * sizeof(double), h->stream)); }
+    if (q) HIPCHK(sc.get(&dq, B * L.n));
+    if (l && u) { HIPCHK(sc.get(&dl, B * L.m)); HIPCHK(sc.get(&du, B * L.m)); }
     DISPATCH_NB(L.NB, {
         if (set_smem(k_export<NB>, h->smem_setup)) return MPCQP_ERR_HIP;
         hipLaunchKernelGGL(k_export<NB>, dim3(h->batch), dim3(NT), h->smem_setup, h->stream, h->L, h->P, dP, dA, dq, dl, du);
@@ -604,7 +626,6 @@ extern "C" int mpcqp_export_qp(mpcqp_handle *h, double *Pm, double *Am, double *
     rc |= get(h, q, dq, B * L.n * sizeof(double));
     if (l && u) { rc |= get(h, l, dl, B * L.m * sizeof(double)); rc |= get(h, u, du, B * L.m * sizeof(double)); }
     HIPCHK(hipStreamSynchronize(h->stream));
-    hipFree(dP); hipFree(dA); hipFree(dq); hipFree(dl); hipFree(du);
     return rc ? MPCQP_ERR_HIP : MPCQP_OK;
 }
 
@@ -634,7 +655,8 @@ extern "C" int mpcqp_debug_kkt_solve(mpcqp_handle *h, const double *rhs, double 
     HIPCHK(hipSetDevice(h->device));
     const Lay &L = h->L; size_t bytes = (size_t)h->batch * L.n * sizeof(double);
     double *dr = nullptr, *ds = nullptr;
-    HIPCHK(hipMalloc((void **)&dr, bytes)); HIPCHK(hipMalloc((void **)&ds, bytes));
+    Scratch sc;
+    HIPCHK(sc.get(&dr, (size_t)h->batch * L.n)); HIPCHK(sc.get(&ds, (size_t)h->batch * L.n));
     HIPCHK(hipMemcpyAsync(dr, rhs, bytes, hipMemcpyDefault, h->stream));
     DISPATCH_NB(L.NB, {
         if (set_smem(k_kkt_solve<NB>, h->smem_setup)) return MPCQP_ERR_HIP;
@@ -643,6 +665,5 @@ extern "C" int mpcqp_debug_kkt_solve(mpcqp_handle *h, const double *rhs, double 
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(sol, ds, bytes, hipMemcpyDefault, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    hipFree(dr); hipFree(ds);
     return MPCQP_OK;
 }

@@ -14,6 +14,7 @@
 struct RunArgs {
     int nsteps;                   // closed-loop steps (LOOP kernels); 0 = one solve of the current data (mpcqp_solve)
     int plain;                    // run exactly max_iter iterations, no termination test / rho adaptation (mpcqp_iterate)
+    int warm_x;                   // x was replaced by mpcqp_warm_start: begin with z = A x
     int part;                     // LOOP = false only.  0: the whole solve.  1: begin + first round; instances that are not
                                   // finished are appended to `pending`.  2: continue the `pending` instances to the end
                                   // (the launch that follows part 1: its workgroup -> instance map IS the pending list, so
@@ -95,10 +96,10 @@ __device__ __noinline__ void run_admm_phase(int iters) {
 }
 
 template <int NB, bool LDSSTATE>
-__device__ __noinline__ void run_begin_phase(int plain) {
+__device__ __noinline__ void run_begin_phase(int plain, int warm_x) {
     const RunKArgs &A = run_kargs();
     RunSmem r = run_smem<LDSSTATE>(A.L, A.P);
-    begin_body<NB>(A.L, A.P, A.S, r.S, __builtin_amdgcn_readfirstlane(plain));
+    begin_body<NB>(A.L, A.P, A.S, r.S, __builtin_amdgcn_readfirstlane(plain), __builtin_amdgcn_readfirstlane(warm_x));
 }
 
 template <int NB, bool LDSSTATE>
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_mpc_run(RunKArgs A_)
 #endif
         int iter = 0, term = 0;
         if (!LOOP && R.part == 2) iter = P.info[b].iter;      // resumed: the first round and its check are done
-        else run_begin_phase<NB, LDSSTATE>(R.plain);
+        else run_begin_phase<NB, LDSSTATE>(R.plain, (R.warm_x && k == 0) ? 1 : 0);
         __syncthreads();
         PHASE_CLOCK(0)
         while (!term) {

@@ -133,7 +133,7 @@ enum { COLD_CHECK = 1, COLD_RHO = 2, COLD_FINAL = 4, COLD_PLAIN = 8 };
 template <int NB> __device__ void run_factor_phase();
 
 template <int NB>
-__device__ __forceinline__ void begin_body(const Lay &L, const Ptrs &P, const mpcqp_settings &S_, Smem &S, int plain) {
+__device__ __forceinline__ void begin_body(const Lay &L, const Ptrs &P, const mpcqp_settings &S_, Smem &S, int plain, int warm_x) {
     const int b = inst_of(P.perm), tid = threadIdx.x;
     const double *model = P.model + (size_t)b * L.model_sz, *step = P.step + (size_t)b * L.step_sz;
     Ctx c{L, S.hot, model + L.hot_sz};
@@ -142,6 +142,8 @@ __device__ __forceinline__ void begin_body(const Lay &L, const Ptrs &P, const mp
     if (!(S_.warm_start || plain)) {
         for (int j = tid; j < L.n; j += NT) gx[j] = 0.0;
         for (int r = tid; r < L.m; r += NT) { gz[r] = 0.0; gy[r] = 0.0; }
+    } else if (warm_x) {                                  // mpcqp_warm_start replaced x: z = A x, as osqp_warm_start does
+        for (int r = tid; r < L.m; r += NT) { double ax = 0.0; A_row(c, r, [&](double co, int idx) { ax += co * gx[idx]; }); gz[r] = ax; }
     }
     // constraint types (bounds may have changed since the last factorization)
     double *om = P.omega + (size_t)b * L.m;

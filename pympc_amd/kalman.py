@@ -22,23 +22,25 @@ def _dare(A, B, Q, R, S=None):
 
 
 def kalman_design(A, B, C, D, Qn, Rn, Nn=None):
-    """General Kalman predictor gain for x+ = Ax + B[u;w], y = Cx + D[u;w] + v (kalman.py:25-72).
-    Returns ``(L, P, W)``: gain, Riccati solution, estimator poles."""
-    A, B, C, D = (np.atleast_2d(np.asarray(M, dtype=float)) for M in (A, B, C, D))
-    Qn, Rn = np.atleast_2d(np.asarray(Qn, dtype=float)), np.atleast_2d(np.asarray(Rn, dtype=float))
-    nw = Qn.shape[0]
-    nu = B.shape[1] - nw
-    ny = C.shape[0]
-    if Nn is None:
-        Nn = np.zeros((nw, ny))
-    Bw, Dw = B[:, nu:], D[:, nu:]
-    Hn = Dw @ Nn
-    Rb = Rn + Hn + Hn.T + Dw @ Qn @ Dw.T
-    Qb = Bw @ Qn @ Bw.T
-    Nb = Bw @ (Qn @ Dw.T + Nn)
-    Qb = (Qb + Qb.T) / 2
-    Rb = (Rb + Rb.T) / 2
-    P, W, K = _dare(A.T, C.T, Qb, Rb, Nb)
+    """General Kalman predictor gain for ``x+ = A x + B [u; w]``, ``y = C x + D [u; w] + v`` with ``E[ww'] = Qn``,
+    ``E[vv'] = Rn``, ``E[wv'] = Nn`` (same call and return values as kalman.py:25-72: ``(L, P, W)`` = gain, Riccati
+    solution, estimator poles).
+
+    Derivation used here: the state sees the noise ``e_x = Bw w`` and the output sees ``e_y = Dw w + v``; the DARE of the
+    predictor needs the joint covariance of ``(e_x, e_y)``, which is ``G Qn G'`` for ``G = [Bw; Dw]`` plus the terms
+    that involve ``v``."""
+    A, B, C, D, Qn, Rn = (np.atleast_2d(np.asarray(M, dtype=float)) for M in (A, B, C, D, Qn, Rn))
+    nx, ny, nw = A.shape[0], C.shape[0], Qn.shape[0]
+    n_known = B.shape[1] - nw                         # leading columns of B, D belong to the known input u
+    G = np.vstack([B[:, n_known:], D[:, n_known:]])   # how w enters (state; output)
+    cross = np.zeros((nw, ny)) if Nn is None else np.atleast_2d(np.asarray(Nn, dtype=float))
+    J = G @ Qn @ G.T
+    Gv = G @ cross                                    # E[(G w) v']
+    J[:, nx:] += Gv
+    J[nx:, :] += Gv.T
+    J[nx:, nx:] += Rn
+    J = (J + J.T) / 2
+    P, W, K = _dare(A.T, C.T, J[:nx, :nx], J[nx:, nx:], J[:nx, nx:])
     return K.T, P, W
 
 
@@ -68,6 +70,7 @@ class LinearStateEstimator:
         self.ny = np.shape(C)[0] if np.size(C) > 1 else 1
 
     def out_y(self, u):
+        """Current output estimate (kalman.py:122-123)."""
         return self.y
 
     def predict(self, u):
@@ -80,17 +83,13 @@ class LinearStateEstimator:
         return self.x
 
     def sim(self, u_seq, x=None):
-        if x is None:
-            x = self.x
-        u_seq = np.asarray(u_seq, dtype=float)
-        Np = 1 if u_seq.size == 1 else u_seq.shape[0]
-        y = np.zeros((Np, self.ny))
-        x_tmp = x
-        for i in range(Np):
-            u_tmp = u_seq[i]
-            y[i, :] = self.C @ x_tmp + self.D @ u_tmp
-            x_tmp = self.A @ x_tmp + self.B @ u_tmp
-        return y
+        """Open-loop output prediction ``y_i = C x_i + D u_i``, ``x_{i+1} = A x_i + B u_i`` from ``x`` (default: the
+        current estimate) over the rows of ``u_seq``; returns ``[len(u_seq), ny]`` (kalman.py:136-152)."""
+        from itertools import accumulate
+        U = np.asarray(u_seq, dtype=float).reshape(-1, self.nu)
+        start = self.x if x is None else x
+        states = accumulate(U[:-1], lambda xi, ui: self.A @ xi + self.B @ ui, initial=np.asarray(start, dtype=float))
+        return np.array([self.C @ xi + self.D @ ui for xi, ui in zip(states, U)]).reshape(len(U), self.ny)
 
 
 class BatchLinearStateEstimator:

@@ -218,7 +218,13 @@ class BatchProblem:
 
         io.w = inp(w, (K, B, nx), 'w'); io.Ap = inp(Ap, (B, nx, nx), 'Ap'); io.Bp = inp(Bp, (B, nx, nu), 'Bp')
         if xref_traj is not None:
-            per = int(np.prod(tuple(xref_traj.shape)[2:])) if len(tuple(xref_traj.shape)) > 2 else 1
+            shp = tuple(xref_traj.shape)
+            if len(shp) < 3 or shp[0] != K or shp[1] != B:
+                raise ValueError('xref_traj must be [nsteps, batch, nx] or [nsteps, batch, Np+1, nx] (or flattened [nsteps, batch, (Np+1)*nx])')
+            per = int(np.prod(shp[2:]))
+            if per not in (nx, (self.Np + 1) * nx):
+                raise ValueError('xref_traj must hold nx or (Np+1)*nx values per step and instance')
+            io.xref_rows = per // nx          # the library checks it again and re-strides its copy accordingly
             io.xref_traj = inp(xref_traj, (K, B, per), 'xref_traj')
         ny = 0
         if estimator is not None:

@@ -3,6 +3,9 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import bench
+from pympc_amd import _lib
+if os.environ.get('MPCQP_LIB'):            # ablation build: point the loader at it BEFORE the first load (scripts only)
+    _lib.LIB_PATH = os.environ['MPCQP_LIB']
 from pympc_amd.solver import BatchProblem
 B = int(os.environ.get('B', 1024)); iters = int(os.environ.get('ITERS', 100))
 NX, NU, NP = (int(os.environ.get(k, v)) for k, v in (('NX', 12), ('NU', 4), ('NP', 30)))

@@ -594,8 +594,8 @@ def test_randomised_controllers_match_oracle(seed):
         assert K.res.info.status == Ko.res.info.status
         (u, info), (uo, infoo) = K.output(return_u_seq=True), Ko.output(return_u_seq=True)
         scale = max(1e-3, np.abs(infoo['u_seq']).max())
-        assert np.abs(info['u_seq'] - infoo['u_seq']).max() <= 2e-6 * scale
+        assert np.abs(info['u_seq'] - infoo['u_seq']).max() <= 1e-6 * scale
         x = kw['Ad'] @ kw['x0'] + kw['Bd'] @ uo
         K.update(x, uo); Ko.update(x, uo)
         assert K.res.info.status == Ko.res.info.status
-        assert np.abs(K.output() - Ko.output()).max() <= 2e-6 * scale
+        assert np.abs(K.output() - Ko.output()).max() <= 1e-6 * scale
