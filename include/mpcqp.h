@@ -194,6 +194,16 @@ int mpcqp_profile(mpcqp_handle *h, int enable, double *run_ms, int64_t *run_laun
 /* Problem sizes: n, m of one instance, bytes of the KKT factor per instance, and nnz(L). */
 int mpcqp_get_dims(mpcqp_handle *h, int *n, int *m, int64_t *factor_doubles, int64_t *nnzL);
 
+/* Bytes one instance streams between memory and its compute unit by design of this implementation: per ADMM iteration
+ * (the KKT factor: forward blocks twice, S^-1 once; plus the iterate where it does not fit LDS), per round of
+ * check_termination iterations (residual evaluation inputs, iterate in/out of LDS), per solve (QP refresh, write-out).
+ * The numerator of the HBM roofline bench.py reports (counterpart of the per-iteration cost 2 nnz(L) + O(n+m) of the
+ * sparse LDL' solve behind pyMPC/mpc.py:369). */
+int mpcqp_get_stream_bytes(mpcqp_handle *h, int64_t *per_iter, int64_t *per_round, int64_t *per_solve);
+
+/* Name of the solve-kernel instantiation this handle launches (loop = 0: mpcqp_solve; 1: mpcqp_mpc_loop), as profilers print it. */
+int mpcqp_kernel_name(mpcqp_handle *h, int loop, char *buf, int buflen);
+
 /* ---- verification surface (used by the parity tests) ------------------------------------ */
 /* Materialise what the device built: dense row-major P [batch][n*n], A [batch][m*n],
  * q [batch][n], l,u [batch][m] (the reference's public attributes, mpc.py:598-606). */

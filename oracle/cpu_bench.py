@@ -12,37 +12,50 @@ if ROOT not in sys.path:
 
 
 def run_instances(args):
+    """Worker: instances first..first+count-1 of the workload recipe, `steps` warm-started closed-loop steps each, through
+    the C driver oracle_mpc_closed_loop (osqp_ref.c) of a build made with -O3 -march=native on this machine.  The QP
+    build and the cold solve (Python, one-off per instance) are not timed; update(q,l,u) + solve of every step are."""
     first, count, steps, eps, nx, nu, Np, xbox, budget = args
     import numpy as np  # noqa: F401
-    from pympc_amd import MPCController, fixtures, qp_build
-    from oracle.osqp_oracle import OSQP
+    from pympc_amd import MPCController, fixtures
+    from oracle import osqp_oracle
+    osqp_oracle.NATIVE = True
     t_solve, n_solve, iters, done = 0.0, 0, 0, 0
     t0 = time.perf_counter()
     for i in range(first, first + count):
         kw = fixtures.random_lti(i, nx=nx, nu=nu, Np=Np, xbox=xbox)
         kw.update(eps_abs=eps, eps_rel=eps)
         K = MPCController(**kw)
-        K.prob = OSQP()
+        K.prob = osqp_oracle.OSQP()
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
             K.setup()
         rng = fixtures.random_lti_noise_rng(i)
-        x = kw['x0']
-        for _ in range(steps):
-            u = K.output()
-            x = kw['Ad'] @ x + kw['Bd'] @ u + 0.01 * rng.standard_normal(nx)
-            K.x0_rh, K.uminus1_rh = x, u
-            q, _ = qp_build.refresh_vectors(K)
-            ts = time.perf_counter()
-            K.prob.update(q=q, l=K.l, u=K.u)
-            K.res = K.prob.solve()
-            t_solve += time.perf_counter() - ts
-            n_solve += 1
-            iters += K.res.info.iter
+        t, it, _, _ = K.prob.closed_loop(K, kw['x0'], 0.01 * rng.standard_normal((steps, nx)))
+        t_solve += t; n_solve += steps; iters += it
         done += 1
         if time.perf_counter() - t0 > budget:
             break
-    return n_solve, t_solve, iters, done
+    return n_solve, t_solve, iters, done, osqp_oracle.BUILD_FLAGS
+
+
+def reference_inputs(args):
+    """Worker: u* of the QPs (instance index, x0, u_{-1}) at tolerance 1e-10 -- the `u*_ref` of BASELINE.json's metric
+    'max |u* - u*_ref|' for a sample of the instances the GPU just solved."""
+    idx, x0s, um1s, nx, nu, Np, xbox = args
+    import numpy as np
+    from pympc_amd import MPCController, fixtures
+    from oracle.osqp_oracle import OSQP
+    out = []
+    for i, x0, um1 in zip(idx, x0s, um1s):
+        kw = fixtures.random_lti(int(i), nx=nx, nu=nu, Np=Np, xbox=xbox)
+        kw.update(x0=np.asarray(x0, dtype=float), uminus1=np.asarray(um1, dtype=float), eps_abs=1e-10, eps_rel=1e-10)
+        K = MPCController(**kw); K.prob = OSQP(); K.solver_settings = dict(max_iter=400000)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            K.setup()
+        out.append(np.array(K.output(), dtype=float) if K.res.info.status == 'solved' else np.full(nu, np.nan))
+    return np.array(out)
 
 
 def usable_cores():
@@ -74,6 +87,16 @@ def all_cores(steps, eps, nx, nu, Np, xbox, budget, per_worker=64):
     jobs = [(10000 + w * per_worker, per_worker, steps, eps, nx, nu, Np, xbox, budget) for w in range(ncores)]
     with mp.get_context('spawn').Pool(ncores) as pool:
         res = pool.map(run_instances, jobs)
-    rate = sum(n / t for n, t, _, _ in res if t > 0)
+    rate = sum(r[0] / r[1] for r in res if r[1] > 0)
     return dict(value=rate, cores=ncores, instances=sum(r[3] for r in res), cpu_seconds=sum(r[1] for r in res),
-                mean_iters=sum(r[2] for r in res) / max(1, sum(r[0] for r in res)))
+                mean_iters=sum(r[2] for r in res) / max(1, sum(r[0] for r in res)), flags=res[0][4])
+
+
+def in_subprocess(fn, args):
+    """Run one worker in a fresh (spawned) process: the parent's GPU state is not inherited and the -march=native build
+    of the oracle is loaded there, not into the bench process."""
+    import multiprocessing as mp
+    for v in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):
+        os.environ[v] = '1'
+    with mp.get_context('spawn').Pool(1) as pool:
+        return pool.apply(fn, (args,))

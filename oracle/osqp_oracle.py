@@ -35,9 +35,23 @@ class Info(C.Structure):
                 ('rho_estimate', C.c_double)]
 
 
+NATIVE = False        # oracle/cpu_bench.py sets this (before the first lib() call of its process) to time a build made
+                      # with -O3 -march=native on the machine it runs on; everything else uses the portable build
+BUILD_FLAGS = 'gcc -O3 -ffp-contract=off (portable build)'
+
+
 def build(force=False):
-    so = os.path.join(_HERE, 'libosqp_ref.so')
+    global BUILD_FLAGS
     src = os.path.join(_HERE, 'osqp_ref.c')
+    if NATIVE:
+        so = os.path.join(_HERE, 'libosqp_ref_native.so')
+        try:          # always rebuilt: a copy made on another machine must not be reused
+            subprocess.check_call(['make', '-s', '-B', '-C', _HERE, 'libosqp_ref_native.so'], stderr=subprocess.DEVNULL)
+            BUILD_FLAGS = 'gcc -O3 -march=native, built on this host'
+            return so
+        except Exception:
+            pass      # no compiler on this machine: the portable build is timed instead (BUILD_FLAGS says so)
+    so = os.path.join(_HERE, 'libosqp_ref.so')
     if force or not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
         subprocess.check_call(['make', '-s', '-C', _HERE, 'libosqp_ref.so'])
     return so
@@ -61,6 +75,8 @@ def lib():
         L.oracle_get_scaling.argtypes = [C.c_void_p, pd, pd, pd]
         L.oracle_get_iterate.argtypes = [C.c_void_p, pd, pd, pd, pd]
         L.oracle_nnzL.argtypes = [C.c_void_p]
+        L.oracle_mpc_closed_loop.restype = C.c_double
+        L.oracle_mpc_closed_loop.argtypes = [C.c_void_p] + [C.c_int] * 5 + [pd] * 12 + [C.POINTER(C.c_int), pd, C.POINTER(C.c_longlong), C.POINTER(C.c_longlong)]
         L.oracle_nnzL.restype = C.c_int64
         _LIB = L
     return _LIB
@@ -136,6 +152,24 @@ class OSQP:
     def warm_start(self, x=None, y=None):
         a = [None if v is None else np.ascontiguousarray(v, dtype=float) for v in (x, y)]
         lib().oracle_warm_start(self._w, _pd(a[0]), _pd(a[1]))
+
+    def closed_loop(self, K, x, noise):
+        """`len(noise)` receding-horizon steps of controller `K` (whose solver this is; last solve in K.res) from plant state
+        `x`, entirely in C (oracle_mpc_closed_loop): returns (seconds in update+solve, ADMM iterations, unsolved steps, x)."""
+        nx, nu, Np, Nc = K.nx, K.nu, K.Np, K.Nc
+        f = lambda a: np.ascontiguousarray(a, dtype=float)
+        ou = (Np + 1) * nx
+        q0 = f(K.q).copy()
+        q0[ou:ou + nu] += f(K.QDu) @ f(K.uminus1_rh)                  # linear cost for u_{-1} = 0
+        q, l, u = f(K.q).copy(), f(K.l).copy(), f(K.u).copy()
+        xs, xsol = f(x).copy(), f(K.res.x).copy()
+        status = C.c_int(K.res.info.status_val)
+        noise = f(noise)
+        it, bad = C.c_longlong(), C.c_longlong()
+        arrs = [f(K.Ad), f(K.Bd), f(K.QDu), f(K.uref), f(np.clip(K.Dumin, -1e30, 1e30)), f(np.clip(K.Dumax, -1e30, 1e30)), q0, q, l, u, xs, xsol]
+        t = lib().oracle_mpc_closed_loop(self._w, len(noise), nx, nu, Np, Nc, *[_pd(a) for a in arrs], C.byref(status), _pd(noise),
+                                         C.byref(it), C.byref(bad))
+        return t, it.value, bad.value, xs
 
     def iterate(self, iters):
         lib().oracle_iterate(self._w, int(iters))

@@ -28,6 +28,7 @@
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  */
+#define _POSIX_C_SOURCE 200809L   /* clock_gettime (closed-loop driver at the end of the file) */
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -551,4 +552,59 @@ int oracle_solve(oracle_work *w, double *x_out, double *y_out, oracle_info *info
     }
     if (info_out) *info_out = w->info;
     return 0;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Closed-loop driver for bench.py's cpu_baseline leg: the caller loop of the reference
+ * (examples/example_point_mass.py:88-101; pyMPC/mpc.py:688-692) around this solver, in C, so that no
+ * interpreter time sits between the solver calls.  Per step:
+ *     u  = first input of the last solution, or uref unless 'solved'          (mpc.py:301-304)
+ *     x+ = Ad x + Bd u + noise_k
+ *     l[:nx] = u[:nx] = -x+ ; Delta-u_0 bounds = Dumin/Dumax + u ; q_U[0:nu] = q0_U[0:nu] - QDu u
+ *                                                  (mpc.py:404-408,441-444; constant xref, uref)
+ *     osqp.update(q, l, u); osqp.solve()                                       (mpc.py:454,369)
+ * q0 is the linear cost for u_{-1} = 0; l, u, q are the caller's full vectors (updated in place); xsol [n] holds the
+ * last solution on entry and exit, *status its status.  Returns the seconds spent in update + solve only.
+ * --------------------------------------------------------------------------------------------- */
+#include <time.h>
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+
+double oracle_mpc_closed_loop(oracle_work *w, int nsteps, int nx, int nu, int Np, int Nc,
+                              const double *Ad, const double *Bd, const double *QDu, const double *uref,
+                              const double *Dumin, const double *Dumax, const double *q0,
+                              double *q, double *l, double *u, double *x, double *xsol, int *status,
+                              const double *noise, long long *iters_out, long long *unsolved_out) {
+    const int64_t ou = (int64_t)(Np + 1) * nx, rdu = 2 * ou + (int64_t)Nc * nu;
+    double *xn = (double *)malloc(sizeof(double) * (size_t)nx), *uk = (double *)malloc(sizeof(double) * (size_t)nu);
+    double spent = 0.0;
+    long long iters = 0, unsolved = 0;
+    for (int k = 0; k < nsteps; k++) {
+        for (int j = 0; j < nu; j++) uk[j] = (*status == ST_SOLVED) ? xsol[ou + j] : uref[j];
+        for (int i = 0; i < nx; i++) {
+            double a = noise ? noise[(size_t)k * nx + i] : 0.0;
+            for (int j = 0; j < nx; j++) a += Ad[i * nx + j] * x[j];
+            for (int j = 0; j < nu; j++) a += Bd[i * nu + j] * uk[j];
+            xn[i] = a;
+        }
+        memcpy(x, xn, sizeof(double) * (size_t)nx);
+        for (int i = 0; i < nx; i++) { l[i] = -x[i]; u[i] = -x[i]; }
+        for (int j = 0; j < nu; j++) {
+            l[rdu + j] = Dumin[j] + uk[j]; u[rdu + j] = Dumax[j] + uk[j];
+            double a = 0.0;
+            for (int t = 0; t < nu; t++) a += QDu[j * nu + t] * uk[t];
+            q[ou + j] = q0[ou + j] - a;
+        }
+        oracle_info info;
+        double t0 = now_s();
+        oracle_update(w, q, l, u);
+        oracle_solve(w, xsol, NULL, &info);
+        spent += now_s() - t0;
+        *status = info.status;
+        iters += info.iter;
+        if (info.status != ST_SOLVED) unsolved++;
+    }
+    free(xn); free(uk);
+    if (iters_out) *iters_out = iters;
+    if (unsolved_out) *unsolved_out = unsolved;
+    return spent;
 }

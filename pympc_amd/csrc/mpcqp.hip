@@ -595,6 +595,43 @@ extern "C" int mpcqp_get_dims(mpcqp_handle *h, int *n, int *m, int64_t *factor_d
     return MPCQP_OK;
 }
 
+// Bytes one instance moves between the memory system (HBM / Infinity Cache / L2) and its compute unit BY DESIGN of these
+// kernels -- the roofline numerator bench.py uses ("Roofline accounting"):
+//   per ADMM iteration : the factor stream.  Forward blocks of N-1 stages are read in the forward elimination and again
+//                        (transposed apply) in the back substitution; S^-1 of all N stages once (packed symmetric for
+//                        16 x 16 stages).  Problems whose iterate does not fit LDS also read and write x, z, y and read
+//                        omega, s, q every iteration; Nc < Np adds the two border matrices.
+//   per round (check)  : residual evaluation inputs (weights, D, E, omega, s, last increments), the round's load/store of
+//                        the LDS-resident iterate and of the per-thread register copies of omega, s, q.
+//   per solve          : the begin phase (step data, E, constraint types, q rebuild) and the solution write-out.
+extern "C" int mpcqp_get_stream_bytes(mpcqp_handle *h, int64_t *per_iter, int64_t *per_round, int64_t *per_solve) {
+    if (!h) return fail(MPCQP_ERR_ARG, "null handle");
+    const Lay &L = h->L;
+    const int64_t n = L.n, m = L.m, nq = L.n_x + L.n_u, NB = L.NB;
+    const int64_t sinv = L.fstage - NB * NB;
+    int64_t it = 2 * (int64_t)(L.N - 1) * NB * NB + (int64_t)L.N * sinv;
+    if (!h->lds_state) it += (2 * n + 4 * m) /* x, z, y read + written */ + (m + L.n_x) /* omega */ + (n + L.n_x) /* s */ + nq /* q */;
+    if (L.border) it += 2 * (int64_t)L.nu * L.N * NB;
+    int64_t rd = (L.model_sz - L.hot_sz) + 2 * n + 2 * m /* D, s, E, omega */ + n + m /* dx, dy */;
+    rd += h->lds_state ? 2 * (n + 2 * m) /* iterate in and out of LDS */ + (m + L.n_x) + (n + L.n_x) + nq : (n + 2 * m);
+    int64_t sv = L.hot_sz + L.step_sz + 3 * m /* E, types, omega */ + nq + 2 * (n + m) /* solution out, iterate read */;
+    if (per_iter) *per_iter = 8 * it;
+    if (per_round) *per_round = 8 * rd;
+    if (per_solve) *per_solve = 8 * sv;
+    return MPCQP_OK;
+}
+
+// Name of the k_mpc_run instantiation the handle's solves (loop = 0) or closed-loop runs (loop = 1) launch, spelled as
+// rocprofv3 prints it (without spaces) -- so that bench.py and the profile summaries name the same kernel.
+extern "C" int mpcqp_kernel_name(mpcqp_handle *h, int loop, char *buf, int buflen) {
+    if (!h || !buf || buflen < 1) return fail(MPCQP_ERR_ARG, "null argument");
+    const Lay &L = h->L;
+    const bool spec = !L.border && ((L.NB == 16 && h->lds_state && L.nx == 12 && L.nu == 4) || (L.NB == 32 && !h->lds_state && L.nx == 20 && L.nu == 8));
+    snprintf(buf, (size_t)buflen, "k_mpc_run<%d,%s,%d,%d,%s,%s>", L.NB, h->lds_state ? "true" : "false", spec ? L.nx : 0, spec ? L.nu : 0,
+             L.border ? "true" : "false", loop ? "true" : "false");
+    return MPCQP_OK;
+}
+
 extern "C" int mpcqp_warm_start(mpcqp_handle *h, const double *x, const double *y) {
     if (!h) return fail(MPCQP_ERR_ARG, "null handle");
     if (!h->is_setup) return fail(MPCQP_ERR_STATE, "warm_start before setup");

@@ -173,6 +173,7 @@ NAMED = {
     'random_12_4_30': lambda: random_lti(0),
     'random_12_4_30_b': lambda: random_lti(7),
     'random_20_8_12': lambda: random_lti(3, nx=20, nu=8, Np=12, xbox=1.0),
+    'random_20_8_100': lambda: random_lti(0, nx=20, nu=8, Np=100, xbox=1.0),      # BASELINE cfg-5, instance 0 of bench.py --workload cfg5
     'random_5_3_8': lambda: random_lti(11, nx=5, nu=3, Np=8, xbox=0.5),
     'random_5_3_8_nc': lambda: dict(random_lti(12, nx=5, nu=3, Np=8, xbox=2.0), Nc=3),
     'quadcopter_nc': lambda: dict(quadcopter(Np=10), Nc=4),

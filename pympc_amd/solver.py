@@ -272,6 +272,17 @@ class BatchProblem:
         _lib.check(self._L.mpcqp_get_stats(self._h, out, int(bool(reset))), 'mpcqp_get_stats')
         return tuple(int(v) for v in out)
 
+    def stream_bytes(self):
+        """(bytes per ADMM iteration, per round, per solve) one instance streams by design (mpcqp_get_stream_bytes)."""
+        a, b, c = C.c_int64(), C.c_int64(), C.c_int64()
+        _lib.check(self._L.mpcqp_get_stream_bytes(self._h, C.byref(a), C.byref(b), C.byref(c)), 'mpcqp_get_stream_bytes')
+        return a.value, b.value, c.value
+
+    def kernel_name(self, loop):
+        buf = C.create_string_buffer(128)
+        _lib.check(self._L.mpcqp_kernel_name(self._h, int(bool(loop)), buf, 128), 'mpcqp_kernel_name')
+        return buf.value.decode()
+
     def profile(self, enable=None, reset=False):
         """(milliseconds, launches) of the solve kernel k_mpc_run accumulated while profiling was enabled."""
         ms, nl = C.c_double(), C.c_int64()

@@ -8,7 +8,7 @@ Runs ONLY in the build container (needs /root/reference).  It imports the refere
 the reference hands to the solver: P, q, A, l, u (mpc.py:456-608) and the refreshed q, l, u
 (mpc.py:386-454).  Only arrays are stored -- no reference source travels.
 
-    python tests/golden/make_golden.py        # writes tests/golden/qp_<name>.npz
+    python tests/golden/make_golden.py [name ...]   # writes tests/golden/qp_<name>.npz (all fixtures by default)
 """
 import os
 import sys
@@ -79,6 +79,8 @@ def main():
     from pympc_amd import fixtures
     MPCController = load_reference()
     for name, make in fixtures.NAMED.items():
+        if sys.argv[1:] and name not in sys.argv[1:]:
+            continue
         kw = make()
         K = MPCController(**{k: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v) for k, v in kw.items()})
         K.setup(solve=False)

@@ -6,7 +6,7 @@ cross-check the small cases with the HiGHS QP solver bundled in scipy, and store
 x*, y*, u0*, objective.  The MPC QP has a unique minimiser whenever Qu>0 or QDu>0
 (SURVEY.md section 8c), so these vectors are solver-independent facts about the reference's QP.
 
-    python tests/golden/make_optimum.py       # writes tests/golden/opt_<name>.npz
+    python tests/golden/make_optimum.py [name ...]  # writes tests/golden/opt_<name>.npz (all fixtures by default)
 """
 import os
 import sys
@@ -59,6 +59,8 @@ def highs_qp(P, q, A, l, u, time_limit=60.0):
 
 def main():
     for name in golden_names():
+        if sys.argv[1:] and name not in sys.argv[1:]:
+            continue
         g = load_golden(name)
         P, A = golden_csc(g, 'P'), golden_csc(g, 'A')
         q, l, u = g['q'], g['l'], g['u']

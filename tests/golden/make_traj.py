@@ -11,8 +11,15 @@ Loops (inputs are the constants of pympc_amd/fixtures.py, cited there):
         (examples/example_point_mass.py:88-101 with the exact discrete step of mpc.py:690 instead of the ODE integrator)
   cart_pole                           : same calls, nonlinear plant + forward Euler of examples/example_inverted_pendulum.py:83-103
   point_mass_nc                       : u = K.output(); x+ = Ad x + Bd u; K.update(x)   (mpc.py:688-692, 2-D xref, Nc < Np)
+  kalman_cart_pole                    : output feedback, the loop of examples/example_inverted_pendulum_kalman.py:135-174 with
+        the REFERENCE's LinearStateEstimator (pyMPC/kalman.py:109-134) next to its MPCController, linear plant and recorded
+        noise:  y = C x + v; u = K.output(); x+ = Ad x + Bd u + w; KF.update(y); KF.predict(u); K.update(KF.x, u).
+        pyMPC/kalman.py imports `control` at module top (absent here; only its design functions use it) and calls the
+        long-removed alias `scipy.size` in LinearStateEstimator.__init__: the script satisfies the import with an empty
+        module and restores the alias (= numpy.size, what it was) for the duration of the run.  The filter gain L is
+        INPUT data (designed by pympc_amd.kalman.kalman_design_simple) and is stored with the trajectory.
 
-    python tests/golden/make_traj.py        # needs /root/reference; writes tests/golden/traj_<name>.npz
+    python tests/golden/make_traj.py [name ...]   # needs /root/reference; writes tests/golden/traj_<name>.npz
 """
 import os
 import sys
@@ -80,16 +87,61 @@ def run(Ctrl, kw, steps, pattern, plant):
     return np.array(xs), np.array(us)
 
 
+def run_kalman(Ctrl, Estimator, kw, steps):
+    """Output-feedback closed loop with the reference's own estimator class; returns everything the replay needs."""
+    from pympc_amd.kalman import kalman_design_simple
+    Ad, Bd = kw['Ad'], kw['Bd']
+    nx, nu = Bd.shape
+    Cd = np.array([[1.0, 0, 0, 0], [0, 0, 1.0, 0]])            # position and angle are measured (example :62-66)
+    Dd = np.zeros((2, nu))
+    L, _, _ = kalman_design_simple(Ad, Bd, Cd, Dd, np.diag([0.1, 10, 0.1, 10]), 0.01 * np.eye(2), type='filter')
+    rng = np.random.default_rng(77)
+    v = 0.01 * rng.standard_normal((steps, 2))
+    w = 0.001 * rng.standard_normal((steps, nx))
+    x = np.array(kw['x0'], dtype=float) * 1.05                 # the controller starts from a wrong estimate
+    x_true0 = x.copy()
+    KF = Estimator(np.array(kw['x0'], dtype=float), Ad, Bd, Cd, Dd, L)
+    K = Ctrl(**kw)
+    xs, xh, us, ys = [x.copy()], [np.array(KF.x, dtype=float)], [], []
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        K.setup()
+        for k in range(steps):
+            y = Cd @ x + v[k]
+            u = K.output()
+            x = Ad @ x + Bd @ u + w[k]
+            KF.update(y)
+            KF.predict(u)
+            K.update(KF.x, u)
+            xs.append(x.copy()); xh.append(np.array(KF.x, dtype=float)); us.append(np.array(u, dtype=float)); ys.append(y)
+    return dict(x=np.array(xs), xhat=np.array(xh), u=np.array(us), y=np.array(ys), v=v, w=w, C=Cd, L=L, x_true0=x_true0)
+
+
 def main():
     from pympc_amd import fixtures
     with tempfile.TemporaryDirectory() as tmp:
         os.makedirs(os.path.join(tmp, 'osqp'))
         with open(os.path.join(tmp, 'osqp', '__init__.py'), 'w') as f:
             f.write(STUB)
+        os.makedirs(os.path.join(tmp, 'control'))
+        with open(os.path.join(tmp, 'control', '__init__.py'), 'w') as f:
+            f.write('# placeholder: pyMPC/kalman.py imports `control` at module top; the estimator class never calls it\n')
         sys.path.insert(0, tmp)
         sys.path.insert(0, '/root/reference')
         from pyMPC.mpc import MPCController as RefController
+        if not sys.argv[1:] or 'kalman_cart_pole' in sys.argv[1:]:
+            import scipy
+            if not hasattr(scipy, 'size'):
+                scipy.size = np.size                            # the alias kalman.py:9-20 was written against
+            from pyMPC.kalman import LinearStateEstimator as RefEstimator
+            kw = dict(fixtures.NAMED['cart_pole']())
+            kw.update(eps_abs=EPS, eps_rel=EPS)
+            out = run_kalman(RefController, RefEstimator, kw, 40)
+            np.savez_compressed(os.path.join(HERE, 'traj_kalman_cart_pole.npz'), pattern='output_feedback', fixture='cart_pole', eps=EPS, **out)
+            print('%-14s %3d steps  |x|max %.3f  |u|max %.3f  u[0] %s' % ('kalman_cart_pole', 40, np.abs(out['x']).max(), np.abs(out['u']).max(), out['u'][0]))
         for name, (fix, steps, pattern) in CASES.items():
+            if sys.argv[1:] and name not in sys.argv[1:]:
+                continue
             kw = dict(fixtures.NAMED[fix]())
             kw.update(eps_abs=EPS, eps_rel=EPS)
             Ad, Bd = kw['Ad'], kw['Bd']

@@ -57,3 +57,33 @@ def test_gpu_controller_follows_reference_closed_loop(name):
     K = MPCController(**kw)
     K.solver_settings = dict(max_iter=400000)
     _closed_loop(K, kw, g, None, feed_golden_states=True, tol=1e-6)
+
+
+@pytest.mark.parametrize('name', traj_names(output_feedback=True))
+def test_host_estimator_and_class_reproduce_reference_output_feedback_loop(name):
+    """pympc_amd.kalman.LinearStateEstimator next to our MPCController (oracle as solver) against the loop the REFERENCE's
+    LinearStateEstimator + MPCController ran (make_traj.py: examples/example_inverted_pendulum_kalman.py:135-174 with a
+    linear plant and recorded noise): estimates, inputs and states to 1e-8 -- pins pyMPC/kalman.py:109-134's
+    predict/update and what update(KF.x, u) does with the estimate."""
+    from pympc_amd import MPCController, fixtures
+    from pympc_amd.kalman import LinearStateEstimator
+    from oracle.osqp_oracle import OSQP
+    g = load_traj(name)
+    kw = dict(fixtures.NAMED[str(g['fixture'])]())
+    kw.update(eps_abs=float(g['eps']), eps_rel=float(g['eps']))
+    Ad, Bd, Cd, L = kw['Ad'], kw['Bd'], g['C'], g['L']
+    K = MPCController(**kw); K.prob = OSQP(); K.solver_settings = dict(max_iter=400000)
+    KF = LinearStateEstimator(np.array(kw['x0'], dtype=float), Ad, Bd, Cd, np.zeros((Cd.shape[0], Bd.shape[1])), L)
+    x = np.array(g['x_true0'], dtype=float)
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        K.setup()
+        for k in range(len(g['u'])):
+            y = Cd @ x + g['v'][k]
+            u = K.output()
+            x = Ad @ x + Bd @ u + g['w'][k]
+            KF.update(y); KF.predict(u)
+            K.update(KF.x, u)
+            assert np.abs(u - g['u'][k]).max() <= 1e-8 * max(1e-3, np.abs(g['u']).max()), k
+            assert np.abs(x - g['x'][k + 1]).max() <= 1e-8 * np.abs(g['x']).max(), k
+            assert np.abs(KF.x - g['xhat'][k + 1]).max() <= 1e-8 * np.abs(g['xhat']).max(), k

@@ -1,0 +1,203 @@
+"""GPU parity tests of the DEVICE-SIDE RECEDING-HORIZON LOOP (mpcqp_mpc_loop, the bench's headline path) against
+things that are not the HIP library itself:
+  (a) the closed-loop golden trajectories produced by the REFERENCE's own controller class (tests/golden/traj_*.npz,
+      made by tests/golden/make_traj.py from /root/reference/pyMPC/mpc.py);
+  (b) the CPU oracle stepping alongside (BASELINE size nx=12, nu=4, Np=30, and the cfg-5 size nx=20, nu=8, Np=100);
+  (c) the output-feedback loop of the reference's LinearStateEstimator + MPCController (traj_kalman_*.npz);
+plus the BASELINE cfg-5 full-size batch (512 x (20,8,100)) through size-independent properties.
+Run on the GPU box with:  python -m pytest tests -m gpu
+"""
+import warnings
+
+import numpy as np
+import pytest
+
+from util import load_traj, load_golden, golden_kwargs, kkt_certificate
+
+pytestmark = pytest.mark.gpu
+
+
+def _stacked_batch(kws, **kw):
+    from pympc_amd import BatchMPCController
+    stack = lambda k: np.stack([np.asarray(d[k], dtype=float) for d in kws])
+    k0 = kws[0]
+    args = dict(Np=k0['Np'], Nc=k0.get('Nc'), x0=stack('x0'), xref=stack('xref'), uref=stack('uref'), uminus1=stack('uminus1'),
+                Qx=stack('Qx'), QxN=stack('QxN'), Qu=stack('Qu'), QDu=stack('QDu'), xmin=stack('xmin'), xmax=stack('xmax'),
+                umin=stack('umin'), umax=stack('umax'), Dumin=stack('Dumin'), Dumax=stack('Dumax'),
+                eps_feas=np.array([[d.get('eps_feas', 1e6)] for d in kws]))
+    args.update(kw)
+    return BatchMPCController(stack('Ad'), stack('Bd'), **args)
+
+
+def _complete(kw):
+    """Fixture dict with every optional controller argument spelled out (what the stacked constructor wants)."""
+    kw = dict(kw)
+    nx, nu = kw['Ad'].shape[0], kw['Bd'].shape[1]
+    kw.setdefault('uref', np.zeros(nu)); kw.setdefault('xref', np.zeros(nx)); kw.setdefault('uminus1', kw['uref'])
+    kw.setdefault('QxN', kw['Qx'])
+    return kw
+
+
+# ---- (a) the reference class's own closed loops, linear plants -------------------------------------------------------
+@pytest.mark.parametrize('name', ['point_mass', 'accel_brake', 'quadcopter', 'point_mass_nc'])
+def test_device_loop_follows_reference_class_trajectories(name):
+    """BatchMPCController.run() -- output, plant, update and warm-started solve of every step inside one kernel launch --
+    against the (x_k, u_k) the REFERENCE controller class visited in the same closed loop (make_traj.py).  Both caller
+    patterns of the reference (update->output and output->update) give the same sequence of QPs: the solve that
+    follows update(x_k, u_{k-1}) has a unique optimum whatever iterate it is started from.  Tolerance: 1e-6 of the
+    input / state range in every step (north-star criterion), the states being the device's own, not the golden ones."""
+    from pympc_amd import fixtures
+    g = load_traj(name)
+    kw = _complete(fixtures.NAMED[str(g['fixture'])]())
+    xs, us = g['x'], g['u']
+    K = _stacked_batch([kw, kw], eps_abs=1e-10, eps_rel=1e-10, max_iter=400000)
+    K.setup()
+    assert all(s == 'solved' for s in K.status())
+    tr = K.run(len(us))
+    assert (tr['status'] == 1).all()
+    su, sx = max(1e-3, np.abs(us).max()), max(1e-3, np.abs(xs).max())
+    for b in range(2):
+        assert np.abs(tr['u'][:, b] - us).max() <= 1e-6 * su, (name, np.abs(tr['u'][:, b] - us).max(axis=1).argmax())
+        assert np.abs(tr['x'][:, b] - xs).max() <= 1e-6 * sx
+    # chained launches (what bench.py does) visit the same trajectory
+    K2 = _stacked_batch([kw], eps_abs=1e-10, eps_rel=1e-10, max_iter=400000); K2.setup()
+    parts = [K2.run(5) for _ in range(len(us) // 5)]
+    uc = np.concatenate([p['u'][:, 0] for p in parts])
+    assert np.abs(uc - us[:len(uc)]).max() <= 1e-6 * su
+
+
+# ---- (b) the oracle stepping alongside --------------------------------------------------------------------------------
+@pytest.mark.parametrize('dims', [(12, 4, 30, 5, 15), (20, 8, 100, 2, 6)])
+def test_device_loop_matches_oracle_closed_loop(dims):
+    """K noisy closed-loop steps of the BASELINE-size (12,4,30) and cfg-5-size (20,8,100, tight state box: slack rows
+    active) instances inside mpcqp_mpc_loop; one CPU-oracle controller per instance is driven through the same states
+    (update(x_{k+1}, u_k) like the device's own update) and must produce the same input at every step to 1e-6."""
+    from pympc_amd import MPCController, fixtures
+    from oracle.osqp_oracle import OSQP
+    nx, nu, Np, B, K_STEPS = dims
+    xbox = 10.0 if nx == 12 else 1.0
+    kws = [_complete(fixtures.random_lti(50 + i, nx=nx, nu=nu, Np=Np, xbox=xbox)) for i in range(B)]
+    rng = np.random.default_rng(21)
+    w = 0.01 * rng.standard_normal((K_STEPS, B, nx))
+    Kd = _stacked_batch(kws, eps_abs=1e-9, eps_rel=1e-9, max_iter=400000); Kd.setup()
+    tr = Kd.run(K_STEPS, w=w)
+    assert (tr['status'] == 1).all()
+    for b, kw in enumerate(kws):
+        kwo = dict(kw); kwo.update(eps_abs=1e-9, eps_rel=1e-9)
+        Ko = MPCController(**kwo); Ko.prob = OSQP(); Ko.solver_settings = dict(max_iter=400000)
+        with warnings.catch_warnings():
+            warnings.simplefilter('error')
+            Ko.setup()
+            for k in range(K_STEPS):
+                uo = Ko.output()
+                assert np.abs(tr['u'][k, b] - uo).max() <= 1e-6 * max(1e-3, np.abs(uo).max()), (b, k)
+                xn = kw['Ad'] @ tr['x'][k, b] + kw['Bd'] @ tr['u'][k, b] + w[k, b]
+                assert np.allclose(xn, tr['x'][k + 1, b], rtol=1e-12, atol=1e-13)
+                Ko.update(tr['x'][k + 1, b], uo)
+
+
+def test_device_loop_default_tolerance_iterates_like_oracle():
+    """At the reference's default eps = 1e-3 (mpc.py:80) the applied input is an ADMM iterate, not the optimum: the loop
+    must then reproduce the oracle's iterate -- same status and iteration count in every step, inputs to 1e-7 --
+    when both are fed the same states and both warm-start from their own previous iterate."""
+    from pympc_amd import MPCController, fixtures
+    from oracle.osqp_oracle import OSQP
+    B, K_STEPS = 4, 10
+    kws = [_complete(fixtures.random_lti(60 + i)) for i in range(B)]
+    rng = np.random.default_rng(22)
+    w = 0.01 * rng.standard_normal((K_STEPS, B, 12))
+    Kd = _stacked_batch(kws); Kd.setup()
+    tr = Kd.run(K_STEPS, w=w)
+    for b, kw in enumerate(kws):
+        Ko = MPCController(**kw); Ko.prob = OSQP()
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            Ko.setup()
+            for k in range(K_STEPS):
+                uo = Ko.output()
+                assert np.abs(tr['u'][k, b] - uo).max() <= 1e-7 * max(1e-3, np.abs(uo).max()), (b, k)
+                Ko.update(tr['x'][k + 1, b], tr['u'][k, b])
+                assert Ko.res.info.iter == tr['iter'][k, b] and Ko.res.info.status_val == tr['status'][k, b], (b, k)
+
+
+# ---- (c) output feedback: reference LinearStateEstimator + MPCController ----------------------------------------------
+@pytest.mark.parametrize('name', ['kalman_cart_pole'])
+def test_device_loop_output_feedback_follows_reference_classes(name):
+    """The loop of examples/example_inverted_pendulum_kalman.py:135-174 run by the REFERENCE's MPCController and
+    LinearStateEstimator (make_traj.py, linear plant, recorded noise) against the same loop inside mpcqp_mpc_loop."""
+    from pympc_amd import fixtures
+    from pympc_amd.kalman import BatchLinearStateEstimator
+    g = load_traj(name)
+    kw = _complete(fixtures.NAMED[str(g['fixture'])]())
+    us, xs, xh = g['u'], g['x'], g['xhat']
+    K_STEPS = len(us)
+    st = lambda M: np.asarray(M, dtype=float)[None]
+    est = BatchLinearStateEstimator(st(kw['x0']), st(kw['Ad']), st(kw['Bd']), st(g['C']), st(g['L']),
+                                    x_true=st(g['x_true0']).copy(), v=g['v'][:, None, :])
+    K = _stacked_batch([kw], eps_abs=1e-10, eps_rel=1e-10, max_iter=400000); K.setup()
+    tr = K.run(K_STEPS, w=g['w'][:, None, :], estimator=est)
+    assert (tr['status'] == 1).all()
+    assert np.abs(tr['u'][:, 0] - us).max() <= 1e-6 * max(1e-3, np.abs(us).max())
+    assert np.abs(tr['x'][:, 0] - xs).max() <= 1e-6 * max(1e-3, np.abs(xs).max())
+    assert np.abs(tr['xhat'][:, 0] - xh).max() <= 1e-6 * max(1e-3, np.abs(xh).max())
+
+
+# ---- BASELINE cfg-5 at full size ---------------------------------------------------------------------------------------
+def test_cfg5_full_size_batch_properties():
+    """BASELINE cfg-5 (512 x (nx=20, nu=8, Np=100), Delta-u rows and slack rows active: state box +-1 with x0 ~ N(0,1)):
+    size-independent properties of every returned solution -- exact dynamics consistency, hard-row satisfaction, slack
+    exactly where the box is violated -- the KKT certificate on sampled instances, and instance 0 against the certified
+    optimum golden vector (opt_random_20_8_100.npz); then a warm-started receding-horizon run of the whole batch."""
+    from pympc_amd import fixtures
+    from pympc_amd.controller import MPCController
+    B, nx, nu, Np = 512, 20, 8, 100
+    kws = [_complete(fixtures.random_lti(i, nx=nx, nu=nu, Np=Np, xbox=1.0)) for i in range(B)]
+    K = _stacked_batch(kws, eps_abs=1e-8, eps_rel=1e-8, max_iter=400000)
+    K.setup()
+    U, info = K.output(return_status=True, return_x_seq=True, return_u_seq=True, return_eps_seq=True)
+    assert all(s == 'solved' for s in info['status'])
+    X, Us, Eps = info['x_seq'], info['u_seq'], info['eps_seq']
+    Ad, Bd = K.Ad, K.Bd
+    pred = np.einsum('bij,bkj->bki', Ad, X[:, :-1]) + np.einsum('bij,bkj->bki', Bd, Us)
+    assert np.abs(pred - X[:, 1:]).max() < 1e-6
+    assert np.abs(X[:, 0] - K.x0).max() < 1e-6
+    assert Us.max() <= 1 + 1e-6 and Us.min() >= -1 - 1e-6
+    dU = np.diff(Us.reshape(B, -1), axis=1)                       # the reference's Delta-u rows difference consecutive SCALARS (mpc.py:570)
+    assert dU.max() <= 0.5 + 1e-6 and dU.min() >= -0.5 - 1e-6
+    assert (np.abs(X + Eps) <= 1 + 1e-6).all()                    # soft box on x_k + eps_k
+    assert (np.abs(Eps) > 1e-3).any()                             # ... and it is active: x0 starts outside the box
+    x, y, _ = K.prob.solution()
+    for i in (0, 255, 511):
+        C = MPCController(**kws[i]); C.prob = object(); C.x0_rh = C.x0; C.uminus1_rh = C.uminus1
+        C._compute_QP_matrices_()
+        stat, pv, comp = kkt_certificate(C.P, C.q, C.A, C.l, C.u, x[i], y[i])
+        assert stat < 1e-6 and pv < 1e-6 and comp < 1e-6, (i, stat, pv, comp)
+    opt = load_golden('random_20_8_100', prefix='opt_')
+    assert np.abs(U[0] - opt['u0']).max() <= 1e-6 * max(1e-3, np.abs(opt['u0']).max())
+    rng = np.random.default_rng(3)
+    tr = K.run(10, w=0.01 * rng.standard_normal((10, B, nx)))
+    assert (tr['status'] == 1).all() and np.isfinite(tr['x']).all()
+    pred = np.einsum('bij,kbj->kbi', Ad, tr['x'][:-1]) + np.einsum('bij,kbj->kbi', Bd, tr['u'])
+    assert np.abs(tr['x'][1:] - pred).max() < 0.1                 # (the disturbance is all that separates them)
+    assert np.abs(tr['u']).max() <= 1 + 1e-6
+
+
+# ---- every solver outcome the MPC QP can produce, against the oracle ---------------------------------------------------
+@pytest.mark.parametrize('max_iter', [10, 25, 40, 50, 75, 125, 200])
+def test_iteration_limit_outcomes_match_oracle(max_iter):
+    """'maximum iterations reached' / 'solved inaccurate' / 'solved' as the iteration limit moves across the point where
+    the 10x-relaxed and then the nominal tolerances are met (OSQP's end-of-run logic): same status, same iteration
+    count, same reported iterate as the oracle.  (A dual-infeasible MPC QP does not exist: P d = 0 implies q'd = 0
+    for the reference's q = -P_X xref, so that certificate can only be exercised on the generic surface.)"""
+    from pympc_amd import MPCController, fixtures
+    from oracle.osqp_oracle import OSQP
+    kw = dict(fixtures.random_lti(77))
+    kw.update(eps_abs=1e-5, eps_rel=1e-5)
+    K = MPCController(**kw); K.solver_settings = dict(max_iter=max_iter)
+    Ko = MPCController(**kw); Ko.prob = OSQP(); Ko.solver_settings = dict(max_iter=max_iter)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        K.setup(); Ko.setup()
+    assert K.res.info.status == Ko.res.info.status and K.res.info.iter == Ko.res.info.iter
+    assert np.abs(K.res.x - Ko.res.x).max() <= 1e-7 * max(1.0, np.abs(Ko.res.x).max())
+    assert np.array_equal(K.output(), Ko.output()) or K.res.info.status == 'solved'

@@ -586,7 +586,7 @@ def test_randomised_controllers_match_oracle(seed):
     """Seeded random controllers (shapes, Nc < Np, one-sided and absent bounds, semidefinite weights, 1-D / 2-D references):
     cold solve and one warm step against the oracle at tight tolerance; statuses must agree too."""
     kw = _random_case(seed)
-    kw.update(eps_abs=1e-9, eps_rel=1e-9)
+    kw.update(eps_abs=1e-10, eps_rel=1e-10)     # the reference author's own parity setting (test_scripts/main_du.py:125)
     K = _gpu_controller(kw, max_iter=400000); Ko = _oracle_controller(kw, max_iter=400000)
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
@@ -599,3 +599,61 @@ def test_randomised_controllers_match_oracle(seed):
         K.update(x, uo); Ko.update(x, uo)
         assert K.res.info.status == Ko.res.info.status
         assert np.abs(K.output() - Ko.output()).max() <= 1e-6 * scale
+
+
+def test_step_after_output_uses_the_output_as_previous_input():
+    """setup() -> output() -> step(x): update(x, u=None) of the reference uses the input returned by the last output()
+    as u_{-1} (mpc.py:330,357-359).  The one-call step must do the same although output() only changed the HOST copy."""
+    from pympc_amd import fixtures
+    kws = [fixtures.random_lti(820 + i) for i in range(4)]
+    for kw in kws:
+        kw['uminus1'] = np.array([0.4, -0.3, 0.2, 0.1])       # differs from what output() will return
+    Ka = _stacked_batch(kws); Ka.setup()
+    Kb = _stacked_batch(kws); Kb.setup()
+    ua, ub = Ka.output(), Kb.output()
+    x = np.einsum('bij,bj->bi', Ka.Ad, Ka.x0_rh) + np.einsum('bij,bj->bi', Ka.Bd, ua)
+    Ka.update(x); ua = Ka.output()
+    ub = Kb.step(x)                                            # no u given: must pick up the output() above
+    assert np.array_equal(ua, ub)
+    x = np.einsum('bij,bj->bi', Ka.Ad, x) + np.einsum('bij,bj->bi', Ka.Bd, ua)
+    Ka.update(x); ua = Ka.output()
+    assert np.array_equal(ua, Kb.step(x))                      # ... and from then on the device's own copy
+
+
+def test_loop_reference_shape_is_checked_and_may_change():
+    """xref_traj must hold nx or (Np+1)*nx values per step; a loop may switch the reference shape like update(x, u, xref)
+    may (mpc.py:414-424), and then equals the stepwise calls."""
+    from pympc_amd import fixtures
+    kws = [fixtures.random_lti(830 + i) for i in range(2)]
+    B, nx, Np = 2, 12, 30
+    Kd = _stacked_batch(kws); Kd.setup()
+    Ks = _stacked_batch(kws); Ks.setup()
+    rng = np.random.default_rng(6)
+    with pytest.raises(ValueError):
+        Kd.run(3, xref_traj=np.zeros((3, B, 5)))
+    xr = 0.1 * rng.standard_normal((4, B, Np + 1, nx))         # constant reference at setup, time-varying in the loop
+    tr = Kd.run(4, xref_traj=xr)
+    for k in range(4):
+        u = Ks.output()
+        assert np.array_equal(u, tr['u'][k]), k
+        Ks.update(tr['x'][k + 1], xref=xr[k])
+    assert np.array_equal(Kd.output(), Ks.output())
+    from pympc_amd import _lib
+    import ctypes as C
+    io = _lib.Loop(); z = np.zeros((1, B, nx)); io.xref_traj = z.ctypes.data; io.xref_rows = 7
+    assert Kd.prob._L.mpcqp_mpc_loop(Kd.prob._h, 1, C.byref(io)) == -1        # MPCQP_ERR_ARG
+
+
+def test_warm_start_sets_z_like_osqp():
+    """osqp.warm_start(x=, y=) also sets z = A x; the next solve must then iterate exactly like the oracle's."""
+    from pympc_amd import fixtures
+    kw = dict(fixtures.random_lti(840))
+    K = _gpu_controller(kw); K.setup()
+    Ko = _oracle_controller(kw); Ko.setup()
+    rng = np.random.default_rng(8)
+    x, y = 0.1 * rng.standard_normal(K.prob.n), 0.1 * rng.standard_normal(K.prob.m)
+    K.prob.warm_start(x=x, y=y); Ko.prob.warm_start(x=x, y=y)
+    K.prob.batch_problem.iterate(3); Ko.prob.iterate(3)
+    xg, zg, yg = K.prob.batch_problem.iterate_state()
+    xo, zo, yo, _ = Ko.prob.iterate_state()
+    assert _rel(xg[0], xo) < 1e-8 and _rel(zg[0], zo) < 1e-8 and np.abs(yg[0] - yo).max() < 1e-8 * max(1.0, np.abs(yo).max())

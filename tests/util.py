@@ -57,9 +57,10 @@ def kkt_certificate(P, q, A, l, u, x, y):
 
 
 # ---- closed-loop golden trajectories (tests/golden/make_traj.py) ------------------------------------------------------
-def traj_names():
-    import glob
-    return sorted(os.path.basename(p)[5:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, 'traj_*.npz')))
+def traj_names(output_feedback=False):
+    """State-feedback closed loops (default) or the output-feedback ones (traj_kalman_*.npz)."""
+    names = sorted(os.path.basename(p)[5:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, 'traj_*.npz')))
+    return [n for n in names if n.startswith('kalman_') == output_feedback]
 
 
 def load_traj(name):
