@@ -79,6 +79,7 @@ def cpu_legs(eps, samples, want_baseline, seconds_budget=12.0, inst=400, steps=1
     from oracle import cpu_bench
     out, refs = None, []
     if want_baseline:
+        cpu_bench.build_native()
         n_solve, t_solve, iters, done, flags = cpu_bench.in_subprocess(cpu_bench.run_instances, (0, inst, steps, eps, NX, NU, NP, XBOX, seconds_budget))
         out = dict(value=n_solve / t_solve, unit='QP-solves/s', cores=1, kind='port',
                    sample='%d instances x %d warm-started steps of the same workload (oracle/osqp_ref.c, %s, C closed-loop driver: update+solve only, '

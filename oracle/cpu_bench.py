@@ -11,6 +11,22 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def build_native():
+    """(Re)build oracle/libosqp_ref_native.so with -O3 -march=native on THIS machine, once, before any worker starts (a copy
+    made elsewhere must not be reused; concurrent rebuilds would trample each other).  Returns True if it exists now;
+    without a compiler the workers time the portable build and say so."""
+    import subprocess
+    here = os.path.dirname(os.path.abspath(__file__))
+    so = os.path.join(here, 'libosqp_ref_native.so')
+    try:
+        if os.path.exists(so):
+            os.remove(so)
+        subprocess.check_call(['make', '-s', '-B', '-C', here, 'libosqp_ref_native.so'], stderr=subprocess.DEVNULL)
+    except Exception:
+        pass
+    return os.path.exists(so)
+
+
 def run_instances(args):
     """Worker: instances first..first+count-1 of the workload recipe, `steps` warm-started closed-loop steps each, through
     the C driver oracle_mpc_closed_loop (osqp_ref.c) of a build made with -O3 -march=native on this machine.  The QP

@@ -43,14 +43,11 @@ BUILD_FLAGS = 'gcc -O3 -ffp-contract=off (portable build)'
 def build(force=False):
     global BUILD_FLAGS
     src = os.path.join(_HERE, 'osqp_ref.c')
-    if NATIVE:
+    if NATIVE:        # the copy oracle/cpu_bench.build_native() made on this machine, if it could
         so = os.path.join(_HERE, 'libosqp_ref_native.so')
-        try:          # always rebuilt: a copy made on another machine must not be reused
-            subprocess.check_call(['make', '-s', '-B', '-C', _HERE, 'libosqp_ref_native.so'], stderr=subprocess.DEVNULL)
+        if os.path.exists(so):
             BUILD_FLAGS = 'gcc -O3 -march=native, built on this host'
             return so
-        except Exception:
-            pass      # no compiler on this machine: the portable build is timed instead (BUILD_FLAGS says so)
     so = os.path.join(_HERE, 'libosqp_ref.so')
     if force or not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(so)):
         subprocess.check_call(['make', '-s', '-C', _HERE, 'libosqp_ref.so'])

@@ -151,11 +151,14 @@ def test_cfg5_full_size_batch_properties():
     from pympc_amd import fixtures
     from pympc_amd.controller import MPCController
     B, nx, nu, Np = 512, 20, 8, 100
-    kws = [_complete(fixtures.random_lti(i, nx=nx, nu=nu, Np=Np, xbox=1.0)) for i in range(B)]
+    # bench.py's instances 0..511, except 276 (replaced by 512): cold-started at eps 1e-8, OSQP's adaptive-rho rule
+    # oscillates on it for ever -- in the CPU oracle exactly as on the GPU (both 'maximum iterations reached' after 400000
+    # iterations and ~845 rho updates; 143 s on the CPU, too slow to repeat here).  At the bench tolerance it solves.
+    kws = [_complete(fixtures.random_lti(i if i != 276 else 512, nx=nx, nu=nu, Np=Np, xbox=1.0)) for i in range(B)]
     K = _stacked_batch(kws, eps_abs=1e-8, eps_rel=1e-8, max_iter=400000)
     K.setup()
     U, info = K.output(return_status=True, return_x_seq=True, return_u_seq=True, return_eps_seq=True)
-    assert all(s == 'solved' for s in info['status'])
+    assert all(s == 'solved' for s in info['status']), [(i, s) for i, s in enumerate(info['status']) if s != 'solved']
     X, Us, Eps = info['x_seq'], info['u_seq'], info['eps_seq']
     Ad, Bd = K.Ad, K.Bd
     pred = np.einsum('bij,bkj->bki', Ad, X[:, :-1]) + np.einsum('bij,bkj->bki', Bd, Us)
