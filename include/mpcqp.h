@@ -152,8 +152,10 @@ int mpcqp_mpc_step(mpcqp_handle *h, const double *x0, const double *uminus1, con
  *   x_traj      [nsteps+1][batch][nx] states x_0..x_K (x_0 = the state of the last update/setup), or NULL
  *   u_traj      [nsteps][batch][nu] applied inputs, or NULL
  *   status_traj, iter_traj  [nsteps][batch] status / ADMM iterations of the solve after step k's update, or NULL
- * Host or device pointers.  Returns when the run is complete; afterwards the handle holds the solution for x_K
- * (mpcqp_get_solution / mpcqp_get_u0 work as after mpcqp_solve). */
+ * Host or device pointers.  Buffers in device memory are read and written in place by the kernel and the call is then
+ * stream-ordered (it returns without waiting, like mpcqp_get_u0 with a device destination); with any host output the call
+ * returns when the run is complete.  Afterwards the handle holds the solution for x_K (mpcqp_get_solution /
+ * mpcqp_get_u0 work as after mpcqp_solve). */
 int mpcqp_mpc_run(mpcqp_handle *h, int nsteps, const double *w, const double *Ap, const double *Bp,
                   double *x_traj, double *u_traj, int32_t *status_traj, int32_t *iter_traj);
 

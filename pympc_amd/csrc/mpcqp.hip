@@ -139,7 +139,9 @@ static Lay make_layout(int nx, int nu, int Np, int Nc) {
     L.model_sz = o;
     L.step_sz = nx + nu + L.N * nx;
     L.xref_rows = 1;
-    L.fstage = L.NB * L.NB + (L.NB == 16 ? SinvFmt<16>::DOUBLES : SinvFmt<32>::DOUBLES);
+    L.fstage = L.NB == 16 ? FactorFmt<16>::STAGE : FactorFmt<32>::STAGE;
+    L.fhead = L.NB == 16 ? FactorFmt<16>::HEAD : FactorFmt<32>::HEAD;
+    L.ffwd = L.NB == 16 ? FactorFmt<16>::FWD : FactorFmt<32>::FWD;
     L.tsz = (L.m + L.N * L.NB) > 6 * L.NB * L.NB ? (L.m + L.N * L.NB) : 6 * L.NB * L.NB;   // [W (m) | Tc (N*NB)] or factor workspace
     return L;
 }
@@ -179,7 +181,7 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     const Lay &L = h->L;
     Ptrs &P = h->P; memset(&P, 0, sizeof(P));
     size_t B = (size_t)batch;
-    P.fsz = (long long)L.N * L.fstage;
+    P.fsz = (long long)L.fhead + (long long)L.N * L.fstage;
     int rc = 0;
     rc |= dalloc(h, &P.model, B * L.model_sz); rc |= dalloc(h, &P.step, B * L.step_sz);
     rc |= dalloc(h, &P.D, B * L.n); rc |= dalloc(h, &P.E, B * L.m); rc |= dalloc(h, &P.c, B);
@@ -466,10 +468,18 @@ extern "C" int mpcqp_mpc_loop(mpcqp_handle *h, int nsteps, const mpcqp_loop *io)
     const Lay &L = h->L;
     const size_t B = (size_t)h->batch, K = (size_t)nsteps, nx = L.nx, nu = L.nu;
     const size_t xblk = (size_t)L.xref_rows * nx;
-    // one staging block on the device; inputs are copied in, outputs copied out (host or device pointers alike)
-    struct Part { const void *src; void *dst; size_t bytes; size_t off; };
-    Part parts[16]; int np = 0; size_t total = 0;
-    auto add = [&](const void *src, void *dst, size_t bytes) { parts[np] = Part{src, dst, bytes, total}; total += (bytes + 15) & ~size_t(15); return np++; };
+    // Buffers the caller keeps in DEVICE memory are used in place (the kernel reads and writes them directly, the call is
+    // stream-ordered and returns without waiting); host buffers go through one staging block on the device: inputs are
+    // copied in before the launch, outputs copied out after it, and the call returns when they have arrived.
+    struct Part { const void *src; void *dst; size_t bytes; size_t off; bool direct; };
+    Part parts[16]; int np = 0; size_t total = 0; bool any_host_out = false;
+    auto add = [&](const void *src, void *dst, size_t bytes) {
+        const void *user = src ? src : dst;
+        const bool direct = bytes && user && is_device_ptr(user);
+        parts[np] = Part{src, dst, bytes, total, direct};
+        if (bytes && !direct) { total += (bytes + 15) & ~size_t(15); if (dst) any_host_out = true; }
+        return np++;
+    };
     const int iw = add(io->w, nullptr, io->w ? 8 * K * B * nx : 0);
     const int iA = add(io->Ap, nullptr, io->Ap ? 8 * B * nx * nx : 0), iB = add(io->Bp, nullptr, io->Bp ? 8 * B * nx * nu : 0);
     const int ir = add(io->xref_traj, nullptr, io->xref_traj ? 8 * K * B * xblk : 0);
@@ -487,9 +497,13 @@ extern "C" int mpcqp_mpc_loop(mpcqp_handle *h, int nsteps, const mpcqp_loop *io)
         h->run_bytes = total;
     }
     char *base = (char *)h->run_buf;
-    auto dev = [&](int i) -> void * { return parts[i].bytes ? base + parts[i].off : nullptr; };
+    auto dev = [&](int i) -> void * {
+        if (!parts[i].bytes) return nullptr;
+        if (parts[i].direct) return parts[i].src ? const_cast<void *>(parts[i].src) : parts[i].dst;
+        return base + parts[i].off;
+    };
     for (int i = 0; i < np; ++i)
-        if (parts[i].src && parts[i].bytes) HIPCHK(hipMemcpyAsync(dev(i), parts[i].src, parts[i].bytes, hipMemcpyDefault, h->stream));
+        if (parts[i].src && parts[i].bytes && !parts[i].direct) HIPCHK(hipMemcpyAsync(dev(i), parts[i].src, parts[i].bytes, hipMemcpyDefault, h->stream));
     RunArgs R; memset(&R, 0, sizeof(R));
     R.nsteps = nsteps;
     R.w = (const double *)dev(iw); R.Ap = (const double *)dev(iA); R.Bp = (const double *)dev(iB);
@@ -500,9 +514,11 @@ extern "C" int mpcqp_mpc_loop(mpcqp_handle *h, int nsteps, const mpcqp_loop *io)
     int rc = launch_run(h, R, 0);
     if (rc) return rc;
     for (int i = 0; i < np; ++i)
-        if (parts[i].dst && parts[i].bytes && get(h, parts[i].dst, dev(i), parts[i].bytes)) return MPCQP_ERR_HIP;
+        if (parts[i].dst && parts[i].bytes && !parts[i].direct && get(h, parts[i].dst, dev(i), parts[i].bytes)) return MPCQP_ERR_HIP;
+    const bool due = h->solves_since_balance >= BALANCE_EVERY;
+    if (!due && !any_host_out) return MPCQP_OK;               // everything the caller gets back is stream-ordered device memory
     HIPCHK(hipStreamSynchronize(h->stream));
-    return rebalance(h);
+    return due ? rebalance(h) : MPCQP_OK;
 }
 
 extern "C" int mpcqp_mpc_run(mpcqp_handle *h, int nsteps, const double *w, const double *Ap, const double *Bp,
@@ -608,8 +624,9 @@ extern "C" int mpcqp_get_stream_bytes(mpcqp_handle *h, int64_t *per_iter, int64_
     if (!h) return fail(MPCQP_ERR_ARG, "null handle");
     const Lay &L = h->L;
     const int64_t n = L.n, m = L.m, nq = L.n_x + L.n_u, NB = L.NB;
-    const int64_t sinv = L.fstage - NB * NB;
-    int64_t it = 2 * (int64_t)(L.N - 1) * NB * NB + (int64_t)L.N * sinv;
+    const int64_t sinv = L.fstage - L.ffwd;
+    int64_t it = L.ffwd ? 2 * (int64_t)(L.N - 1) * L.ffwd + (int64_t)L.N * sinv        // two-slot format
+                        : 2 * (int64_t)L.N * sinv + 2 * (int64_t)L.fhead;              // S^-1-only: S^-1 twice, [G | G'] by each sweeping wave
     if (!h->lds_state) it += (2 * n + 4 * m) /* x, z, y read + written */ + (m + L.n_x) /* omega */ + (n + L.n_x) /* s */ + nq /* q */;
     if (L.border) it += 2 * (int64_t)L.nu * L.N * NB;
     int64_t rd = (L.model_sz - L.hot_sz) + 2 * n + 2 * m /* D, s, E, omega */ + n + m /* dx, dy */;

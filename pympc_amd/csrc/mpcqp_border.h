@@ -42,7 +42,7 @@ __device__ void border_factor(const Ctx &c, const double *om, const double *sv, 
     for (int j = 0; j < nu; ++j) {                         // Z_j = T^-1 B_j
         for (int idx = tid; idx < NP; idx += NT) Tc[idx] = Bb[(size_t)j * NP + idx];
         __syncthreads();
-        kkt_core<NB>(core_args(L, F), Tc);
+        kkt_core<NB>(core_args(L, F, om), Tc);
         for (int idx = tid; idx < NP; idx += NT) Zb[(size_t)j * NP + idx] = Tc[idx];
         __syncthreads();
     }
@@ -121,7 +121,7 @@ __device__ void kkt_solve(const Ctx &c, const double *om, const double *sv, doub
     }
     __syncthreads();
     if (L.border) border_pre<NB>(L, bp.Bb, bp.Zb, bp.Sig, Tc, ubar, bp.red);
-    kkt_core<NB>(core_args(L, F), Tc);
+    kkt_core<NB>(core_args(L, F, om), Tc);
     if (L.border) border_post(L, NB, Tc, ubar);
     for (int idx = threadIdx.x; idx < L.N * NB; idx += NT) {
         int k = idx / NB, a = idx % NB;

@@ -42,6 +42,25 @@ typedef __attribute__((address_space(1))) const d4 cgd4;
 #define MPCQP_SYM_SINV 1
 #endif
 template <int NB> struct SinvFmt { static constexpr bool SYM = MPCQP_SYM_SINV && NB == 16; static constexpr int DOUBLES = SYM ? 164 : NB * NB; };
+// Which factor format a stage size uses.
+//   two-slot (16 x 16 stages): per stage [ forward matrix -Mh_k | S_k^-1 ]; the sweeps stream the forward matrices twice
+//       (elimination, transposed in the back substitution) and S^-1 once.
+//   S^-1-only (32 x 32 stages): per stage only S_k^-1, packed [ sym(S00) 164 | sym(S11) 164 | S01 256 ] doubles; the
+//       off-diagonal blocks K_{k,k+-1} are applied MATRIX-FREE from a constant fragment G = [[Ad, Bd], [0, c QDu']] held in
+//       registers, scaled by the stage's omega (mpcqp_sweeps.h, half_sweep_so).  The factor stream shrinks from
+//       3 NB^2 = 3072 to 2 x 584 doubles per stage and iteration (2.6x); the price is a dependent chain of two mat-vecs
+//       per stage instead of one -- worth it where the stream, not the chain, is the bound (large stages, few
+//       workgroups per CU).  Per instance the factor starts with a header [ G | G' ] in fragment order.
+#ifndef MPCQP_SONLY32
+#define MPCQP_SONLY32 1
+#endif
+template <int NB> struct FactorFmt {
+    static constexpr bool SONLY = MPCQP_SONLY32 && NB == 32;
+    static constexpr int SINV = SONLY ? (164 + 164 + 256) : (MPCQP_SYM_SINV && NB == 16 ? 164 : NB * NB);
+    static constexpr int FWD = SONLY ? 0 : NB * NB;
+    static constexpr int STAGE = FWD + SINV;
+    static constexpr int HEAD = SONLY ? 2 * NB * NB : 0;
+};
 typedef double d4u __attribute__((ext_vector_type(4), aligned(8)));
 typedef __attribute__((address_space(1))) const d4u cgd4u;
 __host__ __device__ inline int sym_cum(int R) { return 16 * R - 2 * R * (R - 1); }
@@ -104,7 +123,7 @@ __device__ int factor_all(const Ctx &c, const double *om, const double *sv, doub
             S[e] -= acc;
             // forward matrix of stage k (the backward sweep applies the same fragment transposed); the middle stage's
             // second forward matrix lives in the otherwise unused slot 0 of stage 0
-            F[(size_t)fwd_stage * L.fstage + frag_pos<NB>(a, b)] = -Mh[e];
+            if constexpr (!FactorFmt<NB>::SONLY) F[(size_t)fwd_stage * L.fstage + frag_pos<NB>(a, b)] = -Mh[e];
         }
         __syncthreads();
     };
@@ -113,7 +132,7 @@ __device__ int factor_all(const Ctx &c, const double *om, const double *sv, doub
         for (int e = tid; e < NB * NB; e += NT) {
             S[e] = kkt_diag_entry(c, om, sv, cc, k, e / NB, e % NB);
             Li[e] = 0.0;
-            if (k == N - 1) F[(size_t)k * L.fstage + e] = 0.0;      // the last stage has no forward matrix (stage 0's slot holds the middle's second one)
+            if constexpr (!FactorFmt<NB>::SONLY) { if (k == N - 1) F[(size_t)k * L.fstage + e] = 0.0; }     // the last stage has no forward matrix (stage 0's slot holds the middle's second one)
         }
         if (use_up) eliminate_neighbour(k, true, SnA);
         if (use_down) eliminate_neighbour(k, false, SnB);
@@ -148,13 +167,31 @@ __device__ int factor_all(const Ctx &c, const double *om, const double *sv, doub
             double acc = 0.0;
             for (int l = max(a, b); l < NB; ++l) acc += Li[l * NB + a] * Li[l * NB + b];
             SnOut[e] = acc;
-            if constexpr (SinvFmt<NB>::SYM) { if ((b >> 2) >= (a >> 2)) F[(size_t)k * L.fstage + NB * NB + sym_pos(a, b)] = acc; }
+            if constexpr (FactorFmt<NB>::SONLY) {                  // [ sym(S00) | sym(S11) | S01 ]
+                double *Fk = F + FactorFmt<NB>::HEAD + (size_t)k * L.fstage;
+                const int A_ = a >> 4, B_ = b >> 4, al = a & 15, bl = b & 15;
+                if (A_ == B_) { if ((bl >> 2) >= (al >> 2)) Fk[164 * A_ + sym_pos(al, bl)] = acc; }
+                else if (A_ == 0) Fk[328 + frag_pos<16>(al, bl)] = acc;
+            }
+            else if constexpr (SinvFmt<NB>::SYM) { if ((b >> 2) >= (a >> 2)) F[(size_t)k * L.fstage + NB * NB + sym_pos(a, b)] = acc; }
             else F[(size_t)k * L.fstage + NB * NB + frag_pos<NB>(a, b)] = acc;
         }
     };
     for (int k = 0; k < mid; ++k) stage(k, k > 0, false, SnA);
     for (int k = N - 1; k > mid; --k) stage(k, false, k < N - 1, SnB);
     stage(mid, true, true, SnA);
+    if constexpr (FactorFmt<NB>::SONLY) {      // header: G = [[Ad, Bd], [0, c QDu']] and G' as fragments (constant per instance)
+        constexpr int NBLK = NB / 16;
+        for (int e = tid; e < NB * NB; e += NT) {
+            const int r = e / NB, q = e % NB;
+            double g = 0.0;
+            if (r < L.nx) g = q < L.nx ? c.Ad()[r * L.nx + q] : (q < L.nb ? c.Bd()[r * L.nu + (q - L.nx)] : 0.0);
+            else if (r < L.nb && q >= L.nx && q < L.nb) g = cc * c.QDu()[(q - L.nx) * L.nu + (r - L.nx)];
+            F[frag_pos<NB>(r, q)] = g;
+            F[NB * NB + frag_pos<NB>(q, r)] = g;
+        }
+        (void)NBLK;
+    }
     __syncthreads();
     if (L.border) border_factor<NB>(c, om, sv, cc, F, bp.Bb, bp.Zb, bp.Sig, W, W + L.m, bp.red);
     return *iflag;

@@ -82,7 +82,7 @@ __device__ __noinline__ void run_factor_phase() {
     const int b = inst_of(P.perm);
     Ctx c{L, r.S.hot, P.model + (size_t)b * L.model_sz + L.hot_sz};
     factor_all<NB>(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], P.F + (size_t)b * P.fsz, r.S.T, r.S.iflag,
-                   border_ptrs(L, P, r.S.red));
+                   border_ptrs(L, P, r.S));
 }
 
 template <int NB, bool LDSSTATE, int NXT, int NUT, bool BORDER>
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(NT) void k_kkt_solve(Lay L, Ptrs P, const double *r
     const double *model = P.model + (size_t)b * L.model_sz, *step = P.step + (size_t)b * L.step_sz;
     load_common(L, model, step, S);
     Ctx c{L, S.hot, model + L.hot_sz};
-    kkt_solve<NB>(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], P.F + (size_t)b * P.fsz, rhs + (size_t)b * L.n, S.T + L.m, sol + (size_t)b * L.n, border_ptrs(L, P, S.red), S.tv);
+    kkt_solve<NB>(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], P.F + (size_t)b * P.fsz, rhs + (size_t)b * L.n, S.T + L.m, sol + (size_t)b * L.n, border_ptrs(L, P, S), S.tv);
     (void)tid;
 }
 

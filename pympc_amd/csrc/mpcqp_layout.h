@@ -19,7 +19,8 @@ struct Lay {
     int oQx, oQxN, oQu, oQDu, model_sz;
     int step_sz;                  // [x0 | um1 | xref(N*nx)]
     int xref_rows;                // 1 or N
-    int fstage;                   // doubles per factor stage: [forward matrix NB*NB | S^-1 (NB = 16: packed upper blocks, 164)]
+    int fstage;                   // doubles per factor stage (FactorFmt<NB>::STAGE): [forward matrix | S^-1] or packed S^-1 only
+    int fhead, ffwd;              // doubles of the per-instance factor header ([G | G'], S^-1-only format) / of a stage's forward matrix
     int tsz;                      // LDS work vector length: max(m, 4*NB*NB)
 };
 

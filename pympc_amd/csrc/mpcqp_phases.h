@@ -11,8 +11,13 @@ __device__ __forceinline__ int row_type(double E, double lo, double hi) {
 }
 __device__ __forceinline__ double row_rho(int type, double rho) { return type < 0 ? RHO_MIN : (type > 0 ? RHO_EQ_OVER_RHO_INEQ * rho : rho); }
 
-__device__ __forceinline__ BorderPtrs border_ptrs(const Lay &L, const Ptrs &P, double *red) {
-    BorderPtrs bp; bp.red = red;
+// Shared prologue: stage the hot model prefix and the step data in LDS.
+struct Smem {
+    double *T, *Qv, *hot, *x0s, *um1s, *red, *tv;
+    int *iflag;
+};
+__device__ __forceinline__ BorderPtrs border_ptrs(const Lay &L, const Ptrs &P, const Smem &S) {
+    BorderPtrs bp; bp.red = S.red;
     const size_t npb = (size_t)L.nu * L.N * L.NB;
     const int b = inst_of(P.perm);
     bp.Bb = L.border ? P.Bb + b * npb : nullptr;
@@ -21,11 +26,6 @@ __device__ __forceinline__ BorderPtrs border_ptrs(const Lay &L, const Ptrs &P, d
     return bp;
 }
 
-// Shared prologue: stage the hot model prefix and the step data in LDS.
-struct Smem {
-    double *T, *Qv, *hot, *x0s, *um1s, *red, *tv;
-    int *iflag;
-};
 __device__ __forceinline__ double *carve(double *&p, int n) { double *r = p; p += n; return r; }
 template <class PT>
 __device__ void smem_common(const Lay &L, const PT &P, double *&p, Smem &S) {
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(NT) void k_setup(Lay L, Ptrs P, mpcqp_settings S_) 
     for (int j = tid; j < L.n; j += NT) sv[j] = S_.sigma / (D[j] * D[j]);
     if (tid == 0) { P.c[b] = cc; P.rho[b] = rho; }
     __syncthreads();
-    int bad = factor_all<NB>(c, om, sv, cc, P.F + (size_t)b * P.fsz, S.T, S.iflag, border_ptrs(L, P, S.red));
+    int bad = factor_all<NB>(c, om, sv, cc, P.F + (size_t)b * P.fsz, S.T, S.iflag, border_ptrs(L, P, S));
     // cold start
     for (int j = tid; j < L.n; j += NT) { P.x[(size_t)b * L.n + j] = 0.0; P.xo[(size_t)b * L.n + j] = 0.0; }
     for (int r = tid; r < L.m; r += NT) { P.z[(size_t)b * L.m + r] = 0.0; P.y[(size_t)b * L.m + r] = 0.0; P.yo[(size_t)b * L.m + r] = 0.0; }
@@ -330,6 +330,10 @@ __device__ __forceinline__ int check_body(const Lay &L, const Ptrs &P, const mpc
 }
 
 // ---- hot-loop pieces.  NXT/NUT: compile-time nx/nu (0 = take them from the layout at run time).
+#ifndef MPCQP_HOT_U
+#define MPCQP_HOT_U 4
+#endif
+constexpr int HOT_U = MPCQP_HOT_U;                   // global-memory iterate: elements per thread whose loads are issued together
 template <int NXT> __device__ __forceinline__ int hx(const Lay &L) { return NXT ? NXT : L.nx; }
 template <int NUT> __device__ __forceinline__ int hu(const Lay &L) { return NUT ? NUT : L.nu; }
 template <int NXT> __device__ __forceinline__ int divx(const Lay &L, int v) { return NXT ? v / NXT : idiv(v, L.rnx); }
@@ -372,7 +376,9 @@ __device__ __forceinline__ void hot_rows_w(const Lay &L, cgdouble *om, const Hot
 #pragma unroll
         for (int j = 0; j < 4; ++j) { const int r = tid + NT * j; if (r < L.m) W[r] = h.om_r[j] * Z[r] - cc * Y[r]; }
     } else {
-        for (int r = tid; r < L.m; r += NT) W[r] = om[r] * Z[r] - cc * Y[r];
+        cgdouble *Zg = (cgdouble *)Z, *Yg = (cgdouble *)Y;
+#pragma unroll HOT_U
+        for (int r = tid; r < L.m; r += NT) W[r] = om[r] * Zg[r] - cc * Yg[r];
     }
     __syncthreads();
 }
@@ -384,13 +390,13 @@ __device__ __forceinline__ void hot_rhs(const Lay &L, const double *hot, cgdoubl
     const int nx = hx<NXT>(L), nu = hu<NUT>(L);
     const double *Ad = hot + L.oAd, *Bd = hot + L.oBd;
     const double cef = cc * hot[L.oeps];
-    auto element = [&](int idx, double sve, double qve, double ws, double svs, bool have) {
+    // xv / xe: the variable's and (x part) its slack's current value
+    auto element = [&](int idx, double sve, double qve, double ws, double svs, double xv, double xe) {
         const int k = idx / NB, a = idx % NB;
         double v = 0.0;
         if (a < nx) {
             const int e = k * nx + a;
-            if (!have) { sve = sv[e]; qve = qv[e]; ws = om[L.rs + e]; svs = sv[L.oe + e]; }
-            double rx = sve * X[e] - cc * qve - W[e];
+            double rx = sve * xv - cc * qve - W[e];
             if (k < L.Np) {
                 const double *w1 = W + (k + 1) * nx;
 #pragma unroll
@@ -398,13 +404,12 @@ __device__ __forceinline__ void hot_rhs(const Lay &L, const double *hot, cgdoubl
                 if (!NXT) for (int r = 0; r < nx; ++r) rx += Ad[r * nx + a] * w1[r];
             }
             const double wsoft = W[L.rs + e];
-            const double te = (svs * X[L.oe + e] + wsoft) / (cef + svs + ws);
+            const double te = (svs * xe + wsoft) / (cef + svs + ws);
             W[L.rs + e] = te;                      // only this thread ever reads W[soft row e]
             v = rx + wsoft - ws * te;
         } else if (a < nx + nu && k < L.Nc) {
             const int jj = a - nx, cu = k * nu + jj;
-            if (!have) { sve = sv[L.ou + cu]; qve = qv[L.n_x + cu]; }
-            double ru = sve * X[L.ou + cu] - cc * qve + W[L.ri + cu] - W[L.rdu + nu + cu];
+            double ru = sve * xv - cc * qve + W[L.ri + cu] - W[L.rdu + nu + cu];
             if (k == 0) ru += W[L.rdu + jj];
             if (cu > 0) ru += W[L.rdu + nu + cu - 1];
             const int s_end = (k == L.Nc - 1) ? L.Np : k + 1;
@@ -420,9 +425,34 @@ __device__ __forceinline__ void hot_rhs(const Lay &L, const double *hot, cgdoubl
     };
     if (REGV) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { const int idx = tid + NT * j; if (idx < L.N * NB) element(idx, h.sv_e[j], h.qv_e[j], h.om_s[j], h.sv_s[j], true); }
+        for (int j = 0; j < 2; ++j) {
+            const int idx = tid + NT * j, k = idx / NB, a = idx % NB;
+            if (idx < L.N * NB) {
+                const double xv = a < nx ? X[k * nx + a] : ((a < nx + nu && k < L.Nc) ? X[L.ou + k * nu + a - nx] : 0.0);
+                const double xe = a < nx ? X[L.oe + k * nx + a] : 0.0;
+                element(idx, h.sv_e[j], h.qv_e[j], h.om_s[j], h.sv_s[j], xv, xe);
+            }
+        }
     } else {
-        for (int idx = tid; idx < L.N * NB; idx += NT) element(idx, 0.0, 0.0, 0.0, 0.0, false);
+        // The iterate and the metric vectors live in global memory here (they do not fit LDS).  HOT_U elements per thread and
+        // pass: all their loads are issued first -- six dependent-latency round trips per element otherwise, one after
+        // the other -- through pointers the compiler knows to be global (a generic pointer means FLAT loads, which it may
+        // not reorder with the LDS stores of the element before).
+        cgdouble *Xg = (cgdouble *)X;
+        for (int i0 = tid; i0 < L.N * NB; i0 += HOT_U * NT) {
+            double sve[HOT_U], qve[HOT_U], ws[HOT_U], svs[HOT_U], xv[HOT_U], xe[HOT_U];
+#pragma unroll
+            for (int u = 0; u < HOT_U; ++u) {
+                const int idx = i0 + u * NT, k = idx / NB, a = idx % NB;
+                sve[u] = qve[u] = svs[u] = xv[u] = xe[u] = 0.0; ws[u] = 1.0;
+                if (idx < L.N * NB) {
+                    if (a < nx) { const int e = k * nx + a; sve[u] = sv[e]; qve[u] = qv[e]; ws[u] = om[L.rs + e]; svs[u] = sv[L.oe + e]; xv[u] = Xg[e]; xe[u] = Xg[L.oe + e]; }
+                    else if (a < nx + nu && k < L.Nc) { const int cu = k * nu + a - nx; sve[u] = sv[L.ou + cu]; qve[u] = qv[L.n_x + cu]; xv[u] = Xg[L.ou + cu]; }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < HOT_U; ++u) { const int idx = i0 + u * NT; if (idx < L.N * NB) element(idx, sve[u], qve[u], ws[u], svs[u], xv[u], xe[u]); }
+        }
     }
     __syncthreads();
 }
@@ -436,38 +466,52 @@ __device__ __forceinline__ void hot_update(const Lay &L, const double *hot, cons
     const int nx = hx<NXT>(L), nu = hu<NUT>(L);
     const double cef = cc * hot[L.oeps];
     // eps_t = te - (omega_soft / kappa) x_t ; x update for the x and eps variables
-    auto x_update = [&](int e, int k, int i, double ws, double svs) {
+    gdouble *Xg = (gdouble *)X, *Zg = (gdouble *)Z, *Yg = (gdouble *)Y;      // (used on the global-memory path only)
+    // xo / eo: current values of the variable and of its slack; returns the new ones
+    auto x_new = [&](int e, int k, int i, double ws, double svs, double xo, double eo, double &xn, double &en) {
         const double xt = Tc[k * NB + i];
         const double et = W[L.rs + e] - (ws / (cef + svs + ws)) * xt;
         W[L.rs + e] = et;
-        const double xo = X[e], eo = X[L.oe + e];
-        const double xn = alpha * xt + (1.0 - alpha) * xo, en = alpha * et + (1.0 - alpha) * eo;
-        X[e] = xn; X[L.oe + e] = en;
+        xn = alpha * xt + (1.0 - alpha) * xo; en = alpha * et + (1.0 - alpha) * eo;
         if (keep_delta) { dxg[e] = xn - xo; dxg[L.oe + e] = en - eo; }
     };
-    auto u_update = [&](int cu, int k, int jj) {
-        const double uo = X[L.ou + cu];
+    auto u_new = [&](int cu, int k, int jj, double uo) {
         const double un = alpha * Tc[k * NB + nx + jj] + (1.0 - alpha) * uo;
-        X[L.ou + cu] = un;
         if (keep_delta) dxg[L.ou + cu] = un - uo;
+        return un;
     };
     if (REGV) {                                          // same padded-variable -> thread map as hot_rhs
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int idx = tid + NT * j, k = idx / NB, a = idx % NB;
             if (idx < L.N * NB) {
-                if (a < nx) x_update(k * nx + a, k, a, h.om_s[j], h.sv_s[j]);
-                else if (a < nx + nu && k < L.Nc) u_update(k * nu + a - nx, k, a - nx);
+                if (a < nx) { const int e = k * nx + a; double xn, en; x_new(e, k, a, h.om_s[j], h.sv_s[j], X[e], X[L.oe + e], xn, en); X[e] = xn; X[L.oe + e] = en; }
+                else if (a < nx + nu && k < L.Nc) { const int cu = k * nu + a - nx; X[L.ou + cu] = u_new(cu, k, a - nx, X[L.ou + cu]); }
             }
         }
-    } else {
-        for (int e = tid; e < L.n_x; e += NT) {
-            const int k = divx<NXT>(L, e), i = e - k * nx;
-            x_update(e, k, i, om[L.rs + e], sv[L.oe + e]);
+    } else {                                             // global-memory iterate: HOT_U elements per pass, loads first (see hot_rhs)
+        for (int e0 = tid; e0 < L.n_x; e0 += HOT_U * NT) {
+            double ws[HOT_U], svs[HOT_U], xo[HOT_U], eo[HOT_U];
+#pragma unroll
+            for (int u = 0; u < HOT_U; ++u) {
+                const int e = min(e0 + u * NT, L.n_x - 1);
+                ws[u] = om[L.rs + e]; svs[u] = sv[L.oe + e]; xo[u] = Xg[e]; eo[u] = Xg[L.oe + e];
+            }
+#pragma unroll
+            for (int u = 0; u < HOT_U; ++u) {
+                const int e = e0 + u * NT;
+                if (e < L.n_x) { const int k = divx<NXT>(L, e), i = e - k * nx; double xn, en; x_new(e, k, i, ws[u], svs[u], xo[u], eo[u], xn, en); Xg[e] = xn; Xg[L.oe + e] = en; }
+            }
         }
-        for (int cu = tid; cu < L.n_u; cu += NT) {
-            const int k = divu<NUT>(L, cu), jj = cu - k * nu;
-            u_update(cu, k, jj);
+        for (int c0 = tid; c0 < L.n_u; c0 += HOT_U * NT) {
+            double uo[HOT_U];
+#pragma unroll
+            for (int u = 0; u < HOT_U; ++u) uo[u] = Xg[L.ou + min(c0 + u * NT, L.n_u - 1)];
+#pragma unroll
+            for (int u = 0; u < HOT_U; ++u) {
+                const int cu = c0 + u * NT;
+                if (cu < L.n_u) { const int k = divu<NUT>(L, cu), jj = cu - k * nu; Xg[L.ou + cu] = u_new(cu, k, jj, uo[u]); }
+            }
         }
     }
     __syncthreads();
@@ -521,7 +565,16 @@ __device__ __forceinline__ void hot_update(const Lay &L, const double *hot, cons
             if (r < L.m) { double zv = Z[r], yv = Y[r]; row_update(r, h.om_r[j], zv, yv); Z[r] = zv; Y[r] = yv; W[r] = h.om_r[j] * zv - cc * yv; }
         }
     } else {
-        for (int r = tid; r < L.m; r += NT) { double zv = Z[r], yv = Y[r]; const double w = om[r]; row_update(r, w, zv, yv); Z[r] = zv; Y[r] = yv; W[r] = w * zv - cc * yv; }
+        for (int r0 = tid; r0 < L.m; r0 += HOT_U * NT) {
+            double zv[HOT_U], yv[HOT_U], w[HOT_U];
+#pragma unroll
+            for (int u = 0; u < HOT_U; ++u) { const int r = min(r0 + u * NT, L.m - 1); zv[u] = Zg[r]; yv[u] = Yg[r]; w[u] = om[r]; }
+#pragma unroll
+            for (int u = 0; u < HOT_U; ++u) {
+                const int r = r0 + u * NT;
+                if (r < L.m) { row_update(r, w[u], zv[u], yv[u]); Zg[r] = zv[u]; Yg[r] = yv[u]; W[r] = w[u] * zv[u] - cc * yv[u]; }
+            }
+        }
     }
     __syncthreads();
 }
@@ -560,7 +613,7 @@ __device__ __forceinline__ void admm_body(const Lay &L, const HotPtrs &P, Smem &
             bp.Bb = (double *)P.Bb + b * npb; bp.Zb = (double *)P.Zb + b * npb; bp.Sig = (double *)P.Sig + (size_t)b * L.nu * L.nu;
         }
         if (BORDER) border_pre<NB>(L, bp.Bb, bp.Zb, bp.Sig, Tc, S.tv, S.red);
-        kkt_core<NB>(core_args(L, opaque_ptr(F)), Tc);
+        kkt_core<NB>(core_args(L, opaque_ptr(F), opaque_ptr((const double *)P.omega + (size_t)b * L.m)), Tc);
         if (BORDER) border_post(L, NB, Tc, S.tv);
 #ifndef MPCQP_ABL_NOPAR
         hot_update<NB, NXT, NUT, LDSSTATE>(L, S.hot, S.x0s, S.um1s, gom, gsv, hr, cc, alpha, X, Z, Y, W, Tc, keep_delta, dxg, dyg);

@@ -331,14 +331,6 @@ __device__ __forceinline__ void sinv_apply_lean(const int N, const int mid, cons
     }
 }
 
-// What the linear-system core needs to know about one instance.
-struct CoreArgs { int N, fstage; const double *F; };
-__device__ __forceinline__ CoreArgs core_args(const Lay &L, const double *F) {
-    CoreArgs a; a.N = L.N; a.fstage = L.fstage; a.F = F; return a;
-}
-
-// Twisted solve: forward elimination of the two half-chains (waves 0, 1), S^-1 of every stage (all waves; wave 0
-// closes the elimination at the middle first), back substitution outwards with the transposed forward matrices.
 #ifdef MPCQP_RUN_TIMING
 __device__ unsigned long long g_ticks[16];
 #define TICK(i) { unsigned long long t_ = wall_clock64(); if (threadIdx.x == 0) atomicAdd(&g_ticks[i], t_ - ttick); ttick = t_; }
@@ -347,6 +339,237 @@ __device__ unsigned long long g_ticks[16];
 #define TICK(i)
 #define TICK_START
 #endif
+
+// What the linear-system core needs to know about one instance.
+struct CoreArgs { int N, fstage, nx, nu, NcT, rdu; const double *F; const double *om; };
+__device__ __forceinline__ CoreArgs core_args(const Lay &L, const double *F, const double *om) {
+    CoreArgs a; a.N = L.N; a.fstage = L.fstage; a.nx = L.nx; a.nu = L.nu; a.NcT = L.NcT; a.rdu = L.rdu; a.F = F; a.om = om; return a;
+}
+
+// ------------------------------------------------------------------------------------------------
+// S^-1-only factor format (FactorFmt<NB>::SONLY): the twisted solve with the off-diagonal blocks applied matrix-free.
+//     forward   w_k = S_k^-1 ( b_k - K_{k,nbr} w_nbr )            top half: nbr = k-1, bottom half: nbr = k+1
+//     middle    x_m = S_m^-1 ( b_m - K_{m,m-1} w_{m-1} - K_{m,m+1} w_{m+1} )
+//     backward  x_k = w_k - S_k^-1 K_{k,nbr} x_nbr                top half: nbr = k+1, bottom half: nbr = k-1
+// With G = [[Ad, Bd], [0, c QDu']] (constant per instance, NB x NB, zero padded), om_s = omega of the dynamics rows of
+// stage s (x lanes; 1 on the others) and wd_s = omega of the Delta-u row that couples u_s[nu-1] with u_{s+1}[0] (mpc.py:570):
+//     -K_{k,k-1} v = mask_k . ( om_k . (G v) )      + e_{nx}      wd_{k-1} v[nx+nu-1]          (neighbour above: "up")
+//     -K_{k,k+1} v = mask_k . ( G' (om_{k+1} . v) ) + e_{nx+nu-1} wd_k     v[nx]               (neighbour below)
+// (kkt_sub_entry in mpcqp_qp.h is the entry-wise definition; mask_k clears the u rows of stages that carry no input and
+// the padding.)  A stage streams its packed S^-1 and 2 omega values per lane; G (top half forward, bottom half backward)
+// or G' sits in registers for the length of a sweep.
+// ------------------------------------------------------------------------------------------------
+template <int NB> struct SoCfg {
+    static constexpr int NBLK = NB / 16, NF = NBLK * NBLK;
+    static constexpr int NS = NB == 16 ? 1 : 3;               // streamed d4 per lane and stage: sym(S) | sym(S00), sym(S11), S01
+#ifndef MPCQP_SO_DEPTH
+#define MPCQP_SO_DEPTH 2
+#endif
+    static constexpr int DEPTH = MPCQP_SO_DEPTH;              // stages in flight (28 VGPRs each at NB = 32)
+};
+__device__ __forceinline__ d4 sym_window(const double *Fm, int lane) {
+    const int R = (lane >> 2) & 3;
+    const d4u w = *(cgd4u *)(Fm + 40 * (lane >> 4) + sym_cum(R) + (lane & 3) * (4 - R));
+    return d4{w[0], w[1], w[2], w[3]};
+}
+__device__ __forceinline__ d4 sym_expand16(const d4 w, int lane) {
+    const int R = (lane >> 2) & 3, k = lane >> 4, i = lane & 3;
+    const double t1 = lane_permute(w[3], 4 * (16 * i + 4 * ((R + 1) & 3) + k));
+    const double t2 = lane_permute(w[2], 4 * (16 * i + 4 * ((R + 2) & 3) + k));
+    const double t3 = lane_permute(w[1], 4 * (16 * i + 4 * ((R + 3) & 3) + k));
+    return d4{w[0], R + 1 >= 4 ? t1 : w[1], R + 2 >= 4 ? t2 : w[2], R + 3 >= 4 ? t3 : w[3]};
+}
+// fragment of the transposed 16 x 16 block: element (r, c) of B' = element (c, r) of B, i.e. step s of lane (k, b, i) is
+// step (4 - s) & 3 of lane (i, (b + s) & 3, k)
+__device__ __forceinline__ d4 frag_transpose16(const d4 w, int lane) {
+    const int b = (lane >> 2) & 3, k = lane >> 4, i = lane & 3;
+    return d4{lane_permute(w[0], 4 * (16 * i + 4 * b + k)), lane_permute(w[3], 4 * (16 * i + 4 * ((b + 1) & 3) + k)),
+              lane_permute(w[2], 4 * (16 * i + 4 * ((b + 2) & 3) + k)), lane_permute(w[1], 4 * (16 * i + 4 * ((b + 3) & 3) + k))};
+}
+template <int NB>
+__device__ __forceinline__ void so_load(const double *Fk, int lane, d4 *A) {
+    if constexpr (NB == 16) A[0] = sym_window(Fk, lane);
+    else { A[0] = sym_window(Fk, lane); A[1] = sym_window(Fk + 164, lane); A[2] = *(cgd4 *)(Fk + 328 + lane * 4); }
+}
+template <int NB>
+__device__ __forceinline__ void so_expand(const d4 *A, int lane, d4 *Sf) {
+    if constexpr (NB == 16) Sf[0] = sym_expand16(A[0], lane);
+    else { Sf[0] = sym_expand16(A[0], lane); Sf[3] = sym_expand16(A[1], lane); Sf[1] = A[2]; Sf[2] = frag_transpose16(A[2], lane); }
+}
+__device__ __forceinline__ double lane_bcast(double x, int src) {
+    const long long xi = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_readlane((int)xi, src), hi = __builtin_amdgcn_readlane((int)(xi >> 32), src);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+template <int NB> struct SoLane {                 // per-lane constants of the operand layout
+    int e[NB / 16];                               // own element per block
+    bool isx[NB / 16], isu[NB / 16];
+};
+template <int NB>
+__device__ __forceinline__ SoLane<NB> so_lane(const CoreArgs &a, int lane) {
+    SoLane<NB> q;
+#pragma unroll
+    for (int bi = 0; bi < NB / 16; ++bi) {
+        q.e[bi] = 16 * bi + vec_lane_offset(lane);
+        q.isx[bi] = q.e[bi] < a.nx; q.isu[bi] = q.e[bi] >= a.nx && q.e[bi] < a.nx + a.nu;
+    }
+    return q;
+}
+// value of element E of a stage vector held one double per lane and block (uniform E)
+template <int NB>
+__device__ __forceinline__ double so_element(const double *v, int E) {
+    const int l = E & 15, src = 16 * (l & 3) + 4 * (l >> 2);
+    if constexpr (NB == 16) return lane_bcast(v[0], src);
+    else { const double a0 = lane_bcast(v[0], src), a1 = lane_bcast(v[1], src); return (E >> 4) ? a1 : a0; }
+}
+// t = -K_{k,nbr} v   (UP: nbr = k-1, uses G; else nbr = k+1, uses G').  sc = om of stage max(k,nbr) on x lanes (1 elsewhere).
+template <int NB, bool UP>
+__device__ __forceinline__ void so_offdiag(const CoreArgs &a, const SoLane<NB> &q, const d4 *Gf, int k, const double *v,
+                                           const double *sc, double wd, double *t) {
+    constexpr int NBLK = NB / 16;
+    double in[NBLK], out[NBLK];
+#pragma unroll
+    for (int bi = 0; bi < NBLK; ++bi) { in[bi] = UP ? v[bi] : sc[bi] * v[bi]; out[bi] = 0.0; }
+    frag_matvec<NB>(Gf, in, out);
+    const int Esrc = UP ? a.nx + a.nu - 1 : a.nx, Edst = UP ? a.nx : a.nx + a.nu - 1;
+    const double cpl = wd * so_element<NB>(v, Esrc);
+    const bool has_u = k < a.NcT;
+#pragma unroll
+    for (int bi = 0; bi < NBLK; ++bi) {
+        const bool live = q.isx[bi] || (q.isu[bi] && has_u);
+        double r = UP ? sc[bi] * out[bi] : out[bi];
+        r = live ? r : 0.0;
+        if (q.e[bi] == Edst) r += cpl;
+        t[bi] = r;
+    }
+}
+template <int NB> struct SoStep { d4 S[SoCfg<NB>::NS]; double sc[NB / 16]; double wd; };
+template <int NB>
+__device__ __forceinline__ void so_step_load(const CoreArgs &a, const SoLane<NB> &q, int lane, int k, int nbr, SoStep<NB> &st) {
+    // Loads only -- nothing here may USE a loaded value (so_step_fix does, at consumption time): inside the scheduling
+    // fences of half_sweep_so a use would sit right behind its load and wait for it.
+    const int hi = max(k, nbr), lo = min(k, nbr);
+    cgdouble *om = (cgdouble *)a.om;
+#pragma unroll
+    for (int bi = 0; bi < NB / 16; ++bi) st.sc[bi] = om[hi * a.nx + (q.isx[bi] ? q.e[bi] : 0)];
+    st.wd = om[a.rdu + a.nu + min(lo, max(a.NcT - 2, 0)) * a.nu + a.nu - 1];      // (clamped: the row only exists for lo <= NcT-2)
+    so_load<NB>(a.F + FactorFmt<NB>::HEAD + (size_t)k * a.fstage, lane, st.S);
+}
+template <int NB>
+__device__ __forceinline__ void so_step_fix(const CoreArgs &a, const SoLane<NB> &q, int k, int nbr, const SoStep<NB> &st, double *sc, double &wd) {
+#pragma unroll
+    for (int bi = 0; bi < NB / 16; ++bi) sc[bi] = q.isx[bi] ? st.sc[bi] : 1.0;
+    wd = (max(k, nbr) < a.NcT) ? st.wd : 0.0;       // the coupling row exists only between two stages that carry inputs
+}
+// One half-chain: stages first+dir, first+2dir, ... (nsteps of them).  FWD: w_k = S_k^-1 (b_k + t_k), the first stage gets
+// w_first = S^-1 b_first;  BWD: x_k = w_k + S_k^-1 t_k, starting from x_first already in Tc.
+// The stage stream (packed S^-1, omega values) runs two stages ahead in two register slots -- the register file holds no
+// more.  A slot is refilled as soon as its contents have been expanded, and the refill loads are fenced with scheduling
+// barriers: left free, the machine scheduler spreads them over the stage and the waits it then needs end up as
+// s_waitcnt vmcnt(0)/(1) every other stage, i.e. no look-ahead at all (seen in the ISA).  With the fences the loads stay
+// a block, in source order, and the compiler's own accounting gives exact vmcnt(9) waits.
+template <int NB, bool FWD, bool UP>
+__device__ __forceinline__ void half_sweep_so(const CoreArgs &a, double *Tc, const int first, const int dir, const int nsteps) {
+    constexpr int NBLK = NB / 16, NF = SoCfg<NB>::NF;
+    const int lane = opaque_lane(threadIdx.x & 63);
+    const SoLane<NB> q = so_lane<NB>(a, lane);
+    double *tb = Tc + vec_lane_offset(lane);
+    const bool writer = vec_lane_writer(lane);
+    d4 Gf[NF];
+    frag_load<NB>(a.F + (UP ? 0 : NB * NB), lane, Gf);
+    auto stage_of = [&](int i) { return first + dir * i; };
+    auto clamp_i = [&](int i) { return i < nsteps ? i : nsteps; };       // (branch-free refills, see chain_sweep)
+    double run[NBLK];
+    if (FWD) {
+        d4 A0[SoCfg<NB>::NS], Sf[NF];
+        so_load<NB>(a.F + FactorFmt<NB>::HEAD + (size_t)first * a.fstage, lane, A0);
+        so_expand<NB>(A0, lane, Sf);
+        double in[NBLK];
+        vec_load<NB>(tb, first, in);
+#pragma unroll
+        for (int bi = 0; bi < NBLK; ++bi) run[bi] = 0.0;
+        frag_matvec<NB>(Sf, in, run);
+        vec_store<NB>(tb, first, run, writer);
+    } else {
+        vec_load<NB>(tb, first, run);
+    }
+    if (nsteps < 1) return;
+    SoStep<NB> ring[2];
+    __builtin_amdgcn_sched_barrier(0);
+    so_step_load<NB>(a, q, lane, stage_of(clamp_i(1)), stage_of(clamp_i(1) - 1), ring[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    so_step_load<NB>(a, q, lane, stage_of(clamp_i(2)), stage_of(clamp_i(2) - 1), ring[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    // (steps past the end repeat the last stage -- computed, not stored -- so that the loop body has no branches)
+    auto stage_step = [&](int i, int inext, SoStep<NB> &slot, bool valid) {
+        const int k = stage_of(i);
+        d4 Sf[NF];
+        double sc[NBLK], wd;
+        so_expand<NB>(slot.S, lane, Sf);
+        so_step_fix<NB>(a, q, k, k - dir, slot, sc, wd);
+        double own[NBLK], t[NBLK];
+        vec_load<NB>(tb, k, own);
+        so_offdiag<NB, UP>(a, q, Gf, k, run, sc, wd, t);
+#pragma unroll
+        for (int bi = 0; bi < NBLK; ++bi) { if (FWD) { t[bi] += own[bi]; run[bi] = 0.0; } else run[bi] = own[bi]; }
+        frag_matvec<NB>(Sf, t, run);
+        if (writer && valid) {
+#pragma unroll
+            for (int bi = 0; bi < NBLK; ++bi) tb[k * NB + bi * 16] = run[bi];
+        }
+        // refill once nothing of the slot is live any more (parts of it pass unchanged into the expanded fragments: refilled
+        // earlier, the slot would move to other registers and come back through copies at the loop end -- behind a vmcnt(0))
+        __builtin_amdgcn_sched_barrier(0);
+        so_step_load<NB>(a, q, lane, stage_of(inext), stage_of(inext - 1), slot);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int i0 = 1; i0 <= nsteps; i0 += 2) {
+        stage_step(clamp_i(i0), clamp_i(i0 + 2), ring[0], true);
+        stage_step(clamp_i(i0 + 1), clamp_i(i0 + 3), ring[1], i0 + 1 <= nsteps);
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ void kkt_core_so(const CoreArgs &a, double *Tc) {
+    constexpr int NBLK = NB / 16, NF = SoCfg<NB>::NF;
+    const int N = a.N, mid = N / 2, wv = logical_wave(), lane = opaque_lane(threadIdx.x & 63);
+    TICK_START
+    if (wv == 0) half_sweep_so<NB, true, true>(a, Tc, 0, +1, mid - 1);                   // w_0 .. w_{mid-1}
+    else if (wv == 1) half_sweep_so<NB, true, false>(a, Tc, N - 1, -1, N - 2 - mid);     // w_{N-1} .. w_{mid+1}
+    __syncthreads();
+    TICK(1)
+    if (wv == 0) {                                                                       // the middle stage sees both halves
+        const SoLane<NB> q = so_lane<NB>(a, lane);
+        double *tb = Tc + vec_lane_offset(lane);
+        SoStep<NB> su, sd;
+        so_step_load<NB>(a, q, lane, mid, mid - 1, su);
+        so_step_load<NB>(a, q, lane, mid, mid + 1, sd);
+        d4 Gf[NF], Sf[NF];
+        double vu[NBLK], vd[NBLK], own[NBLK], tu[NBLK], td[NBLK], out[NBLK];
+        vec_load<NB>(tb, mid - 1, vu); vec_load<NB>(tb, mid + 1, vd); vec_load<NB>(tb, mid, own);
+        frag_load<NB>(a.F, lane, Gf);
+        double scu[NBLK], scd[NBLK], wdu, wdd;
+        so_step_fix<NB>(a, q, mid, mid - 1, su, scu, wdu);
+        so_step_fix<NB>(a, q, mid, mid + 1, sd, scd, wdd);
+        so_offdiag<NB, true>(a, q, Gf, mid, vu, scu, wdu, tu);
+        frag_load<NB>(a.F + NB * NB, lane, Gf);
+        so_offdiag<NB, false>(a, q, Gf, mid, vd, scd, wdd, td);
+        so_expand<NB>(su.S, lane, Sf);
+#pragma unroll
+        for (int bi = 0; bi < NBLK; ++bi) { tu[bi] += own[bi] + td[bi]; out[bi] = 0.0; }
+        frag_matvec<NB>(Sf, tu, out);
+        vec_store<NB>(tb, mid, out, vec_lane_writer(lane));
+    }
+    __syncthreads();
+    TICK(2)
+    if (wv == 0) half_sweep_so<NB, false, false>(a, Tc, mid, -1, mid);                   // x_{mid-1} .. x_0       (neighbour below)
+    else if (wv == 1) half_sweep_so<NB, false, true>(a, Tc, mid, +1, N - 1 - mid);       // x_{mid+1} .. x_{N-1}   (neighbour above)
+    __syncthreads();
+    TICK(3)
+}
+
+// Twisted solve: forward elimination of the two half-chains (waves 0, 1), S^-1 of every stage (all waves; wave 0
+// closes the elimination at the middle first), back substitution outwards with the transposed forward matrices.
 
 template <int NB>
 __device__ __forceinline__ void kkt_core_sweeps(const CoreArgs &a, double *Tc) {
@@ -381,7 +604,7 @@ __device__ __forceinline__ void kkt_core_sweeps(const CoreArgs &a, double *Tc) {
 template <int NB>
 __device__ __forceinline__ void kkt_core(const CoreArgs &a, double *Tc) {
 #ifndef MPCQP_ABL_NOCHAIN
-    kkt_core_sweeps<NB>(a, Tc);
+    if constexpr (FactorFmt<NB>::SONLY) kkt_core_so<NB>(a, Tc); else kkt_core_sweeps<NB>(a, Tc);
 #endif
     __syncthreads();
 }

@@ -17,7 +17,9 @@ ones = lambda k, s: np.full((B, k), s)
 prob.setup(d['Ad'], d['Bd'], eye(NX, 1.0), eye(NX, 1.0), eye(NU, .1), eye(NU, .1), ones(NX, -10.), ones(NX, 10.), ones(NU, -1.), ones(NU, 1.),
            ones(NU, -.5), ones(NU, .5), ones(NU, 0.), np.full((B, 1), 1e6), d['x0'], ones(NU, 0.), np.zeros((B, NX)))
 prob.iterate(10)
+prob.stats(reset=True)
 ts = []
 for _ in range(5):
     t = time.perf_counter(); prob.iterate(iters); ts.append(time.perf_counter() - t)
 print('%-40s B=%d  %.2f us/iteration (batch), min of 5' % (os.environ.get('MPCQP_LIB', 'default'), B, 1e6 * min(ts) / iters))
+prob.stats()        # (a -DMPCQP_RUN_TIMING build prints its per-phase tick sums here: 100 MHz ticks summed over workgroups)
