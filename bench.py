@@ -14,8 +14,7 @@ pyMPC/mpc.py:80), synthetic data, FP64, all inputs resident in HBM when the time
 
 Two ways through the same library, both measured, `--path` chooses which one is `value` (the other is `other_path`):
   device_loop (default): the K steps run inside mpcqp_mpc_loop launches (output -> plant -> update -> solve per
-                         instance on the device), launches of gcd(K, W) steps each so that warm-up and
-                         timed launches are the same kernel doing the same work;
+                         instance on the device, SURVEY 8f-1), at most 25 steps per launch (--chunk);
   stepwise             : the reference's call pattern, update()/solve()/output() per step from the host.
 Both give bit-identical trajectories (tests/test_gpu_parity.py::test_device_loop_*).
 
@@ -104,7 +103,7 @@ def main():
     ap.add_argument('--batch', type=int, default=None, help='instances per GPU (weak scaling; default 1024, cfg5: 512)')
     ap.add_argument('--total-batch', type=int, default=None, help='instances in total, split evenly over the GPUs (strong scaling)')
     ap.add_argument('--eps', type=float, default=1e-3)
-    ap.add_argument('--chunk', type=int, default=None, help='device loop: steps per kernel launch (default gcd(steps, warmup), at most 25)')
+    ap.add_argument('--chunk', type=int, default=None, help='device loop: steps per kernel launch (default: the timed steps in equal launches of at most 25)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-path', action='store_true', help='skip the secondary measurements (other path, parity setting)')
     ap.add_argument('--path', default='device_loop', choices=['stepwise', 'device_loop'],
@@ -221,12 +220,15 @@ def main():
         launch (warm-up and timed) does the same work; the disturbance sequence is synthetic input generated before
         the timed region; with N > 1 the applied inputs of a chunk are all-gathered after it."""
         nonlocal x
+        # steps per launch: a launch ends when its slowest instance has finished its steps (no instance can run ahead of its
+        # own closed loop), so short launches pay the spread of the per-instance iteration counts more often -- at cfg-3,
+        # 5-step launches cost 8 % against 20-step ones.  Default: the whole timed region in launches of at most 25 steps.
         if args.chunk:
             chunk = args.chunk
         else:
-            chunk = math.gcd(steps, warmup) if warmup > 0 else steps
-            while chunk > 25 and chunk % 2 == 0:
-                chunk //= 2
+            chunk = steps
+            while chunk > 25:
+                chunk = next((chunk // d for d in (2, 3, 5, 7) if chunk % d == 0), 25)
         w_all = 0.01 * torch.randn((warmup + steps, B, NX), dtype=f64, device=dev, generator=gen)
         outs = (torch.empty((chunk + 1, B, NX), dtype=f64, device=dev), torch.empty((chunk, B, NU), dtype=f64, device=dev),
                 torch.empty((chunk, B), dtype=torch.int32, device=dev), torch.empty((chunk, B), dtype=torch.int32, device=dev))

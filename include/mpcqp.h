@@ -12,6 +12,8 @@
  *                         + prob.setup(P,q,A,l,u, warm_start=True, eps_abs=, eps_rel=)
  *   mpcqp_update          MPCController.update(): _update_QP_matrices_  pyMPC/mpc.py:338-362,386-454
  *                         + prob.update(l=,u=,q=)
+ *   mpcqp_setup_qp        prob.setup(P,q,A,l,u,...) with caller-built vectors     pyMPC/mpc.py:266
+ *   mpcqp_update_vectors  prob.update(l=,u=,q=) with caller-built vectors         pyMPC/mpc.py:454
  *   mpcqp_solve           MPCController.solve():  prob.solve()          pyMPC/mpc.py:366-375
  *   mpcqp_get_solution    res.x / res.y / res.info.*                    pyMPC/mpc.py:301-327
  *   mpcqp_get_u0          output(): res.x[(Np+1)nx : (Np+1)nx+nu]        pyMPC/mpc.py:301-304
@@ -116,6 +118,20 @@ int mpcqp_setup(mpcqp_handle *h, const mpcqp_model *model,
  * refreshed on the device at the start of the next solve. */
 int mpcqp_update(mpcqp_handle *h, const double *x0, const double *uminus1,
                  const double *xref, int xref_rows);
+
+/* The solver seam as pyMPC itself uses it (mpc.py:266 prob.setup(P, q, A, l, u, ...), mpc.py:454 prob.update(l=, u=, q=)):
+ * the CALLER builds q, l, u (the reference's own _compute_QP_matrices_ / _update_QP_matrices_) and hands them over
+ * verbatim; the library takes q as is and decodes l, u into its bound tables.
+ *   mpcqp_setup_qp        the matrices P, A enter through the controller data they are made of (Ad, Bd, Qx, QxN, Qu, QDu,
+ *                         eps_feas: pympc_amd.qp_recover reads them back out of the reference-layout P and A and checks
+ *                         that rebuilding reproduces both exactly); model->xmin..Dumax are ignored, uref may be NULL;
+ *                         q [batch][n], l, u [batch][m] in the reference's layout.
+ *   mpcqp_update_vectors  any of q, l, u may be NULL (= unchanged), like osqp.update.  l and u must have the reference's
+ *                         structure (stage-periodic boxes, mpc.py:551-580) -- the host wrapper checks it.
+ * After either call the handle is in "raw vector" mode: solves use these vectors instead of rebuilding q, l, u from
+ * (x0, u_{-1}, xref); mpcqp_update / mpcqp_mpc_step switch back, mpcqp_mpc_loop refuses (MPCQP_ERR_STATE). */
+int mpcqp_setup_qp(mpcqp_handle *h, const mpcqp_model *model, const double *q, const double *l, const double *u);
+int mpcqp_update_vectors(mpcqp_handle *h, const double *q, const double *l, const double *u);
 
 /* Replace the iterate (osqp.warm_start(x=, y=)); x [batch][n], y [batch][m], NULL = keep. */
 int mpcqp_warm_start(mpcqp_handle *h, const double *x, const double *y);

@@ -137,7 +137,9 @@ static Lay make_layout(int nx, int nu, int Np, int Nc) {
     L.hot_sz = o;
     L.oQx = o; o += nx * nx; L.oQxN = o; o += nx * nx; L.oQu = o; o += nu * nu; L.oQDu = o; o += nu * nu;
     L.model_sz = o;
-    L.step_sz = nx + nu + L.N * nx;
+    L.odu0 = nx + nu + L.N * nx;
+    L.step_sz = L.odu0 + 2 * nu;
+    L.raw = 0;
     L.xref_rows = 1;
     L.fstage = L.NB == 16 ? FactorFmt<16>::STAGE : FactorFmt<32>::STAGE;
     L.fhead = L.NB == 16 ? FactorFmt<16>::HEAD : FactorFmt<32>::HEAD;
@@ -236,6 +238,13 @@ extern "C" int mpcqp_synchronize(mpcqp_handle *h) {
     return MPCQP_OK;
 }
 
+// true if p points to device memory (results copied there are stream-ordered: the call need not wait for them)
+static bool is_device_ptr(const void *p) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return attr.type == hipMemoryTypeDevice;
+}
+
 // Device scratch of one call: freed when the call returns, on every path.
 struct Scratch {
     std::vector<void *> ptrs;
@@ -304,7 +313,76 @@ extern "C" int mpcqp_update(mpcqp_handle *h, const double *x0, const double *um1
     if (!h) return fail(MPCQP_ERR_ARG, "null handle");
     if (!h->is_setup) return fail(MPCQP_ERR_STATE, "mpcqp_update before mpcqp_setup");
     HIPCHK(hipSetDevice(h->device));
+    h->L.raw = 0;                                   // q, l, u are rebuilt from (x0, u_{-1}, xref) again
     return step_upload(h, x0, um1, xref, xref_rows);
+}
+
+// Stage a [batch][w] array on the device if it lives in host memory (the decode kernel reads it there).
+static int stage_in(mpcqp_handle *h, Scratch &sc, const double *src, size_t count, const double **dev) {
+    *dev = nullptr;
+    if (!src) return 0;
+    if (is_device_ptr(src)) { *dev = src; return 0; }
+    double *d = nullptr;
+    HIPCHK(sc.get(&d, count));
+    HIPCHK(hipMemcpyAsync(d, src, count * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    *dev = d;
+    return 0;
+}
+
+static int upload_vectors(mpcqp_handle *h, const double *q, const double *l, const double *u) {
+    const Lay &L = h->L; const size_t B = (size_t)h->batch;
+    Scratch sc;
+    const double *dq, *dl, *du;
+    if (stage_in(h, sc, q, B * L.n, &dq) || stage_in(h, sc, l, B * L.m, &dl) || stage_in(h, sc, u, B * L.m, &du)) return MPCQP_ERR_HIP;
+    hipLaunchKernelGGL(k_decode_vectors, dim3(h->batch), dim3(64), 0, h->stream, h->L, h->P, dq, dl, du, h->batch);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(h->stream));        // (the staging copies are freed on return)
+    return MPCQP_OK;
+}
+
+extern "C" int mpcqp_update_vectors(mpcqp_handle *h, const double *q, const double *l, const double *u) {
+    if (!h) return fail(MPCQP_ERR_ARG, "null handle");
+    if (!h->is_setup) return fail(MPCQP_ERR_STATE, "mpcqp_update_vectors before setup");
+    HIPCHK(hipSetDevice(h->device));
+    if (!h->L.raw) {
+        // entering raw mode: the vectors that are NOT given now must keep describing the current problem, so the
+        // tables behind them are materialised once from the controller data (q from (xref, uref, u_{-1}); du0 from u_{-1})
+        if (!q || !l || !u) {
+            DISPATCH_NB(h->L.NB, {
+                if (set_smem(k_export<NB>, h->smem_setup)) return MPCQP_ERR_HIP;
+                hipLaunchKernelGGL(k_export<NB>, dim3(h->batch), dim3(NT), h->smem_setup, h->stream, h->L, h->P, (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr, (double *)nullptr);
+            });
+            HIPCHK(hipGetLastError());
+            hipLaunchKernelGGL(k_keep_du0, dim3((h->batch * h->L.nu + 255) / 256), dim3(256), 0, h->stream, h->L, h->P, h->batch);
+            HIPCHK(hipGetLastError());
+        }
+        h->L.raw = 1;
+    }
+    return upload_vectors(h, q, l, u);
+}
+
+extern "C" int mpcqp_setup_qp(mpcqp_handle *h, const mpcqp_model *M, const double *q, const double *l, const double *u) {
+    if (!h || !M || !q || !l || !u) return fail(MPCQP_ERR_ARG, "mpcqp_setup_qp: null argument");
+    if (!M->Ad || !M->Bd || !M->Qx || !M->QxN || !M->Qu || !M->QDu || !M->eps_feas) return fail(MPCQP_ERR_ARG, "mpcqp_setup_qp: null model field");
+    HIPCHK(hipSetDevice(h->device));
+    const Lay &L = h->L; const int nx = L.nx, nu = L.nu, ms = L.model_sz;
+    double *mb = h->P.model;
+    int rc = 0;
+    rc |= put(h, mb, ms, L.oAd, M->Ad, nx * nx); rc |= put(h, mb, ms, L.oBd, M->Bd, nx * nu);
+    rc |= put(h, mb, ms, L.oeps, M->eps_feas, 1);
+    if (M->uref) rc |= put(h, mb, ms, L.ouref, M->uref, nu);          // (only output()'s u_failure reads it; zeros otherwise)
+    rc |= put(h, mb, ms, L.oQx, M->Qx, nx * nx); rc |= put(h, mb, ms, L.oQxN, M->QxN, nx * nx);
+    rc |= put(h, mb, ms, L.oQu, M->Qu, nu * nu); rc |= put(h, mb, ms, L.oQDu, M->QDu, nu * nu);
+    if (rc) return MPCQP_ERR_HIP;
+    h->L.raw = 1;
+    if ((rc = upload_vectors(h, q, l, u))) return rc;
+    DISPATCH_NB(L.NB, {
+        if (set_smem(k_setup<NB>, h->smem_setup)) return MPCQP_ERR_HIP;
+        hipLaunchKernelGGL(k_setup<NB>, dim3(h->batch), dim3(NT), h->smem_setup, h->stream, h->L, h->P, h->S);
+    });
+    HIPCHK(hipGetLastError());
+    h->is_setup = true;
+    return MPCQP_OK;
 }
 
 extern "C" int mpcqp_update_settings(mpcqp_handle *h, const mpcqp_settings *s) {
@@ -441,13 +519,6 @@ extern "C" int mpcqp_iterate(mpcqp_handle *h, int iters) {
     return launch_solve(h, iters);
 }
 
-// true if p points to device memory (results copied there are stream-ordered: the call need not wait for them)
-static bool is_device_ptr(const void *p) {
-    hipPointerAttribute_t attr;
-    if (hipPointerGetAttributes(&attr, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return attr.type == hipMemoryTypeDevice;
-}
-
 static int get(mpcqp_handle *h, void *dst, const void *src, size_t bytes) {
     if (!dst) return 0;
     HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, h->stream));
@@ -465,6 +536,7 @@ extern "C" int mpcqp_mpc_loop(mpcqp_handle *h, int nsteps, const mpcqp_loop *io)
         return fail(MPCQP_ERR_ARG, "mpcqp_mpc_loop: xref_rows must be 0 (as last uploaded), 1 or Np+1");
     HIPCHK(hipSetDevice(h->device));
     if (io->xref_traj && io->xref_rows) h->L.xref_rows = io->xref_rows;     // update(x, u, xref_k) with this reference shape
+    if (h->L.raw) return fail(MPCQP_ERR_STATE, "mpcqp_mpc_loop: the handle holds raw q, l, u (mpcqp_update_vectors); call mpcqp_update first");
     const Lay &L = h->L;
     const size_t B = (size_t)h->batch, K = (size_t)nsteps, nx = L.nx, nu = L.nu;
     const size_t xblk = (size_t)L.xref_rows * nx;
@@ -555,6 +627,7 @@ extern "C" int mpcqp_mpc_step(mpcqp_handle *h, const double *x0, const double *u
     if (!h || !x0 || !u_out) return fail(MPCQP_ERR_ARG, "mpcqp_mpc_step: null argument");
     if (!h->is_setup) return fail(MPCQP_ERR_STATE, "mpcqp_mpc_step before mpcqp_setup");
     HIPCHK(hipSetDevice(h->device));
+    h->L.raw = 0;
     int rc = step_upload(h, x0, uminus1, xref, xref_rows);
     if (rc) return rc;
     if ((rc = launch_solve(h, 0))) return rc;

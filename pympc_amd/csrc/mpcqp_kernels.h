@@ -172,7 +172,7 @@ __global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_mpc_run(RunKArgs A_)
             }
             // ---- update(x): new initial state, previous input (mpc.py:338-364) and, if given, reference
             if (tid < nx) { S.x0s[tid] = xn[tid]; step[tid] = xn[tid]; }
-            if (tid < nu) { S.um1s[tid] = un[tid]; step[nx + tid] = un[tid]; }
+            if (tid < nu) { S.um1s[tid] = un[tid]; step[nx + tid] = un[tid]; S.du0[tid] = S.hot[L.oDumin + tid] + un[tid]; S.du0[nu + tid] = S.hot[L.oDumax + tid] + un[tid]; }
             if (R.xref_traj) for (int i = tid; i < R.xref_blk; i += NT) step[nx + nu + i] = R.xref_traj[kb * R.xref_blk + i];
             __syncthreads();
         }
@@ -225,12 +225,12 @@ __global__ __launch_bounds__(NT) void k_export(Lay L, Ptrs P, double *Pd, double
     const double *model = P.model + (size_t)b * L.model_sz, *step = P.step + (size_t)b * L.step_sz;
     load_common(L, model, step, S);
     Ctx c{L, S.hot, model + L.hot_sz};
-    build_q(c, step, S.Qv);
+    if (!L.raw) build_q(c, step, S.Qv);
     __syncthreads();
     if (Pd) { double *o = Pd + (size_t)b * L.n * L.n; for (int j = tid; j < L.n; j += NT) P_row(c, j, [&](double co, int idx) { o[(size_t)j * L.n + idx] = co; }); }
     if (Ad_) { double *o = Ad_ + (size_t)b * L.m * L.n; for (int r = tid; r < L.m; r += NT) A_row(c, r, [&](double co, int idx) { o[(size_t)r * L.n + idx] = co; }); }
     if (q) for (int j = tid; j < L.n; j += NT) q[(size_t)b * L.n + j] = (j < L.oe) ? S.Qv[j] : 0.0;
-    if (l && u) for (int r = tid; r < L.m; r += NT) { double lo, hi; row_bounds(c, S.x0s, S.um1s, r, lo, hi); l[(size_t)b * L.m + r] = lo; u[(size_t)b * L.m + r] = hi; }
+    if (l && u) for (int r = tid; r < L.m; r += NT) { double lo, hi; row_bounds(c, S.x0s, S.du0, r, lo, hi); l[(size_t)b * L.m + r] = lo; u[(size_t)b * L.m + r] = hi; }
 }
 
 template <int NB>
@@ -248,6 +248,37 @@ __global__ __launch_bounds__(NT) void k_kkt_solve(Lay L, Ptrs P, const double *r
 __global__ void k_gather_u0(Lay L, const double *xo, double *u0, int batch) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < batch * L.nu) { int b = i / L.nu, j = i - b * L.nu; u0[i] = xo[(size_t)b * L.n + L.ou + j]; }
+}
+
+// mpcqp_update_vectors: raw q, l, u of the reference's layout (mpc.py:593-599) -> the tables the kernels work from.
+// q: the x,u part verbatim (the slack part of the reference's q is identically zero).  l, u: row blocks are stage-periodic
+// in the reference (mpc.py:551-580), so one period is stored: x0 = -l[:nx]; state box = soft rows of stage 0; input box =
+// rows of u_0; Delta-u bounds = the rows behind the first nu (which carry Dumin/Dumax + u_{-1} and are kept verbatim).
+__global__ void k_decode_vectors(Lay L, Ptrs P, const double *q, const double *l, const double *u, int batch) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    double *model = P.model + (size_t)b * L.model_sz, *step = P.step + (size_t)b * L.step_sz;
+    if (q) for (int j = tid; j < L.n_x + L.n_u; j += blockDim.x) P.qv[(size_t)b * (L.n_x + L.n_u) + j] = q[(size_t)b * L.n + j];
+    const double *lb = l ? l + (size_t)b * L.m : nullptr, *ub = u ? u + (size_t)b * L.m : nullptr;
+    for (int i = tid; i < L.nx; i += blockDim.x) {
+        if (lb) { step[i] = -lb[i]; model[L.oxmin + i] = lb[L.rs + i]; } else if (ub) step[i] = -ub[i];
+        if (ub) model[L.oxmax + i] = ub[L.rs + i];
+    }
+    for (int j = tid; j < L.nu; j += blockDim.x) {
+        if (lb) { model[L.oumin + j] = lb[L.ri + j]; model[L.oDumin + j] = lb[L.rdu + L.nu + j]; step[L.odu0 + j] = lb[L.rdu + j]; }
+        if (ub) { model[L.oumax + j] = ub[L.ri + j]; model[L.oDumax + j] = ub[L.rdu + L.nu + j]; step[L.odu0 + L.nu + j] = ub[L.rdu + j]; }
+    }
+    (void)batch;
+}
+
+// entering raw-vector mode with only some of q, l, u given: the first Delta-u rows keep their current bounds Dumin/Dumax + u_{-1}
+__global__ void k_keep_du0(Lay L, Ptrs P, int batch) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < batch * L.nu) {
+        const int b = i / L.nu, j = i - b * L.nu;
+        const double *model = P.model + (size_t)b * L.model_sz; double *step = P.step + (size_t)b * L.step_sz;
+        step[L.odu0 + j] = model[L.oDumin + j] + step[L.nx + j];
+        step[L.odu0 + L.nu + j] = model[L.oDumax + j] + step[L.nx + j];
+    }
 }
 
 // output() of mpc.py:271-336 for the whole batch: u = first input of the solution if the status is 'solved', else

@@ -17,7 +17,9 @@ struct Lay {
     // model blob: hot prefix [Ad|Bd|xmin|xmax|umin|umax|Dumin|Dumax|uref|eps_feas] then [Qx|QxN|Qu|QDu]
     int oAd, oBd, oxmin, oxmax, oumin, oumax, oDumin, oDumax, ouref, oeps, hot_sz;
     int oQx, oQxN, oQu, oQDu, model_sz;
-    int step_sz;                  // [x0 | um1 | xref(N*nx)]
+    int step_sz;                  // [x0 | um1 | xref(N*nx) | du0lo(nu) | du0hi(nu)]  (the last two: raw-vector mode only)
+    int odu0;                     // offset of du0lo in the step blob
+    int raw;                      // 1: q and the bounds are what mpcqp_update_vectors uploaded (not rebuilt from x0, u_{-1}, xref)
     int xref_rows;                // 1 or N
     int fstage;                   // doubles per factor stage (FactorFmt<NB>::STAGE): [forward matrix | S^-1] or packed S^-1 only
     int fhead, ffwd;              // doubles of the per-instance factor header ([G | G'], S^-1-only format) / of a stage's forward matrix

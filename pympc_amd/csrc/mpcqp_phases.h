@@ -13,7 +13,7 @@ __device__ __forceinline__ double row_rho(int type, double rho) { return type < 
 
 // Shared prologue: stage the hot model prefix and the step data in LDS.
 struct Smem {
-    double *T, *Qv, *hot, *x0s, *um1s, *red, *tv;
+    double *T, *Qv, *hot, *x0s, *um1s, *du0, *red, *tv;
     int *iflag;
 };
 __device__ __forceinline__ BorderPtrs border_ptrs(const Lay &L, const Ptrs &P, const Smem &S) {
@@ -34,16 +34,23 @@ __device__ void smem_common(const Lay &L, const PT &P, double *&p, Smem &S) {
     S.hot = carve(p, L.hot_sz);
     S.x0s = carve(p, L.nx);
     S.um1s = carve(p, L.nu);
+    S.du0 = carve(p, 2 * L.nu);
     S.red = carve(p, 64);
     S.tv = carve(p, 64);
     S.iflag = (int *)carve(p, 2);
 }
-__host__ __device__ inline int smem_common_doubles(const Lay &L) { return L.tsz + L.hot_sz + L.nx + L.nu + 64 + 64 + 2; }
+__host__ __device__ inline int smem_common_doubles(const Lay &L) { return L.tsz + L.hot_sz + L.nx + 3 * L.nu + 64 + 64 + 2; }
 
 __device__ void load_common(const Lay &L, const double *model, const double *step, Smem &S) {
     for (int i = threadIdx.x; i < L.hot_sz; i += NT) S.hot[i] = model[i];
     for (int i = threadIdx.x; i < L.nx; i += NT) S.x0s[i] = step[i];
-    for (int i = threadIdx.x; i < L.nu; i += NT) S.um1s[i] = step[L.nx + i];
+    for (int i = threadIdx.x; i < L.nu; i += NT) {
+        const double um1 = step[L.nx + i];
+        S.um1s[i] = um1;
+        // first Delta-u rows: Dumin/Dumax + u_{-1} (mpc.py:407-408), or verbatim what mpcqp_update_vectors was given
+        S.du0[i] = L.raw ? step[L.odu0 + i] : model[L.oDumin + i] + um1;
+        S.du0[L.nu + i] = L.raw ? step[L.odu0 + L.nu + i] : model[L.oDumax + i] + um1;
+    }
     __syncthreads();
 }
 
@@ -58,7 +65,7 @@ __global__ __launch_bounds__(NT) void k_setup(Lay L, Ptrs P, mpcqp_settings S_) 
     const double *model = P.model + (size_t)b * L.model_sz, *step = P.step + (size_t)b * L.step_sz;
     load_common(L, model, step, S);
     Ctx c{L, S.hot, model + L.hot_sz};
-    build_q(c, step, S.Qv);
+    if (!L.raw) build_q(c, step, S.Qv);              // (raw vectors: q was uploaded by mpcqp_update_vectors)
     double *D = P.D + (size_t)b * L.n, *E = P.E + (size_t)b * L.m, *Dt = P.Dt + (size_t)b * L.n, *Et = P.Et + (size_t)b * L.m;
     for (int j = tid; j < L.n; j += NT) D[j] = 1.0;
     for (int r = tid; r < L.m; r += NT) E[r] = 1.0;
@@ -100,7 +107,7 @@ __global__ __launch_bounds__(NT) void k_setup(Lay L, Ptrs P, mpcqp_settings S_) 
     double *om = P.omega + (size_t)b * L.m, *sv = P.s + (size_t)b * L.n;
     int *ct = P.ctype + (size_t)b * L.m;
     for (int r = tid; r < L.m; r += NT) {
-        double lo, hi; row_bounds(c, S.x0s, S.um1s, r, lo, hi);
+        double lo, hi; row_bounds(c, S.x0s, S.du0, r, lo, hi);
         int t = row_type(E[r], lo, hi);
         ct[r] = t;
         om[r] = row_rho(t, rho) * E[r] * E[r];
@@ -137,7 +144,7 @@ __device__ __forceinline__ void begin_body(const Lay &L, const Ptrs &P, const mp
     const int b = inst_of(P.perm), tid = threadIdx.x;
     const double *model = P.model + (size_t)b * L.model_sz, *step = P.step + (size_t)b * L.step_sz;
     Ctx c{L, S.hot, model + L.hot_sz};
-    build_q(c, step, S.Qv);
+    if (!L.raw) build_q(c, step, S.Qv);
     double *gx = P.x + (size_t)b * L.n, *gz = P.z + (size_t)b * L.m, *gy = P.y + (size_t)b * L.m;
     if (!(S_.warm_start || plain)) {
         for (int j = tid; j < L.n; j += NT) gx[j] = 0.0;
@@ -152,7 +159,7 @@ __device__ __forceinline__ void begin_body(const Lay &L, const Ptrs &P, const mp
     const double rho = P.rho[b];
     int changed = 0;
     for (int r = tid; r < L.m; r += NT) {
-        double lo, hi; row_bounds(c, S.x0s, S.um1s, r, lo, hi);
+        double lo, hi; row_bounds(c, S.x0s, S.du0, r, lo, hi);
         int t = row_type(E[r], lo, hi);
         if (t != ctp[r]) { changed = 1; ctp[r] = t; om[r] = row_rho(t, rho) * E[r] * E[r]; }
     }
@@ -225,7 +232,7 @@ __device__ __forceinline__ int check_body(const Lay &L, const Ptrs &P, const mpc
         // v = c * delta_y (= E * scaled delta_y), projected on the polar of the recession cone of [l,u]
         double vmax[1] = {0.0}, vs[1] = {0.0};
         for (int r = tid; r < L.m; r += NT) {
-            double lo, hi; row_bounds(c, S.x0s, S.um1s, r, lo, hi);
+            double lo, hi; row_bounds(c, S.x0s, S.du0, r, lo, hi);
             double e = E[r], v = cc * dyg[r];
             if (e * hi > QP_INFTY * MIN_SCALING) { if (e * lo < -QP_INFTY * MIN_SCALING) v = 0.0; else v = fmin(v, 0.0); }
             else if (e * lo < -QP_INFTY * MIN_SCALING) v = fmax(v, 0.0);
@@ -263,7 +270,7 @@ __device__ __forceinline__ int check_body(const Lay &L, const Ptrs &P, const mpc
         }
         for (int r = tid; r < L.m; r += NT) {
             double a = 0.0; A_row(c, r, [&](double co, int idx) { a += co * dxg[idx]; });
-            double lo, hi; row_bounds(c, S.x0s, S.um1s, r, lo, hi);
+            double lo, hi; row_bounds(c, S.x0s, S.du0, r, lo, hi);
             double e = E[r];
             if ((e * hi < QP_INFTY * MIN_SCALING && a > eps * nd) || (e * lo > -QP_INFTY * MIN_SCALING && a < -eps * nd)) bad[0] = 1.0;
         }
@@ -459,7 +466,7 @@ __device__ __forceinline__ void hot_rhs(const Lay &L, const double *hot, cgdoubl
 
 // Steps (4)-(6): slack back-substitution, zt = A xt, relaxation, projection on [l,u], dual update, x update.
 template <int NB, int NXT, int NUT, bool REGV>
-__device__ __forceinline__ void hot_update(const Lay &L, const double *hot, const double *x0s, const double *um1s,
+__device__ __forceinline__ void hot_update(const Lay &L, const double *hot, const double *x0s, const double *du0,
                                            cgdouble *om, cgdouble *sv, const HotRegs &h, double cc, double alpha,
                                            double *X, double *Z, double *Y, double *W, const double *Tc, bool keep_delta, gdouble *dxg, gdouble *dyg) {
     const int tid = opaque_lane(threadIdx.x);        // (keeps the per-thread index arithmetic out of LICM's reach: hoisted, it spills)
@@ -543,7 +550,7 @@ __device__ __forceinline__ void hot_update(const Lay &L, const double *hot, cons
         } else {                                          // Delta-u rows
             const int rr = r - L.rdu, kk = divu<NUT>(L, rr), jj = rr - kk * nu;
             lo = hot[L.oDumin + jj]; hi = hot[L.oDumax + jj];
-            if (rr < nu) { zt = Tc[nx + rr]; lo += um1s[jj]; hi += um1s[jj]; }
+            if (rr < nu) { zt = Tc[nx + rr]; lo = du0[jj]; hi = du0[nu + jj]; }
             else {
                 const int cu = rr - nu, k = kk - 1;       // cu = k*nu + jj
                 zt = -Tc[k * NB + nx + jj];
@@ -616,7 +623,7 @@ __device__ __forceinline__ void admm_body(const Lay &L, const HotPtrs &P, Smem &
         kkt_core<NB>(core_args(L, opaque_ptr(F), opaque_ptr((const double *)P.omega + (size_t)b * L.m)), Tc);
         if (BORDER) border_post(L, NB, Tc, S.tv);
 #ifndef MPCQP_ABL_NOPAR
-        hot_update<NB, NXT, NUT, LDSSTATE>(L, S.hot, S.x0s, S.um1s, gom, gsv, hr, cc, alpha, X, Z, Y, W, Tc, keep_delta, dxg, dyg);
+        hot_update<NB, NXT, NUT, LDSSTATE>(L, S.hot, S.x0s, S.du0, gom, gsv, hr, cc, alpha, X, Z, Y, W, Tc, keep_delta, dxg, dyg);
 #endif
         TICK(4)
     }

@@ -97,8 +97,8 @@ __device__ __forceinline__ void P_row(const Ctx &c, int j, F f) {
 }
 
 // Bounds of row r exactly as mpc.py:551-580 / 404-408 build them, clipped to +-1e30 like osqp's wrapper.
-// x0s/um1s: current x0 and u_{-1}.
-__device__ __forceinline__ void row_bounds(const Ctx &c, const double *x0s, const double *um1s, int r, double &lo, double &hi) {
+// x0s: current x0; du0: bounds of the first nu Delta-u rows, [lower | upper] = Dumin/Dumax + u_{-1} (load_common).
+__device__ __forceinline__ void row_bounds(const Ctx &c, const double *x0s, const double *du0, int r, double &lo, double &hi) {
     const Lay &L = c.L;
     if (r < L.rs) {
         lo = hi = (r < L.nx) ? -x0s[r] : 0.0;
@@ -111,7 +111,7 @@ __device__ __forceinline__ void row_bounds(const Ctx &c, const double *x0s, cons
     } else {
         int rr = r - L.rdu; int k = idiv(rr, L.rnu); int jj = rr - k * L.nu;
         lo = c.hot[L.oDumin + jj]; hi = c.hot[L.oDumax + jj];
-        if (rr < L.nu) { lo += um1s[jj]; hi += um1s[jj]; }
+        if (rr < L.nu) { lo = du0[jj]; hi = du0[L.nu + jj]; }
     }
     lo = lo < -QP_INFTY ? -QP_INFTY : lo;
     hi = hi > QP_INFTY ? QP_INFTY : hi;

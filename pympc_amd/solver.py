@@ -139,6 +139,32 @@ class BatchProblem:
         _lib.check(self._L.mpcqp_synchronize(self._h), 'mpcqp_synchronize')
         self._keep = []
 
+    def setup_qp(self, Ad, Bd, Qx, QxN, Qu, QDu, eps_feas, q, l, u, uref=None):
+        """The solver seam of mpc.py:266 with caller-built vectors (mpcqp_setup_qp): the matrices enter through the
+        blocks they are made of (pympc_amd.qp_recover reads them out of a reference-layout P, A), q [B,n], l, u [B,m]
+        verbatim."""
+        B, nx, nu = self.batch, self.nx, self.nu
+        arrs = dict(Ad=_prep(Ad, (B, nx, nx), 'Ad'), Bd=_prep(Bd, (B, nx, nu), 'Bd'), Qx=_prep(Qx, (B, nx, nx), 'Qx'),
+                    QxN=_prep(QxN, (B, nx, nx), 'QxN'), Qu=_prep(Qu, (B, nu, nu), 'Qu'), QDu=_prep(QDu, (B, nu, nu), 'QDu'),
+                    eps_feas=_prep(eps_feas, (B, 1), 'eps_feas'))
+        if uref is not None:
+            arrs['uref'] = _prep(uref, (B, nu), 'uref')
+        model = _lib.Model()
+        for k, v in arrs.items():
+            setattr(model, k, C.cast(_ptr(v), C.POINTER(C.c_double)))
+        qa, la, ua = _prep(q, (B, self.n), 'q'), self._bound(l, 'l'), self._bound(u, 'u')
+        _lib.check(self._L.mpcqp_setup_qp(self._h, C.byref(model), _ptr(qa), _ptr(la), _ptr(ua)), 'mpcqp_setup_qp')
+        _lib.check(self._L.mpcqp_synchronize(self._h), 'mpcqp_synchronize')
+
+    def _bound(self, v, name):
+        return None if v is None else _prep(v, (self.batch, self.m), name)
+
+    def update_vectors(self, q=None, l=None, u=None):
+        """osqp's update(q=, l=, u=) (mpc.py:454) with caller-built vectors; any of them may be None (unchanged)."""
+        qa = None if q is None else _prep(q, (self.batch, self.n), 'q')
+        la, ua = self._bound(l, 'l'), self._bound(u, 'u')
+        _lib.check(self._L.mpcqp_update_vectors(self._h, _ptr(qa), _ptr(la), _ptr(ua)), 'mpcqp_update_vectors')
+
     def _xref_rows(self, xref):
         shape = tuple(xref.shape)
         per = int(np.prod(shape[1:])) if len(shape) > 1 and shape[0] == self.batch else int(np.prod(shape))
@@ -323,15 +349,44 @@ class BatchProblem:
 
 
 class DeviceProblem:
-    """Single-instance adapter with osqp's call shapes, kept by ``MPCController.prob``."""
+    """Single-instance adapter with osqp's call shapes, kept by ``MPCController.prob`` -- and usable in the REFERENCE's own
+    class in place of ``osqp.OSQP()`` (mpc.py:241): ``setup(P, q, A, l, u, **settings)``, ``update(q=, l=, u=)``,
+    ``solve()`` work on the caller's vectors (the seam of mpc.py:266,454,369).  ``pympc_amd.MPCController`` additionally
+    passes ``mpc=`` / ``mpc_step=`` so that the device builds and refreshes q, l, u itself.
 
-    def __init__(self, device=0):
+    ``nx, nu``: optional hints for reading the controller's dimensions out of P and A (they are inferred otherwise)."""
+
+    def __init__(self, device=0, nx=None, nu=None):
         self.device = device
         self._bp = None
+        self._hint = (nx, nu)
+        self._model = None
+
+    def _setup_from_matrices(self, P, q, A, l, u, **settings):
+        from . import qp_recover
+        mdl = qp_recover.recover_model(P, A, l, u, *self._hint)        # raises unless P, A are pyMPC's matrices
+        self._check_q(mdl, q)
+        self._model = mdl
+        self._bp = BatchProblem(1, mdl['nx'], mdl['nu'], mdl['Np'], mdl['Nc'], device=self.device, **settings)
+        one = lambda a: np.asarray(a, dtype=float)[None]
+        clip = lambda v: np.clip(np.asarray(v, dtype=float), -1e30, 1e30)[None]
+        self._bp.setup_qp(one(mdl['Ad']), one(mdl['Bd']), one(mdl['Qx']), one(mdl['QxN']), one(mdl['Qu']), one(mdl['QDu']),
+                          np.array([[mdl['eps_feas']]]), one(q), clip(l), clip(u))
+        self.n, self.m = self._bp.n, self._bp.m
+
+    @staticmethod
+    def _check_q(mdl, q):
+        from . import qp_recover
+        nq = (mdl['Np'] + 1) * mdl['nx'] + mdl['Nc'] * mdl['nu']
+        q = np.asarray(q, dtype=float)
+        if q.shape != (nq + (mdl['Np'] + 1) * mdl['nx'],) or np.any(q[nq:] != 0.0):
+            raise qp_recover.NotAnMPCQP('q must have length n with a zero slack part (mpc.py:599)')
 
     def setup(self, P=None, q=None, A=None, l=None, u=None, mpc=None, **settings):
         if mpc is None:
-            raise ValueError('DeviceProblem.setup needs the controller data (mpc=...): the device builds P,q,A,l,u itself')
+            if P is None or q is None or A is None or l is None or u is None:
+                raise ValueError('DeviceProblem.setup needs P, q, A, l, u (or the controller data, mpc=...)')
+            return self._setup_from_matrices(P, q, A, l, u, **settings)
         xref = np.asarray(mpc['xref'], dtype=float)
         if xref.ndim == 2 and xref.shape[0] != mpc['Np'] + 1:
             raise ValueError('a time-varying xref must have exactly Np+1 rows')
@@ -343,9 +398,20 @@ class DeviceProblem:
                        one(mpc['x0']), one(mpc['uminus1']), xref.reshape(1, -1))
         self.n, self.m = self._bp.n, self._bp.m
 
-    def update(self, q=None, l=None, u=None, mpc_step=None):
-        if mpc_step is None:
-            raise ValueError('DeviceProblem.update needs mpc_step=dict(x0=, uminus1=, xref=)')
+    def update(self, q=None, l=None, u=None, mpc_step=None, **unsupported):
+        if unsupported:
+            raise NotImplementedError('DeviceProblem.update supports q, l, u (what pyMPC updates, mpc.py:454); got %s' % sorted(unsupported))
+        if mpc_step is None:                              # the caller's vectors, verbatim
+            if self._model is None:
+                from . import qp_recover
+                raise qp_recover.NotAnMPCQP('update(q=, l=, u=) needs a problem set up from P, q, A, l, u')
+            from . import qp_recover
+            qp_recover.check_vectors(self._model, l, u)
+            if q is not None:
+                self._check_q(self._model, q)
+            clip = lambda v: None if v is None else np.clip(np.asarray(v, dtype=float), -1e30, 1e30)[None]
+            self._bp.update_vectors(None if q is None else np.asarray(q, dtype=float)[None], clip(l), clip(u))
+            return
         xref = np.asarray(mpc_step['xref'], dtype=float)
         self._bp.update(np.asarray(mpc_step['x0'], dtype=float).reshape(1, -1),
                         np.asarray(mpc_step['uminus1'], dtype=float).reshape(1, -1), xref.reshape(1, -1))

@@ -1,0 +1,46 @@
+"""pympc_amd.qp_recover: reading the controller data back out of the reference's assembled P, A (the matrices of
+tests/golden/qp_*.npz were captured from the imported reference class) -- what lets ``DeviceProblem`` stand in for
+``osqp.OSQP()`` inside pyMPC's own controller (mpc.py:241,266,454)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from util import golden_names, load_golden, golden_kwargs, golden_csc, update_steps
+from pympc_amd.qp_recover import recover_model, check_vectors, NotAnMPCQP
+
+
+@pytest.mark.parametrize('name', golden_names())
+def test_model_is_recovered_from_reference_matrices(name):
+    g = load_golden(name); kw = golden_kwargs(g)
+    P, A = golden_csc(g, 'P'), golden_csc(g, 'A')
+    m = recover_model(P, A, g['l'], g['u'])                          # dimensions inferred; rebuild-and-compare inside
+    nx, nu = kw['Ad'].shape[0], kw['Bd'].shape[1]
+    assert (m['nx'], m['nu'], m['Np'], m['Nc']) == (nx, nu, kw['Np'], kw.get('Nc', kw['Np']))
+    assert np.array_equal(m['Ad'], kw['Ad']) and np.array_equal(m['Bd'], kw['Bd'])
+    assert np.array_equal(m['Qx'], kw['Qx']) and np.array_equal(m['QxN'], kw.get('QxN', kw['Qx']))
+    assert m['eps_feas'] == kw.get('eps_feas', 1e6)
+    if m['Nc'] >= 2:
+        assert np.allclose(m['Qu'], kw['Qu'], rtol=0, atol=1e-15) and np.array_equal(m['QDu'], kw['QDu'])
+    assert recover_model(sp.triu(P), A, g['l'], g['u'], nx=nx, nu=nu)['Np'] == kw['Np']      # upper triangle + hints
+    for st in update_steps(g):                                       # the reference's refreshed vectors keep the structure
+        check_vectors(m, st['l'], st['u_bound'])
+
+
+def test_foreign_qps_are_refused():
+    g = load_golden('point_mass')
+    P, A, l, u = golden_csc(g, 'P').tolil(), golden_csc(g, 'A').tolil(), g['l'].copy(), g['u'].copy()
+    with pytest.raises(NotAnMPCQP):
+        recover_model(sp.eye(P.shape[0]), sp.eye(P.shape[0]), np.zeros(P.shape[0]), np.ones(P.shape[0]))
+    A2 = A.copy(); A2[7, 3] = 0.123                                   # dynamics of ONE stage differ: not time invariant
+    with pytest.raises(NotAnMPCQP):
+        recover_model(P, A2, l, u)
+    P2 = P.copy(); P2[5, 5] += 1.0                                    # a stage cost that is not Qx
+    with pytest.raises(NotAnMPCQP):
+        recover_model(P2, A, l, u)
+    m = recover_model(P, A, l, u)
+    l2 = l.copy(); l2[m['nx'] * (m['Np'] + 1) + 5] -= 1.0             # a state bound that changes along the horizon
+    with pytest.raises(NotAnMPCQP):
+        check_vectors(m, l2, u)
+    l3 = l.copy(); l3[3] = 1.0                                        # a dynamics row with a nonzero right-hand side
+    with pytest.raises(NotAnMPCQP):
+        check_vectors(m, l3, u)
