@@ -144,7 +144,7 @@ static Lay make_layout(int nx, int nu, int Np, int Nc) {
     L.fstage = L.NB == 16 ? FactorFmt<16>::STAGE : FactorFmt<32>::STAGE;
     L.fhead = L.NB == 16 ? FactorFmt<16>::HEAD : FactorFmt<32>::HEAD;
     L.ffwd = L.NB == 16 ? FactorFmt<16>::FWD : FactorFmt<32>::FWD;
-    L.tsz = (L.m + L.N * L.NB) > 6 * L.NB * L.NB ? (L.m + L.N * L.NB) : 6 * L.NB * L.NB;   // [W (m) | Tc (N*NB)] or factor workspace
+    L.tsz = L.m + L.N * L.NB;                          // [W (m) | Tc (N*NB)]; mpcqp_create widens it where the factorization needs more
     return L;
 }
 
@@ -202,10 +202,16 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->ncu = prop.multiProcessorCount; }
     if (const char *e = getenv("MPCQP_BALANCE")) h->auto_balance = atoi(e) != 0;      // development switch
     if (rc) { std::string msg = g_err; mpcqp_destroy(h); return fail(MPCQP_ERR_HIP, msg); }
-    h->smem_setup = sizeof(double) * (size_t)smem_common_doubles(L);
-    size_t with_state = h->smem_setup + sizeof(double) * (size_t)(L.n + 2 * L.m);
-    h->lds_state = with_state <= 40 * 1024 && L.m <= 4 * NT && L.N * L.NB <= 2 * NT;      // four workgroups per CU; larger problems keep the iterate in L2/HBM   // small problems: x in LDS, z/y in registers; else iterate in L2/HBM
-    h->smem_solve = h->lds_state ? with_state : h->smem_setup;
+    // Small problems keep the iterate x, z, y in LDS behind the common block (four workgroups per CU: 40 KB each); larger
+    // ones keep it in L2/HBM.  The factorization's workspace starts at the work area T, the last part of the common block,
+    // and may run on into the iterate area (dead while a factorization runs); T is widened only where even that is short.
+    const int fws = L.NB == 16 ? FactorCfg<16>::WS : FactorCfg<32>::WS;
+    const size_t state_doubles = (size_t)(L.n + 2 * L.m);
+    h->lds_state = sizeof(double) * ((size_t)smem_common_doubles(L) + state_doubles) <= 40 * 1024 && L.m <= 4 * NT && L.N * L.NB <= 2 * NT;
+    const int avail = L.tsz + (h->lds_state ? (int)state_doubles : 0);
+    if (avail < fws) h->L.tsz += fws - avail;
+    h->smem_setup = sizeof(double) * ((size_t)smem_common_doubles(h->L) + (h->lds_state ? state_doubles : 0));      // every kernel gets the full block
+    h->smem_solve = h->smem_setup;
     if (h->smem_solve > 160 * 1024) { mpcqp_destroy(h); return fail(MPCQP_ERR_UNSUPPORTED, "problem too large for one workgroup's LDS"); }
     *out = h;
     return MPCQP_OK;

@@ -93,79 +93,96 @@ struct BorderPtrs { double *Bb, *Zb, *Sig, *red; };
 
 template <int NB> __device__ void border_factor(const Ctx &, const double *, const double *, double, const double *, double *, double *, double *, double *, double *, double *);
 
+// The two half-chains are independent until the middle stage: for 16 x 16 stages each is factored by one half of the
+// workgroup, side by side (the stage count, not the arithmetic, is what a refactorization costs).  32 x 32 stages keep the
+// whole workgroup on one stage at a time (four entries per thread; two workspaces would not fit next to a second
+// resident workgroup).  S_k^-1 comes from an in-place Gauss-Jordan sweep of S_k -- NB steps, every entry updated in
+// parallel -- instead of Cholesky + a thread-serial triangular inverse + L^-T L^-1; S_k is positive definite, its pivots
+// are the Schur complements a Cholesky would take roots of, and a non-positive one is reported the same way.
+template <int NB> struct FactorCfg {
+    static constexpr int G = NB == 16 ? 2 : 1;          // thread groups working on different stages
+    static constexpr int WS = NB == 16 ? 8 * NB * NB : 5 * NB * NB;      // LDS doubles: per group [S | Ks | Mh | Sn], or [S | Ks | Mh | SnA | SnB]
+};
+
 template <int NB>
 __device__ int factor_all(const Ctx &c, const double *om, const double *sv, double cc, double *F, double *W, int *iflag, BorderPtrs bp) {
     const Lay &L = c.L;
-    double *S = W, *Ks = W + NB * NB, *Mh = W + 2 * NB * NB, *SnA = W + 3 * NB * NB, *Li = W + 4 * NB * NB, *SnB = W + 5 * NB * NB;
+    constexpr int G = FactorCfg<NB>::G, NN = NB * NB;
     const int tid = threadIdx.x;
     const int N = L.N, mid = N / 2;
     if (tid == 0) *iflag = 0;
-    // S -= (Ks Sn) Ks' for the neighbour on side `up` (true: k-1, false: k+1); stores the two fragment copies
-    auto eliminate_neighbour = [&](int k, bool up, const double *Sn) {
+    double *SnA, *SnB;                                   // S^-1 of the stage eliminated last in the top / bottom half
+    if (G == 2) { SnA = W + 3 * NN; SnB = W + 7 * NN; } else { SnA = W + 3 * NN; SnB = W + 4 * NN; }
+    // One stage by the T threads lt = 0..T-1 of a group (barriers are workgroup-wide: every thread makes the same calls;
+    // `on` = this group has a stage in this call).  Ws: the group's [S | Ks | Mh]; SnU / SnD: S^-1 of the neighbours above /
+    // below to eliminate (null = none); SnOut receives S_k^-1.
+    auto stage = [&](bool on, int k, int T, int lt, double *Ws, const double *SnU, const double *SnD, double *SnOut) {
+        double *S = Ws, *Ks = Ws + NN, *Mh = Ws + 2 * NN;
         __syncthreads();
-        for (int e = tid; e < NB * NB; e += NT) {
-            int a = e / NB, b = e % NB;
-            Ks[e] = up ? kkt_sub_entry(c, om, cc, k - 1, a, b) : kkt_sub_entry(c, om, cc, k, b, a);
-        }
-        __syncthreads();
-        for (int e = tid; e < NB * NB; e += NT) {              // Mh = Ks * Sn
-            int a = e / NB, b = e % NB;
-            double acc = 0.0;
-            for (int l = 0; l < NB; ++l) acc += Ks[a * NB + l] * Sn[l * NB + b];
-            Mh[e] = acc;
-        }
-        __syncthreads();
-        const int fwd_stage = (k == mid && !up) ? 0 : k;
-        for (int e = tid; e < NB * NB; e += NT) {              // S -= Mh * Ks'
-            int a = e / NB, b = e % NB;
-            double acc = 0.0;
-            for (int l = 0; l < NB; ++l) acc += Mh[a * NB + l] * Ks[b * NB + l];
-            S[e] -= acc;
-            // forward matrix of stage k (the backward sweep applies the same fragment transposed); the middle stage's
-            // second forward matrix lives in the otherwise unused slot 0 of stage 0
-            if constexpr (!FactorFmt<NB>::SONLY) F[(size_t)fwd_stage * L.fstage + frag_pos<NB>(a, b)] = -Mh[e];
-        }
-        __syncthreads();
-    };
-    auto stage = [&](int k, bool use_up, bool use_down, double *SnOut) {
-        __syncthreads();
-        for (int e = tid; e < NB * NB; e += NT) {
+        if (on) for (int e = lt; e < NN; e += T) {
             S[e] = kkt_diag_entry(c, om, sv, cc, k, e / NB, e % NB);
-            Li[e] = 0.0;
             if constexpr (!FactorFmt<NB>::SONLY) { if (k == N - 1) F[(size_t)k * L.fstage + e] = 0.0; }     // the last stage has no forward matrix (stage 0's slot holds the middle's second one)
         }
-        if (use_up) eliminate_neighbour(k, true, SnA);
-        if (use_down) eliminate_neighbour(k, false, SnB);
-        __syncthreads();
-        // Cholesky of S (lower), right-looking
-        for (int j = 0; j < NB; ++j) {
-            double d = S[j * NB + j];
-            if (!(d > 0.0)) { if (tid == 0) *iflag = 1; d = 1e-300; }
-            d = sqrt(d);
+        for (int side = 0; side < 2; ++side) {           // S -= (Ks Sn) Ks' for the neighbour above (side 0) / below (side 1)
+            const double *Sn = side == 0 ? SnU : SnD;
+            const bool has = on && Sn != nullptr;
+            const bool up = side == 0;
             __syncthreads();
-            for (int i = j + tid; i < NB; i += NT) S[i * NB + j] = (i == j) ? d : S[i * NB + j] / d;
-            __syncthreads();
-            const int rem = NB - 1 - j;
-            for (int e = tid; e < rem * rem; e += NT) {
-                int i = j + 1 + e / rem, l = j + 1 + e % rem;
-                if (l <= i) S[i * NB + l] -= S[i * NB + j] * S[l * NB + j];
+            if (has) for (int e = lt; e < NN; e += T) {
+                const int a = e / NB, b = e % NB;
+                Ks[e] = up ? kkt_sub_entry(c, om, cc, k - 1, a, b) : kkt_sub_entry(c, om, cc, k, b, a);
             }
             __syncthreads();
-        }
-        if (tid < NB) {                                       // Li = L^-1, one thread per column
-            const int col = tid;
-            Li[col * NB + col] = 1.0 / S[col * NB + col];
-            for (int i = col + 1; i < NB; ++i) {
+            if (has) for (int e = lt; e < NN; e += T) {      // Mh = Ks * Sn
+                const int a = e / NB, b = e % NB;
                 double acc = 0.0;
-                for (int l = col; l < i; ++l) acc += S[i * NB + l] * Li[l * NB + col];
-                Li[i * NB + col] = -acc / S[i * NB + i];
+#pragma unroll 8
+                for (int l = 0; l < NB; ++l) acc += Ks[a * NB + l] * Sn[l * NB + b];
+                Mh[e] = acc;
+            }
+            __syncthreads();
+            if (has) {
+                const int fwd_stage = (k == mid && !up) ? 0 : k;
+                for (int e = lt; e < NN; e += T) {           // S -= Mh * Ks'
+                    const int a = e / NB, b = e % NB;
+                    double acc = 0.0;
+#pragma unroll 8
+                    for (int l = 0; l < NB; ++l) acc += Mh[a * NB + l] * Ks[b * NB + l];
+                    S[e] -= acc;
+                    // forward matrix of stage k (the backward sweep applies the same fragment transposed); the middle stage's
+                    // second forward matrix lives in the otherwise unused slot 0 of stage 0
+                    if constexpr (!FactorFmt<NB>::SONLY) F[(size_t)fwd_stage * L.fstage + frag_pos<NB>(a, b)] = -Mh[e];
+                }
             }
         }
         __syncthreads();
-        for (int e = tid; e < NB * NB; e += NT) {              // S^-1 = Li' Li
-            int a = e / NB, b = e % NB;
-            double acc = 0.0;
-            for (int l = max(a, b); l < NB; ++l) acc += Li[l * NB + a] * Li[l * NB + b];
+        // in-place Gauss-Jordan inversion of the SPD block: step p uses the OLD pivot row and column (read, barrier, write)
+        constexpr int EPT = (NN + NT / G - 1) / (NT / G);    // entries per thread (2 with two groups of 128, 4 for 32 x 32)
+        for (int pv = 0; pv < NB; ++pv) {
+            double rip[EPT], rpj[EPT], d = 1.0;
+            if (on) {
+                d = S[pv * NB + pv];
+#pragma unroll
+                for (int u = 0; u < EPT; ++u) { const int e = lt + u * T; if (e < NN) { rip[u] = S[(e / NB) * NB + pv]; rpj[u] = S[pv * NB + (e % NB)]; } }
+            }
+            if (on && !(d > 0.0)) { if (lt == 0) *iflag = 1; d = 1e-300; }
+            __syncthreads();
+            if (on) {
+                const double inv = 1.0 / d;
+#pragma unroll
+                for (int u = 0; u < EPT; ++u) {
+                    const int e = lt + u * T;
+                    if (e < NN) {
+                        const int i = e / NB, j = e % NB;
+                        S[e] = (i == pv) ? (j == pv ? inv : rpj[u] * inv) : (j == pv ? -rip[u] * inv : S[e] - rip[u] * rpj[u] * inv);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        if (on) for (int e = lt; e < NN; e += T) {               // S now holds S_k^-1: symmetrise, keep, store in the factor's format
+            const int a = e / NB, b = e % NB;
+            const double acc = 0.5 * (S[a * NB + b] + S[b * NB + a]);
             SnOut[e] = acc;
             if constexpr (FactorFmt<NB>::SONLY) {                  // [ sym(S00) | sym(S11) | S01 ]
                 double *Fk = F + FactorFmt<NB>::HEAD + (size_t)k * L.fstage;
@@ -177,9 +194,22 @@ __device__ int factor_all(const Ctx &c, const double *om, const double *sv, doub
             else F[(size_t)k * L.fstage + NB * NB + frag_pos<NB>(a, b)] = acc;
         }
     };
-    for (int k = 0; k < mid; ++k) stage(k, k > 0, false, SnA);
-    for (int k = N - 1; k > mid; --k) stage(k, false, k < N - 1, SnB);
-    stage(mid, true, true, SnA);
+    if (G == 2) {
+        const int T = NT / 2, g = tid / T, lt = tid % T;
+        double *Ws = W + g * 4 * NN, *Sn = g == 0 ? SnA : SnB;
+        const int nA = mid, nB = N - 1 - mid, steps = nA > nB ? nA : nB;
+        for (int t = 0; t < steps; ++t) {
+            const bool on = g == 0 ? t < nA : t < nB;
+            const int k = g == 0 ? t : N - 1 - t;
+            // (a group's Sn is its own previous output: reading it as the neighbour and overwriting it at the end of the
+            //  same call are separated by the barriers of the inversion)
+            stage(on, k, T, lt, Ws, (g == 0 && t > 0) ? Sn : nullptr, (g == 1 && t > 0) ? Sn : nullptr, Sn);
+        }
+    } else {
+        for (int k = 0; k < mid; ++k) stage(true, k, NT, tid, W, k > 0 ? SnA : nullptr, nullptr, SnA);
+        for (int k = N - 1; k > mid; --k) stage(true, k, NT, tid, W, nullptr, k < N - 1 ? SnB : nullptr, SnB);
+    }
+    stage(true, mid, NT, tid, W, SnA, SnB, SnA);
     if constexpr (FactorFmt<NB>::SONLY) {      // header: G = [[Ad, Bd], [0, c QDu']] and G' as fragments (constant per instance)
         constexpr int NBLK = NB / 16;
         for (int e = tid; e < NB * NB; e += NT) {

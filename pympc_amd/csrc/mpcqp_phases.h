@@ -27,9 +27,11 @@ __device__ __forceinline__ BorderPtrs border_ptrs(const Lay &L, const Ptrs &P, c
 }
 
 __device__ __forceinline__ double *carve(double *&p, int n) { double *r = p; p += n; return r; }
+// LDS layout of a workgroup: [ hot | x0 | um1 | du0 | red | tv | iflag | T (tsz) ] and, behind it, the LDS-resident iterate
+// [ X | Z | Y ] of small problems.  T comes last so that the factorization, which runs while the iterate copy is dead
+// (before a round loads it, after a check has read it), can let its workspace run on into that area.
 template <class PT>
 __device__ void smem_common(const Lay &L, const PT &P, double *&p, Smem &S) {
-    S.T = carve(p, L.tsz);
     S.Qv = (double *)P.qv + (size_t)inst_of(P.perm) * (L.n_x + L.n_u);
     S.hot = carve(p, L.hot_sz);
     S.x0s = carve(p, L.nx);
@@ -38,6 +40,7 @@ __device__ void smem_common(const Lay &L, const PT &P, double *&p, Smem &S) {
     S.red = carve(p, 64);
     S.tv = carve(p, 64);
     S.iflag = (int *)carve(p, 2);
+    S.T = carve(p, L.tsz);
 }
 __host__ __device__ inline int smem_common_doubles(const Lay &L) { return L.tsz + L.hot_sz + L.nx + 3 * L.nu + 64 + 64 + 2; }
 
