@@ -16,13 +16,15 @@
  * row-by-row numeric phase, the classical algorithm of Davis' "Algorithm 849: a concise sparse
  * Cholesky factorization package") under a caller-supplied fill-reducing permutation.
  *
- * PARITY STATUS: "parity unpinned" against a real OSQP binary (none reachable).  What pins this
- * oracle instead: (1) it consumes P,q,A,l,u that are bit-identical to what the reference builds
- * (tests/golden/qp_*.npz, captured from the imported reference); (2) every optimum it returns at
- * tight tolerance is certified solver-independently by KKT conditions and cross-checked with the
- * HiGHS QP solver bundled in scipy (tests/test_oracle.py, tests/golden/make_optimum.py); (3) plugged
- * into the REFERENCE's own controller class as its `osqp`, it produces the closed-loop golden trajectories
- * of tests/golden/make_traj.py (traj_*.npz), which the product is tested against.
+ * PARITY STATUS: "parity unpinned" against a real OSQP binary (none reachable; tests/test_real_osqp.py holds the
+ * comparison and skips until `import osqp` works).  What pins this oracle instead: (1) it consumes P,q,A,l,u that are
+ * bit-identical to what the reference builds (tests/golden/qp_*.npz, captured from the imported reference); (2) every
+ * optimum it returns at tight tolerance is certified solver-independently by KKT conditions and cross-checked with
+ * the HiGHS QP solver bundled in scipy (tests/test_oracle.py, tests/golden/make_optimum.py); (3) where no inequality
+ * is active it reproduces the condensed closed-form controller of test_scripts/alternative/unconstrained.py:141-183,
+ * restated with dense linear algebra only (tests/closed_form.py, tests/test_closed_form.py); (4) plugged into the
+ * REFERENCE's own controller class as its `osqp` -- and next to the reference's own LinearStateEstimator -- it produces
+ * the closed-loop golden trajectories of tests/golden/make_traj.py (traj_*.npz), which the product is tested against.
  * `adaptive_rho_interval=0` (OSQP: derived from wall-clock setup time, hence not reproducible)
  * is resolved deterministically to 4*check_termination, OSQP's own rule for builds without timers.
  *
