@@ -54,9 +54,12 @@ template <int NB> struct SinvFmt { static constexpr bool SYM = MPCQP_SYM_SINV &&
 #ifndef MPCQP_SONLY32
 #define MPCQP_SONLY32 1
 #endif
+#ifndef MPCQP_SONLY16
+#define MPCQP_SONLY16 0
+#endif
 template <int NB> struct FactorFmt {
-    static constexpr bool SONLY = MPCQP_SONLY32 && NB == 32;
-    static constexpr int SINV = SONLY ? (164 + 164 + 256) : (MPCQP_SYM_SINV && NB == 16 ? 164 : NB * NB);
+    static constexpr bool SONLY = (MPCQP_SONLY32 && NB == 32) || (MPCQP_SONLY16 && NB == 16);
+    static constexpr int SINV = SONLY ? (NB == 32 ? 164 + 164 + 256 : 164) : (MPCQP_SYM_SINV && NB == 16 ? 164 : NB * NB);
     static constexpr int FWD = SONLY ? 0 : NB * NB;
     static constexpr int STAGE = FWD + SINV;
     static constexpr int HEAD = SONLY ? 2 * NB * NB : 0;

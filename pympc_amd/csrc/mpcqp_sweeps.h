@@ -362,10 +362,10 @@ __device__ __forceinline__ CoreArgs core_args(const Lay &L, const double *F, con
 template <int NB> struct SoCfg {
     static constexpr int NBLK = NB / 16, NF = NBLK * NBLK;
     static constexpr int NS = NB == 16 ? 1 : 3;               // streamed d4 per lane and stage: sym(S) | sym(S00), sym(S11), S01
-#ifndef MPCQP_SO_DEPTH
-#define MPCQP_SO_DEPTH 2
+#ifndef MPCQP_SO_DEPTH16
+#define MPCQP_SO_DEPTH16 4
 #endif
-    static constexpr int DEPTH = MPCQP_SO_DEPTH;              // stages in flight (28 VGPRs each at NB = 32)
+    static constexpr int DEPTH = NB == 32 ? 2 : MPCQP_SO_DEPTH16;      // stages in flight (28 VGPRs each at NB = 32: the register file holds two)
 };
 __device__ __forceinline__ d4 sym_window(const double *Fm, int lane) {
     const int R = (lane >> 2) & 3;
@@ -494,12 +494,14 @@ __device__ __forceinline__ void half_sweep_so(const CoreArgs &a, double *Tc, con
         vec_load<NB>(tb, first, run);
     }
     if (nsteps < 1) return;
-    SoStep<NB> ring[2];
+    constexpr int DEPTH = SoCfg<NB>::DEPTH;
+    SoStep<NB> ring[DEPTH];
     __builtin_amdgcn_sched_barrier(0);
-    so_step_load<NB>(a, q, lane, stage_of(clamp_i(1)), stage_of(clamp_i(1) - 1), ring[0]);
-    __builtin_amdgcn_sched_barrier(0);
-    so_step_load<NB>(a, q, lane, stage_of(clamp_i(2)), stage_of(clamp_i(2) - 1), ring[1]);
-    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+        so_step_load<NB>(a, q, lane, stage_of(clamp_i(1 + d)), stage_of(clamp_i(1 + d) - 1), ring[d]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     // (steps past the end repeat the last stage -- computed, not stored -- so that the loop body has no branches)
     auto stage_step = [&](int i, int inext, SoStep<NB> &slot, bool valid) {
         const int k = stage_of(i);
@@ -523,9 +525,9 @@ __device__ __forceinline__ void half_sweep_so(const CoreArgs &a, double *Tc, con
         so_step_load<NB>(a, q, lane, stage_of(inext), stage_of(inext - 1), slot);
         __builtin_amdgcn_sched_barrier(0);
     };
-    for (int i0 = 1; i0 <= nsteps; i0 += 2) {
-        stage_step(clamp_i(i0), clamp_i(i0 + 2), ring[0], true);
-        stage_step(clamp_i(i0 + 1), clamp_i(i0 + 3), ring[1], i0 + 1 <= nsteps);
+    for (int i0 = 1; i0 <= nsteps; i0 += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) stage_step(clamp_i(i0 + d), clamp_i(i0 + d + DEPTH), ring[d], i0 + d <= nsteps);
     }
 }
 
