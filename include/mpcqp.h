@@ -66,6 +66,8 @@ typedef struct {
     int32_t max_iter, check_termination, scaling;
     int32_t adaptive_rho, adaptive_rho_interval;   /* interval 0 -> 4*check_termination */
     int32_t warm_start;
+    int32_t soft_constraints;   /* pyMPC's SOFT_ON switch (mpc.py:237,530-597): 1 (the only public mode) = state box on x_k + eps_k with slack
+                                   columns eps; 0 = hard state box, no slack columns (n = (Np+1)nx + Nc nu).  Fixed at mpcqp_create. */
 } mpcqp_settings;
 
 typedef struct {

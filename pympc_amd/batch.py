@@ -15,7 +15,7 @@ class BatchMPCController:
     def __init__(self, Ad, Bd, Np=20, Nc=None, x0=None, xref=None, uref=None, uminus1=None,
                  Qx=None, QxN=None, Qu=None, QDu=None,
                  xmin=None, xmax=None, umin=None, umax=None, Dumin=None, Dumax=None,
-                 eps_feas=1e6, eps_rel=1e-3, eps_abs=1e-3, device=0, stream=None, **solver_settings):
+                 eps_feas=1e6, eps_rel=1e-3, eps_abs=1e-3, device=0, stream=None, SOFT_ON=True, **solver_settings):
         Ad = np.asarray(Ad, dtype=float)
         Bd = np.asarray(Bd, dtype=float)
         if Ad.ndim != 3 or Ad.shape[1] != Ad.shape[2]:
@@ -62,6 +62,7 @@ class BatchMPCController:
         self.u_failure = self.uref
         self.device, self.stream = device, stream
         self.solver_settings = dict(solver_settings)
+        self.SOFT_ON = bool(SOFT_ON)           # pyMPC's hidden switch (mpc.py:237): False = hard state box, no slack variables
         self.prob = None
         self.uminus1_rh = None
         self.x0_rh = None
@@ -75,7 +76,7 @@ class BatchMPCController:
         self.x0_rh = self.x0.copy()
         self.uminus1_rh = self.uminus1.copy()
         # same kwarg swap as the reference (mpc.py:266)
-        st = dict(warm_start=True, eps_abs=self.eps_rel, eps_rel=self.eps_abs)
+        st = dict(warm_start=True, eps_abs=self.eps_rel, eps_rel=self.eps_abs, soft_constraints=int(self.SOFT_ON))
         st.update(self.solver_settings)
         self.prob = BatchProblem(self.B, self.nx, self.nu, self.Np, self.Nc, device=self.device, stream=self.stream, **st)
         self.prob.setup(self.Ad, self.Bd, self.Qx, self.QxN, self.Qu, self.QDu, self.xmin, self.xmax,
@@ -169,7 +170,7 @@ class BatchMPCController:
             info['u_seq'] = x[:, (Np + 1) * nx:(Np + 1) * nx + Nc * nu].reshape(self.B, Nc, nu)
         if return_eps_seq:
             o = (Np + 1) * nx + Nc * nu
-            info['eps_seq'] = x[:, o:o + (Np + 1) * nx].reshape(self.B, Np + 1, nx)
+            info['eps_seq'] = x[:, o:o + (Np + 1) * nx].reshape(self.B, -1, nx)          # (empty without slack variables)
         if return_status:
             info['status'] = [self.prob.status_string(i.status) for i in infos]
             info['iter'] = np.array([i.iter for i in infos])

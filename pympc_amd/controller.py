@@ -6,6 +6,7 @@ what sits behind ``self.prob``: instead of ``osqp.OSQP()`` (mpc.py:241) it is a
 ``pympc_amd.solver.DeviceProblem`` -- a ctypes handle onto ``libmpcqp_hip.so``, the
 hand-written HIP implementation of the QP build and of the OSQP-style ADMM loop for gfx950.
 
+The hidden switch ``SOFT_ON = False`` (mpc.py:237: hard state box, no slack variables) is honoured on the device.
 There is NO CPU fallback: if the HIP library or a GPU is missing, ``setup()`` raises.
 (Tests that exercise only the host logic inject their own ``prob`` object.)
 """
@@ -162,6 +163,7 @@ class MPCController:
             Dumin=self.Dumin, Dumax=self.Dumax, eps_feas=float(self.eps_feas),
             x0=np.asarray(self.x0_rh, dtype=float), uminus1=np.asarray(self.uminus1_rh, dtype=float),
             xref=np.asarray(self.xref, dtype=float), uref=np.asarray(self.uref, dtype=float),
+            SOFT_ON=bool(self.SOFT_ON),
         )
 
     def _step_data(self):
@@ -175,8 +177,6 @@ class MPCController:
         self.uminus1_rh = np.copy(self.uminus1)
         self._compute_QP_matrices_()
         if self.prob is None:
-            if not self.SOFT_ON:
-                raise NotImplementedError("the HIP solver implements the public SOFT_ON=True formulation only")
             from .solver import DeviceProblem   # raises loudly without the HIP library / a GPU
             self.prob = DeviceProblem()
         # the reference passes eps_abs=self.eps_rel, eps_rel=self.eps_abs (swapped, mpc.py:266)

@@ -93,7 +93,7 @@ extern "C" void mpcqp_default_settings(mpcqp_settings *s) {
     s->eps_abs = 1e-3; s->eps_rel = 1e-3; s->eps_prim_inf = 1e-4; s->eps_dual_inf = 1e-4;
     s->adaptive_rho_tolerance = 5.0;
     s->max_iter = 4000; s->check_termination = 25; s->scaling = 10;
-    s->adaptive_rho = 1; s->adaptive_rho_interval = 0; s->warm_start = 1;
+    s->adaptive_rho = 1; s->adaptive_rho_interval = 0; s->warm_start = 1; s->soft_constraints = 1;
 }
 
 extern "C" const char *mpcqp_status_string(int status) {
@@ -118,11 +118,12 @@ extern "C" int mpcqp_device_count(void) {
     return n;
 }
 
-static Lay make_layout(int nx, int nu, int Np, int Nc) {
+static Lay make_layout(int nx, int nu, int Np, int Nc, int soft) {
     Lay L; memset(&L, 0, sizeof(L));
     L.nx = nx; L.nu = nu; L.Np = Np; L.Nc = Nc; L.N = Np + 1; L.nb = nx + nu;
     L.n_x = L.N * nx; L.n_u = Nc * nu;
-    L.n = 2 * L.n_x + L.n_u; L.m = 2 * L.n_x + L.n_u + (Nc + 1) * nu;
+    L.soft = soft ? 1 : 0;
+    L.n = (L.soft ? 2 : 1) * L.n_x + L.n_u; L.m = 2 * L.n_x + L.n_u + (Nc + 1) * nu;
     L.ou = L.n_x; L.oe = L.n_x + L.n_u;
     L.rs = L.n_x; L.ri = 2 * L.n_x; L.rdu = 2 * L.n_x + L.n_u;
     L.NB = L.nb <= 16 ? 16 : 32;
@@ -169,8 +170,8 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     h->device = device; h->batch = batch; h->is_setup = false; h->u0_dev = nullptr; h->run_buf = nullptr; h->run_bytes = 0; h->perm_dev = nullptr; h->solves_since_balance = 0; h->auto_balance = 1; h->ncu = 0;
     h->profiling = false; h->run_ms = 0.0; h->run_launches = 0; h->ev_count = 0; h->nevents = 0; h->stream = nullptr; h->own_stream = false;
     h->warm_x_pending = false;
-    h->L = make_layout(nx, nu, Np, Nc);
     if (s) h->S = *s; else mpcqp_default_settings(&h->S);
+    h->L = make_layout(nx, nu, Np, Nc, h->S.soft_constraints);
     // (every failure from here on releases what has been created so far: mpcqp_destroy copes with a partial handle)
     auto hip_fail = [&](hipError_t e, const char *what) { std::string msg = std::string(what) + ": " + hipGetErrorString(e); mpcqp_destroy(h); return fail(MPCQP_ERR_HIP, msg); };
     { hipError_t e = hipStreamCreate(&h->stream); if (e != hipSuccess) { h->stream = nullptr; return hip_fail(e, "hipStreamCreate"); } }
@@ -396,6 +397,7 @@ extern "C" int mpcqp_update_settings(mpcqp_handle *h, const mpcqp_settings *s) {
     double rho = h->S.rho, sigma = h->S.sigma; int scaling = h->S.scaling;
     h->S = *s;
     h->S.rho = rho; h->S.sigma = sigma; h->S.scaling = scaling;   // fixed at setup (they shape the factorization)
+    h->S.soft_constraints = h->L.soft;                            // fixed at creation (it shapes the problem)
     return MPCQP_OK;
 }
 
@@ -685,7 +687,7 @@ extern "C" int mpcqp_get_dims(mpcqp_handle *h, int *n, int *m, int64_t *factor_d
         int64_t full = T * (nb * (nb + 1) / 2) + (int64_t)(L.N - T) * (nx * (nx + 1) / 2);
         int64_t sub = (T > 0 ? (T - 1) * (nx * nb + (int64_t)L.nu * L.nu) + nx * nb : 0) + (int64_t)(L.N - 1 - T) * nx * nx;
         int64_t border = L.border ? (int64_t)L.nu * (L.n_x + T * L.nu) + (int64_t)L.nu * (L.nu + 1) / 2 : 0;
-        *nnzL = full + sub + border + 2 * (int64_t)L.n_x;
+        *nnzL = full + sub + border + (L.soft ? 2 * (int64_t)L.n_x : 0);
     }
     return MPCQP_OK;
 }

@@ -113,8 +113,8 @@ __device__ void kkt_solve(const Ctx &c, const double *om, const double *sv, doub
         if (a < L.nx) {
             int e = k * L.nx + a;
             double ws = om[L.rs + e];
-            double te = rg[L.oe + e] / (cef + sv[L.oe + e] + ws);
-            out[L.oe + e] = te;
+            double te = 0.0;
+            if (L.soft) { te = rg[L.oe + e] / (cef + sv[L.oe + e] + ws); out[L.oe + e] = te; }
             v = rg[e] - ws * te;
         } else if (a < L.nb && k < L.Nc) v = rg[L.ou + k * L.nu + (a - L.nx)];
         Tc[idx] = v;
@@ -130,7 +130,7 @@ __device__ void kkt_solve(const Ctx &c, const double *om, const double *sv, doub
             double ws = om[L.rs + e];
             double xe = Tc[idx];
             out[e] = xe;
-            out[L.oe + e] -= (ws / (cef + sv[L.oe + e] + ws)) * xe;
+            if (L.soft) out[L.oe + e] -= (ws / (cef + sv[L.oe + e] + ws)) * xe;
         } else if (a < L.nb && k < L.Nc) out[L.ou + k * L.nu + (a - L.nx)] = Tc[idx];
     }
     __syncthreads();

@@ -10,6 +10,7 @@ constexpr int MAXEV = 64;         // profiling: launches whose HIP events may be
 struct Lay {
     int nx, nu, Np, Nc, N, nb, n, m, n_x, n_u, ou, oe, rs, ri, rdu;
     int NB;                       // padded stage block size (16 or 32)
+    int soft;                     // 1: slack columns eps_k (soft state box, pyMPC's SOFT_ON); 0: none, the state box is hard
     int NcT;                      // stages 0..NcT-1 carry their input u_k inside the block-tridiagonal part
     int border;                   // 1 if Nc < Np: the held last input u_{Nc-1} couples to every later stage and is
                                   // handled as a bordered (Schur-complement) correction, see border_* below

@@ -372,7 +372,7 @@ __device__ __forceinline__ void load_hot_regs(const Lay &L, cgdouble *om, cgdoub
         const int idx = tid + NT * j, k = idx / NB, a = idx % NB;
         h.sv_e[j] = 0.0; h.qv_e[j] = 0.0; h.om_s[j] = 1.0; h.sv_s[j] = 0.0;
         if (idx < L.N * NB) {
-            if (a < nx) { const int e = k * nx + a; h.sv_e[j] = sv[e]; h.qv_e[j] = qv[e]; h.om_s[j] = om[L.rs + e]; h.sv_s[j] = sv[L.oe + e]; }
+            if (a < nx) { const int e = k * nx + a; h.sv_e[j] = sv[e]; h.qv_e[j] = qv[e]; h.om_s[j] = om[L.rs + e]; h.sv_s[j] = L.soft ? sv[L.oe + e] : 0.0; }
             else if (a < nx + nu && k < L.Nc) { const int cu = k * nu + a - nx; h.sv_e[j] = sv[L.ou + cu]; h.qv_e[j] = qv[L.n_x + cu]; }
         }
     }
@@ -414,7 +414,7 @@ __device__ __forceinline__ void hot_rhs(const Lay &L, const double *hot, cgdoubl
                 if (!NXT) for (int r = 0; r < nx; ++r) rx += Ad[r * nx + a] * w1[r];
             }
             const double wsoft = W[L.rs + e];
-            const double te = (svs * xe + wsoft) / (cef + svs + ws);
+            const double te = L.soft ? (svs * xe + wsoft) / (cef + svs + ws) : 0.0;      // (hard box: no slack to eliminate)
             W[L.rs + e] = te;                      // only this thread ever reads W[soft row e]
             v = rx + wsoft - ws * te;
         } else if (a < nx + nu && k < L.Nc) {
@@ -439,7 +439,7 @@ __device__ __forceinline__ void hot_rhs(const Lay &L, const double *hot, cgdoubl
             const int idx = tid + NT * j, k = idx / NB, a = idx % NB;
             if (idx < L.N * NB) {
                 const double xv = a < nx ? X[k * nx + a] : ((a < nx + nu && k < L.Nc) ? X[L.ou + k * nu + a - nx] : 0.0);
-                const double xe = a < nx ? X[L.oe + k * nx + a] : 0.0;
+                const double xe = (a < nx && L.soft) ? X[L.oe + k * nx + a] : 0.0;
                 element(idx, h.sv_e[j], h.qv_e[j], h.om_s[j], h.sv_s[j], xv, xe);
             }
         }
@@ -456,7 +456,7 @@ __device__ __forceinline__ void hot_rhs(const Lay &L, const double *hot, cgdoubl
                 const int idx = i0 + u * NT, k = idx / NB, a = idx % NB;
                 sve[u] = qve[u] = svs[u] = xv[u] = xe[u] = 0.0; ws[u] = 1.0;
                 if (idx < L.N * NB) {
-                    if (a < nx) { const int e = k * nx + a; sve[u] = sv[e]; qve[u] = qv[e]; ws[u] = om[L.rs + e]; svs[u] = sv[L.oe + e]; xv[u] = Xg[e]; xe[u] = Xg[L.oe + e]; }
+                    if (a < nx) { const int e = k * nx + a; sve[u] = sv[e]; qve[u] = qv[e]; ws[u] = om[L.rs + e]; xv[u] = Xg[e]; if (L.soft) { svs[u] = sv[L.oe + e]; xe[u] = Xg[L.oe + e]; } }
                     else if (a < nx + nu && k < L.Nc) { const int cu = k * nu + a - nx; sve[u] = sv[L.ou + cu]; qve[u] = qv[L.n_x + cu]; xv[u] = Xg[L.ou + cu]; }
                 }
             }
@@ -480,10 +480,10 @@ __device__ __forceinline__ void hot_update(const Lay &L, const double *hot, cons
     // xo / eo: current values of the variable and of its slack; returns the new ones
     auto x_new = [&](int e, int k, int i, double ws, double svs, double xo, double eo, double &xn, double &en) {
         const double xt = Tc[k * NB + i];
-        const double et = W[L.rs + e] - (ws / (cef + svs + ws)) * xt;
+        const double et = L.soft ? W[L.rs + e] - (ws / (cef + svs + ws)) * xt : 0.0;
         W[L.rs + e] = et;
         xn = alpha * xt + (1.0 - alpha) * xo; en = alpha * et + (1.0 - alpha) * eo;
-        if (keep_delta) { dxg[e] = xn - xo; dxg[L.oe + e] = en - eo; }
+        if (keep_delta) { dxg[e] = xn - xo; if (L.soft) dxg[L.oe + e] = en - eo; }
     };
     auto u_new = [&](int cu, int k, int jj, double uo) {
         const double un = alpha * Tc[k * NB + nx + jj] + (1.0 - alpha) * uo;
@@ -495,7 +495,7 @@ __device__ __forceinline__ void hot_update(const Lay &L, const double *hot, cons
         for (int j = 0; j < 2; ++j) {
             const int idx = tid + NT * j, k = idx / NB, a = idx % NB;
             if (idx < L.N * NB) {
-                if (a < nx) { const int e = k * nx + a; double xn, en; x_new(e, k, a, h.om_s[j], h.sv_s[j], X[e], X[L.oe + e], xn, en); X[e] = xn; X[L.oe + e] = en; }
+                if (a < nx) { const int e = k * nx + a; double xn, en; x_new(e, k, a, h.om_s[j], h.sv_s[j], X[e], L.soft ? X[L.oe + e] : 0.0, xn, en); X[e] = xn; if (L.soft) X[L.oe + e] = en; }
                 else if (a < nx + nu && k < L.Nc) { const int cu = k * nu + a - nx; X[L.ou + cu] = u_new(cu, k, a - nx, X[L.ou + cu]); }
             }
         }
@@ -505,12 +505,13 @@ __device__ __forceinline__ void hot_update(const Lay &L, const double *hot, cons
 #pragma unroll
             for (int u = 0; u < HOT_U; ++u) {
                 const int e = min(e0 + u * NT, L.n_x - 1);
-                ws[u] = om[L.rs + e]; svs[u] = sv[L.oe + e]; xo[u] = Xg[e]; eo[u] = Xg[L.oe + e];
+                ws[u] = om[L.rs + e]; xo[u] = Xg[e]; svs[u] = 0.0; eo[u] = 0.0;
+                if (L.soft) { svs[u] = sv[L.oe + e]; eo[u] = Xg[L.oe + e]; }
             }
 #pragma unroll
             for (int u = 0; u < HOT_U; ++u) {
                 const int e = e0 + u * NT;
-                if (e < L.n_x) { const int k = divx<NXT>(L, e), i = e - k * nx; double xn, en; x_new(e, k, i, ws[u], svs[u], xo[u], eo[u], xn, en); Xg[e] = xn; Xg[L.oe + e] = en; }
+                if (e < L.n_x) { const int k = divx<NXT>(L, e), i = e - k * nx; double xn, en; x_new(e, k, i, ws[u], svs[u], xo[u], eo[u], xn, en); Xg[e] = xn; if (L.soft) Xg[L.oe + e] = en; }
             }
         }
         for (int c0 = tid; c0 < L.n_u; c0 += HOT_U * NT) {

@@ -25,7 +25,7 @@ __device__ __forceinline__ void A_row(const Ctx &c, int r, F f) {
     } else if (r < L.ri) {                            // soft state box: x_k + eps_k  (mpc.py:555-559)
         int j = r - L.rs;
         f(1.0, j);
-        f(1.0, L.oe + j);
+        if (L.soft) f(1.0, L.oe + j);             // (SOFT_ON = False: the box is on x_k itself, mpc.py:555-557 without the eps block)
     } else if (r < L.rdu) {                           // input box  (mpc.py:561-565)
         f(1.0, L.ou + (r - L.ri));
     } else {                                          // Delta-u rows  (mpc.py:569-580)
@@ -186,9 +186,9 @@ __device__ __forceinline__ double kkt_diag_entry(const Ctx &c, const double *om,
         if (k < L.Np) for (int r = 0; r < L.nx; ++r) v += Ad[r * L.nx + a] * omd[r] * Ad[r * L.nx + b];
         if (a == b) {
             int e = k * L.nx + a;
-            double ws = om[L.rs + e], se = sv[L.oe + e];
-            double ce = cc * c.eps_feas() + se;
-            v += sv[e] + om[e] + ws * (ce / (ce + ws));     // soft row with eps eliminated
+            double ws = om[L.rs + e];
+            if (L.soft) { const double ce = cc * c.eps_feas() + sv[L.oe + e]; ws *= ce / (ce + ws); }     // soft row with eps eliminated
+            v += sv[e] + om[e] + ws;
         }
     } else if (a >= L.nx && b >= L.nx) {
         int ja = a - L.nx, jb = b - L.nx;

@@ -178,4 +178,16 @@ NAMED = {
     'random_5_3_8_nc': lambda: dict(random_lti(12, nx=5, nu=3, Np=8, xbox=2.0), Nc=3),
     'quadcopter_nc': lambda: dict(quadcopter(Np=10), Nc=4),
     'cart_pole_nc1': lambda: dict(cart_pole(Np=12), Nc=1),
+    # SOFT_ON = False (hidden switch, mpc.py:237): hard state box, no slack columns.  Keys starting with '_' are attributes set
+    # on the controller after construction, not constructor arguments.
+    'point_mass_hard': lambda: dict(point_mass(), _SOFT_ON=False),
+    'accel_brake_hard': lambda: dict(accel_brake(), _SOFT_ON=False),              # the velocity bound 0.8 is active along the horizon
+    'random_12_4_30_hard': lambda: dict(random_lti(7), _SOFT_ON=False),
+    'random_5_3_8_nc_hard': lambda: dict(random_lti(12, nx=5, nu=3, Np=8, xbox=2.0), Nc=3, _SOFT_ON=False),
+    'random_20_8_12_hard': lambda: dict(random_lti(3, nx=20, nu=8, Np=12, xbox=3.0), _SOFT_ON=False),
 }
+
+
+def split_attrs(kw):
+    """(constructor kwargs, attributes to set afterwards) of a fixture dict."""
+    return ({k: v for k, v in kw.items() if not k.startswith('_')}, {k[1:]: v for k, v in kw.items() if k.startswith('_')})

@@ -390,7 +390,8 @@ class DeviceProblem:
         xref = np.asarray(mpc['xref'], dtype=float)
         if xref.ndim == 2 and xref.shape[0] != mpc['Np'] + 1:
             raise ValueError('a time-varying xref must have exactly Np+1 rows')
-        self._bp = BatchProblem(1, mpc['nx'], mpc['nu'], mpc['Np'], mpc['Nc'], device=self.device, **settings)
+        self._bp = BatchProblem(1, mpc['nx'], mpc['nu'], mpc['Np'], mpc['Nc'], device=self.device,
+                                soft_constraints=int(bool(mpc.get('SOFT_ON', True))), **settings)
         one = lambda a: np.asarray(a, dtype=float)[None]
         self._bp.setup(one(mpc['Ad']), one(mpc['Bd']), one(mpc['Qx']), one(mpc['QxN']), one(mpc['Qu']), one(mpc['QDu']),
                        one(mpc['xmin']), one(mpc['xmax']), one(mpc['umin']), one(mpc['umax']),

@@ -81,10 +81,12 @@ def main():
     for name, make in fixtures.NAMED.items():
         if sys.argv[1:] and name not in sys.argv[1:]:
             continue
-        kw = make()
+        kw, attrs = fixtures.split_attrs(make())
         K = MPCController(**{k: (np.array(v, copy=True) if isinstance(v, np.ndarray) else v) for k, v in kw.items()})
+        for k, v in attrs.items():                # hidden switches of mpc.py:233-238 (SOFT_ON)
+            setattr(K, k, v)
         K.setup(solve=False)
-        out = {}
+        out = {'attr_' + k: np.bool_(v) for k, v in attrs.items()}
         for k, v in kw.items():
             out['in_' + k] = np.asarray(v, dtype=float) if not isinstance(v, (int, np.integer)) else np.int64(v)
         Pd, Pi, Pp, Ps = csc_parts(K.P)

@@ -11,6 +11,9 @@ Loops (inputs are the constants of pympc_amd/fixtures.py, cited there):
         (examples/example_point_mass.py:88-101 with the exact discrete step of mpc.py:690 instead of the ODE integrator)
   cart_pole                           : same calls, nonlinear plant + forward Euler of examples/example_inverted_pendulum.py:83-103
   point_mass_nc                       : u = K.output(); x+ = Ad x + Bd u; K.update(x)   (mpc.py:688-692, 2-D xref, Nc < Np)
+  no_slack_point_mass                 : the REFERENCE's older class pyMPC/mpc_no_slack.py (hard state box) through the loop of its own
+        __main__ (mpc_no_slack.py:362-371): u = K.step(); x+ = Ad x + Bd u; K.update(x), constants of mpc_no_slack.py:296-349
+        (= the point-mass fixture with the state box [-10,-10]..[7,10]); tolerance as hard-coded there (1e-4) AND tight.
   kalman_cart_pole                    : output feedback, the loop of examples/example_inverted_pendulum_kalman.py:135-174 with
         the REFERENCE's LinearStateEstimator (pyMPC/kalman.py:109-134) next to its MPCController, linear plant and recorded
         noise:  y = C x + v; u = K.output(); x+ = Ad x + Bd u + w; KF.update(y); KF.predict(u); K.update(KF.x, u).
@@ -36,9 +39,12 @@ STUB = '''
 import sys
 sys.path.insert(0, %r)
 from oracle.osqp_oracle import OSQP as _Oracle
+TIGHT = None
 class OSQP(_Oracle):
     def setup(self, *a, **kw):
         kw.setdefault('max_iter', 400000)
+        if TIGHT is not None:
+            kw['eps_abs'] = kw['eps_rel'] = TIGHT
         return super().setup(*a, **kw)
 ''' % REPO
 
@@ -129,6 +135,24 @@ def main():
         sys.path.insert(0, tmp)
         sys.path.insert(0, '/root/reference')
         from pyMPC.mpc import MPCController as RefController
+        if not sys.argv[1:] or 'no_slack_point_mass' in sys.argv[1:]:
+            import pyMPC.mpc_no_slack as ref_ns
+            kw = {k: v for k, v in fixtures.point_mass().items() if k != 'eps_feas'}
+            kw.update(xmin=np.array([-10.0, -10.0]), xmax=np.array([7.0, 10.0]))
+            K = ref_ns.MPCController(**kw)
+            # mpc_no_slack.py:119 hard-codes eps 1e-4 in its setup call; the stub solver is told to use the tight tolerance instead
+            # (the optimum is what is stored; the shim's own 1e-4 behaviour is compared with the oracle at 1e-4 in the tests)
+            ref_ns.osqp.TIGHT = EPS
+            K.setup()
+            x = np.array(kw['x0'], dtype=float); xs, us = [x.copy()], []
+            for _ in range(40):                        # (stops short of the position bound: ON a hard bound x0 = 7 + 1e-10 makes the
+                                                       #  next QP infeasible at this tolerance and the reference raises -- why mpc.py has slack)
+                u = K.step(); x = kw['Ad'] @ x + kw['Bd'] @ u; K.update(x)
+                xs.append(x.copy()); us.append(np.array(u, dtype=float))
+            ref_ns.osqp.TIGHT = None
+            np.savez_compressed(os.path.join(HERE, 'traj_no_slack_point_mass.npz'), x=np.array(xs), u=np.array(us), pattern='step_update', fixture='point_mass', eps=EPS,
+                                xmin=kw['xmin'], xmax=kw['xmax'])
+            print('%-14s %3d steps  |x|max %.3f  |u|max %.3f  u[0] %s' % ('no_slack_point_mass', 40, np.abs(xs).max(), np.abs(us).max(), us[0]))
         if not sys.argv[1:] or 'kalman_cart_pole' in sys.argv[1:]:
             import scipy
             if not hasattr(scipy, 'size'):

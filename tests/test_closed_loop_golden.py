@@ -87,3 +87,56 @@ def test_host_estimator_and_class_reproduce_reference_output_feedback_loop(name)
             assert np.abs(u - g['u'][k]).max() <= 1e-8 * max(1e-3, np.abs(g['u']).max()), k
             assert np.abs(x - g['x'][k + 1]).max() <= 1e-8 * np.abs(g['x']).max(), k
             assert np.abs(KF.x - g['xhat'][k + 1]).max() <= 1e-8 * np.abs(g['xhat']).max(), k
+
+
+def _no_slack_loop(K, g, tol):
+    """u = K.step(); x+ = Ad x + Bd u; K.update(x)  -- the loop of mpc_no_slack.py:362-371."""
+    xs, us = g['x'], g['u']
+    K.setup()
+    x = xs[0].copy()
+    for k in range(len(us)):
+        u = K.step()
+        assert np.abs(u - us[k]).max() <= tol * max(1e-3, np.abs(us).max()), (k, u, us[k])
+        x = K.Ad @ x + K.Bd @ u
+        assert np.abs(x - xs[k + 1]).max() <= tol * np.abs(xs).max(), k
+        K.update(x)
+
+
+def _no_slack_controller(g):
+    from pympc_amd import fixtures
+    from pympc_amd.mpc_no_slack import MPCController
+    kw = {k: v for k, v in fixtures.point_mass().items() if k != 'eps_feas'}
+    kw.update(xmin=g['xmin'], xmax=g['xmax'])
+    K = MPCController(**kw)
+    K.eps_abs = K.eps_rel = float(g['eps'])          # (the golden run was made at tight tolerance; the class's own is 1e-4)
+    K.solver_settings = dict(max_iter=400000)
+    return K
+
+
+def test_no_slack_shim_with_oracle_reproduces_reference_class():
+    """pympc_amd.mpc_no_slack.MPCController (oracle as its solver) against the trajectory the REFERENCE's
+    pyMPC/mpc_no_slack.py class produced in the loop of its own __main__ (make_traj.py): hard state box, step()/update()."""
+    from oracle.osqp_oracle import OSQP
+    g = load_traj('no_slack_point_mass')
+    K = _no_slack_controller(g)
+    K.prob = OSQP()
+    _no_slack_loop(K, g, 1e-8)
+    assert K.P.shape[0] == (K.Np + 1) * K.nx + K.Np * K.nu           # no slack columns
+    K2 = _no_slack_controller(g); K2.prob = OSQP(); K2.setup()
+    K2.update(np.array([0.1, 0.2]), np.array([9.0]))                  # u_{-1} far outside the input box: infeasible -> step() raises
+    with pytest.raises(ValueError, match='OSQP did not solve the problem!'):
+        K2.step()
+
+
+def test_no_slack_shim_rejects_more_than_one_input():
+    from pympc_amd import fixtures
+    from pympc_amd.mpc_no_slack import MPCController
+    kw = {k: v for k, v in fixtures.accel_brake().items() if k != 'eps_feas'}
+    with pytest.raises(ValueError, match='single input'):
+        MPCController(**kw).setup()
+
+
+@pytest.mark.gpu
+def test_no_slack_shim_on_gpu_follows_reference_class():
+    g = load_traj('no_slack_point_mass')
+    _no_slack_loop(_no_slack_controller(g), g, 1e-6)

@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 import scipy.sparse as sp
 
-from util import golden_names, load_golden, golden_kwargs, golden_csc, update_steps
+from util import golden_names, load_golden, golden_kwargs, golden_csc, update_steps, apply_attrs
 
 pytestmark = pytest.mark.gpu
 
@@ -20,7 +20,7 @@ DEVICE_FIXTURES = golden_names()
 
 def _gpu_controller(kw, **settings):
     from pympc_amd import MPCController
-    K = MPCController(**kw)
+    K = apply_attrs(MPCController(**kw), kw)
     K.solver_settings = dict(settings)
     return K
 
@@ -28,7 +28,7 @@ def _gpu_controller(kw, **settings):
 def _oracle_controller(kw, **settings):
     from pympc_amd import MPCController
     from oracle.osqp_oracle import OSQP
-    K = MPCController(**kw)
+    K = apply_attrs(MPCController(**kw), kw)
     K.prob = OSQP()
     K.solver_settings = dict(settings)
     return K

@@ -9,7 +9,7 @@ import warnings
 import numpy as np
 import pytest
 
-from util import golden_names, load_golden, golden_csc, golden_kwargs, kkt_certificate, update_steps
+from util import golden_names, load_golden, golden_csc, golden_kwargs, kkt_certificate, update_steps, apply_attrs
 from oracle.osqp_oracle import OSQP
 
 
@@ -32,7 +32,7 @@ def test_oracle_reaches_certified_optimum(name):
 def test_oracle_default_tolerance_and_warm_start(name):
     from pympc_amd import MPCController
     g = load_golden(name)
-    K = MPCController(**golden_kwargs(g))
+    K = apply_attrs(MPCController(**golden_kwargs(g)), golden_kwargs(g))
     K.prob = OSQP()
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')

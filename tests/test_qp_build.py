@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from pympc_amd.controller import MPCController
-from util import golden_names, load_golden, golden_kwargs, golden_csc, update_steps
+from util import golden_names, load_golden, golden_kwargs, golden_csc, update_steps, apply_attrs
 
 
 class _NullProb:
@@ -25,7 +25,7 @@ class _NullProb:
 @pytest.mark.parametrize('name', golden_names())
 def test_build_matches_reference(name):
     g = load_golden(name)
-    K = MPCController(**golden_kwargs(g))
+    K = apply_attrs(MPCController(**golden_kwargs(g)), golden_kwargs(g))
     K.prob = _NullProb()
     K.setup(solve=False)
     for which, M in (('P', K.P), ('A', K.A)):
@@ -46,7 +46,7 @@ def test_build_matches_reference(name):
 @pytest.mark.parametrize('name', golden_names())
 def test_update_matches_reference(name):
     g = load_golden(name)
-    K = MPCController(**golden_kwargs(g))
+    K = apply_attrs(MPCController(**golden_kwargs(g)), golden_kwargs(g))
     K.prob = _NullProb()
     K.setup(solve=False)
     for s, st in enumerate(update_steps(g)):

@@ -16,14 +16,26 @@ def load_golden(name, prefix='qp_'):
     return np.load(os.path.join(GOLDEN_DIR, '%s%s.npz' % (prefix, name)))
 
 
+class KW(dict):
+    """Constructor kwargs of a fixture; ``attrs`` = hidden switches to set on the controller afterwards (SOFT_ON, mpc.py:233-238)."""
+    attrs = {}
+
+
 def golden_kwargs(g):
-    """Constructor kwargs stored in a golden file (keys ``in_*``)."""
-    kw = {}
+    """Constructor kwargs stored in a golden file (keys ``in_*``), attribute switches (keys ``attr_*``) in ``.attrs``."""
+    kw = KW()
     for k in g.files:
         if k.startswith('in_'):
             v = g[k]
             kw[k[3:]] = int(v) if k[3:] in ('Np', 'Nc') else (float(v) if v.ndim == 0 else np.array(v))
+    kw.attrs = {k[5:]: bool(g[k]) for k in g.files if k.startswith('attr_')}
     return kw
+
+
+def apply_attrs(K, kw):
+    for k, v in getattr(kw, 'attrs', {}).items():
+        setattr(K, k, v)
+    return K
 
 
 def golden_csc(g, which):
@@ -58,9 +70,10 @@ def kkt_certificate(P, q, A, l, u, x, y):
 
 # ---- closed-loop golden trajectories (tests/golden/make_traj.py) ------------------------------------------------------
 def traj_names(output_feedback=False):
-    """State-feedback closed loops (default) or the output-feedback ones (traj_kalman_*.npz)."""
+    """State-feedback closed loops of pyMPC/mpc.py (default) or the output-feedback ones (traj_kalman_*.npz); the loop of
+    the older mpc_no_slack.py class (traj_no_slack_*.npz) has a test of its own."""
     names = sorted(os.path.basename(p)[5:-4] for p in glob.glob(os.path.join(GOLDEN_DIR, 'traj_*.npz')))
-    return [n for n in names if n.startswith('kalman_') == output_feedback]
+    return [n for n in names if n.startswith('kalman_') == output_feedback and not n.startswith('no_slack_')]
 
 
 def load_traj(name):
