@@ -54,15 +54,26 @@ template <int NB> struct SinvFmt { static constexpr bool SYM = MPCQP_SYM_SINV &&
 #ifndef MPCQP_SONLY32
 #define MPCQP_SONLY32 1
 #endif
+//   hybrid (16 x 16 stages): the two-slot stage [ -Mh_k | sym(S_k^-1) ] plus [ G | G' ] behind the last stage -- one stored
+//       format, two ways to run the back substitution, chosen per launch (Lay::hybrid, set by the host from the batch size).
+//       Forward elimination as in the two-slot format (one mat-vec per stage from the forward matrix), but NO separate S^-1
+//       phase and no second read of the forward matrices: the back substitution is  x_k = S_k^-1 ( yh_k - K_{k,nbr} x_nbr )
+//       with the off-diagonal block applied matrix-free (because Mh_{k+1}' = S_k^-1 K_{k,k+1}).  Per stage and iteration
+//       2 KB + 1.3 KB instead of 2 + 1.3 + 2 KB.
 #ifndef MPCQP_SONLY16
 #define MPCQP_SONLY16 0
 #endif
+#ifndef MPCQP_HYBRID16
+#define MPCQP_HYBRID16 1                   // 1: the header exists and the kernels choose per launch (Lay::hybrid); 0: two-slot only
+#endif
 template <int NB> struct FactorFmt {
     static constexpr bool SONLY = (MPCQP_SONLY32 && NB == 32) || (MPCQP_SONLY16 && NB == 16);
+    static constexpr bool HYBRID = !SONLY && MPCQP_HYBRID16 && NB == 16;
     static constexpr int SINV = SONLY ? (NB == 32 ? 164 + 164 + 256 : 164) : (MPCQP_SYM_SINV && NB == 16 ? 164 : NB * NB);
     static constexpr int FWD = SONLY ? 0 : NB * NB;
     static constexpr int STAGE = FWD + SINV;
-    static constexpr int HEAD = SONLY ? 2 * NB * NB : 0;
+    static constexpr int HEAD = (SONLY || HYBRID) ? 2 * NB * NB : 0;     // [G | G']: in front of the stages (S^-1-only) or behind them (hybrid)
+    static constexpr int SOFF = FWD;                                    // offset of S^-1 inside a stage
 };
 typedef double d4u __attribute__((ext_vector_type(4), aligned(8)));
 typedef __attribute__((address_space(1))) const d4u cgd4u;
@@ -188,7 +199,7 @@ __device__ int factor_all(const Ctx &c, const double *om, const double *sv, doub
             const double acc = 0.5 * (S[a * NB + b] + S[b * NB + a]);
             SnOut[e] = acc;
             if constexpr (FactorFmt<NB>::SONLY) {                  // [ sym(S00) | sym(S11) | S01 ]
-                double *Fk = F + FactorFmt<NB>::HEAD + (size_t)k * L.fstage;
+                double *Fk = F + FactorFmt<NB>::HEAD + (size_t)k * L.fstage;     // (S^-1-only: the header comes first)
                 const int A_ = a >> 4, B_ = b >> 4, al = a & 15, bl = b & 15;
                 if (A_ == B_) { if ((bl >> 2) >= (al >> 2)) Fk[164 * A_ + sym_pos(al, bl)] = acc; }
                 else if (A_ == 0) Fk[328 + frag_pos<16>(al, bl)] = acc;
@@ -213,15 +224,16 @@ __device__ int factor_all(const Ctx &c, const double *om, const double *sv, doub
         for (int k = N - 1; k > mid; --k) stage(true, k, NT, tid, W, nullptr, k < N - 1 ? SnB : nullptr, SnB);
     }
     stage(true, mid, NT, tid, W, SnA, SnB, SnA);
-    if constexpr (FactorFmt<NB>::SONLY) {      // header: G = [[Ad, Bd], [0, c QDu']] and G' as fragments (constant per instance)
+    if constexpr (FactorFmt<NB>::HEAD > 0) {   // G = [[Ad, Bd], [0, c QDu']] and G' as fragments (constant per instance)
         constexpr int NBLK = NB / 16;
+        double *Fg = FactorFmt<NB>::SONLY ? F : F + (size_t)N * L.fstage;
         for (int e = tid; e < NB * NB; e += NT) {
             const int r = e / NB, q = e % NB;
             double g = 0.0;
             if (r < L.nx) g = q < L.nx ? c.Ad()[r * L.nx + q] : (q < L.nb ? c.Bd()[r * L.nu + (q - L.nx)] : 0.0);
             else if (r < L.nb && q >= L.nx && q < L.nb) g = cc * c.QDu()[(q - L.nx) * L.nu + (r - L.nx)];
-            F[frag_pos<NB>(r, q)] = g;
-            F[NB * NB + frag_pos<NB>(q, r)] = g;
+            Fg[frag_pos<NB>(r, q)] = g;
+            Fg[NB * NB + frag_pos<NB>(q, r)] = g;
         }
         (void)NBLK;
     }

@@ -341,9 +341,14 @@ __device__ unsigned long long g_ticks[16];
 #endif
 
 // What the linear-system core needs to know about one instance.
-struct CoreArgs { int N, fstage, nx, nu, NcT, rdu; const double *F; const double *om; };
+// F: the stages; G: the [G | G'] header of the formats that apply off-diagonal blocks matrix-free (in front of the stages in
+// the S^-1-only format, behind them in the hybrid one).
+struct CoreArgs { int N, fstage, nx, nu, NcT, rdu; const double *F; const double *G; const double *om; };
 __device__ __forceinline__ CoreArgs core_args(const Lay &L, const double *F, const double *om) {
-    CoreArgs a; a.N = L.N; a.fstage = L.fstage; a.nx = L.nx; a.nu = L.nu; a.NcT = L.NcT; a.rdu = L.rdu; a.F = F; a.om = om; return a;
+    CoreArgs a; a.N = L.N; a.fstage = L.fstage; a.nx = L.nx; a.nu = L.nu; a.NcT = L.NcT; a.rdu = L.rdu; a.om = om;
+    a.F = L.ffwd ? F : F + L.fhead;
+    a.G = L.ffwd ? F + (size_t)L.N * L.fstage : F;
+    return a;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -453,7 +458,7 @@ __device__ __forceinline__ void so_step_load(const CoreArgs &a, const SoLane<NB>
 #pragma unroll
     for (int bi = 0; bi < NB / 16; ++bi) st.sc[bi] = om[hi * a.nx + (q.isx[bi] ? q.e[bi] : 0)];
     st.wd = om[a.rdu + a.nu + min(lo, max(a.NcT - 2, 0)) * a.nu + a.nu - 1];      // (clamped: the row only exists for lo <= NcT-2)
-    so_load<NB>(a.F + FactorFmt<NB>::HEAD + (size_t)k * a.fstage, lane, st.S);
+    so_load<NB>(a.F + (size_t)k * a.fstage + FactorFmt<NB>::SOFF, lane, st.S);
 }
 template <int NB>
 __device__ __forceinline__ void so_step_fix(const CoreArgs &a, const SoLane<NB> &q, int k, int nbr, const SoStep<NB> &st, double *sc, double &wd) {
@@ -468,7 +473,9 @@ __device__ __forceinline__ void so_step_fix(const CoreArgs &a, const SoLane<NB> 
 // barriers: left free, the machine scheduler spreads them over the stage and the waits it then needs end up as
 // s_waitcnt vmcnt(0)/(1) every other stage, i.e. no look-ahead at all (seen in the ISA).  With the fences the loads stay
 // a block, in source order, and the compiler's own accounting gives exact vmcnt(9) waits.
-template <int NB, bool FWD, bool UP>
+// SOLVE_FIRST: the first stage's vector is a right-hand side still to be multiplied by its S^-1 (forward sweep of the
+// S^-1-only format); otherwise it is final (back substitutions, which start from the middle stage).
+template <int NB, bool FWD, bool UP, bool SOLVE_FIRST = FWD>
 __device__ __forceinline__ void half_sweep_so(const CoreArgs &a, double *Tc, const int first, const int dir, const int nsteps) {
     constexpr int NBLK = NB / 16, NF = SoCfg<NB>::NF;
     const int lane = opaque_lane(threadIdx.x & 63);
@@ -476,13 +483,13 @@ __device__ __forceinline__ void half_sweep_so(const CoreArgs &a, double *Tc, con
     double *tb = Tc + vec_lane_offset(lane);
     const bool writer = vec_lane_writer(lane);
     d4 Gf[NF];
-    frag_load<NB>(a.F + (UP ? 0 : NB * NB), lane, Gf);
+    frag_load<NB>(a.G + (UP ? 0 : NB * NB), lane, Gf);
     auto stage_of = [&](int i) { return first + dir * i; };
     auto clamp_i = [&](int i) { return i < nsteps ? i : nsteps; };       // (branch-free refills, see chain_sweep)
     double run[NBLK];
-    if (FWD) {
+    if (SOLVE_FIRST) {
         d4 A0[SoCfg<NB>::NS], Sf[NF];
-        so_load<NB>(a.F + FactorFmt<NB>::HEAD + (size_t)first * a.fstage, lane, A0);
+        so_load<NB>(a.F + (size_t)first * a.fstage + FactorFmt<NB>::SOFF, lane, A0);
         so_expand<NB>(A0, lane, Sf);
         double in[NBLK];
         vec_load<NB>(tb, first, in);
@@ -549,12 +556,12 @@ __device__ __forceinline__ void kkt_core_so(const CoreArgs &a, double *Tc) {
         d4 Gf[NF], Sf[NF];
         double vu[NBLK], vd[NBLK], own[NBLK], tu[NBLK], td[NBLK], out[NBLK];
         vec_load<NB>(tb, mid - 1, vu); vec_load<NB>(tb, mid + 1, vd); vec_load<NB>(tb, mid, own);
-        frag_load<NB>(a.F, lane, Gf);
+        frag_load<NB>(a.G, lane, Gf);
         double scu[NBLK], scd[NBLK], wdu, wdd;
         so_step_fix<NB>(a, q, mid, mid - 1, su, scu, wdu);
         so_step_fix<NB>(a, q, mid, mid + 1, sd, scd, wdd);
         so_offdiag<NB, true>(a, q, Gf, mid, vu, scu, wdu, tu);
-        frag_load<NB>(a.F + NB * NB, lane, Gf);
+        frag_load<NB>(a.G + NB * NB, lane, Gf);
         so_offdiag<NB, false>(a, q, Gf, mid, vd, scd, wdd, td);
         so_expand<NB>(su.S, lane, Sf);
 #pragma unroll
@@ -599,14 +606,55 @@ __device__ __forceinline__ void kkt_core_sweeps(const CoreArgs &a, double *Tc) {
     TICK(3)
 }
 
+// Hybrid format: forward elimination from the forward matrices (chain_sweep), the middle stage, then back substitution
+//     x_k = S_k^-1 ( yh_k - K_{k,nbr} x_nbr )
+// outwards from the middle with the off-diagonal blocks applied matrix-free -- S^-1 is read once, the forward matrices once.
+template <int NB>
+__device__ __forceinline__ void kkt_core_hybrid(const CoreArgs &a, double *Tc) {
+    constexpr int NBLK = NB / 16, NF = SoCfg<NB>::NF;
+    const int N = a.N, fstage = a.fstage, mid = N / 2, wv = logical_wave(), lane = opaque_lane(threadIdx.x & 63);
+    const double *F = a.F;
+    TICK_START
+    if (wv == 0) chain_sweep<NB, false>(0, +1, mid - 1, fstage, F, -1, Tc);               // yh_1 .. yh_{mid-1}
+    else if (wv == 1) chain_sweep<NB, false>(N - 1, -1, N - 2 - mid, fstage, F, -1, Tc);  // yh_{N-2} .. yh_{mid+1}
+    __syncthreads();
+    TICK(1)
+    if (wv == 0) {                                   // yh_mid = b_mid - Mh_mid yh_{mid-1} - Mt_mid yh_{mid+1};  x_mid = S_mid^-1 yh_mid
+        double *tb = Tc + vec_lane_offset(lane);
+        d4 A0[NF], A2[NF], Am[SoCfg<NB>::NS], Sf[NF];
+        frag_load<NB>(F + (size_t)mid * fstage, lane, A0);
+        frag_load<NB>(F, lane, A2);                  // the middle's second forward matrix (kept in stage 0's slot)
+        so_load<NB>(F + (size_t)mid * fstage + FactorFmt<NB>::SOFF, lane, Am);
+        double up[NBLK], dn[NBLK], acc[NBLK], out[NBLK];
+        vec_load<NB>(tb, mid, acc); vec_load<NB>(tb, mid - 1, up); vec_load<NB>(tb, mid + 1, dn);
+        frag_matvec<NB>(A0, up, acc);
+        frag_matvec<NB>(A2, dn, acc);
+        so_expand<NB>(Am, lane, Sf);
+#pragma unroll
+        for (int bi = 0; bi < NBLK; ++bi) out[bi] = 0.0;
+        frag_matvec<NB>(Sf, acc, out);
+        vec_store<NB>(tb, mid, out, vec_lane_writer(lane));
+    }
+    __syncthreads();
+    TICK(2)
+    if (wv == 0) half_sweep_so<NB, true, false, false>(a, Tc, mid, -1, mid);              // x_{mid-1} .. x_0       (neighbour below)
+    else if (wv == 1) half_sweep_so<NB, true, true, false>(a, Tc, mid, +1, N - 1 - mid);  // x_{mid+1} .. x_{N-1}   (neighbour above)
+    __syncthreads();
+    TICK(3)
+}
+
 // Tc <- K_xu^-1 Tc (eps already eliminated).  All threads call; barriers inside.  Waves 0 and 1 sweep the two
 // half-chains of the twisted factorization concurrently.  Tc must be seen by the compiler as an LDS pointer
 // (a pointer laundered through an integer becomes FLAT: flat LDS accesses count on vmcnt AND lgkmcnt and force a
 // full s_waitcnt vmcnt(0) -- draining the factor prefetch -- before every stage).
-template <int NB>
+// HYB (16 x 16 stages only): the hybrid back substitution instead of the two-slot one -- a template parameter, not a run-time
+// branch: compiled into one function the two paths share a register allocation and the two-slot one loses 3 % to it.
+template <int NB, bool HYB = false>
 __device__ __forceinline__ void kkt_core(const CoreArgs &a, double *Tc) {
 #ifndef MPCQP_ABL_NOCHAIN
-    if constexpr (FactorFmt<NB>::SONLY) kkt_core_so<NB>(a, Tc); else kkt_core_sweeps<NB>(a, Tc);
+    if constexpr (FactorFmt<NB>::SONLY) kkt_core_so<NB>(a, Tc);
+    else if constexpr (FactorFmt<NB>::HYBRID && HYB) kkt_core_hybrid<NB>(a, Tc);
+    else kkt_core_sweeps<NB>(a, Tc);
 #endif
     __syncthreads();
 }
