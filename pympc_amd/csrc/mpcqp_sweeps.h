@@ -23,13 +23,17 @@ __device__ __forceinline__ int vec_lane_offset(int lane) { return 4 * ((lane >> 
 __device__ __forceinline__ bool vec_lane_writer(int lane) { return (lane & 3) == 0; }
 
 // rotate every 16-lane row by 4*sft lanes: lane (k, b, j) receives the value of lane (k, (b+sft)%4, j)
+// (`old` operand of the DPP move: with row_ror every lane receives a value, so what the destination held before is
+//  irrelevant -- an unspecified register instead of a zero saves the two v_mov_b32 the compiler would otherwise emit per
+//  rotation, ~500 instructions per workgroup and iteration in the sweeps)
+#define DPP_MOVE(src, ctrl) __builtin_amdgcn_mov_dpp((src), (ctrl), 0xF, 0xF, false)      // (v_mov_b32_dpp with an undefined `old`)
 template <int SFT>
 __device__ __forceinline__ double rot_blocks(double x) {
     if (SFT == 0) return x;
     constexpr int CTRL = 0x120 | (16 - 4 * SFT);          // row_ror:n gives dst[i] = src[(i - n) mod 16]
     const long long xi = __builtin_bit_cast(long long, x);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)xi, CTRL, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(xi >> 32), CTRL, 0xF, 0xF, false);
+    const int lo = DPP_MOVE((int)xi, CTRL);
+    const int hi = DPP_MOVE((int)(xi >> 32), CTRL);
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
 }
 
@@ -104,8 +108,8 @@ __device__ __forceinline__ double lane_permute(double x, int byte_addr) {
 template <int CTRL>
 __device__ __forceinline__ double dpp_move(double x) {
     const long long xi = __builtin_bit_cast(long long, x);
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)xi, CTRL, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(xi >> 32), CTRL, 0xF, 0xF, false);
+    const int lo = DPP_MOVE((int)xi, CTRL);      // (quad_perm: every lane written too)
+    const int hi = DPP_MOVE((int)(xi >> 32), CTRL);
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
 }
 __device__ __forceinline__ int transpose_lane_addr(int lane) { return 4 * (16 * (lane & 3) + (lane & 12) + (lane >> 4)); }
