@@ -145,6 +145,7 @@ static Lay make_layout(int nx, int nu, int Np, int Nc, int soft) {
     L.fstage = L.NB == 16 ? FactorFmt<16>::STAGE : FactorFmt<32>::STAGE;
     L.fhead = L.NB == 16 ? FactorFmt<16>::HEAD : FactorFmt<32>::HEAD;
     L.ffwd = L.NB == 16 ? FactorFmt<16>::FWD : FactorFmt<32>::FWD;
+    L.ftab = L.NB == 16 ? FactorFmt<16>::TAB : FactorFmt<32>::TAB;
     L.tsz = L.m + L.N * L.NB;                          // [W (m) | Tc (N*NB)]; mpcqp_create widens it where the factorization needs more
     return L;
 }
@@ -661,7 +662,9 @@ extern "C" int mpcqp_get_stats(mpcqp_handle *h, uint64_t *out4, int reset) {
 #ifdef MPCQP_RUN_TIMING
     { uint64_t t[4]; hipMemcpy(t, h->P.stats + 4, sizeof(t), hipMemcpyDeviceToHost); fprintf(stderr, "phase wall-clock ticks: begin %llu admm %llu check %llu\n", (unsigned long long)t[0], (unsigned long long)t[1], (unsigned long long)t[2]);
       unsigned long long g[16]; hipMemcpyFromSymbol(g, HIP_SYMBOL(g_ticks), sizeof(g)); unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_ticks), z, sizeof(z));
-      fprintf(stderr, "iteration ticks: rhs %llu fwd %llu sinv %llu bwd %llu (kkt tail in update) update %llu\n", g[0], g[1], g[2], g[3], g[4]); }
+      { double tot = 0; for (int i = 0; i < 6; ++i) tot += (double)g[i]; if (tot <= 0) tot = 1;
+        fprintf(stderr, "iteration cycles (thread 0, summed over workgroups): rhs %.1f%% fwd %.1f%% mid/sinv %.1f%% bwd %.1f%% x-update %.1f%% rows %.1f%%  total %.3g\n",
+                100 * g[0] / tot, 100 * g[1] / tot, 100 * g[2] / tot, 100 * g[3] / tot, 100 * g[4] / tot, 100 * g[5] / tot, tot); } }
 #endif
     if (reset) HIPCHK(hipMemsetAsync(h->P.stats, 0, 8 * sizeof(uint64_t), h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -710,9 +713,9 @@ extern "C" int mpcqp_get_stream_bytes(mpcqp_handle *h, int64_t *per_iter, int64_
     if (!h) return fail(MPCQP_ERR_ARG, "null handle");
     const Lay &L = h->L;
     const int64_t n = L.n, m = L.m, nq = L.n_x + L.n_u, NB = L.NB;
-    const int64_t sinv = L.fstage - L.ffwd;
+    const int64_t sinv = L.fstage - L.ffwd - L.ftab;
     int64_t it = !L.ffwd ? 2 * (int64_t)L.N * sinv + 2 * (int64_t)L.fhead              // S^-1-only: S^-1 twice, [G | G'] by each sweeping wave
-               : L.hybrid ? (int64_t)(L.N - 1) * L.ffwd + (int64_t)L.N * sinv + L.fhead // hybrid back substitution: forward matrices once, S^-1 once, G / G' once each
+               : L.hybrid ? (int64_t)(L.N - 1) * L.ffwd + (int64_t)L.N * sinv + (int64_t)(L.N - 1) * L.ftab + L.fhead // hybrid back substitution: forward matrices once, S^-1 once, the tables, G / G' once each
                          : 2 * (int64_t)(L.N - 1) * L.ffwd + (int64_t)L.N * sinv;       // two-slot: forward matrices twice, S^-1 once
     if (!h->lds_state) it += (2 * n + 4 * m) /* x, z, y read + written */ + (m + L.n_x) /* omega */ + (n + L.n_x) /* s */ + nq /* q */;
     if (L.border) it += 2 * (int64_t)L.nu * L.N * NB;

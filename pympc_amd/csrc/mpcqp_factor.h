@@ -59,7 +59,10 @@ template <int NB> struct SinvFmt { static constexpr bool SYM = MPCQP_SYM_SINV &&
 //       Forward elimination as in the two-slot format (one mat-vec per stage from the forward matrix), but NO separate S^-1
 //       phase and no second read of the forward matrices: the back substitution is  x_k = S_k^-1 ( yh_k - K_{k,nbr} x_nbr )
 //       with the off-diagonal block applied matrix-free (because Mh_{k+1}' = S_k^-1 K_{k,k+1}).  Per stage and iteration
-//       2 KB + 1.3 KB instead of 2 + 1.3 + 2 KB.
+//       2 KB + 1.3 KB instead of 2 + 1.3 + 2 KB.  What the matrix-free product needs of omega sits behind S^-1 as a table of
+//       (scale, coupling weight) pairs per stage element, written by the factorization (omega changes only when it runs); and
+//       the stored S^-1 has ZERO rows and columns where the stage has no variable (padding, inputs beyond the control
+//       horizon) instead of the identity, so that the back substitution needs no row mask.
 #ifndef MPCQP_SONLY16
 #define MPCQP_SONLY16 0
 #endif
@@ -71,7 +74,8 @@ template <int NB> struct FactorFmt {
     static constexpr bool HYBRID = !SONLY && MPCQP_HYBRID16 && NB == 16;
     static constexpr int SINV = SONLY ? (NB == 32 ? 164 + 164 + 256 : 164) : (MPCQP_SYM_SINV && NB == 16 ? 164 : NB * NB);
     static constexpr int FWD = SONLY ? 0 : NB * NB;
-    static constexpr int STAGE = FWD + SINV;
+    static constexpr int TAB = HYBRID ? 2 * NB : 0;                      // hybrid: per element (omega scaling, Delta-u coupling weight) of the stage's off-diagonal block
+    static constexpr int STAGE = FWD + SINV + TAB;
     static constexpr int HEAD = (SONLY || HYBRID) ? 2 * NB * NB : 0;     // [G | G']: in front of the stages (S^-1-only) or behind them (hybrid)
     static constexpr int SOFF = FWD;                                    // offset of S^-1 inside a stage
 };
@@ -204,8 +208,29 @@ __device__ int factor_all(const Ctx &c, const double *om, const double *sv, doub
                 if (A_ == B_) { if ((bl >> 2) >= (al >> 2)) Fk[164 * A_ + sym_pos(al, bl)] = acc; }
                 else if (A_ == 0) Fk[328 + frag_pos<16>(al, bl)] = acc;
             }
-            else if constexpr (SinvFmt<NB>::SYM) { if ((b >> 2) >= (a >> 2)) F[(size_t)k * L.fstage + NB * NB + sym_pos(a, b)] = acc; }
-            else F[(size_t)k * L.fstage + NB * NB + frag_pos<NB>(a, b)] = acc;
+            else {
+                // (hybrid: rows / columns without a variable stored as zero -- see FactorFmt; the LDS copy SnOut stays the true inverse)
+                const bool dead = FactorFmt<NB>::HYBRID && (a >= L.nb || b >= L.nb || ((a >= L.nx || b >= L.nx) && k >= L.NcT));
+                const double st = dead ? 0.0 : acc;
+                if constexpr (SinvFmt<NB>::SYM) { if ((b >> 2) >= (a >> 2)) F[(size_t)k * L.fstage + NB * NB + sym_pos(a, b)] = st; }
+                else F[(size_t)k * L.fstage + NB * NB + frag_pos<NB>(a, b)] = st;
+            }
+        }
+        if constexpr (FactorFmt<NB>::TAB > 0) {
+            // table of the stage's off-diagonal block towards the neighbour the back substitution comes from (k+1 in the top half,
+            // k-1 in the bottom half; kkt_sub_entry is the entry-wise definition): element e -> (omega of the dynamics row, 1 off the
+            // x part;  omega of the Delta-u row that couples the two stages, on the one element it enters, 0 elsewhere)
+            if (on && lt < NB) {
+                const int e = lt, nbr = k < mid ? k + 1 : k - 1, hi = max(k, nbr), lo = min(k, nbr);
+                double sc = 1.0, cw = 0.0;
+                if (k != mid) {
+                    if (e < L.nx) sc = om[hi * L.nx + e];
+                    const int edst = k < mid ? L.nx + L.nu - 1 : L.nx;
+                    if (e == edst && hi < L.NcT) cw = om[L.rdu + L.nu + min(lo, max(L.NcT - 2, 0)) * L.nu + L.nu - 1];
+                }
+                double *tab = F + (size_t)k * L.fstage + FactorFmt<NB>::FWD + FactorFmt<NB>::SINV;
+                tab[2 * e] = sc; tab[2 * e + 1] = cw;
+            }
         }
     };
     if (G == 2) {

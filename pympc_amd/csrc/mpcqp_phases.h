@@ -526,6 +526,7 @@ __device__ __forceinline__ void hot_update(const Lay &L, const double *hot, cons
         }
     }
     __syncthreads();
+    TICK(4)
     const double *Ad = hot + L.oAd, *Bd = hot + L.oBd;
     auto row_update = [&](int r, double w, double &zv, double &yv) {
         double zt, lo, hi;
@@ -611,6 +612,7 @@ __device__ __forceinline__ void admm_body(const Lay &L, const HotPtrs &P, Smem &
 #ifndef MPCQP_ABL_NOPAR
     hot_rows_w<LDSSTATE>(L, gom, hr, cc, Z, Y, W);
 #endif
+    TICK_RESET
     for (int it = 1; it <= iters; ++it) {
         const bool keep_delta = it == iters;         // the increments feed the infeasibility certificates of the check
         TICK_START
@@ -629,8 +631,9 @@ __device__ __forceinline__ void admm_body(const Lay &L, const HotPtrs &P, Smem &
 #ifndef MPCQP_ABL_NOPAR
         hot_update<NB, NXT, NUT, LDSSTATE>(L, S.hot, S.x0s, S.du0, gom, gsv, hr, cc, alpha, X, Z, Y, W, Tc, keep_delta, dxg, dyg);
 #endif
-        TICK(4)
+        TICK(5)
     }
+    TICK_FLUSH
     if (LDSSTATE) {
         for (int j = tid; j < L.n; j += NT) gx[j] = X[j];
         for (int r = tid; r < L.m; r += NT) { gz[r] = Z[r]; gy[r] = Y[r]; }

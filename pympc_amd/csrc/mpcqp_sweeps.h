@@ -38,21 +38,42 @@ __device__ __forceinline__ double rot_blocks(double x) {
 }
 
 // out[bi] += sum_bj A(bi,bj) * in[bj]   with A given as fragments (one d4 per block per lane)
+// The four MFMAs of a block are issued as TWO dependent pairs whose partial sums are added on the vector ALU: a stage of a
+// sweep is a latency chain, and a dependent f64 4x4x4 MFMA costs ~44 cycles -- two in a row plus one add instead of four.
+#ifndef MPCQP_MFMA_PAIRS
+#define MPCQP_MFMA_PAIRS 1
+#endif
 template <int NB>
 __device__ __forceinline__ void frag_matvec(const d4 *A, const double *in, double *out) {
     constexpr int NBLK = NB / 16;
+#if MPCQP_MFMA_PAIRS
+    double side[NBLK];
+#pragma unroll
+    for (int bi = 0; bi < NBLK; ++bi) side[bi] = 0.0;
+#endif
 #pragma unroll
     for (int bj = 0; bj < NBLK; ++bj) {
         const double r0 = in[bj], r1 = rot_blocks<1>(in[bj]), r2 = rot_blocks<2>(in[bj]), r3 = rot_blocks<3>(in[bj]);
 #pragma unroll
         for (int bi = 0; bi < NBLK; ++bi) {
             const d4 a = A[bi * NBLK + bj];
+#if MPCQP_MFMA_PAIRS
+            out[bi] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[0], r0, out[bi], 0, 0, 0);
+            side[bi] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[2], r2, side[bi], 0, 0, 0);
+            out[bi] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[1], r1, out[bi], 0, 0, 0);
+            side[bi] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[3], r3, side[bi], 0, 0, 0);
+#else
             out[bi] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[0], r0, out[bi], 0, 0, 0);
             out[bi] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[1], r1, out[bi], 0, 0, 0);
             out[bi] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[2], r2, out[bi], 0, 0, 0);
             out[bi] = __builtin_amdgcn_mfma_f64_4x4x4f64(a[3], r3, out[bi], 0, 0, 0);
+#endif
         }
     }
+#if MPCQP_MFMA_PAIRS
+#pragma unroll
+    for (int bi = 0; bi < NBLK; ++bi) out[bi] += side[bi];
+#endif
 }
 
 template <int NB>
@@ -180,10 +201,17 @@ __device__ __forceinline__ void chain_sweep(const int first, const int dir, cons
     for (int d = 0; d < DEPTH; ++d) frag_load<NB>(frag_clamped(1 + d), lane, ring[d]);
     double va[NBLK], vb[NBLK];
     vec_load<NB>(tb, first, va);
+    // The stage's own vector is read from LDS ONE STAGE AHEAD (oa / ob alternate): read where it is used, its LDS round trip
+    // sits on the dependent chain of every stage.  (Stage k+dir is not written before its own step.)
+    double oa[NBLK], ob[NBLK];
+    vec_load<NB>(tb, stage_of(1), oa);
     auto stage_step = [&](int i, int d) {
         const int k = stage_of(i);
         double *src = (d & 1) ? vb : va, *dst = (d & 1) ? va : vb;
-        vec_load<NB>(tb, k, dst);
+        double *own = (d & 1) ? ob : oa, *nxt = (d & 1) ? oa : ob;
+        vec_load<NB>(tb, stage_of(i < nsteps ? i + 1 : i), nxt);
+#pragma unroll
+        for (int bi = 0; bi < NBLK; ++bi) dst[bi] = own[bi];
         if (TRANSPOSED) frag_matvec_T<NB>(ring[d], src, dst, perm_addr);
         else frag_matvec<NB>(ring[d], src, dst);
         vec_store<NB>(tb, k, dst, writer);
@@ -336,12 +364,19 @@ __device__ __forceinline__ void sinv_apply_lean(const int N, const int mid, cons
 }
 
 #ifdef MPCQP_RUN_TIMING
+// Development build: shader-clock cycles between phase boundaries as seen by thread 0, summed in LDS and flushed to g_ticks once
+// per ADMM phase (an atomic per tick would perturb what it measures).
 __device__ unsigned long long g_ticks[16];
-#define TICK(i) { unsigned long long t_ = wall_clock64(); if (threadIdx.x == 0) atomicAdd(&g_ticks[i], t_ - ttick); ttick = t_; }
-#define TICK_START unsigned long long ttick = wall_clock64();
+__device__ __forceinline__ unsigned long long *tick_slots() { __shared__ unsigned long long s[16]; return s; }
+#define TICK(i) { if (threadIdx.x == 0) { unsigned long long *s_ = tick_slots(); const unsigned long long t_ = clock64(); s_[i] += t_ - s_[15]; s_[15] = t_; } }
+#define TICK_START { if (threadIdx.x == 0) tick_slots()[15] = clock64(); }
+#define TICK_RESET { if (threadIdx.x < 16) tick_slots()[threadIdx.x] = 0; __syncthreads(); }
+#define TICK_FLUSH { __syncthreads(); if (threadIdx.x < 15) atomicAdd(&g_ticks[threadIdx.x], tick_slots()[threadIdx.x]); }
 #else
 #define TICK(i)
 #define TICK_START
+#define TICK_RESET
+#define TICK_FLUSH
 #endif
 
 // What the linear-system core needs to know about one instance.
@@ -542,6 +577,112 @@ __device__ __forceinline__ void half_sweep_so(const CoreArgs &a, double *Tc, con
     }
 }
 
+// One 16 x 16 fragment times a stage vector as the two partial sums of frag_matvec's MFMA pairs -- the caller adds them where
+// the wait for the matrix pipe does not hold up instructions that could issue meanwhile.
+__device__ __forceinline__ void frag_matvec_halves16(const d4 a, const double in, double &p, double &s) {
+    const double r1 = rot_blocks<1>(in), r2 = rot_blocks<2>(in), r3 = rot_blocks<3>(in);
+    p = __builtin_amdgcn_mfma_f64_4x4x4f64(a[0], in, 0.0, 0, 0, 0);
+    s = __builtin_amdgcn_mfma_f64_4x4x4f64(a[2], r2, 0.0, 0, 0, 0);
+    p = __builtin_amdgcn_mfma_f64_4x4x4f64(a[1], r1, p, 0, 0, 0);
+    s = __builtin_amdgcn_mfma_f64_4x4x4f64(a[3], r3, s, 0, 0, 0);
+}
+__device__ __forceinline__ void pin_here(double &v) { asm volatile("" : "+v"(v)); }      // the value is computed before, and used after, this point
+
+// Hybrid format (16 x 16 stages), back substitution of one half-chain:  x_k = S_k^-1 ( yh_k - K_{k,nbr} x_nbr ),  k = first+dir,
+// first+2dir, ... starting from x_first in Tc;  UP: the neighbour is the stage above (nbr = k-1, uses G), else below (G').
+//     -K_{k,k-1} v = sc_k . (G v)   + cw_k v[nx+nu-1]          -K_{k,k+1} v = G' (sc_k . v) + cw_k v[nx]
+// with (sc, cw) per element from the stage's table (FactorFmt); rows without a variable need no mask, S_k^-1 is zero there.
+// A single wave issues in order, and this loop is bound by the number of instructions it issues, not by memory: the stage is
+// laid out by hand so that everything that does not depend on the running vector sits in the shadow of the stage's two
+// dependent MFMA groups -- in the first the permutes that rebuild the next S^-1 from its packed half and the LDS read of the
+// next yh; in the second the selects that finish it and the refill of the slot just consumed -- and scheduling fences pin that
+// order (left alone, the scheduler puts the permutes and their waits in front of the first MFMA of their own stage).
+#ifndef MPCQP_HYB_DEPTH
+#define MPCQP_HYB_DEPTH 4
+#endif
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) const d2 cgd2;
+struct HybSlot { d4 S; d2 tab; };
+template <bool UP>
+__device__ __forceinline__ void hybrid_back_sweep(const CoreArgs &a, double *Tc, const int first, const int dir, const int nsteps) {
+    constexpr int NB = 16, DEPTH = MPCQP_HYB_DEPTH;
+    constexpr bool SYM = SinvFmt<NB>::SYM;
+    const int lane = opaque_lane(threadIdx.x & 63);
+    const int el = vec_lane_offset(lane);                                 // the lane's element of a stage vector
+    double *tb = Tc + el;
+    const bool writer = vec_lane_writer(lane);
+    d4 Gf[1];
+    frag_load<NB>(a.G + (UP ? 0 : NB * NB), lane, Gf);
+    auto stage_of = [&](int i) { return first + dir * i; };
+    auto clamp_i = [&](int i) { return i < nsteps ? i : nsteps; };       // (branch-free refills, see chain_sweep)
+    // (per-lane byte offsets inside a stage, formed once: uniform stage base + 32-bit lane offset is one address operand)
+    const unsigned s_off = (unsigned)opaque_lane(8 * (FactorFmt<NB>::SOFF + (SYM ? 40 * (lane >> 4) + sym_cum((lane >> 2) & 3) + (lane & 3) * (4 - ((lane >> 2) & 3)) : lane * 4)));
+    const unsigned t_off = (unsigned)opaque_lane(8 * (FactorFmt<NB>::SOFF + FactorFmt<NB>::SINV + 2 * el));
+    auto load = [&](int i, HybSlot &s) {
+        const char *Fk = (const char *)(a.F + (size_t)stage_of(i) * a.fstage);
+        if constexpr (SYM) { const d4u w = *(cgd4u *)(Fk + s_off); s.S = d4{w[0], w[1], w[2], w[3]}; } else s.S = *(cgd4 *)(Fk + s_off);
+        s.tab = *(cgd2 *)(Fk + t_off);
+    };
+    double run = tb[first * NB];
+    if (nsteps < 1) return;
+    HybSlot ring[DEPTH];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+        load(clamp_i(1 + d), ring[d]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // permute addresses and select masks of the symmetric expansion (sym_expand16), constant per lane
+    const int R = (lane >> 2) & 3, kk = lane >> 4, li = lane & 3;
+    const int pa1 = 4 * (16 * li + 4 * ((R + 1) & 3) + kk), pa2 = 4 * (16 * li + 4 * ((R + 2) & 3) + kk), pa3 = 4 * (16 * li + 4 * ((R + 3) & 3) + kk);
+    const bool m1 = R + 1 >= 4, m2 = R + 2 >= 4, m3 = R + 3 >= 4;
+    const int Esrc = UP ? a.nx + a.nu - 1 : a.nx;                         // the element of the neighbour that the Delta-u row couples
+    const int src_lane = 16 * (Esrc & 3) + 4 * ((Esrc & 15) >> 2);
+    if constexpr (SYM) ring[0].S = sym_expand16(ring[0].S, lane);         // stage 1: nothing to hide behind yet
+    double own = tb[stage_of(1) * NB];
+    auto stage_step = [&](int i, int inext, HybSlot &slot, HybSlot &nslot, bool valid) {
+        const int k = stage_of(i);
+        // (1) first dependent group: G (or G') times the neighbour's solution; beside it the part of the right-hand side that does
+        //     not wait for it
+        const double sc = slot.tab[0];
+        const double in = UP ? run : sc * run;
+        double o1, o2;
+        frag_matvec_halves16(Gf[0], in, o1, o2);
+        double base = fma(slot.tab[1], lane_bcast(run, src_lane), own);
+        pin_here(base);
+        __builtin_amdgcn_sched_barrier(0);
+        // (2) in its shadow: permutes for the next stage's S^-1, next stage's own vector
+        const d4 w = nslot.S;
+        double t1 = 0.0, t2 = 0.0, t3 = 0.0;
+        if constexpr (SYM) { t1 = lane_permute(w[3], pa1); t2 = lane_permute(w[2], pa2); t3 = lane_permute(w[1], pa3); }
+        const double own_next = tb[stage_of(clamp_i(i + 1)) * NB];
+        __builtin_amdgcn_sched_barrier(0);
+        // (3) right-hand side of the stage
+        const double t = UP ? fma(sc, o1 + o2, base) : (o1 + o2) + base;
+        // (4) second dependent group: S_k^-1 times it
+        double x1, x2;
+        frag_matvec_halves16(slot.S, t, x1, x2);
+        __builtin_amdgcn_sched_barrier(0);
+        // (5) in its shadow: finish the next stage's S^-1, refill this stage's slot
+        if constexpr (SYM) {
+            double e1 = m1 ? t1 : w[1], e2 = m2 ? t2 : w[2], e3 = m3 ? t3 : w[3];
+            pin_here(e1); pin_here(e2); pin_here(e3);
+            nslot.S = d4{w[0], e1, e2, e3};
+        }
+        load(inext, slot);
+        __builtin_amdgcn_sched_barrier(0);
+        // (6)
+        const double x = x1 + x2;
+        run = x; own = own_next;
+        if (writer && valid) tb[k * NB] = x;
+    };
+    for (int i0 = 1; i0 <= nsteps; i0 += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+            stage_step(clamp_i(i0 + d), clamp_i(i0 + d + DEPTH), ring[d], ring[(d + 1) % DEPTH], i0 + d <= nsteps);
+    }
+}
+
 template <int NB>
 __device__ __forceinline__ void kkt_core_so(const CoreArgs &a, double *Tc) {
     constexpr int NBLK = NB / 16, NF = SoCfg<NB>::NF;
@@ -641,8 +782,8 @@ __device__ __forceinline__ void kkt_core_hybrid(const CoreArgs &a, double *Tc) {
     }
     __syncthreads();
     TICK(2)
-    if (wv == 0) half_sweep_so<NB, true, false, false>(a, Tc, mid, -1, mid);              // x_{mid-1} .. x_0       (neighbour below)
-    else if (wv == 1) half_sweep_so<NB, true, true, false>(a, Tc, mid, +1, N - 1 - mid);  // x_{mid+1} .. x_{N-1}   (neighbour above)
+    if (wv == 0) hybrid_back_sweep<false>(a, Tc, mid, -1, mid);                            // x_{mid-1} .. x_0       (neighbour below)
+    else if (wv == 1) hybrid_back_sweep<true>(a, Tc, mid, +1, N - 1 - mid);                // x_{mid+1} .. x_{N-1}   (neighbour above)
     __syncthreads();
     TICK(3)
 }
@@ -658,7 +799,8 @@ __device__ __forceinline__ void kkt_core(const CoreArgs &a, double *Tc) {
 #ifndef MPCQP_ABL_NOCHAIN
     if constexpr (FactorFmt<NB>::SONLY) kkt_core_so<NB>(a, Tc);
     else if constexpr (FactorFmt<NB>::HYBRID && HYB) kkt_core_hybrid<NB>(a, Tc);
-    else kkt_core_sweeps<NB>(a, Tc);
-#endif
+    else kkt_core_sweeps<NB>(a, Tc);                 // (each of them ends with a barrier)
+#else
     __syncthreads();
+#endif
 }
