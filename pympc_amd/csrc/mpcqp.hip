@@ -714,7 +714,7 @@ extern "C" int mpcqp_get_stream_bytes(mpcqp_handle *h, int64_t *per_iter, int64_
     const Lay &L = h->L;
     const int64_t n = L.n, m = L.m, nq = L.n_x + L.n_u, NB = L.NB;
     const int64_t sinv = L.fstage - L.ffwd - L.ftab;
-    int64_t it = !L.ffwd ? 2 * (int64_t)L.N * sinv + 2 * (int64_t)L.fhead              // S^-1-only: S^-1 twice, [G | G'] by each sweeping wave
+    int64_t it = !L.ffwd ? 2 * (int64_t)L.N * sinv + (int64_t)L.N * L.ftab + 2 * (int64_t)L.fhead   // S^-1-only: S^-1 twice, one of the two tables per sweep, [G | G'] by each sweeping wave
                : L.hybrid ? (int64_t)(L.N - 1) * L.ffwd + (int64_t)L.N * sinv + (int64_t)(L.N - 1) * L.ftab + L.fhead // hybrid back substitution: forward matrices once, S^-1 once, the tables, G / G' once each
                          : 2 * (int64_t)(L.N - 1) * L.ffwd + (int64_t)L.N * sinv;       // two-slot: forward matrices twice, S^-1 once
     if (!h->lds_state) it += (2 * n + 4 * m) /* x, z, y read + written */ + (m + L.n_x) /* omega */ + (n + L.n_x) /* s */ + nq /* q */;

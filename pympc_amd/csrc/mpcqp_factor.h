@@ -74,7 +74,9 @@ template <int NB> struct FactorFmt {
     static constexpr bool HYBRID = !SONLY && MPCQP_HYBRID16 && NB == 16;
     static constexpr int SINV = SONLY ? (NB == 32 ? 164 + 164 + 256 : 164) : (MPCQP_SYM_SINV && NB == 16 ? 164 : NB * NB);
     static constexpr int FWD = SONLY ? 0 : NB * NB;
-    static constexpr int TAB = HYBRID ? 2 * NB : 0;                      // hybrid: per element (omega scaling, Delta-u coupling weight) of the stage's off-diagonal block
+    // per element (omega scaling, Delta-u coupling weight) of the stage's off-diagonal blocks: hybrid -- towards the neighbour the back
+    // substitution comes from; S^-1-only -- towards the stage above, then towards the stage below (each sweep uses one)
+    static constexpr int TAB = HYBRID ? 2 * NB : (SONLY ? 4 * NB : 0);
     static constexpr int STAGE = FWD + SINV + TAB;
     static constexpr int HEAD = (SONLY || HYBRID) ? 2 * NB * NB : 0;     // [G | G']: in front of the stages (S^-1-only) or behind them (hybrid)
     static constexpr int SOFF = FWD;                                    // offset of S^-1 inside a stage
@@ -202,34 +204,40 @@ __device__ int factor_all(const Ctx &c, const double *om, const double *sv, doub
             const int a = e / NB, b = e % NB;
             const double acc = 0.5 * (S[a * NB + b] + S[b * NB + a]);
             SnOut[e] = acc;
+            // (formats with matrix-free off-diagonal blocks: rows / columns without a variable stored as zero -- see FactorFmt; the
+            //  LDS copy SnOut stays the true inverse)
+            const bool dead = (FactorFmt<NB>::HYBRID || FactorFmt<NB>::SONLY) && (a >= L.nb || b >= L.nb || ((a >= L.nx || b >= L.nx) && k >= L.NcT));
+            const double st = dead ? 0.0 : acc;
             if constexpr (FactorFmt<NB>::SONLY) {                  // [ sym(S00) | sym(S11) | S01 ]
                 double *Fk = F + FactorFmt<NB>::HEAD + (size_t)k * L.fstage;     // (S^-1-only: the header comes first)
                 const int A_ = a >> 4, B_ = b >> 4, al = a & 15, bl = b & 15;
-                if (A_ == B_) { if ((bl >> 2) >= (al >> 2)) Fk[164 * A_ + sym_pos(al, bl)] = acc; }
-                else if (A_ == 0) Fk[328 + frag_pos<16>(al, bl)] = acc;
+                if (A_ == B_) { if ((bl >> 2) >= (al >> 2)) Fk[164 * A_ + sym_pos(al, bl)] = st; }
+                else if (A_ == 0) Fk[328 + frag_pos<16>(al, bl)] = st;
             }
             else {
-                // (hybrid: rows / columns without a variable stored as zero -- see FactorFmt; the LDS copy SnOut stays the true inverse)
-                const bool dead = FactorFmt<NB>::HYBRID && (a >= L.nb || b >= L.nb || ((a >= L.nx || b >= L.nx) && k >= L.NcT));
-                const double st = dead ? 0.0 : acc;
                 if constexpr (SinvFmt<NB>::SYM) { if ((b >> 2) >= (a >> 2)) F[(size_t)k * L.fstage + NB * NB + sym_pos(a, b)] = st; }
                 else F[(size_t)k * L.fstage + NB * NB + frag_pos<NB>(a, b)] = st;
             }
         }
         if constexpr (FactorFmt<NB>::TAB > 0) {
-            // table of the stage's off-diagonal block towards the neighbour the back substitution comes from (k+1 in the top half,
-            // k-1 in the bottom half; kkt_sub_entry is the entry-wise definition): element e -> (omega of the dynamics row, 1 off the
-            // x part;  omega of the Delta-u row that couples the two stages, on the one element it enters, 0 elsewhere)
+            // tables of the stage's off-diagonal blocks (kkt_sub_entry is the entry-wise definition): element e -> (omega of the
+            // dynamics row between the two stages, 1 off the x part;  omega of the Delta-u row that couples them, on the one
+            // element of this stage it enters, 0 elsewhere)
             if (on && lt < NB) {
-                const int e = lt, nbr = k < mid ? k + 1 : k - 1, hi = max(k, nbr), lo = min(k, nbr);
-                double sc = 1.0, cw = 0.0;
-                if (k != mid) {
-                    if (e < L.nx) sc = om[hi * L.nx + e];
-                    const int edst = k < mid ? L.nx + L.nu - 1 : L.nx;
-                    if (e == edst && hi < L.NcT) cw = om[L.rdu + L.nu + min(lo, max(L.NcT - 2, 0)) * L.nu + L.nu - 1];
-                }
-                double *tab = F + (size_t)k * L.fstage + FactorFmt<NB>::FWD + FactorFmt<NB>::SINV;
-                tab[2 * e] = sc; tab[2 * e + 1] = cw;
+                const int e = lt;
+                auto entry = [&](int nbr, double *dst) {
+                    double sc = 1.0, cw = 0.0;
+                    if (nbr >= 0 && nbr < N) {
+                        const int hi = max(k, nbr), lo = min(k, nbr);
+                        if (e < L.nx) sc = om[hi * L.nx + e];
+                        const int edst = nbr > k ? L.nx + L.nu - 1 : L.nx;
+                        if (e == edst && hi < L.NcT) cw = om[L.rdu + L.nu + min(lo, max(L.NcT - 2, 0)) * L.nu + L.nu - 1];
+                    }
+                    dst[2 * e] = sc; dst[2 * e + 1] = cw;
+                };
+                double *tab = F + (FactorFmt<NB>::SONLY ? FactorFmt<NB>::HEAD : 0) + (size_t)k * L.fstage + FactorFmt<NB>::FWD + FactorFmt<NB>::SINV;
+                if constexpr (FactorFmt<NB>::SONLY) { entry(k - 1, tab); entry(k + 1, tab + 2 * NB); }
+                else entry(k == mid ? -1 : (k < mid ? k + 1 : k - 1), tab);
             }
         }
     };

@@ -505,181 +505,170 @@ __device__ __forceinline__ void so_step_fix(const CoreArgs &a, const SoLane<NB> 
     for (int bi = 0; bi < NB / 16; ++bi) sc[bi] = q.isx[bi] ? st.sc[bi] : 1.0;
     wd = (max(k, nbr) < a.NcT) ? st.wd : 0.0;       // the coupling row exists only between two stages that carry inputs
 }
-// One half-chain: stages first+dir, first+2dir, ... (nsteps of them).  FWD: w_k = S_k^-1 (b_k + t_k), the first stage gets
-// w_first = S^-1 b_first;  BWD: x_k = w_k + S_k^-1 t_k, starting from x_first already in Tc.
-// The stage stream (packed S^-1, omega values) runs two stages ahead in two register slots -- the register file holds no
-// more.  A slot is refilled as soon as its contents have been expanded, and the refill loads are fenced with scheduling
-// barriers: left free, the machine scheduler spreads them over the stage and the waits it then needs end up as
-// s_waitcnt vmcnt(0)/(1) every other stage, i.e. no look-ahead at all (seen in the ISA).  With the fences the loads stay
-// a block, in source order, and the compiler's own accounting gives exact vmcnt(9) waits.
-// SOLVE_FIRST: the first stage's vector is a right-hand side still to be multiplied by its S^-1 (forward sweep of the
-// S^-1-only format); otherwise it is final (back substitutions, which start from the middle stage).
-template <int NB, bool FWD, bool UP, bool SOLVE_FIRST = FWD>
-__device__ __forceinline__ void half_sweep_so(const CoreArgs &a, double *Tc, const int first, const int dir, const int nsteps) {
-    constexpr int NBLK = NB / 16, NF = SoCfg<NB>::NF;
+// ------------------------------------------------------------------------------------------------
+// One half-chain of the formats that apply the off-diagonal blocks matrix-free, stages first+dir*i for i = ibegin .. nsteps:
+//     SOLVE (forward sweep of the S^-1-only format, back substitution of the hybrid one):  v_k = S_k^-1 ( own_k - K_{k,nbr} v_nbr )
+//     !SOLVE (back substitution of the S^-1-only format):                                   v_k = own_k - S_k^-1 K_{k,nbr} v_nbr
+// own_k is what Tc holds for the stage, v_k replaces it; UP: the neighbour is the stage above (k-1, block from G), else below (G').
+//     -K_{k,k-1} v = sc_k . (G v)   + cw_k v[nx+nu-1]          -K_{k,k+1} v = G' (sc_k . v) + cw_k v[nx]
+// with (sc, cw) per element from the stage's table (FactorFmt) -- no row mask: S_k^-1 is stored with zero rows where the stage has
+// no variable.  ibegin = 0 starts from a zero neighbour (v_first = S^-1 own_first), ibegin = 1 from v_first already in Tc.
+//
+// A sweeping wave issues in order, and at the large stage size it is alone on its SIMD: the loop is bound by the instructions it
+// issues and by where it has to wait, not by memory (scripts/diag/stage_ubench.hip).  The stage is therefore laid out by hand:
+// everything that does not depend on the running vector sits in the shadow of the stage's two dependent MFMA groups, pinned by
+// scheduling fences (left alone, the scheduler puts loads, permutes and their waits in front of the first MFMA of the stage):
+//     (1) G mat-vec issued            shadow A: selects that finish THIS stage's S^-1 (permutes issued a stage ago), LDS read of
+//                                               the next own vector
+//     (3) right-hand side, (4) S^-1 mat-vec issued
+//                                     shadow B: cross-lane permutes for the NEXT stage's S^-1 (its packed half arrived a stage
+//                                               ago), refill of this stage's slot (free once the MFMAs have read it)
+//     (6) sum of the MFMA pairs, store
+// (A gather of the fragment straight from the packed record -- 8-byte loads at per-lane offsets, no permutes -- was measured
+// too: equal at 16 x 16, 12 % slower at 32 x 32, where twelve scattered loads per stage cost more in the address unit than
+// twenty permutes in the LDS crossbar.)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pin_here(double &v) { asm volatile("" : "+v"(v)); }      // the value is computed before, and used after, this point
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(1))) const d2 cgd2;
+template <int NB> struct SoSlot { d4 S[SoCfg<NB>::NF]; d2 tab[NB / 16]; };
+template <int NB> struct SoPerm { double s0[3], s1[3], tr[4]; };                 // permuted values on their way into a slot
+struct SoLaneK { int pa[4]; bool m1, m2, m3; unsigned win, direct, tab; };      // per-lane constants: permute addresses, select masks, byte offsets
+template <int NB, bool UP>
+__device__ __forceinline__ SoLaneK so_lane_consts(int lane) {
+    SoLaneK c;
+    const int R = (lane >> 2) & 3, k = lane >> 4, i = lane & 3;
+#pragma unroll
+    for (int x = 0; x < 4; ++x) c.pa[x] = opaque_lane(4 * (16 * i + 4 * ((R + x) & 3) + k));
+    c.m1 = R + 1 >= 4; c.m2 = R + 2 >= 4; c.m3 = R + 3 >= 4;
+    constexpr bool SYM = NB == 32 || SinvFmt<NB>::SYM;
+    c.win = (unsigned)opaque_lane(8 * (FactorFmt<NB>::SOFF + (SYM ? 40 * k + sym_cum(R) + i * (4 - R) : lane * 4)));
+    c.direct = (unsigned)opaque_lane(8 * (FactorFmt<NB>::SOFF + 328 + lane * 4));
+    const int tabs = FactorFmt<NB>::SONLY && !UP ? 2 * NB : 0;                   // (S^-1-only: the table towards the stage below comes second)
+    c.tab = (unsigned)opaque_lane(8 * (FactorFmt<NB>::SOFF + FactorFmt<NB>::SINV + tabs + 2 * vec_lane_offset(lane)));
+    return c;
+}
+// packed record -> slot (loads only)
+template <int NB>
+__device__ __forceinline__ void so_slot_load(const char *Fk, const SoLaneK &c, SoSlot<NB> &s) {
+    auto window = [&](unsigned extra) { const d4u w = *(cgd4u *)(Fk + extra + c.win); return d4{w[0], w[1], w[2], w[3]}; };
+    if constexpr (NB == 16) {
+        if constexpr (SinvFmt<NB>::SYM) s.S[0] = window(0); else s.S[0] = *(cgd4 *)(Fk + c.win);
+    } else { s.S[0] = window(0); s.S[3] = window(8 * 164); s.S[1] = *(cgd4 *)(Fk + c.direct); }
+#pragma unroll
+    for (int bi = 0; bi < NB / 16; ++bi) s.tab[bi] = *(cgd2 *)(Fk + c.tab + bi * 256);
+}
+// the cross-lane half of the expansion (sym_expand16 / frag_transpose16): issue ...
+template <int NB>
+__device__ __forceinline__ void so_expand_issue(const SoSlot<NB> &s, const SoLaneK &c, SoPerm<NB> &t) {
+    if constexpr (NB == 32 || SinvFmt<NB>::SYM) {
+        const d4 w = s.S[0];
+        t.s0[0] = lane_permute(w[3], c.pa[1]); t.s0[1] = lane_permute(w[2], c.pa[2]); t.s0[2] = lane_permute(w[1], c.pa[3]);
+    }
+    if constexpr (NB == 32) {
+        const d4 w = s.S[3], v = s.S[1];
+        t.s1[0] = lane_permute(w[3], c.pa[1]); t.s1[1] = lane_permute(w[2], c.pa[2]); t.s1[2] = lane_permute(w[1], c.pa[3]);
+        t.tr[0] = lane_permute(v[0], c.pa[0]); t.tr[1] = lane_permute(v[3], c.pa[1]); t.tr[2] = lane_permute(v[2], c.pa[2]); t.tr[3] = lane_permute(v[1], c.pa[3]);
+    }
+}
+// ... and finish: the selects (pinned where they are written, or they sink to the first use)
+template <int NB>
+__device__ __forceinline__ void so_expand_finish(SoSlot<NB> &s, const SoLaneK &c, const SoPerm<NB> &t) {
+    auto sel = [&](const d4 w, const double *p) {
+        double e1 = c.m1 ? p[0] : w[1], e2 = c.m2 ? p[1] : w[2], e3 = c.m3 ? p[2] : w[3];
+        pin_here(e1); pin_here(e2); pin_here(e3);
+        return d4{w[0], e1, e2, e3};
+    };
+    if constexpr (NB == 32 || SinvFmt<NB>::SYM) s.S[0] = sel(s.S[0], t.s0);
+    if constexpr (NB == 32) { s.S[3] = sel(s.S[3], t.s1); s.S[2] = d4{t.tr[0], t.tr[1], t.tr[2], t.tr[3]}; }
+}
+template <int NB, bool SOLVE, bool UP>
+__device__ __forceinline__ void so_sweep(const CoreArgs &a, double *Tc, const int first, const int dir, const int ibegin, const int nsteps) {
+    constexpr int NBLK = NB / 16, DEPTH = SoCfg<NB>::DEPTH;
     const int lane = opaque_lane(threadIdx.x & 63);
-    const SoLane<NB> q = so_lane<NB>(a, lane);
     double *tb = Tc + vec_lane_offset(lane);
     const bool writer = vec_lane_writer(lane);
-    d4 Gf[NF];
+    const SoLaneK lc = so_lane_consts<NB, UP>(lane);
+    d4 Gf[SoCfg<NB>::NF];
     frag_load<NB>(a.G + (UP ? 0 : NB * NB), lane, Gf);
     auto stage_of = [&](int i) { return first + dir * i; };
     auto clamp_i = [&](int i) { return i < nsteps ? i : nsteps; };       // (branch-free refills, see chain_sweep)
-    double run[NBLK];
-    if (SOLVE_FIRST) {
-        d4 A0[SoCfg<NB>::NS], Sf[NF];
-        so_load<NB>(a.F + (size_t)first * a.fstage + FactorFmt<NB>::SOFF, lane, A0);
-        so_expand<NB>(A0, lane, Sf);
-        double in[NBLK];
-        vec_load<NB>(tb, first, in);
+    auto load = [&](int i, SoSlot<NB> &s) { so_slot_load<NB>((const char *)(a.F + (size_t)stage_of(i) * a.fstage), lc, s); };
+    if (nsteps < ibegin) return;
+    double run[NBLK], own[NBLK];
 #pragma unroll
-        for (int bi = 0; bi < NBLK; ++bi) run[bi] = 0.0;
-        frag_matvec<NB>(Sf, in, run);
-        vec_store<NB>(tb, first, run, writer);
-    } else {
-        vec_load<NB>(tb, first, run);
-    }
-    if (nsteps < 1) return;
-    constexpr int DEPTH = SoCfg<NB>::DEPTH;
-    SoStep<NB> ring[DEPTH];
+    for (int bi = 0; bi < NBLK; ++bi) { run[bi] = ibegin ? tb[first * NB + 16 * bi] : 0.0; own[bi] = tb[stage_of(ibegin) * NB + 16 * bi]; }
+    SoSlot<NB> ring[DEPTH];
+    SoPerm<NB> pm;
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
-        so_step_load<NB>(a, q, lane, stage_of(clamp_i(1 + d)), stage_of(clamp_i(1 + d) - 1), ring[d]);
+        load(clamp_i(ibegin + d), ring[d]);
         __builtin_amdgcn_sched_barrier(0);
     }
-    // (steps past the end repeat the last stage -- computed, not stored -- so that the loop body has no branches)
-    auto stage_step = [&](int i, int inext, SoStep<NB> &slot, bool valid) {
+    so_expand_issue<NB>(ring[0], lc, pm);                                 // the first stage has nothing to hide behind yet
+    const int Esrc = UP ? a.nx + a.nu - 1 : a.nx;                         // the element of the neighbour that the Delta-u row couples
+    auto stage_step = [&](int i, int inext, SoSlot<NB> &slot, SoSlot<NB> &nslot, bool valid) {
         const int k = stage_of(i);
-        d4 Sf[NF];
-        double sc[NBLK], wd;
-        so_expand<NB>(slot.S, lane, Sf);
-        so_step_fix<NB>(a, q, k, k - dir, slot, sc, wd);
-        double own[NBLK], t[NBLK];
-        vec_load<NB>(tb, k, own);
-        so_offdiag<NB, UP>(a, q, Gf, k, run, sc, wd, t);
+        // (1) first dependent group: G (or G') times the neighbour's vector; beside it what does not wait for it
+        double in[NBLK], p[NBLK], q[NBLK], base[NBLK];
 #pragma unroll
-        for (int bi = 0; bi < NBLK; ++bi) { if (FWD) { t[bi] += own[bi]; run[bi] = 0.0; } else run[bi] = own[bi]; }
-        frag_matvec<NB>(Sf, t, run);
+        for (int bi = 0; bi < NBLK; ++bi) { in[bi] = UP ? run[bi] : slot.tab[bi][0] * run[bi]; p[bi] = 0.0; q[bi] = 0.0; }
+#pragma unroll
+        for (int bj = 0; bj < NBLK; ++bj) {
+            const double r1 = rot_blocks<1>(in[bj]), r2 = rot_blocks<2>(in[bj]), r3 = rot_blocks<3>(in[bj]);
+#pragma unroll
+            for (int bi = 0; bi < NBLK; ++bi) {
+                const d4 g = Gf[bi * NBLK + bj];
+                p[bi] = __builtin_amdgcn_mfma_f64_4x4x4f64(g[0], in[bj], p[bi], 0, 0, 0);
+                q[bi] = __builtin_amdgcn_mfma_f64_4x4x4f64(g[2], r2, q[bi], 0, 0, 0);
+                p[bi] = __builtin_amdgcn_mfma_f64_4x4x4f64(g[1], r1, p[bi], 0, 0, 0);
+                q[bi] = __builtin_amdgcn_mfma_f64_4x4x4f64(g[3], r3, q[bi], 0, 0, 0);
+            }
+        }
+        const double nsrc = so_element<NB>(run, Esrc);
+#pragma unroll
+        for (int bi = 0; bi < NBLK; ++bi) { base[bi] = SOLVE ? fma(slot.tab[bi][1], nsrc, own[bi]) : slot.tab[bi][1] * nsrc; pin_here(base[bi]); }
+        __builtin_amdgcn_sched_barrier(0);
+        // shadow A: finish this stage's S^-1; the next stage's own vector
+        so_expand_finish<NB>(slot, lc, pm);
+        double own_next[NBLK];
+#pragma unroll
+        for (int bi = 0; bi < NBLK; ++bi) own_next[bi] = tb[stage_of(clamp_i(i + 1)) * NB + 16 * bi];
+        __builtin_amdgcn_sched_barrier(0);
+        // (3) what S_k^-1 multiplies
+        double t[NBLK], xp[NBLK], xq[NBLK];
+#pragma unroll
+        for (int bi = 0; bi < NBLK; ++bi) { t[bi] = UP ? fma(slot.tab[bi][0], p[bi] + q[bi], base[bi]) : (p[bi] + q[bi]) + base[bi]; xp[bi] = 0.0; xq[bi] = 0.0; }
+        // (4) second dependent group
+#pragma unroll
+        for (int bj = 0; bj < NBLK; ++bj) {
+            const double r1 = rot_blocks<1>(t[bj]), r2 = rot_blocks<2>(t[bj]), r3 = rot_blocks<3>(t[bj]);
+#pragma unroll
+            for (int bi = 0; bi < NBLK; ++bi) {
+                const d4 sf = slot.S[bi * NBLK + bj];
+                xp[bi] = __builtin_amdgcn_mfma_f64_4x4x4f64(sf[0], t[bj], xp[bi], 0, 0, 0);
+                xq[bi] = __builtin_amdgcn_mfma_f64_4x4x4f64(sf[2], r2, xq[bi], 0, 0, 0);
+                xp[bi] = __builtin_amdgcn_mfma_f64_4x4x4f64(sf[1], r1, xp[bi], 0, 0, 0);
+                xq[bi] = __builtin_amdgcn_mfma_f64_4x4x4f64(sf[3], r3, xq[bi], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // shadow B: permutes for the next stage's S^-1 (loaded a stage ago), refill of this slot
+        so_expand_issue<NB>(nslot, lc, pm);
+        load(inext, slot);
+        __builtin_amdgcn_sched_barrier(0);
+        // (6)
+#pragma unroll
+        for (int bi = 0; bi < NBLK; ++bi) { run[bi] = SOLVE ? xp[bi] + xq[bi] : (xp[bi] + xq[bi]) + own[bi]; own[bi] = own_next[bi]; }
         if (writer && valid) {
 #pragma unroll
             for (int bi = 0; bi < NBLK; ++bi) tb[k * NB + bi * 16] = run[bi];
         }
-        // refill once nothing of the slot is live any more (parts of it pass unchanged into the expanded fragments: refilled
-        // earlier, the slot would move to other registers and come back through copies at the loop end -- behind a vmcnt(0))
-        __builtin_amdgcn_sched_barrier(0);
-        so_step_load<NB>(a, q, lane, stage_of(inext), stage_of(inext - 1), slot);
-        __builtin_amdgcn_sched_barrier(0);
     };
-    for (int i0 = 1; i0 <= nsteps; i0 += DEPTH) {
+    for (int i0 = ibegin; i0 <= nsteps; i0 += DEPTH) {
 #pragma unroll
-        for (int d = 0; d < DEPTH; ++d) stage_step(clamp_i(i0 + d), clamp_i(i0 + d + DEPTH), ring[d], i0 + d <= nsteps);
-    }
-}
-
-// One 16 x 16 fragment times a stage vector as the two partial sums of frag_matvec's MFMA pairs -- the caller adds them where
-// the wait for the matrix pipe does not hold up instructions that could issue meanwhile.
-__device__ __forceinline__ void frag_matvec_halves16(const d4 a, const double in, double &p, double &s) {
-    const double r1 = rot_blocks<1>(in), r2 = rot_blocks<2>(in), r3 = rot_blocks<3>(in);
-    p = __builtin_amdgcn_mfma_f64_4x4x4f64(a[0], in, 0.0, 0, 0, 0);
-    s = __builtin_amdgcn_mfma_f64_4x4x4f64(a[2], r2, 0.0, 0, 0, 0);
-    p = __builtin_amdgcn_mfma_f64_4x4x4f64(a[1], r1, p, 0, 0, 0);
-    s = __builtin_amdgcn_mfma_f64_4x4x4f64(a[3], r3, s, 0, 0, 0);
-}
-__device__ __forceinline__ void pin_here(double &v) { asm volatile("" : "+v"(v)); }      // the value is computed before, and used after, this point
-
-// Hybrid format (16 x 16 stages), back substitution of one half-chain:  x_k = S_k^-1 ( yh_k - K_{k,nbr} x_nbr ),  k = first+dir,
-// first+2dir, ... starting from x_first in Tc;  UP: the neighbour is the stage above (nbr = k-1, uses G), else below (G').
-//     -K_{k,k-1} v = sc_k . (G v)   + cw_k v[nx+nu-1]          -K_{k,k+1} v = G' (sc_k . v) + cw_k v[nx]
-// with (sc, cw) per element from the stage's table (FactorFmt); rows without a variable need no mask, S_k^-1 is zero there.
-// A single wave issues in order, and this loop is bound by the number of instructions it issues, not by memory: the stage is
-// laid out by hand so that everything that does not depend on the running vector sits in the shadow of the stage's two
-// dependent MFMA groups -- in the first the permutes that rebuild the next S^-1 from its packed half and the LDS read of the
-// next yh; in the second the selects that finish it and the refill of the slot just consumed -- and scheduling fences pin that
-// order (left alone, the scheduler puts the permutes and their waits in front of the first MFMA of their own stage).
-#ifndef MPCQP_HYB_DEPTH
-#define MPCQP_HYB_DEPTH 4
-#endif
-typedef double d2 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(1))) const d2 cgd2;
-struct HybSlot { d4 S; d2 tab; };
-template <bool UP>
-__device__ __forceinline__ void hybrid_back_sweep(const CoreArgs &a, double *Tc, const int first, const int dir, const int nsteps) {
-    constexpr int NB = 16, DEPTH = MPCQP_HYB_DEPTH;
-    constexpr bool SYM = SinvFmt<NB>::SYM;
-    const int lane = opaque_lane(threadIdx.x & 63);
-    const int el = vec_lane_offset(lane);                                 // the lane's element of a stage vector
-    double *tb = Tc + el;
-    const bool writer = vec_lane_writer(lane);
-    d4 Gf[1];
-    frag_load<NB>(a.G + (UP ? 0 : NB * NB), lane, Gf);
-    auto stage_of = [&](int i) { return first + dir * i; };
-    auto clamp_i = [&](int i) { return i < nsteps ? i : nsteps; };       // (branch-free refills, see chain_sweep)
-    // (per-lane byte offsets inside a stage, formed once: uniform stage base + 32-bit lane offset is one address operand)
-    const unsigned s_off = (unsigned)opaque_lane(8 * (FactorFmt<NB>::SOFF + (SYM ? 40 * (lane >> 4) + sym_cum((lane >> 2) & 3) + (lane & 3) * (4 - ((lane >> 2) & 3)) : lane * 4)));
-    const unsigned t_off = (unsigned)opaque_lane(8 * (FactorFmt<NB>::SOFF + FactorFmt<NB>::SINV + 2 * el));
-    auto load = [&](int i, HybSlot &s) {
-        const char *Fk = (const char *)(a.F + (size_t)stage_of(i) * a.fstage);
-        if constexpr (SYM) { const d4u w = *(cgd4u *)(Fk + s_off); s.S = d4{w[0], w[1], w[2], w[3]}; } else s.S = *(cgd4 *)(Fk + s_off);
-        s.tab = *(cgd2 *)(Fk + t_off);
-    };
-    double run = tb[first * NB];
-    if (nsteps < 1) return;
-    HybSlot ring[DEPTH];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) {
-        load(clamp_i(1 + d), ring[d]);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    // permute addresses and select masks of the symmetric expansion (sym_expand16), constant per lane
-    const int R = (lane >> 2) & 3, kk = lane >> 4, li = lane & 3;
-    const int pa1 = 4 * (16 * li + 4 * ((R + 1) & 3) + kk), pa2 = 4 * (16 * li + 4 * ((R + 2) & 3) + kk), pa3 = 4 * (16 * li + 4 * ((R + 3) & 3) + kk);
-    const bool m1 = R + 1 >= 4, m2 = R + 2 >= 4, m3 = R + 3 >= 4;
-    const int Esrc = UP ? a.nx + a.nu - 1 : a.nx;                         // the element of the neighbour that the Delta-u row couples
-    const int src_lane = 16 * (Esrc & 3) + 4 * ((Esrc & 15) >> 2);
-    if constexpr (SYM) ring[0].S = sym_expand16(ring[0].S, lane);         // stage 1: nothing to hide behind yet
-    double own = tb[stage_of(1) * NB];
-    auto stage_step = [&](int i, int inext, HybSlot &slot, HybSlot &nslot, bool valid) {
-        const int k = stage_of(i);
-        // (1) first dependent group: G (or G') times the neighbour's solution; beside it the part of the right-hand side that does
-        //     not wait for it
-        const double sc = slot.tab[0];
-        const double in = UP ? run : sc * run;
-        double o1, o2;
-        frag_matvec_halves16(Gf[0], in, o1, o2);
-        double base = fma(slot.tab[1], lane_bcast(run, src_lane), own);
-        pin_here(base);
-        __builtin_amdgcn_sched_barrier(0);
-        // (2) in its shadow: permutes for the next stage's S^-1, next stage's own vector
-        const d4 w = nslot.S;
-        double t1 = 0.0, t2 = 0.0, t3 = 0.0;
-        if constexpr (SYM) { t1 = lane_permute(w[3], pa1); t2 = lane_permute(w[2], pa2); t3 = lane_permute(w[1], pa3); }
-        const double own_next = tb[stage_of(clamp_i(i + 1)) * NB];
-        __builtin_amdgcn_sched_barrier(0);
-        // (3) right-hand side of the stage
-        const double t = UP ? fma(sc, o1 + o2, base) : (o1 + o2) + base;
-        // (4) second dependent group: S_k^-1 times it
-        double x1, x2;
-        frag_matvec_halves16(slot.S, t, x1, x2);
-        __builtin_amdgcn_sched_barrier(0);
-        // (5) in its shadow: finish the next stage's S^-1, refill this stage's slot
-        if constexpr (SYM) {
-            double e1 = m1 ? t1 : w[1], e2 = m2 ? t2 : w[2], e3 = m3 ? t3 : w[3];
-            pin_here(e1); pin_here(e2); pin_here(e3);
-            nslot.S = d4{w[0], e1, e2, e3};
-        }
-        load(inext, slot);
-        __builtin_amdgcn_sched_barrier(0);
-        // (6)
-        const double x = x1 + x2;
-        run = x; own = own_next;
-        if (writer && valid) tb[k * NB] = x;
-    };
-    for (int i0 = 1; i0 <= nsteps; i0 += DEPTH) {
-#pragma unroll
-        for (int d = 0; d < DEPTH; ++d)
-            stage_step(clamp_i(i0 + d), clamp_i(i0 + d + DEPTH), ring[d], ring[(d + 1) % DEPTH], i0 + d <= nsteps);
+        for (int d = 0; d < DEPTH; ++d) stage_step(clamp_i(i0 + d), clamp_i(i0 + d + DEPTH), ring[d], ring[(d + 1) % DEPTH], i0 + d <= nsteps);
     }
 }
 
@@ -688,8 +677,8 @@ __device__ __forceinline__ void kkt_core_so(const CoreArgs &a, double *Tc) {
     constexpr int NBLK = NB / 16, NF = SoCfg<NB>::NF;
     const int N = a.N, mid = N / 2, wv = logical_wave(), lane = opaque_lane(threadIdx.x & 63);
     TICK_START
-    if (wv == 0) half_sweep_so<NB, true, true>(a, Tc, 0, +1, mid - 1);                   // w_0 .. w_{mid-1}
-    else if (wv == 1) half_sweep_so<NB, true, false>(a, Tc, N - 1, -1, N - 2 - mid);     // w_{N-1} .. w_{mid+1}
+    if (wv == 0) so_sweep<NB, true, true>(a, Tc, 0, +1, 0, mid - 1);                     // w_0 .. w_{mid-1}
+    else if (wv == 1) so_sweep<NB, true, false>(a, Tc, N - 1, -1, 0, N - 2 - mid);       // w_{N-1} .. w_{mid+1}
     __syncthreads();
     TICK(1)
     if (wv == 0) {                                                                       // the middle stage sees both halves
@@ -716,8 +705,8 @@ __device__ __forceinline__ void kkt_core_so(const CoreArgs &a, double *Tc) {
     }
     __syncthreads();
     TICK(2)
-    if (wv == 0) half_sweep_so<NB, false, false>(a, Tc, mid, -1, mid);                   // x_{mid-1} .. x_0       (neighbour below)
-    else if (wv == 1) half_sweep_so<NB, false, true>(a, Tc, mid, +1, N - 1 - mid);       // x_{mid+1} .. x_{N-1}   (neighbour above)
+    if (wv == 0) so_sweep<NB, false, false>(a, Tc, mid, -1, 1, mid);                     // x_{mid-1} .. x_0       (neighbour below)
+    else if (wv == 1) so_sweep<NB, false, true>(a, Tc, mid, +1, 1, N - 1 - mid);         // x_{mid+1} .. x_{N-1}   (neighbour above)
     __syncthreads();
     TICK(3)
 }
@@ -782,8 +771,8 @@ __device__ __forceinline__ void kkt_core_hybrid(const CoreArgs &a, double *Tc) {
     }
     __syncthreads();
     TICK(2)
-    if (wv == 0) hybrid_back_sweep<false>(a, Tc, mid, -1, mid);                            // x_{mid-1} .. x_0       (neighbour below)
-    else if (wv == 1) hybrid_back_sweep<true>(a, Tc, mid, +1, N - 1 - mid);                // x_{mid+1} .. x_{N-1}   (neighbour above)
+    if (wv == 0) so_sweep<NB, true, false>(a, Tc, mid, -1, 1, mid);                        // x_{mid-1} .. x_0       (neighbour below)
+    else if (wv == 1) so_sweep<NB, true, true>(a, Tc, mid, +1, 1, N - 1 - mid);            // x_{mid+1} .. x_{N-1}   (neighbour above)
     __syncthreads();
     TICK(3)
 }

@@ -3,7 +3,7 @@
 //   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -o /tmp/stage_ubench scripts/diag/stage_ubench.hip
 #include "../../pympc_amd/csrc/mpcqp.hip"
 
-// MODE 0: chain_sweep forward; 1: chain_sweep transposed; 2: hybrid back substitution (half_sweep_so)
+// MODE 0: chain_sweep forward; 1: chain_sweep transposed; 2 / 4: hybrid back substitution (so_sweep) with G' / G
 // HELP 0: waves 2, 3 idle; 1: they touch one dword per cache line of the chain's stages (L2 warm-up) while the sweepers run
 template <int MODE, int HELP>
 __global__ __launch_bounds__(NT) void ub(const double *F, const double *G, const double *om, double *out, int nst, int fstride, int wgstride, int reps) {
@@ -21,9 +21,8 @@ __global__ __launch_bounds__(NT) void ub(const double *F, const double *G, const
             double *Tw = Tc + wv * (nst + 1) * 16;
             if (MODE == 0) chain_sweep<16, false>(0, +1, nst, fstride, Fc, -1, Tw);
             if (MODE == 1) chain_sweep<16, true>(0, +1, nst, fstride, Fc, -1, Tw);
-            if (MODE == 2) { CoreArgs b = a; b.F = Fc; hybrid_back_sweep<false>(b, Tw, nst, -1, nst); }
-            if (MODE == 3) { CoreArgs b = a; b.F = Fc; half_sweep_so<16, true, false, false>(b, Tw, nst, -1, nst); }
-            if (MODE == 4) { CoreArgs b = a; b.F = Fc; hybrid_back_sweep<true>(b, Tw, 0, +1, nst); }
+            if (MODE == 2) { CoreArgs b = a; b.F = Fc; so_sweep<16, true, false>(b, Tw, nst, -1, 1, nst); }
+            if (MODE == 4) { CoreArgs b = a; b.F = Fc; so_sweep<16, true, true>(b, Tw, 0, +1, 1, nst); }
         } else if (HELP) {
             const double *Fc = Fb + (size_t)(wv - 2) * (nst + 1) * fstride;
             const int doubles = (nst + 1) * fstride;                       // one dword per 128-byte line
@@ -64,7 +63,6 @@ int main() {
             run<1, 0>("transposed", grid, F, G, om, out, nst, fstride, per_wg, smem);
             run<2, 0>("hybrid back (G')", grid, F, G, om, out, nst, fstride, per_wg, smem);
             run<4, 0>("hybrid back (G)", grid, F, G, om, out, nst, fstride, per_wg, smem);
-            run<3, 0>("half_sweep_so back", grid, F, G, om, out, nst, fstride, per_wg, smem);
         }
         if (grid == 1) run<0, 1>("forward + L2 touch", grid, F, G, om, out, nst, fst, per_wg, smem);
     }
