@@ -203,11 +203,6 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     rc |= dalloc(h, &h->pending_dev, B); rc |= dalloc(h, &h->npending_dev, 4);
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->ncu = prop.multiProcessorCount; }
     if (const char *e = getenv("MPCQP_BALANCE")) h->auto_balance = atoi(e) != 0;      // development switch
-    // 16 x 16 stages: which back substitution (mpcqp_factor.h, "hybrid").  Reading S^-1 once and applying the off-diagonal
-    // blocks matrix-free moves 102 KB per iteration instead of 163 KB but has the longer dependent chain: it wins once three
-    // or more workgroups share a CU (cfg-3: +4.5 % at 1024 instances, -4 % at 512 and below).
-    h->L.hybrid = (h->L.NB == 16 && FactorFmt<16>::HYBRID && h->ncu > 0 && batch >= 3 * h->ncu) ? 1 : 0;
-    if (const char *e = getenv("MPCQP_HYBRID")) h->L.hybrid = (h->L.NB == 16 && FactorFmt<16>::HYBRID && atoi(e) != 0) ? 1 : 0;      // development switch
     if (rc) { std::string msg = g_err; mpcqp_destroy(h); return fail(MPCQP_ERR_HIP, msg); }
     // Small problems keep the iterate x, z, y in LDS behind the common block (four workgroups per CU: 40 KB each); larger
     // ones keep it in L2/HBM.  The factorization's workspace starts at the work area T, the last part of the common block,
@@ -714,9 +709,8 @@ extern "C" int mpcqp_get_stream_bytes(mpcqp_handle *h, int64_t *per_iter, int64_
     const Lay &L = h->L;
     const int64_t n = L.n, m = L.m, nq = L.n_x + L.n_u, NB = L.NB;
     const int64_t sinv = L.fstage - L.ffwd - L.ftab;
-    int64_t it = !L.ffwd ? 2 * (int64_t)L.N * sinv + (int64_t)L.N * L.ftab + 2 * (int64_t)L.fhead   // S^-1-only: S^-1 twice, one of the two tables per sweep, [G | G'] by each sweeping wave
-               : L.hybrid ? (int64_t)(L.N - 1) * L.ffwd + (int64_t)L.N * sinv + (int64_t)(L.N - 1) * L.ftab + L.fhead // hybrid back substitution: forward matrices once, S^-1 once, the tables, G / G' once each
-                         : 2 * (int64_t)(L.N - 1) * L.ffwd + (int64_t)L.N * sinv;       // two-slot: forward matrices twice, S^-1 once
+    int64_t it = !L.ffwd ? 2 * (int64_t)L.N * sinv + (int64_t)L.N * L.ftab + 2 * (int64_t)L.fhead   // S^-1-only build: S^-1 twice, one of the two tables per sweep, [G | G'] by each sweeping wave
+                         : (int64_t)(L.N - 1) * L.ffwd + (int64_t)L.N * sinv + (int64_t)(L.N - 1) * L.ftab + L.fhead;   // forward matrices once, S^-1 once, the tables, G / G' once each
     if (!h->lds_state) it += (2 * n + 4 * m) /* x, z, y read + written */ + (m + L.n_x) /* omega */ + (n + L.n_x) /* s */ + nq /* q */;
     if (L.border) it += 2 * (int64_t)L.nu * L.N * NB;
     int64_t rd = (L.model_sz - L.hot_sz) + 2 * n + 2 * m /* D, s, E, omega */ + n + m /* dx, dy */;

@@ -37,48 +37,38 @@ typedef __attribute__((address_space(1))) double gdouble;     // explicit global
 typedef __attribute__((address_space(1))) const double cgdouble;  // not flat_* (which also counts on lgkmcnt)
 typedef __attribute__((address_space(1))) const d4 cgd4;
 
-// Storage format of the S^-1 slot (explained next to its reader, frag_load_sinv / sym_expand in mpcqp_sweeps.h).
-#ifndef MPCQP_SYM_SINV
-#define MPCQP_SYM_SINV 1
-#endif
-template <int NB> struct SinvFmt { static constexpr bool SYM = MPCQP_SYM_SINV && NB == 16; static constexpr int DOUBLES = SYM ? 164 : NB * NB; };
-// Which factor format a stage size uses.
-//   two-slot (16 x 16 stages): per stage [ forward matrix -Mh_k | S_k^-1 ]; the sweeps stream the forward matrices twice
-//       (elimination, transposed in the back substitution) and S^-1 once.
-//   S^-1-only (32 x 32 stages): per stage only S_k^-1, packed [ sym(S00) 164 | sym(S11) 164 | S01 256 ] doubles; the
-//       off-diagonal blocks K_{k,k+-1} are applied MATRIX-FREE from a constant fragment G = [[Ad, Bd], [0, c QDu']] held in
-//       registers, scaled by the stage's omega (mpcqp_sweeps.h, half_sweep_so).  The factor stream shrinks from
-//       3 NB^2 = 3072 to 2 x 584 doubles per stage and iteration (2.6x); the price is a dependent chain of two mat-vecs
-//       per stage instead of one -- worth it where the stream, not the chain, is the bound (large stages, few
-//       workgroups per CU).  Per instance the factor starts with a header [ G | G' ] in fragment order.
+// The factor of one instance.  Per stage  [ forward matrix -Mh_k | packed S_k^-1 | table ]  and, behind the last stage, the
+// constant fragments [ G | G' ],  G = [[Ad, Bd], [0, c QDu']]:
+//   * forward elimination runs from the forward matrices (one MFMA mat-vec per stage, chain_sweep);
+//   * there is NO separate S^-1 phase and no second read of the forward matrices: the back substitution is
+//         x_k = S_k^-1 ( yh_k - K_{k,nbr} x_nbr )          (because Mh_{k+1}' = S_k^-1 K_{k,k+1})
+//     with the off-diagonal block K_{k,k+-1} applied MATRIX-FREE from G / G' (held in registers for a whole sweep), scaled by
+//     the stage's omega (so_sweep in mpcqp_sweeps.h);
+//   * S_k^-1 is symmetric and stored packed: 16 x 16 stages  sym(S) = 164 doubles;  32 x 32 stages
+//     [ sym(S00) 164 | sym(S11) 164 | S01 256 ]  (mpcqp_sweeps.h: sym_window / sym_expand16 / frag_transpose16), and with ZERO rows
+//     and columns where the stage has no variable (padding, inputs beyond the control horizon) instead of the identity, so that
+//     the back substitution needs no row mask;
+//   * the table holds what the matrix-free product needs of omega: per stage element (scale, Delta-u coupling weight) towards
+//     the neighbour the back substitution comes from, written by the factorization (omega changes only when it runs).
+// Per stage and iteration the sweeps stream NB^2 + SINV + 2 NB doubles (16: 3.6 KB, 32: 13.4 KB) instead of the 2 NB^2 + SINV of
+// a format that also runs the back substitution from (transposed) forward matrices.
+// 32 x 32 stages use the S^-1-ONLY variant (MPCQP_SONLY32 = 1, the default): NO forward matrices -- header first, per stage
+// [ packed S^-1 | table towards the stage above | table towards the stage below ] -- and both sweeps run through S^-1 and G:
+//     forward   w_k = S_k^-1 ( b_k - K_{k,nbr} w_nbr )        backward   x_k = w_k - S_k^-1 K_{k,nbr} x_nbr
+// 2 x 5.7 KB per stage and iteration instead of 8 + 4.7 + 0.5 KB.  Measured on cfg-5 (scripts/diag/ab_cfg5.sh): the forward
+// matrices cost 12 % throughput at 1024 instances and 7 % at the parity tolerance (the stream is the bound there), and win
+// 7 % on the 512-instance default run, where one straggling instance's critical path sets the time; MPCQP_SONLY32 = 0 builds
+// that alternative.  16 x 16 stages: the forward-matrix format wins at every batch size (+7 .. 10 % over reading S^-1 twice).
 #ifndef MPCQP_SONLY32
 #define MPCQP_SONLY32 1
 #endif
-//   hybrid (16 x 16 stages): the two-slot stage [ -Mh_k | sym(S_k^-1) ] plus [ G | G' ] behind the last stage -- one stored
-//       format, two ways to run the back substitution, chosen per launch (Lay::hybrid, set by the host from the batch size).
-//       Forward elimination as in the two-slot format (one mat-vec per stage from the forward matrix), but NO separate S^-1
-//       phase and no second read of the forward matrices: the back substitution is  x_k = S_k^-1 ( yh_k - K_{k,nbr} x_nbr )
-//       with the off-diagonal block applied matrix-free (because Mh_{k+1}' = S_k^-1 K_{k,k+1}).  Per stage and iteration
-//       2 KB + 1.3 KB instead of 2 + 1.3 + 2 KB.  What the matrix-free product needs of omega sits behind S^-1 as a table of
-//       (scale, coupling weight) pairs per stage element, written by the factorization (omega changes only when it runs); and
-//       the stored S^-1 has ZERO rows and columns where the stage has no variable (padding, inputs beyond the control
-//       horizon) instead of the identity, so that the back substitution needs no row mask.
-#ifndef MPCQP_SONLY16
-#define MPCQP_SONLY16 0
-#endif
-#ifndef MPCQP_HYBRID16
-#define MPCQP_HYBRID16 1                   // 1: the header exists and the kernels choose per launch (Lay::hybrid); 0: two-slot only
-#endif
 template <int NB> struct FactorFmt {
-    static constexpr bool SONLY = (MPCQP_SONLY32 && NB == 32) || (MPCQP_SONLY16 && NB == 16);
-    static constexpr bool HYBRID = !SONLY && MPCQP_HYBRID16 && NB == 16;
-    static constexpr int SINV = SONLY ? (NB == 32 ? 164 + 164 + 256 : 164) : (MPCQP_SYM_SINV && NB == 16 ? 164 : NB * NB);
+    static constexpr bool SONLY = MPCQP_SONLY32 && NB == 32;
+    static constexpr int SINV = NB == 32 ? 164 + 164 + 256 : 164;
     static constexpr int FWD = SONLY ? 0 : NB * NB;
-    // per element (omega scaling, Delta-u coupling weight) of the stage's off-diagonal blocks: hybrid -- towards the neighbour the back
-    // substitution comes from; S^-1-only -- towards the stage above, then towards the stage below (each sweep uses one)
-    static constexpr int TAB = HYBRID ? 2 * NB : (SONLY ? 4 * NB : 0);
+    static constexpr int TAB = SONLY ? 4 * NB : 2 * NB;
     static constexpr int STAGE = FWD + SINV + TAB;
-    static constexpr int HEAD = (SONLY || HYBRID) ? 2 * NB * NB : 0;     // [G | G']: in front of the stages (S^-1-only) or behind them (hybrid)
+    static constexpr int HEAD = 2 * NB * NB;                              // [G | G']: behind the stages (in front of them in the S^-1-only format)
     static constexpr int SOFF = FWD;                                    // offset of S^-1 inside a stage
 };
 typedef double d4u __attribute__((ext_vector_type(4), aligned(8)));
@@ -169,8 +159,7 @@ __device__ int factor_all(const Ctx &c, const double *om, const double *sv, doub
 #pragma unroll 8
                     for (int l = 0; l < NB; ++l) acc += Mh[a * NB + l] * Ks[b * NB + l];
                     S[e] -= acc;
-                    // forward matrix of stage k (the backward sweep applies the same fragment transposed); the middle stage's
-                    // second forward matrix lives in the otherwise unused slot 0 of stage 0
+                    // forward matrix of stage k; the middle stage's second forward matrix lives in the otherwise unused slot of stage 0
                     if constexpr (!FactorFmt<NB>::SONLY) F[(size_t)fwd_stage * L.fstage + frag_pos<NB>(a, b)] = -Mh[e];
                 }
             }
@@ -204,22 +193,17 @@ __device__ int factor_all(const Ctx &c, const double *om, const double *sv, doub
             const int a = e / NB, b = e % NB;
             const double acc = 0.5 * (S[a * NB + b] + S[b * NB + a]);
             SnOut[e] = acc;
-            // (formats with matrix-free off-diagonal blocks: rows / columns without a variable stored as zero -- see FactorFmt; the
-            //  LDS copy SnOut stays the true inverse)
-            const bool dead = (FactorFmt<NB>::HYBRID || FactorFmt<NB>::SONLY) && (a >= L.nb || b >= L.nb || ((a >= L.nx || b >= L.nx) && k >= L.NcT));
+            // (rows / columns without a variable are stored as zero -- see FactorFmt; the LDS copy SnOut stays the true inverse)
+            const bool dead = a >= L.nb || b >= L.nb || ((a >= L.nx || b >= L.nx) && k >= L.NcT);
             const double st = dead ? 0.0 : acc;
-            if constexpr (FactorFmt<NB>::SONLY) {                  // [ sym(S00) | sym(S11) | S01 ]
-                double *Fk = F + FactorFmt<NB>::HEAD + (size_t)k * L.fstage;     // (S^-1-only: the header comes first)
+            double *Sk = F + (FactorFmt<NB>::SONLY ? FactorFmt<NB>::HEAD : 0) + (size_t)k * L.fstage + FactorFmt<NB>::SOFF;
+            if constexpr (NB == 32) {                              // [ sym(S00) | sym(S11) | S01 ]
                 const int A_ = a >> 4, B_ = b >> 4, al = a & 15, bl = b & 15;
-                if (A_ == B_) { if ((bl >> 2) >= (al >> 2)) Fk[164 * A_ + sym_pos(al, bl)] = st; }
-                else if (A_ == 0) Fk[328 + frag_pos<16>(al, bl)] = st;
-            }
-            else {
-                if constexpr (SinvFmt<NB>::SYM) { if ((b >> 2) >= (a >> 2)) F[(size_t)k * L.fstage + NB * NB + sym_pos(a, b)] = st; }
-                else F[(size_t)k * L.fstage + NB * NB + frag_pos<NB>(a, b)] = st;
-            }
+                if (A_ == B_) { if ((bl >> 2) >= (al >> 2)) Sk[164 * A_ + sym_pos(al, bl)] = st; }
+                else if (A_ == 0) Sk[328 + frag_pos<16>(al, bl)] = st;
+            } else if ((b >> 2) >= (a >> 2)) Sk[sym_pos(a, b)] = st;
         }
-        if constexpr (FactorFmt<NB>::TAB > 0) {
+        {
             // tables of the stage's off-diagonal blocks (kkt_sub_entry is the entry-wise definition): element e -> (omega of the
             // dynamics row between the two stages, 1 off the x part;  omega of the Delta-u row that couples them, on the one
             // element of this stage it enters, 0 elsewhere)
@@ -257,7 +241,7 @@ __device__ int factor_all(const Ctx &c, const double *om, const double *sv, doub
         for (int k = N - 1; k > mid; --k) stage(true, k, NT, tid, W, nullptr, k < N - 1 ? SnB : nullptr, SnB);
     }
     stage(true, mid, NT, tid, W, SnA, SnB, SnA);
-    if constexpr (FactorFmt<NB>::HEAD > 0) {   // G = [[Ad, Bd], [0, c QDu']] and G' as fragments (constant per instance)
+    {   // G = [[Ad, Bd], [0, c QDu']] and G' as fragments (constant per instance)
         constexpr int NBLK = NB / 16;
         double *Fg = FactorFmt<NB>::SONLY ? F : F + (size_t)N * L.fstage;
         for (int e = tid; e < NB * NB; e += NT) {

@@ -85,14 +85,14 @@ __device__ __noinline__ void run_factor_phase() {
                    border_ptrs(L, P, r.S));
 }
 
-template <int NB, bool LDSSTATE, int NXT, int NUT, bool BORDER, bool HYB>
+template <int NB, bool LDSSTATE, int NXT, int NUT, bool BORDER>
 __device__ __noinline__ void run_admm_phase(int iters) {
     const RunKArgs &A = run_kargs();
     const Lay &L = A.L; const Ptrs &P = A.P;
     RunSmem r = run_smem<LDSSTATE>(L, P);
     HotPtrs hp; hp.model = P.model; hp.step = P.step; hp.omega = P.omega; hp.s = P.s; hp.qv = P.qv; hp.F = P.F; hp.c = P.c;
     hp.Bb = P.Bb; hp.Zb = P.Zb; hp.Sig = P.Sig; hp.x = P.x; hp.z = P.z; hp.y = P.y; hp.dx = P.dx; hp.dy = P.dy; hp.perm = P.perm; hp.fsz = P.fsz;
-    admm_body<NB, LDSSTATE, NXT, NUT, BORDER, HYB>(L, hp, r.S, r.X, r.Z, r.Y, A.S.alpha, __builtin_amdgcn_readfirstlane(iters));
+    admm_body<NB, LDSSTATE, NXT, NUT, BORDER>(L, hp, r.S, r.X, r.Z, r.Y, A.S.alpha, __builtin_amdgcn_readfirstlane(iters));
 }
 
 template <int NB, bool LDSSTATE>
@@ -189,8 +189,7 @@ __global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_mpc_run(RunKArgs A_)
         PHASE_CLOCK(0)
         while (!term) {
             const int nxt = next_stop(iter, R.max_iter, R.chk, R.rho_every);
-            if (FactorFmt<NB>::HYBRID && L.hybrid) run_admm_phase<NB, LDSSTATE, NXT, NUT, BORDER, FactorFmt<NB>::HYBRID>(nxt - iter);
-            else run_admm_phase<NB, LDSSTATE, NXT, NUT, BORDER, false>(nxt - iter);
+            run_admm_phase<NB, LDSSTATE, NXT, NUT, BORDER>(nxt - iter);
             iter = nxt;
             __syncthreads();
             PHASE_CLOCK(1)

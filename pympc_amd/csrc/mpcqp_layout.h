@@ -22,8 +22,7 @@ struct Lay {
     int odu0;                     // offset of du0lo in the step blob
     int raw;                      // 1: q and the bounds are what mpcqp_update_vectors uploaded (not rebuilt from x0, u_{-1}, xref)
     int xref_rows;                // 1 or N
-    int fstage;                   // doubles per factor stage (FactorFmt<NB>::STAGE): [forward matrix | S^-1] or packed S^-1 only
-    int hybrid;                   // 16 x 16 stages: 1 = back substitution through S^-1 with matrix-free off-diagonal blocks (large batches), 0 = two-slot sweeps
+    int fstage;                   // doubles per factor stage (FactorFmt<NB>::STAGE): [forward matrix | packed S^-1 | table]
     int fhead, ffwd, ftab;        // doubles of the per-instance factor header ([G | G']) / of a stage's forward matrix / of its off-diagonal table (hybrid)
     int tsz;                      // LDS work vector length: max(m, 4*NB*NB)
 };

@@ -593,7 +593,7 @@ __device__ __forceinline__ void hot_update(const Lay &L, const double *hot, cons
 
 // `iters` ADMM iterations of this workgroup's instance.  Expects the hot model prefix and the step data in LDS
 // (load_common) and, with LDSSTATE, X/Z/Y carved behind the common area.
-template <int NB, bool LDSSTATE, int NXT, int NUT, bool BORDER, bool HYB>
+template <int NB, bool LDSSTATE, int NXT, int NUT, bool BORDER>
 __device__ __forceinline__ void admm_body(const Lay &L, const HotPtrs &P, Smem &S, double *X, double *Z, double *Y, double alpha, int iters) {
     const int b = inst_of(P.perm), tid = threadIdx.x;
     double *gx = P.x + (size_t)b * L.n, *gz = P.z + (size_t)b * L.m, *gy = P.y + (size_t)b * L.m;
@@ -626,7 +626,7 @@ __device__ __forceinline__ void admm_body(const Lay &L, const HotPtrs &P, Smem &
             bp.Bb = (double *)P.Bb + b * npb; bp.Zb = (double *)P.Zb + b * npb; bp.Sig = (double *)P.Sig + (size_t)b * L.nu * L.nu;
         }
         if (BORDER) border_pre<NB>(L, bp.Bb, bp.Zb, bp.Sig, Tc, S.tv, S.red);
-        kkt_core<NB, HYB>(core_args(L, opaque_ptr(F), opaque_ptr((const double *)P.omega + (size_t)b * L.m)), Tc);
+        kkt_core<NB>(core_args(L, opaque_ptr(F), opaque_ptr((const double *)P.omega + (size_t)b * L.m)), Tc);
         if (BORDER) border_post(L, NB, Tc, S.tv);
 #ifndef MPCQP_ABL_NOPAR
         hot_update<NB, NXT, NUT, LDSSTATE>(L, S.hot, S.x0s, S.du0, gom, gsv, hr, cc, alpha, X, Z, Y, W, Tc, keep_delta, dxg, dyg);

@@ -82,81 +82,26 @@ __device__ __forceinline__ void frag_load(const double *Fm, int lane, d4 *A) {
 #pragma unroll
     for (int b = 0; b < NBLK * NBLK; ++b) A[b] = *(cgd4 *)(Fm + b * 256 + lane * 4);
 }
-__device__ __forceinline__ double lane_permute(double x, int byte_addr);
-
-// S_k^-1 is symmetric.  For 16 x 16 stages only the 4x4 blocks on and above the block diagonal are stored -- 160 of 256
-// doubles, packed per operand-layout lane: a lane of block row R owns its 4-R values (steps 0..3-R) back to back,
+// S_k^-1 is symmetric: of a 16 x 16 block only the 4x4 blocks on and above the block diagonal are stored -- 160 of 256 doubles,
+// packed per operand-layout lane: a lane of block row R owns its 4-R values (steps 0..3-R) back to back,
 //     offset(lane = 16k + 4R + i) = 40 k + cum(R) + i (4-R),   cum = 0, 16, 28, 36      (+4 doubles of slack per fragment)
-// A lane loads a 4-double window at its offset (the tail of the window belongs to the next lane and is discarded) and
-// sym_expand rebuilds the missing steps from the transposed block: step s of block row R with R+s >= 4 is block
-// (R, R+s-4) = block (R+s-4, R)', i.e. step 4-s of lane 16 i + 4 (R+s-4) + k -- three cross-lane permutes.
-// The MFMA mat-vec then runs on the full fragment as before; a quarter fewer bytes per S^-1 read.
-template <int NB>
-__device__ __forceinline__ void frag_load_sinv(const double *Fm, int lane, d4 *A) {
-    if constexpr (SinvFmt<NB>::SYM) {
-        const int R = (lane >> 2) & 3;
-        const d4u w = *(cgd4u *)(Fm + 40 * (lane >> 4) + sym_cum(R) + (lane & 3) * (4 - R));
-        A[0] = d4{w[0], w[1], w[2], w[3]};
-    } else {
-        frag_load<NB>(Fm, lane, A);
-    }
-}
-template <int NB>
-__device__ __forceinline__ void sym_expand(d4 *A, int lane) {
-    if constexpr (SinvFmt<NB>::SYM) {
-        const int R = (lane >> 2) & 3, k = lane >> 4, i = lane & 3;
-        const d4 w = A[0];
-        const double t1 = lane_permute(w[3], 4 * (16 * i + 4 * ((R + 1) & 3) + k));
-        const double t2 = lane_permute(w[2], 4 * (16 * i + 4 * ((R + 2) & 3) + k));
-        const double t3 = lane_permute(w[1], 4 * (16 * i + 4 * ((R + 3) & 3) + k));
-        A[0] = d4{w[0], R + 1 >= 4 ? t1 : w[1], R + 2 >= 4 ? t2 : w[2], R + 3 >= 4 ? t3 : w[3]};
-    }
-}
-
-// The TRANSPOSED product from the same fragments:  out[bj] += sum_bi A(bi,bj)' * in[bi].
-// The backward substitution needs Mh' where the forward elimination needed Mh; the MFMA always contracts over the
-// index that sits in the 16-lane-row position of the operand layout (the column of the stored block), so the
-// transposed product is done on the vector ALU instead -- and the factor stream loses its third block per stage:
-//   xl        lane (k,b,j) <- element 4b+j of `in`            (one cross-lane permute of the stage vector)
-//   p_s = a[s] * xl                                            = M[4b+j][4((b+s)&3)+k] * in[4b+j]
-//   t   = p_0 + rot_3(p_1) + rot_2(p_2) + rot_1(p_3)           block (b-s, b) contributes to output block b
-//   out += sum over the four lanes j of t                      (two DPP quad steps), again replicated over j
+// A lane loads a 4-double window at its offset (the tail of the window belongs to the next lane and is discarded) and the
+// missing steps are rebuilt from the transposed block: step s of block row R with R+s >= 4 is block (R, R+s-4) =
+// block (R+s-4, R)', i.e. step 4-s of lane 16 i + 4 (R+s-4) + k -- three cross-lane permutes (sym_expand16).
 __device__ __forceinline__ double lane_permute(double x, int byte_addr) {
     const long long xi = __builtin_bit_cast(long long, x);
     const int lo = __builtin_amdgcn_ds_bpermute(byte_addr, (int)xi), hi = __builtin_amdgcn_ds_bpermute(byte_addr, (int)(xi >> 32));
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
 }
-template <int CTRL>
-__device__ __forceinline__ double dpp_move(double x) {
-    const long long xi = __builtin_bit_cast(long long, x);
-    const int lo = DPP_MOVE((int)xi, CTRL);      // (quad_perm: every lane written too)
-    const int hi = DPP_MOVE((int)(xi >> 32), CTRL);
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
-}
-__device__ __forceinline__ int transpose_lane_addr(int lane) { return 4 * (16 * (lane & 3) + (lane & 12) + (lane >> 4)); }
-template <int NB>
-__device__ __forceinline__ void frag_matvec_T(const d4 *A, const double *in, double *out, int perm_addr) {
-    constexpr int NBLK = NB / 16;
-#pragma unroll
-    for (int bi = 0; bi < NBLK; ++bi) {
-        const double xl = lane_permute(in[bi], perm_addr);
-#pragma unroll
-        for (int bj = 0; bj < NBLK; ++bj) {
-            const d4 a = A[bi * NBLK + bj];
-            double t = (a[0] * xl + rot_blocks<3>(a[1] * xl)) + (rot_blocks<2>(a[2] * xl) + rot_blocks<1>(a[3] * xl));
-            t += dpp_move<0xB1>(t);                            // quad_perm [1,0,3,2]
-            t += dpp_move<0x4E>(t);                            // quad_perm [2,3,0,1]
-            out[bj] += t;
-        }
-    }
-}
-
 template <int NB> struct SweepCfg {
     static constexpr int NF = (NB / 16) * (NB / 16);
 #ifndef MPCQP_DEPTH
 #define MPCQP_DEPTH 4
 #endif
-    static constexpr int DEPTH = MPCQP_DEPTH;                  // factor stages kept in flight in registers (even)
+#ifndef MPCQP_DEPTH32
+#define MPCQP_DEPTH32 4
+#endif
+    static constexpr int DEPTH = NB == 32 ? MPCQP_DEPTH32 : MPCQP_DEPTH;   // factor stages kept in flight in registers (8 VGPRs each at NB = 16, 32 at NB = 32)
 };
 
 // The sweeping waves are dependent MFMA chains: two of them on one SIMD share its matrix pipe and slow each other
@@ -171,26 +116,17 @@ __device__ __forceinline__ int logical_wave() {
 #endif
 }
 
-// Sequential sweep over `nsteps` stages by ONE wave: for i = 1..nsteps, k = first + dir*i:
-//     forward elimination (TRANSPOSED = false):  Tc[k] <- Tc[k] + Fwd(k)        * Tc[k - dir]
-//     back substitution   (TRANSPOSED = true) :  Tc[k] <- Tc[k] + Fwd(k - dir)' * Tc[k - dir]
-// (Fwd(k) = slot 0 of stage k holds the negated factor block; `first_stage` >= 0 names the stage whose slot replaces
-// Fwd(first) -- the middle stage's second forward matrix.)  The factor fragments of the next DEPTH stages are prefetched into a
-// register ring; the running vector ping-pongs between two register sets (no copies between MFMAs).
-template <int NB, bool TRANSPOSED>
-__device__ __forceinline__ void chain_sweep(const int first, const int dir, const int nsteps,
-                                            const int fstage, const double *F, const int first_stage, double *Tc) {
+// Forward elimination of one half-chain by ONE wave: for i = 1..nsteps, k = first + dir*i:   Tc[k] <- Tc[k] + Fwd(k) * Tc[k - dir]
+// (Fwd(k) = the forward-matrix slot of stage k, which holds the negated factor block).  The factor fragments of the next DEPTH
+// stages are prefetched into a register ring; the running vector ping-pongs between two register sets (no copies between MFMAs).
+template <int NB>
+__device__ __forceinline__ void chain_sweep(const int first, const int dir, const int nsteps, const int fstage, const double *F, double *Tc) {
     constexpr int NBLK = NB / 16, NF = SweepCfg<NB>::NF, DEPTH = SweepCfg<NB>::DEPTH;
     const int lane = opaque_lane(threadIdx.x & 63);
     double *tb = Tc + vec_lane_offset(lane);
     const bool writer = vec_lane_writer(lane);
-    const int perm_addr = transpose_lane_addr(lane);
     auto stage_of = [&](int i) { return first + dir * i; };
-    auto frag_of = [&](int i) {                                // (offsets, not pointer selects)
-        int st = TRANSPOSED ? stage_of(i - 1) : stage_of(i);
-        if (TRANSPOSED && i == 1 && first_stage >= 0) st = first_stage;
-        return F + (size_t)st * fstage;
-    };
+    auto frag_of = [&](int i) { return F + (size_t)stage_of(i) * fstage; };
     // The group loop below is branch-free on purpose: with conditionals around the refills the compiler can no longer
     // count the loads in flight across the back edge and falls back to s_waitcnt vmcnt(0) -- the whole memory latency
     // once per group.  Refills past the end re-read the last stage (clamped index), the tail group runs separately.
@@ -212,8 +148,7 @@ __device__ __forceinline__ void chain_sweep(const int first, const int dir, cons
         vec_load<NB>(tb, stage_of(i < nsteps ? i + 1 : i), nxt);
 #pragma unroll
         for (int bi = 0; bi < NBLK; ++bi) dst[bi] = own[bi];
-        if (TRANSPOSED) frag_matvec_T<NB>(ring[d], src, dst, perm_addr);
-        else frag_matvec<NB>(ring[d], src, dst);
+        frag_matvec<NB>(ring[d], src, dst);
         vec_store<NB>(tb, k, dst, writer);
     };
     int i0 = 1;
@@ -227,140 +162,6 @@ __device__ __forceinline__ void chain_sweep(const int first, const int dir, cons
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
         if (i0 + d <= nsteps) stage_step(i0 + d, d);
-}
-
-// w_k = S_k^-1 yh_k for all stages (independent MFMA groups, dealt to the four waves).  Wave 0 first finishes the
-// forward elimination at the middle stage: yh_mid = b_mid - Mh_mid yh_{mid-1} - Mt_mid yh_{mid+1}; it owns the three
-// stages around the middle (it reads yh_{mid-1}, yh_{mid+1}, so no other wave may overwrite them with w meanwhile).
-// The other N-3 stages are spread so that the four waves finish together: wave 0 takes every 7th of them on top of
-// its 3.5 stage-equivalents, waves 1..3 the rest in turn.  The wave's t-th stage in closed form:
-static_assert(NWAVES == 4, "stage-to-wave map below assumes four waves");
-__device__ __forceinline__ int sinv_stage(int wv, int t, int N, int mid) {        // -1: the wave has no t-th stage
-    int j;                                                   // index among the stages outside {mid-1, mid, mid+1}
-    if (wv == 0) j = 7 * t; else { const int p = 3 * t + (wv - 1); j = p + p / 6 + 1; }
-    if (j >= N - 3) return -1;
-    return j < mid - 1 ? j : j + 3;
-}
-// The fragment loads are software-pipelined two stages ahead; the first pair (and wave 0's five fragments around the
-// middle) is requested BEFORE the barrier that ends the forward elimination (sinv_prefetch), so that waves 2 and 3,
-// idle during the sweeps, have their data long before they may start.
-template <int NB> struct SinvPre {
-    d4 P0[SweepCfg<NB>::NF], P1[SweepCfg<NB>::NF];          // the wave's first two stages
-    d4 A0[SweepCfg<NB>::NF], A2[SweepCfg<NB>::NF], Am[SweepCfg<NB>::NF], B0[SweepCfg<NB>::NF], B1[SweepCfg<NB>::NF];   // wave 0
-    int nt, klast;                                           // number of stages of this wave, the last one (clamp target)
-};
-template <int NB>
-__device__ __forceinline__ void sinv_prefetch(const int N, const int mid, const int fstage, const double *F, SinvPre<NB> &pre) {
-    const int lane = opaque_lane(threadIdx.x & 63), wv = logical_wave();
-    const double *Fs = F + NB * NB;
-    int nt = 0, klast = 0;
-    for (int t = 0; t < N; ++t) { const int k = sinv_stage(wv, t, N, mid); if (k < 0) break; klast = k; ++nt; }
-    pre.nt = nt; pre.klast = klast;
-    auto kc = [&](int t) { const int k = sinv_stage(wv, t, N, mid); return k < 0 ? klast : k; };
-    if (wv == 0) {
-        frag_load<NB>(F + (size_t)mid * fstage, lane, pre.A0);
-        frag_load<NB>(F, lane, pre.A2);                      // the middle's second forward matrix (kept in stage 0's slot)
-        frag_load_sinv<NB>(Fs + (size_t)mid * fstage, lane, pre.Am);
-        frag_load_sinv<NB>(Fs + (size_t)(mid - 1) * fstage, lane, pre.B0);
-        frag_load_sinv<NB>(Fs + (size_t)(mid + 1) * fstage, lane, pre.B1);
-    }
-    frag_load_sinv<NB>(Fs + (size_t)kc(0) * fstage, lane, pre.P0);
-    frag_load_sinv<NB>(Fs + (size_t)kc(1) * fstage, lane, pre.P1);
-}
-template <int NB>
-__device__ __forceinline__ void sinv_apply(const int N, const int mid, const int fstage, const double *F, double *Tc, SinvPre<NB> &pre) {
-    constexpr int NBLK = NB / 16, NF = SweepCfg<NB>::NF;
-    const int lane = opaque_lane(threadIdx.x & 63), wv = logical_wave();
-    double *tb = Tc + vec_lane_offset(lane);
-    const bool writer = vec_lane_writer(lane);
-    auto apply = [&](int k, const d4 *A, bool valid) {       // (invalid: a clamped repeat of the last stage -- computed, not stored)
-        double in[NBLK], out[NBLK];
-        vec_load<NB>(tb, k, in);
-#pragma unroll
-        for (int b = 0; b < NBLK; ++b) out[b] = 0.0;
-        d4 Af[NF];
-#pragma unroll
-        for (int b = 0; b < NF; ++b) Af[b] = A[b];
-        sym_expand<NB>(Af, lane);
-        frag_matvec<NB>(Af, in, out);
-        vec_store<NB>(tb, k, out, writer && valid);
-    };
-    const double *Fs = F + NB * NB;
-    const int nt = pre.nt, klast = pre.klast;
-    auto kc = [&](int t) { const int k = sinv_stage(wv, t, N, mid); return k < 0 ? klast : k; };
-    if (wv == 0) {
-        double up[NBLK], dn[NBLK], acc[NBLK];
-        vec_load<NB>(tb, mid, acc);
-        vec_load<NB>(tb, mid - 1, up);
-        vec_load<NB>(tb, mid + 1, dn);
-        frag_matvec<NB>(pre.A0, up, acc);
-        frag_matvec<NB>(pre.A2, dn, acc);
-        vec_store<NB>(tb, mid, acc, writer);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        apply(mid, pre.Am, true); apply(mid - 1, pre.B0, true); apply(mid + 1, pre.B1, true);
-    }
-    d4 Q0[NF], Q1[NF];
-    for (int t = 0; t < nt; t += 4) {                        // branch-free body (exact vmcnt waits), see chain_sweep
-        frag_load_sinv<NB>(Fs + (size_t)kc(t + 2) * fstage, lane, Q0);
-        frag_load_sinv<NB>(Fs + (size_t)kc(t + 3) * fstage, lane, Q1);
-        apply(kc(t), pre.P0, true); apply(kc(t + 1), pre.P1, t + 1 < nt);
-        frag_load_sinv<NB>(Fs + (size_t)kc(t + 4) * fstage, lane, pre.P0);
-        frag_load_sinv<NB>(Fs + (size_t)kc(t + 5) * fstage, lane, pre.P1);
-        apply(kc(t + 2), Q0, t + 2 < nt); apply(kc(t + 3), Q1, t + 3 < nt);
-    }
-}
-
-// The same phase for 32 x 32 stages (four fragments = 32 VGPRs per stage): two fragment buffers in all -- the current
-// stage and the next one in flight -- instead of the seven of the pipelined version, which does not fit the register file.
-template <int NB>
-__device__ __forceinline__ void sinv_apply_lean(const int N, const int mid, const int fstage, const double *F, double *Tc) {
-    constexpr int NBLK = NB / 16, NF = SweepCfg<NB>::NF;
-    const int lane = opaque_lane(threadIdx.x & 63), wv = logical_wave();
-    double *tb = Tc + vec_lane_offset(lane);
-    const bool writer = vec_lane_writer(lane);
-    auto apply = [&](int k, const d4 *A) {
-        double in[NBLK], out[NBLK];
-        vec_load<NB>(tb, k, in);
-#pragma unroll
-        for (int b = 0; b < NBLK; ++b) out[b] = 0.0;
-        frag_matvec<NB>(A, in, out);
-        vec_store<NB>(tb, k, out, writer);
-    };
-    const double *Fs = F + NB * NB;
-    d4 A[NF], B[NF];
-    if (wv == 0) {
-        double up[NBLK], dn[NBLK], acc[NBLK];
-        frag_load<NB>(F + (size_t)mid * fstage, lane, A);
-        frag_load<NB>(F, lane, B);                            // the middle's second forward matrix (kept in stage 0's slot)
-        vec_load<NB>(tb, mid, acc);
-        vec_load<NB>(tb, mid - 1, up);
-        vec_load<NB>(tb, mid + 1, dn);
-        frag_matvec<NB>(A, up, acc);
-        frag_load_sinv<NB>(Fs + (size_t)mid * fstage, lane, A);
-        frag_matvec<NB>(B, dn, acc);
-        frag_load_sinv<NB>(Fs + (size_t)(mid - 1) * fstage, lane, B);
-        vec_store<NB>(tb, mid, acc, writer);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        apply(mid, A);
-        frag_load_sinv<NB>(Fs + (size_t)(mid + 1) * fstage, lane, A);
-        apply(mid - 1, B);
-        apply(mid + 1, A);
-    }
-    int k = sinv_stage(wv, 0, N, mid);
-    if (k >= 0) frag_load_sinv<NB>(Fs + (size_t)k * fstage, lane, A);
-    for (int t = 0; k >= 0; t += 2) {                         // A holds stage t; B is filled with stage t+1 while A is applied
-        const int k1 = sinv_stage(wv, t + 1, N, mid);
-        if (k1 >= 0) frag_load_sinv<NB>(Fs + (size_t)k1 * fstage, lane, B);
-        apply(k, A);
-        if (k1 < 0) break;
-        k = sinv_stage(wv, t + 2, N, mid);
-        if (k >= 0) frag_load_sinv<NB>(Fs + (size_t)k * fstage, lane, A);
-        apply(k1, B);
-    }
 }
 
 #ifdef MPCQP_RUN_TIMING
@@ -541,8 +342,7 @@ __device__ __forceinline__ SoLaneK so_lane_consts(int lane) {
 #pragma unroll
     for (int x = 0; x < 4; ++x) c.pa[x] = opaque_lane(4 * (16 * i + 4 * ((R + x) & 3) + k));
     c.m1 = R + 1 >= 4; c.m2 = R + 2 >= 4; c.m3 = R + 3 >= 4;
-    constexpr bool SYM = NB == 32 || SinvFmt<NB>::SYM;
-    c.win = (unsigned)opaque_lane(8 * (FactorFmt<NB>::SOFF + (SYM ? 40 * k + sym_cum(R) + i * (4 - R) : lane * 4)));
+    c.win = (unsigned)opaque_lane(8 * (FactorFmt<NB>::SOFF + 40 * k + sym_cum(R) + i * (4 - R)));
     c.direct = (unsigned)opaque_lane(8 * (FactorFmt<NB>::SOFF + 328 + lane * 4));
     const int tabs = FactorFmt<NB>::SONLY && !UP ? 2 * NB : 0;                   // (S^-1-only: the table towards the stage below comes second)
     c.tab = (unsigned)opaque_lane(8 * (FactorFmt<NB>::SOFF + FactorFmt<NB>::SINV + tabs + 2 * vec_lane_offset(lane)));
@@ -553,7 +353,7 @@ template <int NB>
 __device__ __forceinline__ void so_slot_load(const char *Fk, const SoLaneK &c, SoSlot<NB> &s) {
     auto window = [&](unsigned extra) { const d4u w = *(cgd4u *)(Fk + extra + c.win); return d4{w[0], w[1], w[2], w[3]}; };
     if constexpr (NB == 16) {
-        if constexpr (SinvFmt<NB>::SYM) s.S[0] = window(0); else s.S[0] = *(cgd4 *)(Fk + c.win);
+        s.S[0] = window(0);
     } else { s.S[0] = window(0); s.S[3] = window(8 * 164); s.S[1] = *(cgd4 *)(Fk + c.direct); }
 #pragma unroll
     for (int bi = 0; bi < NB / 16; ++bi) s.tab[bi] = *(cgd2 *)(Fk + c.tab + bi * 256);
@@ -561,7 +361,7 @@ __device__ __forceinline__ void so_slot_load(const char *Fk, const SoLaneK &c, S
 // the cross-lane half of the expansion (sym_expand16 / frag_transpose16): issue ...
 template <int NB>
 __device__ __forceinline__ void so_expand_issue(const SoSlot<NB> &s, const SoLaneK &c, SoPerm<NB> &t) {
-    if constexpr (NB == 32 || SinvFmt<NB>::SYM) {
+    {
         const d4 w = s.S[0];
         t.s0[0] = lane_permute(w[3], c.pa[1]); t.s0[1] = lane_permute(w[2], c.pa[2]); t.s0[2] = lane_permute(w[1], c.pa[3]);
     }
@@ -579,7 +379,7 @@ __device__ __forceinline__ void so_expand_finish(SoSlot<NB> &s, const SoLaneK &c
         pin_here(e1); pin_here(e2); pin_here(e3);
         return d4{w[0], e1, e2, e3};
     };
-    if constexpr (NB == 32 || SinvFmt<NB>::SYM) s.S[0] = sel(s.S[0], t.s0);
+    s.S[0] = sel(s.S[0], t.s0);
     if constexpr (NB == 32) { s.S[3] = sel(s.S[3], t.s1); s.S[2] = d4{t.tr[0], t.tr[1], t.tr[2], t.tr[3]}; }
 }
 template <int NB, bool SOLVE, bool UP>
@@ -711,35 +511,6 @@ __device__ __forceinline__ void kkt_core_so(const CoreArgs &a, double *Tc) {
     TICK(3)
 }
 
-// Twisted solve: forward elimination of the two half-chains (waves 0, 1), S^-1 of every stage (all waves; wave 0
-// closes the elimination at the middle first), back substitution outwards with the transposed forward matrices.
-
-template <int NB>
-__device__ __forceinline__ void kkt_core_sweeps(const CoreArgs &a, double *Tc) {
-    const int N = a.N, fstage = a.fstage, mid = N / 2, wv = logical_wave();
-    const double *F = a.F;
-    TICK_START
-    if (wv == 0) chain_sweep<NB, false>(0, +1, mid - 1, fstage, F, -1, Tc);               // stages 1 .. mid-1
-    else if (wv == 1) chain_sweep<NB, false>(N - 1, -1, N - 2 - mid, fstage, F, -1, Tc);  // stages N-2 .. mid+1
-    if constexpr (NB <= 16) {
-        SinvPre<NB> pre;
-        sinv_prefetch<NB>(N, mid, fstage, F, pre);
-        __syncthreads();
-        TICK(1)
-        sinv_apply<NB>(N, mid, fstage, F, Tc, pre);
-    } else {
-        __syncthreads();
-        TICK(1)
-        sinv_apply_lean<NB>(N, mid, fstage, F, Tc);
-    }
-    __syncthreads();
-    TICK(2)
-    if (wv == 0) chain_sweep<NB, true>(mid, -1, mid, fstage, F, -1, Tc);                  // stages mid-1 .. 0
-    else if (wv == 1) chain_sweep<NB, true>(mid, +1, N - 1 - mid, fstage, F, 0, Tc);           // stages mid+1 .. N-1
-    __syncthreads();
-    TICK(3)
-}
-
 // Hybrid format: forward elimination from the forward matrices (chain_sweep), the middle stage, then back substitution
 //     x_k = S_k^-1 ( yh_k - K_{k,nbr} x_nbr )
 // outwards from the middle with the off-diagonal blocks applied matrix-free -- S^-1 is read once, the forward matrices once.
@@ -749,8 +520,8 @@ __device__ __forceinline__ void kkt_core_hybrid(const CoreArgs &a, double *Tc) {
     const int N = a.N, fstage = a.fstage, mid = N / 2, wv = logical_wave(), lane = opaque_lane(threadIdx.x & 63);
     const double *F = a.F;
     TICK_START
-    if (wv == 0) chain_sweep<NB, false>(0, +1, mid - 1, fstage, F, -1, Tc);               // yh_1 .. yh_{mid-1}
-    else if (wv == 1) chain_sweep<NB, false>(N - 1, -1, N - 2 - mid, fstage, F, -1, Tc);  // yh_{N-2} .. yh_{mid+1}
+    if (wv == 0) chain_sweep<NB>(0, +1, mid - 1, fstage, F, Tc);                          // yh_1 .. yh_{mid-1}
+    else if (wv == 1) chain_sweep<NB>(N - 1, -1, N - 2 - mid, fstage, F, Tc);             // yh_{N-2} .. yh_{mid+1}
     __syncthreads();
     TICK(1)
     if (wv == 0) {                                   // yh_mid = b_mid - Mh_mid yh_{mid-1} - Mt_mid yh_{mid+1};  x_mid = S_mid^-1 yh_mid
@@ -781,14 +552,11 @@ __device__ __forceinline__ void kkt_core_hybrid(const CoreArgs &a, double *Tc) {
 // half-chains of the twisted factorization concurrently.  Tc must be seen by the compiler as an LDS pointer
 // (a pointer laundered through an integer becomes FLAT: flat LDS accesses count on vmcnt AND lgkmcnt and force a
 // full s_waitcnt vmcnt(0) -- draining the factor prefetch -- before every stage).
-// HYB (16 x 16 stages only): the hybrid back substitution instead of the two-slot one -- a template parameter, not a run-time
-// branch: compiled into one function the two paths share a register allocation and the two-slot one loses 3 % to it.
-template <int NB, bool HYB = false>
+template <int NB>
 __device__ __forceinline__ void kkt_core(const CoreArgs &a, double *Tc) {
 #ifndef MPCQP_ABL_NOCHAIN
     if constexpr (FactorFmt<NB>::SONLY) kkt_core_so<NB>(a, Tc);
-    else if constexpr (FactorFmt<NB>::HYBRID && HYB) kkt_core_hybrid<NB>(a, Tc);
-    else kkt_core_sweeps<NB>(a, Tc);                 // (each of them ends with a barrier)
+    else kkt_core_hybrid<NB>(a, Tc);                 // (each of them ends with a barrier)
 #else
     __syncthreads();
 #endif

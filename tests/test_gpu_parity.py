@@ -659,39 +659,3 @@ def test_warm_start_sets_z_like_osqp():
     assert _rel(xg[0], xo) < 1e-8 and _rel(zg[0], zo) < 1e-8 and np.abs(yg[0] - yo).max() < 1e-8 * max(1.0, np.abs(yo).max())
 
 
-@pytest.mark.parametrize('name', ['point_mass', 'cart_pole_nc1', 'quadcopter', 'random_12_4_30', 'random_5_3_8_nc', 'accel_brake_hard'])
-def test_hybrid_back_substitution_matches_references(name, monkeypatch):
-    """16 x 16 stages have two back substitutions over one stored factor (mpcqp_factor.h): the library picks the
-    S^-1 / matrix-free one for batches of three or more workgroups per CU (the 1024-instance tests and bench.py run it);
-    here it is forced on single controllers: reduced-KKT solve against dense numpy, the certified optimum, and a warm
-    closed loop against the oracle -- and the device loop stays bit-identical to the stepwise API under it."""
-    monkeypatch.setenv('MPCQP_HYBRID', '1')
-    g = load_golden(name); opt = load_golden(name, prefix='opt_')
-    kw = golden_kwargs(g)
-    K = _gpu_controller(kw); K.setup(solve=False)
-    bp = K.prob.batch_problem
-    D, E, c, rho = bp.scaling()
-    P, A = _eff(golden_csc(g, 'P')), golden_csc(g, 'A').toarray()
-    ls, us = E[0] * _clip(g['l']), E[0] * _clip(g['u'])
-    rho_vec = np.where((ls < -1e26) & (us > 1e26), 1e-6, np.where(us - ls < 1e-4, 1e3 * rho[0], rho[0]))
-    Kmat = c[0] * P + np.diag(1e-6 / D[0] ** 2) + A.T @ np.diag(rho_vec * E[0] ** 2) @ A
-    rhs = np.random.default_rng(5).standard_normal(P.shape[0])
-    assert _rel(bp.kkt_solve(rhs[None])[0], np.linalg.solve(Kmat, rhs)) < 1e-8
-    kw.update(eps_abs=1e-11, eps_rel=1e-11)
-    K = _gpu_controller(kw, max_iter=400000); Ko = _oracle_controller(kw, max_iter=400000)
-    K.setup(); Ko.setup()
-    assert np.abs(K.output() - opt['u0']).max() <= 1e-6 * max(np.abs(opt['u0']).max(), 1e-3)
-    x = np.array(kw['x0'], dtype=float)
-    for step in range(5):
-        uo = Ko.output(); K.output()
-        x = kw['Ad'] @ x + kw['Bd'] @ uo
-        K.update(x, uo); Ko.update(x, uo)
-        assert np.abs(K.output() - Ko.output()).max() <= 1e-6 * max(np.abs(uo).max(), 1e-3), step
-    if name == 'random_12_4_30':
-        from pympc_amd import fixtures
-        kws = [fixtures.random_lti(300 + i) for i in range(5)]
-        Kd = _stacked_batch(kws); Kd.setup(); Ks = _stacked_batch(kws); Ks.setup()
-        tr = Kd.run(6)
-        for k in range(6):
-            assert np.array_equal(Ks.output(), tr['u'][k]), k
-            Ks.update(tr['x'][k + 1])
