@@ -209,7 +209,7 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     // and may run on into the iterate area (dead while a factorization runs); T is widened only where even that is short.
     const int fws = L.NB == 16 ? FactorCfg<16>::WS : FactorCfg<32>::WS;
     const size_t state_doubles = (size_t)(L.n + 2 * L.m);
-    h->lds_state = sizeof(double) * ((size_t)smem_common_doubles(L) + state_doubles) <= 40 * 1024 && L.m <= 4 * NT && L.N * L.NB <= 2 * NT;
+    h->lds_state = sizeof(double) * ((size_t)smem_common_doubles(L) + state_doubles) <= 40 * 1024 && L.m <= 4 * NT && L.N * L.NB <= 2 * NT && L.n_u + L.nu <= NT;      // (the owner map of the parallel phases: two state elements and one input element per thread)
     const int avail = L.tsz + (h->lds_state ? (int)state_doubles : 0);
     if (avail < fws) h->L.tsz += fws - avail;
     h->smem_setup = sizeof(double) * ((size_t)smem_common_doubles(h->L) + (h->lds_state ? state_doubles : 0));      // every kernel gets the full block

@@ -353,48 +353,17 @@ template <int NUT> __device__ __forceinline__ int divu(const Lay &L, int v) { re
 //   W = omega z - c y                       (rows, flat; left behind by hot_rows_w / the previous hot_update)
 //   rhs = s x - c q + A' W                  (variables)
 //   te = rhs_eps / kappa -> W[soft row]     Tc[k][a] = rhs_x - omega_soft te  |  rhs_u  |  0 (padding)
-// Small problems (REGV; m <= 4 NT rows and N NB <= 2 NT padded variables, the same condition as the LDS-resident
-// iterate): a thread always handles the same rows r = tid + NT j and the same padded variables idx = tid + NT j, and
-// what it needs of the iteration-invariant vectors omega, s, q stays in its registers for the whole round -- the
-// parallel phases then touch no global memory at all (ten dependent global-load latencies per iteration otherwise).
-struct HotRegs {
-    double om_r[4];                                  // omega of the thread's rows
-    double sv_e[2], qv_e[2];                         // per padded variable: its s and its linear cost q
-    double om_s[2], sv_s[2];                         // (x part only) omega of its soft row, s of its slack
-};
-template <int NB, int NXT, int NUT>
-__device__ __forceinline__ void load_hot_regs(const Lay &L, cgdouble *om, cgdouble *sv, cgdouble *qv, HotRegs &h) {
-    const int tid = threadIdx.x, nx = hx<NXT>(L), nu = hu<NUT>(L);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { const int r = tid + NT * j; h.om_r[j] = r < L.m ? om[r] : 1.0; }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int idx = tid + NT * j, k = idx / NB, a = idx % NB;
-        h.sv_e[j] = 0.0; h.qv_e[j] = 0.0; h.om_s[j] = 1.0; h.sv_s[j] = 0.0;
-        if (idx < L.N * NB) {
-            if (a < nx) { const int e = k * nx + a; h.sv_e[j] = sv[e]; h.qv_e[j] = qv[e]; h.om_s[j] = om[L.rs + e]; h.sv_s[j] = L.soft ? sv[L.oe + e] : 0.0; }
-            else if (a < nx + nu && k < L.Nc) { const int cu = k * nu + a - nx; h.sv_e[j] = sv[L.ou + cu]; h.qv_e[j] = qv[L.n_x + cu]; }
-        }
-    }
-}
-
 // W = omega z - c y for the first iteration of a round (afterwards hot_update leaves it behind: a thread owns its rows).
-template <bool REGV>
-__device__ __forceinline__ void hot_rows_w(const Lay &L, cgdouble *om, const HotRegs &h, double cc, const double *Z, const double *Y, double *W) {
+__device__ __forceinline__ void hot_rows_w(const Lay &L, cgdouble *om, double cc, const double *Z, const double *Y, double *W) {
     const int tid = opaque_lane(threadIdx.x);
-    if (REGV) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const int r = tid + NT * j; if (r < L.m) W[r] = h.om_r[j] * Z[r] - cc * Y[r]; }
-    } else {
-        cgdouble *Zg = (cgdouble *)Z, *Yg = (cgdouble *)Y;
+    cgdouble *Zg = (cgdouble *)Z, *Yg = (cgdouble *)Y;
 #pragma unroll HOT_U
-        for (int r = tid; r < L.m; r += NT) W[r] = om[r] * Zg[r] - cc * Yg[r];
-    }
+    for (int r = tid; r < L.m; r += NT) W[r] = om[r] * Zg[r] - cc * Yg[r];
     __syncthreads();
 }
 
-template <int NB, int NXT, int NUT, bool REGV>
-__device__ __forceinline__ void hot_rhs(const Lay &L, const double *hot, cgdouble *om, cgdouble *sv, cgdouble *qv, const HotRegs &h, double cc,
+template <int NB, int NXT, int NUT>
+__device__ __forceinline__ void hot_rhs(const Lay &L, const double *hot, cgdouble *om, cgdouble *sv, cgdouble *qv, double cc,
                                         const double *X, const double *Z, const double *Y, double *W, double *Tc) {
     const int tid = opaque_lane(threadIdx.x);        // (keeps the per-thread index arithmetic out of LICM's reach: hoisted, it spills)
     const int nx = hx<NXT>(L), nu = hu<NUT>(L);
@@ -433,17 +402,7 @@ __device__ __forceinline__ void hot_rhs(const Lay &L, const double *hot, cgdoubl
         }
         Tc[idx] = v;
     };
-    if (REGV) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int idx = tid + NT * j, k = idx / NB, a = idx % NB;
-            if (idx < L.N * NB) {
-                const double xv = a < nx ? X[k * nx + a] : ((a < nx + nu && k < L.Nc) ? X[L.ou + k * nu + a - nx] : 0.0);
-                const double xe = (a < nx && L.soft) ? X[L.oe + k * nx + a] : 0.0;
-                element(idx, h.sv_e[j], h.qv_e[j], h.om_s[j], h.sv_s[j], xv, xe);
-            }
-        }
-    } else {
+    {
         // The iterate and the metric vectors live in global memory here (they do not fit LDS).  HOT_U elements per thread and
         // pass: all their loads are issued first -- six dependent-latency round trips per element otherwise, one after
         // the other -- through pointers the compiler knows to be global (a generic pointer means FLAT loads, which it may
@@ -468,9 +427,9 @@ __device__ __forceinline__ void hot_rhs(const Lay &L, const double *hot, cgdoubl
 }
 
 // Steps (4)-(6): slack back-substitution, zt = A xt, relaxation, projection on [l,u], dual update, x update.
-template <int NB, int NXT, int NUT, bool REGV>
+template <int NB, int NXT, int NUT>
 __device__ __forceinline__ void hot_update(const Lay &L, const double *hot, const double *x0s, const double *du0,
-                                           cgdouble *om, cgdouble *sv, const HotRegs &h, double cc, double alpha,
+                                           cgdouble *om, cgdouble *sv, double cc, double alpha,
                                            double *X, double *Z, double *Y, double *W, const double *Tc, bool keep_delta, gdouble *dxg, gdouble *dyg) {
     const int tid = opaque_lane(threadIdx.x);        // (keeps the per-thread index arithmetic out of LICM's reach: hoisted, it spills)
     const int nx = hx<NXT>(L), nu = hu<NUT>(L);
@@ -490,16 +449,7 @@ __device__ __forceinline__ void hot_update(const Lay &L, const double *hot, cons
         if (keep_delta) dxg[L.ou + cu] = un - uo;
         return un;
     };
-    if (REGV) {                                          // same padded-variable -> thread map as hot_rhs
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int idx = tid + NT * j, k = idx / NB, a = idx % NB;
-            if (idx < L.N * NB) {
-                if (a < nx) { const int e = k * nx + a; double xn, en; x_new(e, k, a, h.om_s[j], h.sv_s[j], X[e], L.soft ? X[L.oe + e] : 0.0, xn, en); X[e] = xn; if (L.soft) X[L.oe + e] = en; }
-                else if (a < nx + nu && k < L.Nc) { const int cu = k * nu + a - nx; X[L.ou + cu] = u_new(cu, k, a - nx, X[L.ou + cu]); }
-            }
-        }
-    } else {                                             // global-memory iterate: HOT_U elements per pass, loads first (see hot_rhs)
+    {                                                    // global-memory iterate: HOT_U elements per pass, loads first (see hot_rhs)
         for (int e0 = tid; e0 < L.n_x; e0 += HOT_U * NT) {
             double ws[HOT_U], svs[HOT_U], xo[HOT_U], eo[HOT_U];
 #pragma unroll
@@ -570,13 +520,7 @@ __device__ __forceinline__ void hot_update(const Lay &L, const double *hot, cons
         yv += dy; zv = zn;
         if (keep_delta) dyg[r] = dy;
     };
-    if (REGV) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = tid + NT * j;
-            if (r < L.m) { double zv = Z[r], yv = Y[r]; row_update(r, h.om_r[j], zv, yv); Z[r] = zv; Y[r] = yv; W[r] = h.om_r[j] * zv - cc * yv; }
-        }
-    } else {
+    {
         for (int r0 = tid; r0 < L.m; r0 += HOT_U * NT) {
             double zv[HOT_U], yv[HOT_U], w[HOT_U];
 #pragma unroll
@@ -587,6 +531,156 @@ __device__ __forceinline__ void hot_update(const Lay &L, const double *hot, cons
                 if (r < L.m) { row_update(r, w[u], zv[u], yv[u]); Zg[r] = zv[u]; Yg[r] = yv[u]; W[r] = w[u] * zv[u] - cc * yv[u]; }
             }
         }
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same parallel phases for the LDS-resident iterate (small problems), with an OWNER map instead of flat row / variable
+// loops: thread t owns, for j = 0, 1, the state element e = t + NT j = (stage k, component a) -- the variable x_k[a], its slack,
+// the dynamics row e and the state-box row rs + e, which all share that index -- and the input element cu = t = (k, jj) -- the
+// variable u_k[jj], its box row ri + cu, the Delta-u row rdu + nu + cu and, for cu < nu, the first-step row rdu + cu.
+//   * every pass runs ONE kind of item (no divergent tree over four row types and two variable kinds per wave: the flat
+//     loops spent most of their instructions on that tree, on index arithmetic and on scalar reloads inside it);
+//   * what the thread needs of omega, s, c q sits in its registers for the round (15 doubles);
+//   * slack back-substitution, relaxation and the row updates of an element happen in one pass (the slack value never leaves
+//     the thread), so the barrier between "variables" and "rows" is gone;
+//   * one division per row (c y / omega; omega / c is a multiplication by 1/c).
+// Needs n_x <= 2 NT and n_u + nu <= NT (the host only chooses the LDS-resident mode then).  Layouts of X, Z, Y, W are unchanged.
+// ------------------------------------------------------------------------------------------------
+struct OwnRegs {
+    double sv_x[2], cq_x[2], sv_e[2], om_s[2], om_d[2];      // per state element: s of x and of its slack, c q, omega of the box row / of the dynamics row
+    double sv_u, cq_u, om_i, om_du, om_d0;                    // input element: s, c q, omega of the box row, of Delta-u row nu + cu, of first-step row cu
+};
+template <int NB, int NXT, int NUT>
+__device__ __forceinline__ void own_load(const Lay &L, cgdouble *om, cgdouble *sv, cgdouble *qv, double cc, OwnRegs &h) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int e = tid + NT * j;
+        const bool v = e < L.n_x;
+        h.sv_x[j] = v ? sv[e] : 0.0; h.cq_x[j] = v ? cc * qv[e] : 0.0; h.sv_e[j] = (v && L.soft) ? sv[L.oe + e] : 0.0;
+        h.om_s[j] = v ? om[L.rs + e] : 1.0; h.om_d[j] = v ? om[e] : 1.0;
+    }
+    const int cu = tid;
+    const bool v = cu < L.n_u;
+    h.sv_u = v ? sv[L.ou + cu] : 0.0; h.cq_u = v ? cc * qv[L.n_x + cu] : 0.0;
+    h.om_i = v ? om[L.ri + cu] : 1.0; h.om_du = v ? om[L.rdu + L.nu + cu] : 1.0; h.om_d0 = cu < L.nu ? om[L.rdu + cu] : 1.0;
+}
+// W = omega z - c y of the thread's rows (first iteration of a round; afterwards own_update leaves it behind); zero padding of Tc
+template <int NB>
+__device__ __forceinline__ void own_rows_w(const Lay &L, const OwnRegs &h, double cc, const double *Z, const double *Y, double *W, double *Tc) {
+    const int tid = opaque_lane(threadIdx.x);
+    for (int i = tid; i < L.N * NB; i += NT) Tc[i] = 0.0;      // (padding and absent inputs stay zero through the solves: the factor has zero rows there)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int e = tid + NT * j;
+        if (e < L.n_x) { W[e] = h.om_d[j] * Z[e] - cc * Y[e]; W[L.rs + e] = h.om_s[j] * Z[L.rs + e] - cc * Y[L.rs + e]; }
+    }
+    if (tid < L.n_u) {
+        const int ri = L.ri + tid, rd = L.rdu + L.nu + tid;
+        W[ri] = h.om_i * Z[ri] - cc * Y[ri]; W[rd] = h.om_du * Z[rd] - cc * Y[rd];
+        if (tid < L.nu) { const int r0 = L.rdu + tid; W[r0] = h.om_d0 * Z[r0] - cc * Y[r0]; }
+    }
+    __syncthreads();
+}
+// rhs = s x - c q + A' W with the slack eliminated (see hot_rhs), into Tc
+template <int NB, int NXT, int NUT>
+__device__ __forceinline__ void own_rhs(const Lay &L, const double *hot, const OwnRegs &h, double cc, const double *X, double *W, double *Tc) {
+    const int tid = opaque_lane(threadIdx.x);        // (keeps the per-thread index arithmetic out of LICM's reach: hoisted, it spills)
+    const int nx = hx<NXT>(L), nu = hu<NUT>(L);
+    const double *Ad = hot + L.oAd, *Bd = hot + L.oBd;
+    const double cef = cc * hot[L.oeps];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int e = tid + NT * j;
+        if (e < L.n_x) {
+            const int k = divx<NXT>(L, e), a = e - k * nx;
+            double rx = h.sv_x[j] * X[e] - h.cq_x[j] - W[e];
+            if (k < L.Np) {
+                const double *w1 = W + (k + 1) * nx;
+#pragma unroll
+                for (int r = 0; r < (NXT ? NXT : 1); ++r) if (NXT) rx += Ad[r * nx + a] * w1[r];
+                if (!NXT) for (int r = 0; r < nx; ++r) rx += Ad[r * nx + a] * w1[r];
+            }
+            const double wsoft = W[L.rs + e];
+            const double te = L.soft ? (h.sv_e[j] * X[L.oe + e] + wsoft) / (cef + h.sv_e[j] + h.om_s[j]) : 0.0;      // (hard box: no slack to eliminate)
+            W[L.rs + e] = te;                          // read back by this thread in own_update
+            Tc[k * NB + a] = rx + wsoft - h.om_s[j] * te;
+        }
+    }
+    if (tid < L.n_u) {
+        const int cu = tid, k = divu<NUT>(L, cu), jj = cu - k * nu;
+        double ru = h.sv_u * X[L.ou + cu] - h.cq_u + W[L.ri + cu] - W[L.rdu + nu + cu];
+        if (k == 0) ru += W[L.rdu + jj];
+        if (cu > 0) ru += W[L.rdu + nu + cu - 1];
+        const int s_end = (k == L.Nc - 1) ? L.Np : k + 1;
+        for (int s = k + 1; s <= s_end; ++s) {
+            const double *w1 = W + s * nx;
+#pragma unroll
+            for (int r = 0; r < (NXT ? NXT : 1); ++r) if (NXT) ru += Bd[r * nu + jj] * w1[r];
+            if (!NXT) for (int r = 0; r < nx; ++r) ru += Bd[r * nu + jj] * w1[r];
+        }
+        Tc[k * NB + nx + jj] = ru;
+    }
+    __syncthreads();
+}
+// slack back-substitution, zt = A xt, relaxation, projection on [l,u], dual update, x update (see hot_update)
+template <int NB, int NXT, int NUT>
+__device__ __forceinline__ void own_update(const Lay &L, const double *hot, const double *x0s, const double *du0, const OwnRegs &h, double cc, double alpha,
+                                           double *X, double *Z, double *Y, double *W, const double *Tc, bool keep_delta, gdouble *dxg, gdouble *dyg) {
+    const int tid = opaque_lane(threadIdx.x);
+    const int nx = hx<NXT>(L), nu = hu<NUT>(L);
+    const double *Ad = hot + L.oAd, *Bd = hot + L.oBd;
+    const double cef = cc * hot[L.oeps], cinv = 1.0 / cc, beta = 1.0 - alpha;
+    auto row = [&](int r, double w, double zt, double lo, double hi) {
+        lo = lo < -QP_INFTY ? -QP_INFTY : lo;
+        hi = hi > QP_INFTY ? QP_INFTY : hi;
+        const double zv = Z[r], yv = Y[r];
+        const double zr = alpha * zt + beta * zv;
+        const double zn = fmin(fmax(zr + cc * yv / w, lo), hi);
+        const double dy = (w * cinv) * (zr - zn), yn = yv + dy;
+        Z[r] = zn; Y[r] = yn; W[r] = w * zn - cc * yn;
+        if (keep_delta) dyg[r] = dy;
+    };
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int e = tid + NT * j;
+        if (e < L.n_x) {
+            const int k = divx<NXT>(L, e), a = e - k * nx;
+            const double xt = Tc[k * NB + a];
+            const double et = L.soft ? W[L.rs + e] - (h.om_s[j] / (cef + h.sv_e[j] + h.om_s[j])) * xt : 0.0;
+            const double xo = X[e], xn = alpha * xt + beta * xo;
+            X[e] = xn;
+            if (keep_delta) dxg[e] = xn - xo;
+            if (L.soft) { const double eo = X[L.oe + e], en = alpha * et + beta * eo; X[L.oe + e] = en; if (keep_delta) dxg[L.oe + e] = en - eo; }
+            double zt = -xt;                           // dynamics row e
+            if (k > 0) {
+                const double *xp = Tc + (k - 1) * NB;
+                const double *up = Tc + min(k - 1, L.Nc - 1) * NB + nx;
+#pragma unroll
+                for (int i = 0; i < (NXT ? NXT : 1); ++i) if (NXT) zt += Ad[a * nx + i] * xp[i];
+                if (!NXT) for (int i = 0; i < nx; ++i) zt += Ad[a * nx + i] * xp[i];
+#pragma unroll
+                for (int i = 0; i < (NUT ? NUT : 1); ++i) if (NUT) zt += Bd[a * nu + i] * up[i];
+                if (!NUT) for (int i = 0; i < nu; ++i) zt += Bd[a * nu + i] * up[i];
+            }
+            const double b0 = k == 0 ? -x0s[a] : 0.0;
+            row(e, h.om_d[j], zt, b0, b0);
+            row(L.rs + e, h.om_s[j], xt + et, hot[L.oxmin + a], hot[L.oxmax + a]);      // state-box row (soft: x + eps)
+        }
+    }
+    if (tid < L.n_u) {
+        const int cu = tid, k = divu<NUT>(L, cu), jj = cu - k * nu;
+        const double ut = Tc[k * NB + nx + jj];
+        const double uo = X[L.ou + cu], un = alpha * ut + beta * uo;
+        X[L.ou + cu] = un;
+        if (keep_delta) dxg[L.ou + cu] = un - uo;
+        row(L.ri + cu, h.om_i, ut, hot[L.oumin + jj], hot[L.oumax + jj]);
+        double zt = -ut;                               // Delta-u row nu + cu: next flattened input minus this one (mpc.py:570)
+        if (cu + 1 < L.n_u) zt += (jj + 1 < nu) ? Tc[k * NB + nx + jj + 1] : Tc[(k + 1) * NB + nx];
+        row(L.rdu + nu + cu, h.om_du, zt, hot[L.oDumin + jj], hot[L.oDumax + jj]);
+        if (cu < nu) row(L.rdu + cu, h.om_d0, ut, du0[cu], du0[nu + cu]);              // first step: u_0 - u_{-1}
     }
     __syncthreads();
 }
@@ -607,17 +701,19 @@ __device__ __forceinline__ void admm_body(const Lay &L, const HotPtrs &P, Smem &
     gdouble *dxg = (gdouble *)(P.dx + (size_t)b * L.n), *dyg = (gdouble *)(P.dy + (size_t)b * L.m);
     const double *F = P.F + (size_t)b * P.fsz;
     const double cc = P.c[b];
-    HotRegs hr;
-    if (LDSSTATE) load_hot_regs<NB, NXT, NUT>(L, gom, gsv, gqv, hr);
+    OwnRegs hr;
+    if (LDSSTATE) own_load<NB, NXT, NUT>(L, gom, gsv, gqv, cc, hr);
 #ifndef MPCQP_ABL_NOPAR
-    hot_rows_w<LDSSTATE>(L, gom, hr, cc, Z, Y, W);
+    if (LDSSTATE) own_rows_w<NB>(L, hr, cc, Z, Y, W, Tc);
+    else hot_rows_w(L, gom, cc, Z, Y, W);
 #endif
     TICK_RESET
     for (int it = 1; it <= iters; ++it) {
         const bool keep_delta = it == iters;         // the increments feed the infeasibility certificates of the check
         TICK_START
 #ifndef MPCQP_ABL_NOPAR
-        hot_rhs<NB, NXT, NUT, LDSSTATE>(L, S.hot, gom, gsv, gqv, hr, cc, X, Z, Y, W, Tc);
+        if (LDSSTATE) own_rhs<NB, NXT, NUT>(L, S.hot, hr, cc, X, W, Tc);
+        else hot_rhs<NB, NXT, NUT>(L, S.hot, gom, gsv, gqv, cc, X, Z, Y, W, Tc);
 #endif
         TICK(0)
         BorderPtrs bp; bp.red = S.red;
@@ -629,7 +725,8 @@ __device__ __forceinline__ void admm_body(const Lay &L, const HotPtrs &P, Smem &
         kkt_core<NB>(core_args(L, opaque_ptr(F), opaque_ptr((const double *)P.omega + (size_t)b * L.m)), Tc);
         if (BORDER) border_post(L, NB, Tc, S.tv);
 #ifndef MPCQP_ABL_NOPAR
-        hot_update<NB, NXT, NUT, LDSSTATE>(L, S.hot, S.x0s, S.du0, gom, gsv, hr, cc, alpha, X, Z, Y, W, Tc, keep_delta, dxg, dyg);
+        if (LDSSTATE) own_update<NB, NXT, NUT>(L, S.hot, S.x0s, S.du0, hr, cc, alpha, X, Z, Y, W, Tc, keep_delta, dxg, dyg);
+        else hot_update<NB, NXT, NUT>(L, S.hot, S.x0s, S.du0, gom, gsv, cc, alpha, X, Z, Y, W, Tc, keep_delta, dxg, dyg);
 #endif
         TICK(5)
     }

@@ -3,7 +3,7 @@
 //   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -o /tmp/stage_ubench scripts/diag/stage_ubench.hip
 #include "../../pympc_amd/csrc/mpcqp.hip"
 
-// MODE 0: chain_sweep forward; 1: chain_sweep transposed; 2 / 4: hybrid back substitution (so_sweep) with G' / G
+// MODE 0: chain_sweep forward; 2 / 4: hybrid back substitution (so_sweep) with G' / G
 // HELP 0: waves 2, 3 idle; 1: they touch one dword per cache line of the chain's stages (L2 warm-up) while the sweepers run
 template <int MODE, int HELP>
 __global__ __launch_bounds__(NT) void ub(const double *F, const double *G, const double *om, double *out, int nst, int fstride, int wgstride, int reps) {
@@ -19,8 +19,7 @@ __global__ __launch_bounds__(NT) void ub(const double *F, const double *G, const
         if (wv < 2) {
             const double *Fc = Fb + (size_t)wv * (nst + 1) * fstride;      // the wave's half of the instance's stages
             double *Tw = Tc + wv * (nst + 1) * 16;
-            if (MODE == 0) chain_sweep<16, false>(0, +1, nst, fstride, Fc, -1, Tw);
-            if (MODE == 1) chain_sweep<16, true>(0, +1, nst, fstride, Fc, -1, Tw);
+            if (MODE == 0) chain_sweep<16>(0, +1, nst, fstride, Fc, Tw);
             if (MODE == 2) { CoreArgs b = a; b.F = Fc; so_sweep<16, true, false>(b, Tw, nst, -1, 1, nst); }
             if (MODE == 4) { CoreArgs b = a; b.F = Fc; so_sweep<16, true, true>(b, Tw, 0, +1, 1, nst); }
         } else if (HELP) {
@@ -47,8 +46,8 @@ static void run(const char *name, int grid, const double *F, const double *G, co
     printf("%-28s grid %4d  stage stride %4d: %7.0f cycles/stage (mean over workgroups; max %.0f), sweep of %d stages incl. start-up\n", name, grid, fstride, s / grid, mx, nst);
 }
 
-int main() {
-    const int nst = 14, fst = FactorFmt<16>::STAGE, per_wg = 2 * (nst + 1) * fst + 512;
+int main(int argc, char **argv) {
+    const int nst = argc > 1 ? atoi(argv[1]) : 14, fst = FactorFmt<16>::STAGE, per_wg = 2 * (nst + 1) * fst + 512;
     const int maxgrid = 1024;
     double *F, *G, *om, *out;
     hipMalloc(&F, sizeof(double) * (size_t)per_wg * maxgrid); hipMalloc(&G, sizeof(double) * 512); hipMalloc(&om, sizeof(double) * 4096); hipMalloc(&out, sizeof(double) * maxgrid);
@@ -56,11 +55,10 @@ int main() {
     for (size_t i = 0; i < h.size(); ++i) h[i] = 1e-3 * ((i * 7919) % 101) - 0.05;
     hipMemcpy(F, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice);
     hipMemcpy(G, h.data(), 512 * sizeof(double), hipMemcpyHostToDevice); hipMemcpy(om, h.data(), 4096 * sizeof(double), hipMemcpyHostToDevice);
-    const size_t smem = 38 * 1024;                          // the solver's footprint: four workgroups per CU
+    const size_t smem = 38 * 1024 + (nst > 14 ? 2 * (nst - 14) * 16 * 8 : 0);      // the solver's footprint: four workgroups per CU
     for (int grid : {1, 256, 1024}) {
         for (int fstride : {0, fst}) {
             run<0, 0>("forward", grid, F, G, om, out, nst, fstride, per_wg, smem);
-            run<1, 0>("transposed", grid, F, G, om, out, nst, fstride, per_wg, smem);
             run<2, 0>("hybrid back (G')", grid, F, G, om, out, nst, fstride, per_wg, smem);
             run<4, 0>("hybrid back (G)", grid, F, G, om, out, nst, fstride, per_wg, smem);
         }
