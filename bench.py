@@ -290,6 +290,15 @@ def main():
                   'solved_fraction_last_step': sum(1 for i in pinf if i.status == 1) / B}
         samples.append(dict(sample_point(), eps=1e-9))
         prob.update_settings(eps_abs=args.eps, eps_rel=args.eps)
+    # what one rho update costs: the block factorization of every instance, timed alone (mpcqp_refactor rewrites the factor
+    # that is already in place); the steady-state loop above needs none, the cold solve a few per instance
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    prob.refactor(); torch.cuda.synchronize()
+    ev0.record()
+    for _ in range(3):
+        prob.refactor()
+    ev1.record(); torch.cuda.synchronize()
+    refactor_ms = ev0.elapsed_time(ev1) / 3
     kname = prob.kernel_name(loop=args.path == 'device_loop')
     lds_state = ',true,' in kname.split('<')[1][:9]            # second template argument: iterate resident in LDS
 
@@ -318,13 +327,18 @@ def main():
             'mean_admm_iters': iters / max(1, solves),
             'solved_fraction_last_step': n_solved / B,
             'refactorizations_per_solve': refacts / max(1, solves),
+            'refactorization': {'per_solve_timed_region': refacts / max(1, solves), 'ms_per_batch': refactor_ms, 'us_per_instance_amortised': 1e3 * refactor_ms / B,
+                                'note': 'block LDL factorization of all %d instances in one launch (one rho update each); 0 per solve in the warm '
+                                        'receding-horizon loop, a few per instance during the cold solve' % B},
             'roofline': {'bound': 'hbm', 'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK, 'traffic': traffic,
                          'traffic_GBps': (traffic / (admm_ms / max(1, admm_launches) * 1e-3) / 1e9) if traffic else None,
                          'bytes_model': 'design: what k_mpc_run streams per instance (mpcqp_get_stream_bytes) -- per ADMM iteration the KKT factor '
-                                        '(forward blocks of N-1 stages read twice, S^-1 of N stages once%s), per round the residual-evaluation inputs and the '
+                                        '(%s%s), per round the residual-evaluation inputs and the '
                                         'iterate in/out of LDS, per solve the QP refresh and the write-out'
-                                        % ('' if lds_state else '; iterate and metric vectors too: they do not fit LDS at this size'),
+                                        % ('forward matrices of N-1 stages, packed S^-1 of N stages and the stage tables once each, [G|G\'] once' if NX + NU <= 16
+                                           else 'packed S^-1 of N stages twice, one stage table per sweep, [G|G\'] by each sweeping wave',
+                                           '' if lds_state else '; iterate and metric vectors too: they do not fit LDS at this size'),
                          'design_bytes_per_iter_per_qp': per_iter, 'design_bytes_per_round_per_qp': per_round, 'design_bytes_per_solve_per_qp': per_solve,
                          'design_bytes_per_launch': design_bytes / max(1, admm_launches),
                          'measured_bytes_per_iter_per_qp': pmc,

@@ -236,6 +236,11 @@ int mpcqp_debug_kkt_solve(mpcqp_handle *h, const double *rhs, double *sol);
 int mpcqp_get_iterate(mpcqp_handle *h, double *x, double *z, double *y);
 /* Run exactly `iters` ADMM iterations with no termination test and no rho adaptation. */
 int mpcqp_iterate(mpcqp_handle *h, int iters);
+/* Recompute the KKT factor of every instance from its current rho -- the work one adaptive-rho update costs inside
+ * prob.solve() (mpc.py:369; OSQP refactors the KKT matrix whenever it changes rho).  The factor written is the one already in
+ * place: nothing observable changes.  Asynchronous on the handle's stream; bench.py times it to report what a refactorization
+ * costs per instance. */
+int mpcqp_refactor(mpcqp_handle *h);
 
 #ifdef __cplusplus
 }

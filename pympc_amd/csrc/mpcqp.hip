@@ -523,6 +523,19 @@ static int launch_solve(mpcqp_handle *h, int plain_iters) {
 }
 
 extern "C" int mpcqp_solve(mpcqp_handle *h) { if (!h) return fail(MPCQP_ERR_ARG, "null handle"); return launch_solve(h, 0); }
+extern "C" int mpcqp_refactor(mpcqp_handle *h) {
+    if (!h) return fail(MPCQP_ERR_ARG, "null handle");
+    if (!h->is_setup) return fail(MPCQP_ERR_STATE, "mpcqp_refactor before mpcqp_setup");
+    HIPCHK(hipSetDevice(h->device));
+    RunArgs R; memset(&R, 0, sizeof(R));
+    R.part = 3;
+    const int since = h->solves_since_balance;
+    const bool prof = h->profiling;
+    h->profiling = false;                           // (not a solve: keep it out of the k_mpc_run timing and the balancing clock)
+    const int rc = launch_run(h, R, 0);
+    h->profiling = prof; h->solves_since_balance = since;
+    return rc;
+}
 extern "C" int mpcqp_iterate(mpcqp_handle *h, int iters) {
     if (!h || iters < 1) return fail(MPCQP_ERR_ARG, "mpcqp_iterate: bad argument");
     return launch_solve(h, iters);

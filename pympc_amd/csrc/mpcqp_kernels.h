@@ -19,6 +19,7 @@ struct RunArgs {
                                   // finished are appended to `pending`.  2: continue the `pending` instances to the end
                                   // (the launch that follows part 1: its workgroup -> instance map IS the pending list, so
                                   // the unfinished instances spread evenly over the CUs instead of staying where they were)
+                                  // 3: no solve at all -- refactor every instance with its current rho (mpcqp_refactor)
     int *pending, *npending;      // [batch] instance list and its length (device)
     int max_iter, chk, rho_every;
     const double *w;              // [nsteps][batch][nx] additive plant disturbance, or null
@@ -119,6 +120,11 @@ __global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_mpc_run(RunKArgs A_)
     const int b = inst_of(P.perm), tid = threadIdx.x;
     double *step = P.step + (size_t)b * L.step_sz;
     load_common(L, P.model + (size_t)b * L.model_sz, step, S);
+    if (!LOOP && R.part == 3) {                  // mpcqp_refactor: the factorization alone (what one rho update costs)
+        __syncthreads();
+        run_factor_phase<NB>();
+        return;
+    }
     const int nx = L.nx, nu = L.nu;
     const int nrun = LOOP ? R.nsteps : 1;        // LOOP = false: one solve of the current data (mpcqp_solve)
     for (int k = 0; k < nrun; ++k) {

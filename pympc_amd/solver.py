@@ -342,6 +342,10 @@ class BatchProblem:
         _lib.check(self._L.mpcqp_iterate(self._h, int(iters)), 'mpcqp_iterate')
         self.synchronize()
 
+    def refactor(self):
+        """Recompute every instance's KKT factor from its current rho (asynchronous; what one rho update costs)."""
+        _lib.check(self._L.mpcqp_refactor(self._h), 'mpcqp_refactor')
+
     def iterate_state(self):
         x, z, y = np.empty((self.batch, self.n)), np.empty((self.batch, self.m)), np.empty((self.batch, self.m))
         _lib.check(self._L.mpcqp_get_iterate(self._h, _ptr(x), _ptr(z), _ptr(y)), 'mpcqp_get_iterate')

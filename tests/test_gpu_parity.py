@@ -659,3 +659,23 @@ def test_warm_start_sets_z_like_osqp():
     assert _rel(xg[0], xo) < 1e-8 and _rel(zg[0], zo) < 1e-8 and np.abs(yg[0] - yo).max() < 1e-8 * max(1.0, np.abs(yo).max())
 
 
+@pytest.mark.parametrize('name', ['quadcopter', 'random_20_8_12', 'point_mass_nc'])
+def test_refactor_rewrites_the_same_factor(name):
+    """mpcqp_refactor (what bench.py times as the cost of one rho update) recomputes the factor in place from the current rho:
+    the reduced-KKT solve and the next solve are bit-identical with and without it."""
+    g = load_golden(name)
+    kw = golden_kwargs(g)
+    K = _gpu_controller(kw); K.setup(solve=True)
+    bp = K.prob.batch_problem
+    rhs = np.random.default_rng(11).standard_normal((1, bp.n))
+    before = bp.kkt_solve(rhs)
+    bp.refactor(); bp.synchronize()
+    assert np.array_equal(bp.kkt_solve(rhs), before)
+    K2 = _gpu_controller(kw); K2.setup(solve=True)
+    x = np.asarray(kw['x0'], float)
+    for _ in range(3):
+        u = K.output(); u2 = K2.output()
+        assert np.array_equal(u, u2)
+        x = kw['Ad'] @ x + kw['Bd'] @ u
+        K.prob.batch_problem.refactor()
+        K.update(x, u); K2.update(x, u)
