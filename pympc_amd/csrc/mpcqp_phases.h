@@ -349,195 +349,13 @@ template <int NUT> __device__ __forceinline__ int hu(const Lay &L) { return NUT 
 template <int NXT> __device__ __forceinline__ int divx(const Lay &L, int v) { return NXT ? v / NXT : idiv(v, L.rnx); }
 template <int NUT> __device__ __forceinline__ int divu(const Lay &L, int v) { return NUT ? v / NUT : idiv(v, L.rnu); }
 
-// Steps (1)-(2) of the ADMM iteration with the slack elimination fused in:
-//   W = omega z - c y                       (rows, flat; left behind by hot_rows_w / the previous hot_update)
-//   rhs = s x - c q + A' W                  (variables)
-//   te = rhs_eps / kappa -> W[soft row]     Tc[k][a] = rhs_x - omega_soft te  |  rhs_u  |  0 (padding)
-// W = omega z - c y for the first iteration of a round (afterwards hot_update leaves it behind: a thread owns its rows).
-__device__ __forceinline__ void hot_rows_w(const Lay &L, cgdouble *om, double cc, const double *Z, const double *Y, double *W) {
-    const int tid = opaque_lane(threadIdx.x);
-    cgdouble *Zg = (cgdouble *)Z, *Yg = (cgdouble *)Y;
-#pragma unroll HOT_U
-    for (int r = tid; r < L.m; r += NT) W[r] = om[r] * Zg[r] - cc * Yg[r];
-    __syncthreads();
-}
-
-template <int NB, int NXT, int NUT>
-__device__ __forceinline__ void hot_rhs(const Lay &L, const double *hot, cgdouble *om, cgdouble *sv, cgdouble *qv, double cc,
-                                        const double *X, const double *Z, const double *Y, double *W, double *Tc) {
-    const int tid = opaque_lane(threadIdx.x);        // (keeps the per-thread index arithmetic out of LICM's reach: hoisted, it spills)
-    const int nx = hx<NXT>(L), nu = hu<NUT>(L);
-    const double *Ad = hot + L.oAd, *Bd = hot + L.oBd;
-    const double cef = cc * hot[L.oeps];
-    // xv / xe: the variable's and (x part) its slack's current value
-    auto element = [&](int idx, double sve, double qve, double ws, double svs, double xv, double xe) {
-        const int k = idx / NB, a = idx % NB;
-        double v = 0.0;
-        if (a < nx) {
-            const int e = k * nx + a;
-            double rx = sve * xv - cc * qve - W[e];
-            if (k < L.Np) {
-                const double *w1 = W + (k + 1) * nx;
-#pragma unroll
-                for (int r = 0; r < (NXT ? NXT : 1); ++r) if (NXT) rx += Ad[r * nx + a] * w1[r];
-                if (!NXT) for (int r = 0; r < nx; ++r) rx += Ad[r * nx + a] * w1[r];
-            }
-            const double wsoft = W[L.rs + e];
-            const double te = L.soft ? (svs * xe + wsoft) / (cef + svs + ws) : 0.0;      // (hard box: no slack to eliminate)
-            W[L.rs + e] = te;                      // only this thread ever reads W[soft row e]
-            v = rx + wsoft - ws * te;
-        } else if (a < nx + nu && k < L.Nc) {
-            const int jj = a - nx, cu = k * nu + jj;
-            double ru = sve * xv - cc * qve + W[L.ri + cu] - W[L.rdu + nu + cu];
-            if (k == 0) ru += W[L.rdu + jj];
-            if (cu > 0) ru += W[L.rdu + nu + cu - 1];
-            const int s_end = (k == L.Nc - 1) ? L.Np : k + 1;
-            for (int s = k + 1; s <= s_end; ++s) {
-                const double *w1 = W + s * nx;
-#pragma unroll
-                for (int r = 0; r < (NXT ? NXT : 1); ++r) if (NXT) ru += Bd[r * nu + jj] * w1[r];
-                if (!NXT) for (int r = 0; r < nx; ++r) ru += Bd[r * nu + jj] * w1[r];
-            }
-            v = ru;
-        }
-        Tc[idx] = v;
-    };
-    {
-        // The iterate and the metric vectors live in global memory here (they do not fit LDS).  HOT_U elements per thread and
-        // pass: all their loads are issued first -- six dependent-latency round trips per element otherwise, one after
-        // the other -- through pointers the compiler knows to be global (a generic pointer means FLAT loads, which it may
-        // not reorder with the LDS stores of the element before).
-        cgdouble *Xg = (cgdouble *)X;
-        for (int i0 = tid; i0 < L.N * NB; i0 += HOT_U * NT) {
-            double sve[HOT_U], qve[HOT_U], ws[HOT_U], svs[HOT_U], xv[HOT_U], xe[HOT_U];
-#pragma unroll
-            for (int u = 0; u < HOT_U; ++u) {
-                const int idx = i0 + u * NT, k = idx / NB, a = idx % NB;
-                sve[u] = qve[u] = svs[u] = xv[u] = xe[u] = 0.0; ws[u] = 1.0;
-                if (idx < L.N * NB) {
-                    if (a < nx) { const int e = k * nx + a; sve[u] = sv[e]; qve[u] = qv[e]; ws[u] = om[L.rs + e]; xv[u] = Xg[e]; if (L.soft) { svs[u] = sv[L.oe + e]; xe[u] = Xg[L.oe + e]; } }
-                    else if (a < nx + nu && k < L.Nc) { const int cu = k * nu + a - nx; sve[u] = sv[L.ou + cu]; qve[u] = qv[L.n_x + cu]; xv[u] = Xg[L.ou + cu]; }
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < HOT_U; ++u) { const int idx = i0 + u * NT; if (idx < L.N * NB) element(idx, sve[u], qve[u], ws[u], svs[u], xv[u], xe[u]); }
-        }
-    }
-    __syncthreads();
-}
-
-// Steps (4)-(6): slack back-substitution, zt = A xt, relaxation, projection on [l,u], dual update, x update.
-template <int NB, int NXT, int NUT>
-__device__ __forceinline__ void hot_update(const Lay &L, const double *hot, const double *x0s, const double *du0,
-                                           cgdouble *om, cgdouble *sv, double cc, double alpha,
-                                           double *X, double *Z, double *Y, double *W, const double *Tc, bool keep_delta, gdouble *dxg, gdouble *dyg) {
-    const int tid = opaque_lane(threadIdx.x);        // (keeps the per-thread index arithmetic out of LICM's reach: hoisted, it spills)
-    const int nx = hx<NXT>(L), nu = hu<NUT>(L);
-    const double cef = cc * hot[L.oeps];
-    // eps_t = te - (omega_soft / kappa) x_t ; x update for the x and eps variables
-    gdouble *Xg = (gdouble *)X, *Zg = (gdouble *)Z, *Yg = (gdouble *)Y;      // (used on the global-memory path only)
-    // xo / eo: current values of the variable and of its slack; returns the new ones
-    auto x_new = [&](int e, int k, int i, double ws, double svs, double xo, double eo, double &xn, double &en) {
-        const double xt = Tc[k * NB + i];
-        const double et = L.soft ? W[L.rs + e] - (ws / (cef + svs + ws)) * xt : 0.0;
-        W[L.rs + e] = et;
-        xn = alpha * xt + (1.0 - alpha) * xo; en = alpha * et + (1.0 - alpha) * eo;
-        if (keep_delta) { dxg[e] = xn - xo; if (L.soft) dxg[L.oe + e] = en - eo; }
-    };
-    auto u_new = [&](int cu, int k, int jj, double uo) {
-        const double un = alpha * Tc[k * NB + nx + jj] + (1.0 - alpha) * uo;
-        if (keep_delta) dxg[L.ou + cu] = un - uo;
-        return un;
-    };
-    {                                                    // global-memory iterate: HOT_U elements per pass, loads first (see hot_rhs)
-        for (int e0 = tid; e0 < L.n_x; e0 += HOT_U * NT) {
-            double ws[HOT_U], svs[HOT_U], xo[HOT_U], eo[HOT_U];
-#pragma unroll
-            for (int u = 0; u < HOT_U; ++u) {
-                const int e = min(e0 + u * NT, L.n_x - 1);
-                ws[u] = om[L.rs + e]; xo[u] = Xg[e]; svs[u] = 0.0; eo[u] = 0.0;
-                if (L.soft) { svs[u] = sv[L.oe + e]; eo[u] = Xg[L.oe + e]; }
-            }
-#pragma unroll
-            for (int u = 0; u < HOT_U; ++u) {
-                const int e = e0 + u * NT;
-                if (e < L.n_x) { const int k = divx<NXT>(L, e), i = e - k * nx; double xn, en; x_new(e, k, i, ws[u], svs[u], xo[u], eo[u], xn, en); Xg[e] = xn; if (L.soft) Xg[L.oe + e] = en; }
-            }
-        }
-        for (int c0 = tid; c0 < L.n_u; c0 += HOT_U * NT) {
-            double uo[HOT_U];
-#pragma unroll
-            for (int u = 0; u < HOT_U; ++u) uo[u] = Xg[L.ou + min(c0 + u * NT, L.n_u - 1)];
-#pragma unroll
-            for (int u = 0; u < HOT_U; ++u) {
-                const int cu = c0 + u * NT;
-                if (cu < L.n_u) { const int k = divu<NUT>(L, cu), jj = cu - k * nu; Xg[L.ou + cu] = u_new(cu, k, jj, uo[u]); }
-            }
-        }
-    }
-    __syncthreads();
-    TICK(4)
-    const double *Ad = hot + L.oAd, *Bd = hot + L.oBd;
-    auto row_update = [&](int r, double w, double &zv, double &yv) {
-        double zt, lo, hi;
-        if (r < L.rs) {                                   // dynamics
-            const int k = divx<NXT>(L, r), i = r - k * nx;
-            zt = -Tc[k * NB + i];
-            if (k > 0) {
-                const double *xp = Tc + (k - 1) * NB;
-                const double *up = Tc + min(k - 1, L.Nc - 1) * NB + nx;
-#pragma unroll
-                for (int j = 0; j < (NXT ? NXT : 1); ++j) if (NXT) zt += Ad[i * nx + j] * xp[j];
-                if (!NXT) for (int j = 0; j < nx; ++j) zt += Ad[i * nx + j] * xp[j];
-#pragma unroll
-                for (int j = 0; j < (NUT ? NUT : 1); ++j) if (NUT) zt += Bd[i * nu + j] * up[j];
-                if (!NUT) for (int j = 0; j < nu; ++j) zt += Bd[i * nu + j] * up[j];
-            }
-            lo = hi = (r < nx) ? -x0s[r] : 0.0;
-        } else if (r < L.ri) {                            // soft state box
-            const int e = r - L.rs, k = divx<NXT>(L, e), i = e - k * nx;
-            zt = Tc[k * NB + i] + W[r];
-            lo = hot[L.oxmin + i]; hi = hot[L.oxmax + i];
-        } else if (r < L.rdu) {                           // input box
-            const int cu = r - L.ri, k = divu<NUT>(L, cu), jj = cu - k * nu;
-            zt = Tc[k * NB + nx + jj];
-            lo = hot[L.oumin + jj]; hi = hot[L.oumax + jj];
-        } else {                                          // Delta-u rows
-            const int rr = r - L.rdu, kk = divu<NUT>(L, rr), jj = rr - kk * nu;
-            lo = hot[L.oDumin + jj]; hi = hot[L.oDumax + jj];
-            if (rr < nu) { zt = Tc[nx + rr]; lo = du0[jj]; hi = du0[nu + jj]; }
-            else {
-                const int cu = rr - nu, k = kk - 1;       // cu = k*nu + jj
-                zt = -Tc[k * NB + nx + jj];
-                if (cu + 1 < L.n_u) zt += (jj + 1 < nu) ? Tc[k * NB + nx + jj + 1] : Tc[(k + 1) * NB + nx];
-            }
-        }
-        lo = lo < -QP_INFTY ? -QP_INFTY : lo;
-        hi = hi > QP_INFTY ? QP_INFTY : hi;
-        const double zr = alpha * zt + (1.0 - alpha) * zv;
-        const double zn = fmin(fmax(zr + cc * yv / w, lo), hi);
-        const double dy = (w / cc) * (zr - zn);
-        yv += dy; zv = zn;
-        if (keep_delta) dyg[r] = dy;
-    };
-    {
-        for (int r0 = tid; r0 < L.m; r0 += HOT_U * NT) {
-            double zv[HOT_U], yv[HOT_U], w[HOT_U];
-#pragma unroll
-            for (int u = 0; u < HOT_U; ++u) { const int r = min(r0 + u * NT, L.m - 1); zv[u] = Zg[r]; yv[u] = Yg[r]; w[u] = om[r]; }
-#pragma unroll
-            for (int u = 0; u < HOT_U; ++u) {
-                const int r = r0 + u * NT;
-                if (r < L.m) { row_update(r, w[u], zv[u], yv[u]); Zg[r] = zv[u]; Yg[r] = yv[u]; W[r] = w[u] * zv[u] - cc * yv[u]; }
-            }
-        }
-    }
-    __syncthreads();
-}
-
 // ------------------------------------------------------------------------------------------------
-// The same parallel phases for the LDS-resident iterate (small problems), with an OWNER map instead of flat row / variable
-// loops: thread t owns, for j = 0, 1, the state element e = t + NT j = (stage k, component a) -- the variable x_k[a], its slack,
+// Steps (1)-(2) and (4)-(6) of the ADMM iteration -- the parallel phases around the KKT solve:
+//   W = omega z - c y                       (rows; left behind by the previous update)
+//   rhs = s x - c q + A' W                  (variables), with the slack elimination fused in:
+//   te = rhs_eps / kappa -> W[box row]      Tc[k][a] = rhs_x - omega_box te  |  rhs_u  |  0 (padding)
+//   [solve]  slack back-substitution, zt = A xt, relaxation, projection on [l,u], dual update, x update.
+// For the LDS-resident iterate (small problems) with an OWNER map instead of flat row / variable loops: thread t owns, for j = 0, 1, the state element e = t + NT j = (stage k, component a) -- the variable x_k[a], its slack,
 // the dynamics row e and the state-box row rs + e, which all share that index -- and the input element cu = t = (k, jj) -- the
 // variable u_k[jj], its box row ri + cu, the Delta-u row rdu + nu + cu and, for cu < nu, the first-step row rdu + cu.
 //   * every pass runs ONE kind of item (no divergent tree over four row types and two variable kinds per wave: the flat
@@ -584,7 +402,7 @@ __device__ __forceinline__ void own_rows_w(const Lay &L, const OwnRegs &h, doubl
     }
     __syncthreads();
 }
-// rhs = s x - c q + A' W with the slack eliminated (see hot_rhs), into Tc
+// rhs = s x - c q + A' W with the slack eliminated, into Tc
 template <int NB, int NXT, int NUT>
 __device__ __forceinline__ void own_rhs(const Lay &L, const double *hot, const OwnRegs &h, double cc, const double *X, double *W, double *Tc) {
     const int tid = opaque_lane(threadIdx.x);        // (keeps the per-thread index arithmetic out of LICM's reach: hoisted, it spills)
@@ -625,7 +443,7 @@ __device__ __forceinline__ void own_rhs(const Lay &L, const double *hot, const O
     }
     __syncthreads();
 }
-// slack back-substitution, zt = A xt, relaxation, projection on [l,u], dual update, x update (see hot_update)
+// slack back-substitution, zt = A xt, relaxation, projection on [l,u], dual update, x update
 template <int NB, int NXT, int NUT>
 __device__ __forceinline__ void own_update(const Lay &L, const double *hot, const double *x0s, const double *du0, const OwnRegs &h, double cc, double alpha,
                                            double *X, double *Z, double *Y, double *W, const double *Tc, bool keep_delta, gdouble *dxg, gdouble *dyg) {
@@ -685,6 +503,168 @@ __device__ __forceinline__ void own_update(const Lay &L, const double *hot, cons
     __syncthreads();
 }
 
+// ------------------------------------------------------------------------------------------------
+// The owner map for problems whose iterate does not fit LDS (x, z, y, omega, s in global memory): the same items, as many
+// passes as it takes (state element e = t + NT j, input element cu = t + NT j), HOT_U items per thread at a time with ALL their
+// global loads issued first -- through pointers the compiler knows to be global (a generic pointer means FLAT loads, which it
+// may not reorder with the LDS stores of the item before) -- so a pass costs one memory round trip, not one per operand.
+// Against the flat loops this replaces (one over the padded variables, one over the variables again, one over the m rows with
+// a four-way branch per row): a third of the round trips and no divergent tree.
+// ------------------------------------------------------------------------------------------------
+template <int NB> struct GownCfg { static constexpr int U = NB == 32 ? HOT_U : 2; };      // items per thread in flight (128 VGPRs at 16 x 16 stages: ten operands per input item)
+template <int NB>
+__device__ __forceinline__ void gown_rows_w(const Lay &L, cgdouble *om, double cc, const double *Z, const double *Y, double *W, double *Tc) {
+    const int tid = opaque_lane(threadIdx.x);
+    cgdouble *Zg = (cgdouble *)Z, *Yg = (cgdouble *)Y;
+    for (int i = tid; i < L.N * NB; i += NT) Tc[i] = 0.0;      // (padding and absent inputs stay zero through the solves: the factor has zero rows there)
+#pragma unroll HOT_U
+    for (int r = tid; r < L.m; r += NT) W[r] = om[r] * Zg[r] - cc * Yg[r];
+    __syncthreads();
+}
+template <int NB, int NXT, int NUT>
+__device__ __forceinline__ void gown_rhs(const Lay &L, const double *hot, cgdouble *om, cgdouble *sv, cgdouble *qv, double cc, const double *X, double *W, double *Tc) {
+    constexpr int GU = GownCfg<NB>::U;
+    const int tid = opaque_lane(threadIdx.x);
+    const int nx = hx<NXT>(L), nu = hu<NUT>(L);
+    const double *Ad = hot + L.oAd, *Bd = hot + L.oBd;
+    const double cef = cc * hot[L.oeps];
+    cgdouble *Xg = (cgdouble *)X;
+    for (int e0 = tid; e0 < L.n_x; e0 += GU * NT) {
+        double svx[GU], qx[GU], oms[GU], xv[GU], sve[GU], xe[GU];
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int e = min(e0 + u * NT, L.n_x - 1);
+            svx[u] = sv[e]; qx[u] = qv[e]; oms[u] = om[L.rs + e]; xv[u] = Xg[e]; sve[u] = 0.0; xe[u] = 0.0;
+            if (L.soft) { sve[u] = sv[L.oe + e]; xe[u] = Xg[L.oe + e]; }
+        }
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int e = e0 + u * NT;
+            if (e < L.n_x) {
+                const int k = divx<NXT>(L, e), a = e - k * nx;
+                double rx = svx[u] * xv[u] - cc * qx[u] - W[e];
+                if (k < L.Np) {
+                    const double *w1 = W + (k + 1) * nx;
+#pragma unroll
+                    for (int r = 0; r < (NXT ? NXT : 1); ++r) if (NXT) rx += Ad[r * nx + a] * w1[r];
+                    if (!NXT) for (int r = 0; r < nx; ++r) rx += Ad[r * nx + a] * w1[r];
+                }
+                const double wsoft = W[L.rs + e];
+                const double te = L.soft ? (sve[u] * xe[u] + wsoft) / (cef + sve[u] + oms[u]) : 0.0;      // (hard box: no slack to eliminate)
+                W[L.rs + e] = te;                      // read back by this thread in gown_update
+                Tc[k * NB + a] = rx + wsoft - oms[u] * te;
+            }
+        }
+    }
+    for (int c0 = tid; c0 < L.n_u; c0 += GU * NT) {
+        double svu[GU], qu[GU], uv[GU];
+#pragma unroll
+        for (int u = 0; u < GU; ++u) { const int cu = min(c0 + u * NT, L.n_u - 1); svu[u] = sv[L.ou + cu]; qu[u] = qv[L.n_x + cu]; uv[u] = Xg[L.ou + cu]; }
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int cu = c0 + u * NT;
+            if (cu < L.n_u) {
+                const int k = divu<NUT>(L, cu), jj = cu - k * nu;
+                double ru = svu[u] * uv[u] - cc * qu[u] + W[L.ri + cu] - W[L.rdu + nu + cu];
+                if (k == 0) ru += W[L.rdu + jj];
+                if (cu > 0) ru += W[L.rdu + nu + cu - 1];
+                const int s_end = (k == L.Nc - 1) ? L.Np : k + 1;
+                for (int s = k + 1; s <= s_end; ++s) {
+                    const double *w1 = W + s * nx;
+#pragma unroll
+                    for (int r = 0; r < (NXT ? NXT : 1); ++r) if (NXT) ru += Bd[r * nu + jj] * w1[r];
+                    if (!NXT) for (int r = 0; r < nx; ++r) ru += Bd[r * nu + jj] * w1[r];
+                }
+                Tc[k * NB + nx + jj] = ru;
+            }
+        }
+    }
+    __syncthreads();
+}
+template <int NB, int NXT, int NUT>
+__device__ __forceinline__ void gown_update(const Lay &L, const double *hot, const double *x0s, const double *du0, cgdouble *om, cgdouble *sv, double cc, double alpha,
+                                            double *X, double *Z, double *Y, double *W, const double *Tc, bool keep_delta, gdouble *dxg, gdouble *dyg) {
+    constexpr int GU = GownCfg<NB>::U;
+    const int tid = opaque_lane(threadIdx.x);
+    const int nx = hx<NXT>(L), nu = hu<NUT>(L);
+    const double *Ad = hot + L.oAd, *Bd = hot + L.oBd;
+    const double cef = cc * hot[L.oeps], cinv = 1.0 / cc, beta = 1.0 - alpha;
+    gdouble *Xg = (gdouble *)X, *Zg = (gdouble *)Z, *Yg = (gdouble *)Y;
+    // one row: relaxation, projection, dual step; z, y come in as loaded and leave through global stores
+    auto row = [&](int r, double w, double zt, double lo, double hi, double zv, double yv) {
+        lo = lo < -QP_INFTY ? -QP_INFTY : lo;
+        hi = hi > QP_INFTY ? QP_INFTY : hi;
+        const double zr = alpha * zt + beta * zv;
+        const double zn = fmin(fmax(zr + cc * yv / w, lo), hi);
+        const double dy = (w * cinv) * (zr - zn), yn = yv + dy;
+        Zg[r] = zn; Yg[r] = yn; W[r] = w * zn - cc * yn;
+        if (keep_delta) dyg[r] = dy;
+    };
+    for (int e0 = tid; e0 < L.n_x; e0 += GU * NT) {
+        double oms[GU], omd[GU], sve[GU], xo[GU], eo[GU], zd[GU], yd[GU], zs[GU], ys[GU];
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int e = min(e0 + u * NT, L.n_x - 1);
+            oms[u] = om[L.rs + e]; omd[u] = om[e]; xo[u] = Xg[e]; zd[u] = Zg[e]; yd[u] = Yg[e]; zs[u] = Zg[L.rs + e]; ys[u] = Yg[L.rs + e];
+            sve[u] = 0.0; eo[u] = 0.0;
+            if (L.soft) { sve[u] = sv[L.oe + e]; eo[u] = Xg[L.oe + e]; }
+        }
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int e = e0 + u * NT;
+            if (e < L.n_x) {
+                const int k = divx<NXT>(L, e), a = e - k * nx;
+                const double xt = Tc[k * NB + a];
+                const double et = L.soft ? W[L.rs + e] - (oms[u] / (cef + sve[u] + oms[u])) * xt : 0.0;
+                const double xn = alpha * xt + beta * xo[u];
+                Xg[e] = xn;
+                if (keep_delta) dxg[e] = xn - xo[u];
+                if (L.soft) { const double en = alpha * et + beta * eo[u]; Xg[L.oe + e] = en; if (keep_delta) dxg[L.oe + e] = en - eo[u]; }
+                double zt = -xt;                       // dynamics row e
+                if (k > 0) {
+                    const double *xp = Tc + (k - 1) * NB;
+                    const double *up = Tc + min(k - 1, L.Nc - 1) * NB + nx;
+#pragma unroll
+                    for (int i = 0; i < (NXT ? NXT : 1); ++i) if (NXT) zt += Ad[a * nx + i] * xp[i];
+                    if (!NXT) for (int i = 0; i < nx; ++i) zt += Ad[a * nx + i] * xp[i];
+#pragma unroll
+                    for (int i = 0; i < (NUT ? NUT : 1); ++i) if (NUT) zt += Bd[a * nu + i] * up[i];
+                    if (!NUT) for (int i = 0; i < nu; ++i) zt += Bd[a * nu + i] * up[i];
+                }
+                const double b0 = k == 0 ? -x0s[a] : 0.0;
+                row(e, omd[u], zt, b0, b0, zd[u], yd[u]);
+                row(L.rs + e, oms[u], xt + et, hot[L.oxmin + a], hot[L.oxmax + a], zs[u], ys[u]);      // state-box row (soft: x + eps)
+            }
+        }
+    }
+    for (int c0 = tid; c0 < L.n_u; c0 += GU * NT) {
+        double uo[GU], omi[GU], omu[GU], om0[GU], zi[GU], yi[GU], zu[GU], yu[GU], z0[GU], y0[GU];
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int cu = min(c0 + u * NT, L.n_u - 1), r0 = L.rdu + min(cu, nu - 1);
+            uo[u] = Xg[L.ou + cu]; omi[u] = om[L.ri + cu]; omu[u] = om[L.rdu + nu + cu]; zi[u] = Zg[L.ri + cu]; yi[u] = Yg[L.ri + cu];
+            zu[u] = Zg[L.rdu + nu + cu]; yu[u] = Yg[L.rdu + nu + cu]; om0[u] = om[r0]; z0[u] = Zg[r0]; y0[u] = Yg[r0];
+        }
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int cu = c0 + u * NT;
+            if (cu < L.n_u) {
+                const int k = divu<NUT>(L, cu), jj = cu - k * nu;
+                const double ut = Tc[k * NB + nx + jj];
+                const double un = alpha * ut + beta * uo[u];
+                Xg[L.ou + cu] = un;
+                if (keep_delta) dxg[L.ou + cu] = un - uo[u];
+                row(L.ri + cu, omi[u], ut, hot[L.oumin + jj], hot[L.oumax + jj], zi[u], yi[u]);
+                double zt = -ut;                       // Delta-u row nu + cu: next flattened input minus this one (mpc.py:570)
+                if (cu + 1 < L.n_u) zt += (jj + 1 < nu) ? Tc[k * NB + nx + jj + 1] : Tc[(k + 1) * NB + nx];
+                row(L.rdu + nu + cu, omu[u], zt, hot[L.oDumin + jj], hot[L.oDumax + jj], zu[u], yu[u]);
+                if (cu < nu) row(L.rdu + cu, om0[u], ut, du0[cu], du0[nu + cu], z0[u], y0[u]);      // first step: u_0 - u_{-1}
+            }
+        }
+    }
+    __syncthreads();
+}
+
 // `iters` ADMM iterations of this workgroup's instance.  Expects the hot model prefix and the step data in LDS
 // (load_common) and, with LDSSTATE, X/Z/Y carved behind the common area.
 template <int NB, bool LDSSTATE, int NXT, int NUT, bool BORDER>
@@ -705,7 +685,7 @@ __device__ __forceinline__ void admm_body(const Lay &L, const HotPtrs &P, Smem &
     if (LDSSTATE) own_load<NB, NXT, NUT>(L, gom, gsv, gqv, cc, hr);
 #ifndef MPCQP_ABL_NOPAR
     if (LDSSTATE) own_rows_w<NB>(L, hr, cc, Z, Y, W, Tc);
-    else hot_rows_w(L, gom, cc, Z, Y, W);
+    else gown_rows_w<NB>(L, gom, cc, Z, Y, W, Tc);
 #endif
     TICK_RESET
     for (int it = 1; it <= iters; ++it) {
@@ -713,7 +693,7 @@ __device__ __forceinline__ void admm_body(const Lay &L, const HotPtrs &P, Smem &
         TICK_START
 #ifndef MPCQP_ABL_NOPAR
         if (LDSSTATE) own_rhs<NB, NXT, NUT>(L, S.hot, hr, cc, X, W, Tc);
-        else hot_rhs<NB, NXT, NUT>(L, S.hot, gom, gsv, gqv, cc, X, Z, Y, W, Tc);
+        else gown_rhs<NB, NXT, NUT>(L, S.hot, gom, gsv, gqv, cc, X, W, Tc);
 #endif
         TICK(0)
         BorderPtrs bp; bp.red = S.red;
@@ -726,7 +706,7 @@ __device__ __forceinline__ void admm_body(const Lay &L, const HotPtrs &P, Smem &
         if (BORDER) border_post(L, NB, Tc, S.tv);
 #ifndef MPCQP_ABL_NOPAR
         if (LDSSTATE) own_update<NB, NXT, NUT>(L, S.hot, S.x0s, S.du0, hr, cc, alpha, X, Z, Y, W, Tc, keep_delta, dxg, dyg);
-        else hot_update<NB, NXT, NUT>(L, S.hot, S.x0s, S.du0, gom, gsv, cc, alpha, X, Z, Y, W, Tc, keep_delta, dxg, dyg);
+        else gown_update<NB, NXT, NUT>(L, S.hot, S.x0s, S.du0, gom, gsv, cc, alpha, X, Z, Y, W, Tc, keep_delta, dxg, dyg);
 #endif
         TICK(5)
     }
