@@ -106,6 +106,7 @@ def main():
     ap.add_argument('--chunk', type=int, default=None, help='device loop: steps per kernel launch (default: the timed steps in equal launches of at most 25)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-path', action='store_true', help='skip the secondary measurements (other path, parity setting)')
+    ap.add_argument('--no-refactor-timing', action='store_true', help='skip the timing of the factorization alone (profiling runs: its launches carry the solve kernel\'s name)')
     ap.add_argument('--path', default='device_loop', choices=['stepwise', 'device_loop'],
                     help='stepwise: update()/solve()/output() per step from the host (the reference call pattern); '
                          'device_loop: the same K steps inside mpcqp_mpc_loop (SURVEY 8f-1)')
@@ -292,13 +293,15 @@ def main():
         prob.update_settings(eps_abs=args.eps, eps_rel=args.eps)
     # what one rho update costs: the block factorization of every instance, timed alone (mpcqp_refactor rewrites the factor
     # that is already in place); the steady-state loop above needs none, the cold solve a few per instance
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    prob.refactor(); torch.cuda.synchronize()
-    ev0.record()
-    for _ in range(3):
-        prob.refactor()
-    ev1.record(); torch.cuda.synchronize()
-    refactor_ms = ev0.elapsed_time(ev1) / 3
+    refactor_ms = None
+    if not args.no_refactor_timing:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        prob.refactor(); torch.cuda.synchronize()
+        ev0.record()
+        for _ in range(3):
+            prob.refactor()
+        ev1.record(); torch.cuda.synchronize()
+        refactor_ms = ev0.elapsed_time(ev1) / 3
     kname = prob.kernel_name(loop=args.path == 'device_loop')
     lds_state = ',true,' in kname.split('<')[1][:9]            # second template argument: iterate resident in LDS
 
@@ -327,7 +330,7 @@ def main():
             'mean_admm_iters': iters / max(1, solves),
             'solved_fraction_last_step': n_solved / B,
             'refactorizations_per_solve': refacts / max(1, solves),
-            'refactorization': {'per_solve_timed_region': refacts / max(1, solves), 'ms_per_batch': refactor_ms, 'us_per_instance_amortised': 1e3 * refactor_ms / B,
+            'refactorization': {'per_solve_timed_region': refacts / max(1, solves), 'ms_per_batch': refactor_ms, 'us_per_instance_amortised': (1e3 * refactor_ms / B) if refactor_ms else None,
                                 'note': 'block LDL factorization of all %d instances in one launch (one rho update each); 0 per solve in the warm '
                                         'receding-horizon loop, a few per instance during the cold solve' % B},
             'roofline': {'bound': 'hbm', 'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',

@@ -1,5 +1,6 @@
 #!/bin/bash
 # usage (on the GPU box, from the repo root): scripts/profile_round.sh <tag> [workload] [extra bench flags]
+# (give runs with extra flags their own tag, e.g. `profile_round.sh r2b4096 cfg3 --batch 4096`: the output names carry tag and workload only)
 # For both bench paths of <workload> (cfg3 | cfg5): rocprofv3 kernel stats + the PMC passes (FETCH_SIZE, WRITE_SIZE and
 # TCC_HIT_sum/TCC_MISS_sum each in a run of its own, with --kernel-trace only, as MI355X_MICROARCH.md prescribes) of the
 # bench command the driver uses.  Summaries land in gpurun_out/<tag>_<workload>_<path>_*; copy the ones to be judged into
@@ -9,7 +10,7 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 for path in device_loop stepwise; do
   T=${tag}_${wl}_${path}
-  CMD="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-path --workload $wl --path $path $*"
+  CMD="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-path --no-refactor-timing --workload $wl --path $path $*"
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_stats -o ks -- $CMD > $O/${T}_bench_under_rocprof.json 2> $O/${T}_stats.log
   cp $O/${T}_stats/ks_kernel_stats.csv $O/${T}_kernel_stats.csv
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${T}_pmc_f -o f -- $CMD > $O/${T}_bench_under_pmc.json 2> $O/${T}_pmc_f.log
