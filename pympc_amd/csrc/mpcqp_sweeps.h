@@ -208,7 +208,7 @@ template <int NB> struct SoCfg {
     static constexpr int NBLK = NB / 16, NF = NBLK * NBLK;
     static constexpr int NS = NB == 16 ? 1 : 3;               // streamed d4 per lane and stage: sym(S) | sym(S00), sym(S11), S01
 #ifndef MPCQP_SO_DEPTH16
-#define MPCQP_SO_DEPTH16 4
+#define MPCQP_SO_DEPTH16 3
 #endif
     static constexpr int DEPTH = NB == 32 ? 2 : MPCQP_SO_DEPTH16;      // stages in flight (28 VGPRs each at NB = 32: the register file holds two)
 };

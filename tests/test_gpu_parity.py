@@ -420,11 +420,13 @@ def test_device_loop_output_feedback_matches_reference_style_loop():
 
 
 @pytest.mark.parametrize('dims', [(1, 1, 2, 2), (2, 1, 3, 1), (3, 2, 5, 5), (13, 3, 6, 6), (12, 5, 4, 2), (24, 8, 4, 4), (20, 12, 3, 3),
-                                  (4, 1, 150, 75), (2, 2, 64, 64)])
+                                  (4, 1, 150, 75), (2, 2, 64, 64), (3, 12, 20, 20), (3, 12, 22, 22)])
 def test_boundary_dimensions_match_oracle(dims):
     """Shapes at the edges of the device code paths: smallest problem (nx=nu=1, Np=2), nx+nu = 16/17 (block size switch),
     nx+nu = 32 (largest supported), Nc = 1, long horizons with Nc < Np (the reference's Kalman example uses Np=150, Nc=75),
-    LDS-resident and global-memory iterate.  u* against the oracle at tight tolerance, plus one warm step."""
+    LDS-resident and global-memory iterate, and the two sides of the owner map's limit (one input element per thread:
+    (3,12,20) has 252 input elements and rows, (3,12,22) 276 and falls back to the global-memory passes although it would fit
+    LDS).  u* against the oracle at tight tolerance, plus one warm step."""
     from pympc_amd import fixtures
     nx, nu, Np, Nc = dims
     kw = dict(fixtures.random_lti(900 + nx * 7 + nu, nx=nx, nu=nu, Np=Np, xbox=3.0))
