@@ -671,7 +671,7 @@ extern "C" int mpcqp_get_stats(mpcqp_handle *h, uint64_t *out4, int reset) {
     { uint64_t t[4]; hipMemcpy(t, h->P.stats + 4, sizeof(t), hipMemcpyDeviceToHost); fprintf(stderr, "phase wall-clock ticks: begin %llu admm %llu check %llu\n", (unsigned long long)t[0], (unsigned long long)t[1], (unsigned long long)t[2]);
       unsigned long long g[16]; hipMemcpyFromSymbol(g, HIP_SYMBOL(g_ticks), sizeof(g)); unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_ticks), z, sizeof(z));
       { double tot = 0; for (int i = 0; i < 6; ++i) tot += (double)g[i]; if (tot <= 0) tot = 1;
-        fprintf(stderr, "iteration cycles (thread 0, summed over workgroups): rhs %.1f%% fwd %.1f%% mid/sinv %.1f%% bwd %.1f%% x-update %.1f%% rows %.1f%%  total %.3g\n",
+        fprintf(stderr, "iteration cycles (thread 0, summed over workgroups): rhs %.1f%% fwd %.1f%% middle %.1f%% bwd %.1f%% (unused) %.1f%% update %.1f%%  total %.3g\n",
                 100 * g[0] / tot, 100 * g[1] / tot, 100 * g[2] / tot, 100 * g[3] / tot, 100 * g[4] / tot, 100 * g[5] / tot, tot); } }
 #endif
     if (reset) HIPCHK(hipMemsetAsync(h->P.stats, 0, 8 * sizeof(uint64_t), h->stream));
@@ -710,10 +710,10 @@ extern "C" int mpcqp_get_dims(mpcqp_handle *h, int *n, int *m, int64_t *factor_d
 
 // Bytes one instance moves between the memory system (HBM / Infinity Cache / L2) and its compute unit BY DESIGN of these
 // kernels -- the roofline numerator bench.py uses ("Roofline accounting"):
-//   per ADMM iteration : the factor stream.  Forward blocks of N-1 stages are read in the forward elimination and again
-//                        (transposed apply) in the back substitution; S^-1 of all N stages once (packed symmetric for
-//                        16 x 16 stages).  Problems whose iterate does not fit LDS also read and write x, z, y and read
-//                        omega, s, q every iteration; Nc < Np adds the two border matrices.
+//   per ADMM iteration : the factor stream (FactorFmt, mpcqp_factor.h).  16 x 16 stages: forward matrices of N-1 stages, packed
+//                        S^-1 of N stages, N-1 stage tables and [G | G'], once each; 32 x 32 stages (S^-1-only): packed S^-1
+//                        twice, one table per sweep, [G | G'] by each sweeping wave.  Problems whose iterate does not fit
+//                        LDS also read and write x, z, y and read omega, s, q every iteration; Nc < Np adds the two border matrices.
 //   per round (check)  : residual evaluation inputs (weights, D, E, omega, s, last increments), the round's load/store of
 //                        the LDS-resident iterate and of the per-thread register copies of omega, s, q.
 //   per solve          : the begin phase (step data, E, constraint types, q rebuild) and the solution write-out.

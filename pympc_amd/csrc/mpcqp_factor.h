@@ -18,8 +18,7 @@
 // 16-lane row by 4, 8, 12 lanes: DPP row_ror.  So a stage vector is ONE double per lane, stage outputs feed the next
 // stage through three DPP rotations and no LDS traffic, and a lane's four fragment values (one per step) are
 // contiguous: fragment element (r, c) -> lane 16(c&3) + 4(r>>2) + (r&3), step ((c>>2) - (r>>2)) & 3.
-// Per stage k:  [ forward matrix | S_k^-1 ]   (2 NB^2 doubles, 32 B per lane per block); the back substitution
-// applies the forward matrix of the neighbouring stage TRANSPOSED from the same fragments (frag_matvec_T).
+// (Stage record formats: FactorFmt below.)
 // ------------------------------------------------------------------------------------------------
 // Optimisation barriers: values the compiler would otherwise hoist out of the ADMM iteration loop (loop-invariant
 // loads and address arithmetic of the sweeps) and keep live across ALL phases, pushing the kernel into scratch spills.

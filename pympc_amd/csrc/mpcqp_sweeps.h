@@ -1,10 +1,11 @@
 // mpcqp_sweeps.h -- part of libmpcqp_hip (included by mpcqp.hip, one translation unit).
-// Triangular solves with the factor: MFMA stage sweeps, transposed VALU apply, pipelined S^-1 phase.
+// The solve with the factor: forward elimination from the forward matrices (chain_sweep), the sweeps that apply the
+// off-diagonal blocks matrix-free (so_sweep), the twisted solve built from them (kkt_core).
 #pragma once
 
 // The sweeps work on Tc: the x,u part of the right-hand side / solution in STAGE-MAJOR PADDED layout,
 // Tc[k*NB + a] = element a of stage k (a < nx: x_k[a]; nx <= a < nb: u_k[a-nx]; everything else is padding
-// and stays exactly zero because the factor is the identity there).  In the operand layout lane 16k + 4b + j
+// and stays exactly zero because the stored S^-1 has zero rows there).  In the operand layout lane 16k + 4b + j
 // holds element 4b + k (+16 per block): one 8-byte LDS read per lane and block.
 template <int NB>
 __device__ __forceinline__ void vec_load(const double *tb, int k, double *v) {
@@ -181,8 +182,7 @@ __device__ __forceinline__ unsigned long long *tick_slots() { __shared__ unsigne
 #endif
 
 // What the linear-system core needs to know about one instance.
-// F: the stages; G: the [G | G'] header of the formats that apply off-diagonal blocks matrix-free (in front of the stages in
-// the S^-1-only format, behind them in the hybrid one).
+// F: the stages; G: the constant fragments [G | G'] (in front of the stages in the S^-1-only format, behind them otherwise).
 struct CoreArgs { int N, fstage, nx, nu, NcT, rdu; const double *F; const double *G; const double *om; };
 __device__ __forceinline__ CoreArgs core_args(const Lay &L, const double *F, const double *om) {
     CoreArgs a; a.N = L.N; a.fstage = L.fstage; a.nx = L.nx; a.nu = L.nu; a.NcT = L.NcT; a.rdu = L.rdu; a.om = om;
@@ -210,7 +210,10 @@ template <int NB> struct SoCfg {
 #ifndef MPCQP_SO_DEPTH16
 #define MPCQP_SO_DEPTH16 3
 #endif
-    static constexpr int DEPTH = NB == 32 ? 2 : MPCQP_SO_DEPTH16;      // stages in flight (28 VGPRs each at NB = 32: the register file holds two)
+#ifndef MPCQP_SO_DEPTH32
+#define MPCQP_SO_DEPTH32 2
+#endif
+    static constexpr int DEPTH = NB == 32 ? MPCQP_SO_DEPTH32 : MPCQP_SO_DEPTH16;      // stages in flight (12 VGPRs each at NB = 16, 40 at NB = 32)
 };
 __device__ __forceinline__ d4 sym_window(const double *Fm, int lane) {
     const int R = (lane >> 2) & 3;
@@ -291,8 +294,8 @@ __device__ __forceinline__ void so_offdiag(const CoreArgs &a, const SoLane<NB> &
 template <int NB> struct SoStep { d4 S[SoCfg<NB>::NS]; double sc[NB / 16]; double wd; };
 template <int NB>
 __device__ __forceinline__ void so_step_load(const CoreArgs &a, const SoLane<NB> &q, int lane, int k, int nbr, SoStep<NB> &st) {
-    // Loads only -- nothing here may USE a loaded value (so_step_fix does, at consumption time): inside the scheduling
-    // fences of half_sweep_so a use would sit right behind its load and wait for it.
+    // (middle stage of the S^-1-only format: omega straight from the metric vector.)  Loads only -- so_step_fix applies the
+    // lane masks at consumption time.
     const int hi = max(k, nbr), lo = min(k, nbr);
     cgdouble *om = (cgdouble *)a.om;
 #pragma unroll
@@ -308,7 +311,7 @@ __device__ __forceinline__ void so_step_fix(const CoreArgs &a, const SoLane<NB> 
 }
 // ------------------------------------------------------------------------------------------------
 // One half-chain of the formats that apply the off-diagonal blocks matrix-free, stages first+dir*i for i = ibegin .. nsteps:
-//     SOLVE (forward sweep of the S^-1-only format, back substitution of the hybrid one):  v_k = S_k^-1 ( own_k - K_{k,nbr} v_nbr )
+//     SOLVE (forward sweep of the S^-1-only format, back substitution of the forward-matrix one):  v_k = S_k^-1 ( own_k - K_{k,nbr} v_nbr )
 //     !SOLVE (back substitution of the S^-1-only format):                                   v_k = own_k - S_k^-1 K_{k,nbr} v_nbr
 // own_k is what Tc holds for the stage, v_k replaces it; UP: the neighbour is the stage above (k-1, block from G), else below (G').
 //     -K_{k,k-1} v = sc_k . (G v)   + cw_k v[nx+nu-1]          -K_{k,k+1} v = G' (sc_k . v) + cw_k v[nx]
@@ -511,11 +514,11 @@ __device__ __forceinline__ void kkt_core_so(const CoreArgs &a, double *Tc) {
     TICK(3)
 }
 
-// Hybrid format: forward elimination from the forward matrices (chain_sweep), the middle stage, then back substitution
+// Forward-matrix format: forward elimination from the forward matrices (chain_sweep), the middle stage, then back substitution
 //     x_k = S_k^-1 ( yh_k - K_{k,nbr} x_nbr )
 // outwards from the middle with the off-diagonal blocks applied matrix-free -- S^-1 is read once, the forward matrices once.
 template <int NB>
-__device__ __forceinline__ void kkt_core_hybrid(const CoreArgs &a, double *Tc) {
+__device__ __forceinline__ void kkt_core_fwd(const CoreArgs &a, double *Tc) {
     constexpr int NBLK = NB / 16, NF = SoCfg<NB>::NF;
     const int N = a.N, fstage = a.fstage, mid = N / 2, wv = logical_wave(), lane = opaque_lane(threadIdx.x & 63);
     const double *F = a.F;
@@ -556,7 +559,7 @@ template <int NB>
 __device__ __forceinline__ void kkt_core(const CoreArgs &a, double *Tc) {
 #ifndef MPCQP_ABL_NOCHAIN
     if constexpr (FactorFmt<NB>::SONLY) kkt_core_so<NB>(a, Tc);
-    else kkt_core_hybrid<NB>(a, Tc);                 // (each of them ends with a barrier)
+    else kkt_core_fwd<NB>(a, Tc);                 // (each of them ends with a barrier)
 #else
     __syncthreads();
 #endif
