@@ -385,20 +385,28 @@ __device__ __forceinline__ void own_load(const Lay &L, cgdouble *om, cgdouble *s
     h.sv_u = v ? sv[L.ou + cu] : 0.0; h.cq_u = v ? cc * qv[L.n_x + cu] : 0.0;
     h.om_i = v ? om[L.ri + cu] : 1.0; h.om_du = v ? om[L.rdu + L.nu + cu] : 1.0; h.om_d0 = cu < L.nu ? om[L.rdu + cu] : 1.0;
 }
+// Inside a round the dual variable is carried as ys = c y / omega: the projection  z+ = clamp(zr + c y / omega)  and the dual step
+// y+ = y + (omega / c)(zr - z+)  become  z+ = clamp(zr + ys),  ys+ = ys + (zr - z+),  W = omega (z+ - ys+)  -- no division per row
+// and iteration.  Rows are converted when a round starts (own_rows_w / gown_rows_w) and back when it ends (own_finish /
+// gown_finish); every other phase sees y itself.
+__device__ __forceinline__ void own_scale_row(double w, double cc, const double *Z, double *Y, double *W, int r) {
+    const double ys = cc * Y[r] / w;
+    Y[r] = ys; W[r] = w * (Z[r] - ys);
+}
 // W = omega z - c y of the thread's rows (first iteration of a round; afterwards own_update leaves it behind); zero padding of Tc
 template <int NB>
-__device__ __forceinline__ void own_rows_w(const Lay &L, const OwnRegs &h, double cc, const double *Z, const double *Y, double *W, double *Tc) {
+__device__ __forceinline__ void own_rows_w(const Lay &L, const OwnRegs &h, double cc, const double *Z, double *Y, double *W, double *Tc) {
     const int tid = opaque_lane(threadIdx.x);
     for (int i = tid; i < L.N * NB; i += NT) Tc[i] = 0.0;      // (padding and absent inputs stay zero through the solves: the factor has zero rows there)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int e = tid + NT * j;
-        if (e < L.n_x) { W[e] = h.om_d[j] * Z[e] - cc * Y[e]; W[L.rs + e] = h.om_s[j] * Z[L.rs + e] - cc * Y[L.rs + e]; }
+        if (e < L.n_x) { own_scale_row(h.om_d[j], cc, Z, Y, W, e); own_scale_row(h.om_s[j], cc, Z, Y, W, L.rs + e); }
     }
     if (tid < L.n_u) {
         const int ri = L.ri + tid, rd = L.rdu + L.nu + tid;
-        W[ri] = h.om_i * Z[ri] - cc * Y[ri]; W[rd] = h.om_du * Z[rd] - cc * Y[rd];
-        if (tid < L.nu) { const int r0 = L.rdu + tid; W[r0] = h.om_d0 * Z[r0] - cc * Y[r0]; }
+        own_scale_row(h.om_i, cc, Z, Y, W, ri); own_scale_row(h.om_du, cc, Z, Y, W, rd);
+        if (tid < L.nu) own_scale_row(h.om_d0, cc, Z, Y, W, L.rdu + tid);
     }
     __syncthreads();
 }
@@ -454,12 +462,12 @@ __device__ __forceinline__ void own_update(const Lay &L, const double *hot, cons
     auto row = [&](int r, double w, double zt, double lo, double hi) {
         lo = lo < -QP_INFTY ? -QP_INFTY : lo;
         hi = hi > QP_INFTY ? QP_INFTY : hi;
-        const double zv = Z[r], yv = Y[r];
+        const double zv = Z[r], ys = Y[r];            // (ys = c y / omega, see own_scale_row)
         const double zr = alpha * zt + beta * zv;
-        const double zn = fmin(fmax(zr + cc * yv / w, lo), hi);
-        const double dy = (w * cinv) * (zr - zn), yn = yv + dy;
-        Z[r] = zn; Y[r] = yn; W[r] = w * zn - cc * yn;
-        if (keep_delta) dyg[r] = dy;
+        const double zn = fmin(fmax(zr + ys, lo), hi);
+        const double d = zr - zn, ysn = ys + d;
+        Z[r] = zn; Y[r] = ysn; W[r] = w * (zn - ysn);
+        if (keep_delta) dyg[r] = (w * cinv) * d;
     };
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -503,6 +511,22 @@ __device__ __forceinline__ void own_update(const Lay &L, const double *hot, cons
     __syncthreads();
 }
 
+// end of a round: the thread's rows back from ys = c y / omega to y
+__device__ __forceinline__ void own_finish(const Lay &L, const OwnRegs &h, double cc, double *Y) {
+    const int tid = opaque_lane(threadIdx.x);
+    const double cinv = 1.0 / cc;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int e = tid + NT * j;
+        if (e < L.n_x) { Y[e] *= h.om_d[j] * cinv; Y[L.rs + e] *= h.om_s[j] * cinv; }
+    }
+    if (tid < L.n_u) {
+        Y[L.ri + tid] *= h.om_i * cinv; Y[L.rdu + L.nu + tid] *= h.om_du * cinv;
+        if (tid < L.nu) Y[L.rdu + tid] *= h.om_d0 * cinv;
+    }
+    __syncthreads();
+}
+
 // ------------------------------------------------------------------------------------------------
 // The owner map for problems whose iterate does not fit LDS (x, z, y, omega, s in global memory): the same items, as many
 // passes as it takes (state element e = t + NT j, input element cu = t + NT j), HOT_U items per thread at a time with ALL their
@@ -513,12 +537,21 @@ __device__ __forceinline__ void own_update(const Lay &L, const double *hot, cons
 // ------------------------------------------------------------------------------------------------
 template <int NB> struct GownCfg { static constexpr int U = NB == 32 ? HOT_U : 2; };      // items per thread in flight (128 VGPRs at 16 x 16 stages: ten operands per input item)
 template <int NB>
-__device__ __forceinline__ void gown_rows_w(const Lay &L, cgdouble *om, double cc, const double *Z, const double *Y, double *W, double *Tc) {
+__device__ __forceinline__ void gown_rows_w(const Lay &L, cgdouble *om, double cc, const double *Z, double *Y, double *W, double *Tc) {
     const int tid = opaque_lane(threadIdx.x);
     cgdouble *Zg = (cgdouble *)Z, *Yg = (cgdouble *)Y;
     for (int i = tid; i < L.N * NB; i += NT) Tc[i] = 0.0;      // (padding and absent inputs stay zero through the solves: the factor has zero rows there)
 #pragma unroll HOT_U
-    for (int r = tid; r < L.m; r += NT) W[r] = om[r] * Zg[r] - cc * Yg[r];
+    for (int r = tid; r < L.m; r += NT) { const double w = om[r], ys = cc * Yg[r] / w; ((gdouble *)Y)[r] = ys; W[r] = w * (Zg[r] - ys); }      // (y -> c y / omega, see own_scale_row)
+    __syncthreads();
+}
+// end of a round: y back from c y / omega
+__device__ __forceinline__ void gown_finish(const Lay &L, cgdouble *om, double cc, double *Y) {
+    const int tid = opaque_lane(threadIdx.x);
+    const double cinv = 1.0 / cc;
+    gdouble *Yg = (gdouble *)Y;
+#pragma unroll HOT_U
+    for (int r = tid; r < L.m; r += NT) Yg[r] = Yg[r] * (om[r] * cinv);
     __syncthreads();
 }
 template <int NB, int NXT, int NUT>
@@ -591,14 +624,14 @@ __device__ __forceinline__ void gown_update(const Lay &L, const double *hot, con
     const double cef = cc * hot[L.oeps], cinv = 1.0 / cc, beta = 1.0 - alpha;
     gdouble *Xg = (gdouble *)X, *Zg = (gdouble *)Z, *Yg = (gdouble *)Y;
     // one row: relaxation, projection, dual step; z, y come in as loaded and leave through global stores
-    auto row = [&](int r, double w, double zt, double lo, double hi, double zv, double yv) {
+    auto row = [&](int r, double w, double zt, double lo, double hi, double zv, double ys) {      // (ys = c y / omega, see own_scale_row)
         lo = lo < -QP_INFTY ? -QP_INFTY : lo;
         hi = hi > QP_INFTY ? QP_INFTY : hi;
         const double zr = alpha * zt + beta * zv;
-        const double zn = fmin(fmax(zr + cc * yv / w, lo), hi);
-        const double dy = (w * cinv) * (zr - zn), yn = yv + dy;
-        Zg[r] = zn; Yg[r] = yn; W[r] = w * zn - cc * yn;
-        if (keep_delta) dyg[r] = dy;
+        const double zn = fmin(fmax(zr + ys, lo), hi);
+        const double d = zr - zn, ysn = ys + d;
+        Zg[r] = zn; Yg[r] = ysn; W[r] = w * (zn - ysn);
+        if (keep_delta) dyg[r] = (w * cinv) * d;
     };
     for (int e0 = tid; e0 < L.n_x; e0 += GU * NT) {
         double oms[GU], omd[GU], sve[GU], xo[GU], eo[GU], zd[GU], yd[GU], zs[GU], ys[GU];
@@ -711,6 +744,10 @@ __device__ __forceinline__ void admm_body(const Lay &L, const HotPtrs &P, Smem &
         TICK(5)
     }
     TICK_FLUSH
+#ifndef MPCQP_ABL_NOPAR
+    if (LDSSTATE) own_finish(L, hr, cc, Y);
+    else gown_finish(L, gom, cc, Y);
+#endif
     if (LDSSTATE) {
         for (int j = tid; j < L.n; j += NT) gx[j] = X[j];
         for (int r = tid; r < L.m; r += NT) { gz[r] = Z[r]; gy[r] = Y[r]; }
