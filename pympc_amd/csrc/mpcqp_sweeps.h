@@ -21,6 +21,11 @@ __device__ __forceinline__ void vec_store(double *tb, int k, const double *v, bo
 }
 // per-lane base of a stage vector in Tc: lane 16k + 4b + j holds element 4b + k
 __device__ __forceinline__ int vec_lane_offset(int lane) { return 4 * ((lane >> 2) & 3) + (lane >> 4); }
+// A stage vector is replicated over the four lanes j of a row position; one of them writes it back -- or, inside the sweeps,
+// all four (MPCQP_STORE_ALL: the same value to the same address, no exec-mask juggling and no extra basic block per stage).
+#ifndef MPCQP_STORE_ALL
+#define MPCQP_STORE_ALL 1
+#endif
 __device__ __forceinline__ bool vec_lane_writer(int lane) { return (lane & 3) == 0; }
 
 // rotate every 16-lane row by 4*sft lanes: lane (k, b, j) receives the value of lane (k, (b+sft)%4, j)
@@ -125,7 +130,7 @@ __device__ __forceinline__ void chain_sweep(const int first, const int dir, cons
     constexpr int NBLK = NB / 16, NF = SweepCfg<NB>::NF, DEPTH = SweepCfg<NB>::DEPTH;
     const int lane = opaque_lane(threadIdx.x & 63);
     double *tb = Tc + vec_lane_offset(lane);
-    const bool writer = vec_lane_writer(lane);
+    const bool writer = MPCQP_STORE_ALL ? true : vec_lane_writer(lane);
     auto stage_of = [&](int i) { return first + dir * i; };
     auto frag_of = [&](int i) { return F + (size_t)stage_of(i) * fstage; };
     // The group loop below is branch-free on purpose: with conditionals around the refills the compiler can no longer
@@ -390,7 +395,7 @@ __device__ __forceinline__ void so_sweep(const CoreArgs &a, double *Tc, const in
     constexpr int NBLK = NB / 16, DEPTH = SoCfg<NB>::DEPTH;
     const int lane = opaque_lane(threadIdx.x & 63);
     double *tb = Tc + vec_lane_offset(lane);
-    const bool writer = vec_lane_writer(lane);
+    const bool writer = MPCQP_STORE_ALL ? true : vec_lane_writer(lane);
     const SoLaneK lc = so_lane_consts<NB, UP>(lane);
     d4 Gf[SoCfg<NB>::NF];
     frag_load<NB>(a.G + (UP ? 0 : NB * NB), lane, Gf);
