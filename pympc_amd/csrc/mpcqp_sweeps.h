@@ -82,6 +82,23 @@ __device__ __forceinline__ void frag_matvec(const d4 *A, const double *in, doubl
 #endif
 }
 
+// The 32 x 32 sweeps read the factor stream through BUFFER loads: resource = the instance's factor, scalar offset = the stage,
+// vector offset = the lane's constant byte offset inside a stage record -- the address of a load needs no vector arithmetic at
+// all (a global load takes a 64-bit per-lane address, formed with one or two VALU instructions per load and stage: ten of the
+// ~150 instructions of a stage).  cfg-5 +1 %; at 16 x 16 (three loads per stage) it measured -0.7 %, so those keep global loads.
+#ifndef MPCQP_BUFFER_LOADS
+#define MPCQP_BUFFER_LOADS 1
+#endif
+typedef unsigned int bu4 __attribute__((ext_vector_type(4)));
+typedef unsigned int bu2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t factor_rsrc(const double *F) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *)F, 0, 0x7fffffff, 0x00020000);       // raw buffer, no range check worth having
+}
+__device__ __forceinline__ double bu_double(unsigned lo, unsigned hi) { return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo); }
+__device__ __forceinline__ d4 buf_load_d4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    const bu4 a = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0), b = __builtin_amdgcn_raw_buffer_load_b128(r, voff + 16, soff, 0);
+    return d4{bu_double(a[0], a[1]), bu_double(a[2], a[3]), bu_double(b[0], b[1]), bu_double(b[2], b[3])};
+}
 template <int NB>
 __device__ __forceinline__ void frag_load(const double *Fm, int lane, d4 *A) {
     constexpr int NBLK = NB / 16;
@@ -137,10 +154,11 @@ __device__ __forceinline__ void chain_sweep(const int first, const int dir, cons
     // count the loads in flight across the back edge and falls back to s_waitcnt vmcnt(0) -- the whole memory latency
     // once per group.  Refills past the end re-read the last stage (clamped index), the tail group runs separately.
     auto frag_clamped = [&](int i) { return frag_of(i < nsteps ? i : nsteps); };
+    auto ring_load = [&](int i, d4 *A) { frag_load<NB>(frag_clamped(i), lane, A); };
     d4 ring[DEPTH][NF];
     if (nsteps < 1) return;
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) frag_load<NB>(frag_clamped(1 + d), lane, ring[d]);
+    for (int d = 0; d < DEPTH; ++d) ring_load(1 + d, ring[d]);
     double va[NBLK], vb[NBLK];
     vec_load<NB>(tb, first, va);
     // The stage's own vector is read from LDS ONE STAGE AHEAD (oa / ob alternate): read where it is used, its LDS round trip
@@ -162,7 +180,7 @@ __device__ __forceinline__ void chain_sweep(const int first, const int dir, cons
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             stage_step(i0 + d, d);
-            frag_load<NB>(frag_clamped(i0 + d + DEPTH), lane, ring[d]);
+            ring_load(i0 + d + DEPTH, ring[d]);
         }
     }
 #pragma unroll
@@ -366,6 +384,18 @@ __device__ __forceinline__ void so_slot_load(const char *Fk, const SoLaneK &c, S
 #pragma unroll
     for (int bi = 0; bi < NB / 16; ++bi) s.tab[bi] = *(cgd2 *)(Fk + c.tab + bi * 256);
 }
+// the same through buffer loads: rs = the instance's factor, soff = byte offset of the stage
+template <int NB>
+__device__ __forceinline__ void so_slot_load(__amdgpu_buffer_rsrc_t rs, unsigned soff, const SoLaneK &c, SoSlot<NB> &s) {
+    if constexpr (NB == 16) {
+        s.S[0] = buf_load_d4(rs, c.win, soff);
+    } else { s.S[0] = buf_load_d4(rs, c.win, soff); s.S[3] = buf_load_d4(rs, c.win + 8 * 164, soff); s.S[1] = buf_load_d4(rs, c.direct, soff); }
+#pragma unroll
+    for (int bi = 0; bi < NB / 16; ++bi) {
+        const bu4 t = __builtin_amdgcn_raw_buffer_load_b128(rs, c.tab + bi * 256, soff, 0);
+        s.tab[bi] = d2{bu_double(t[0], t[1]), bu_double(t[2], t[3])};
+    }
+}
 // the cross-lane half of the expansion (sym_expand16 / frag_transpose16): issue ...
 template <int NB>
 __device__ __forceinline__ void so_expand_issue(const SoSlot<NB> &s, const SoLaneK &c, SoPerm<NB> &t) {
@@ -401,7 +431,11 @@ __device__ __forceinline__ void so_sweep(const CoreArgs &a, double *Tc, const in
     frag_load<NB>(a.G + (UP ? 0 : NB * NB), lane, Gf);
     auto stage_of = [&](int i) { return first + dir * i; };
     auto clamp_i = [&](int i) { return i < nsteps ? i : nsteps; };       // (branch-free refills, see chain_sweep)
-    auto load = [&](int i, SoSlot<NB> &s) { so_slot_load<NB>((const char *)(a.F + (size_t)stage_of(i) * a.fstage), lc, s); };
+    const __amdgpu_buffer_rsrc_t rs = factor_rsrc(a.F);
+    auto load = [&](int i, SoSlot<NB> &s) {
+        if constexpr (MPCQP_BUFFER_LOADS && NB == 32) so_slot_load<NB>(rs, (unsigned)(stage_of(i) * a.fstage) * 8u, lc, s);
+        else so_slot_load<NB>((const char *)(a.F + (size_t)stage_of(i) * a.fstage), lc, s);
+    };
     if (nsteps < ibegin) return;
     double run[NBLK], own[NBLK];
 #pragma unroll
