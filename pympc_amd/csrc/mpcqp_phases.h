@@ -535,7 +535,7 @@ __device__ __forceinline__ void own_finish(const Lay &L, const OwnRegs &h, doubl
 // Against the flat loops this replaces (one over the padded variables, one over the variables again, one over the m rows with
 // a four-way branch per row): a third of the round trips and no divergent tree.
 // ------------------------------------------------------------------------------------------------
-template <int NB> struct GownCfg { static constexpr int U = NB == 32 ? HOT_U : 2; };      // items per thread in flight (128 VGPRs at 16 x 16 stages: ten operands per input item)
+template <int NB> struct GownCfg { static constexpr int U = 2; };      // items per thread in flight (ten operands per input item; 2 / 4 / 8 measured at cfg-5: 95.0 / 94.2 / 92.2 k solves/s)
 template <int NB>
 __device__ __forceinline__ void gown_rows_w(const Lay &L, cgdouble *om, double cc, const double *Z, double *Y, double *W, double *Tc) {
     const int tid = opaque_lane(threadIdx.x);
