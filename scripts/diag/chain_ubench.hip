@@ -2,6 +2,15 @@
 //   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value -o /tmp/chain_ubench scripts/diag/chain_ubench.hip
 #include "../../pympc_amd/csrc/mpcqp.hip"
 
+// one 16 x 16 fragment times a stage vector as the two partial sums of the MFMA pairs (what a stage of so_sweep issues)
+__device__ __forceinline__ void frag_matvec_halves16(const d4 a, const double in, double &p, double &s) {
+    const double r1 = rot_blocks<1>(in), r2 = rot_blocks<2>(in), r3 = rot_blocks<3>(in);
+    p = __builtin_amdgcn_mfma_f64_4x4x4f64(a[0], in, 0.0, 0, 0, 0);
+    s = __builtin_amdgcn_mfma_f64_4x4x4f64(a[2], r2, 0.0, 0, 0, 0);
+    p = __builtin_amdgcn_mfma_f64_4x4x4f64(a[1], r1, p, 0, 0, 0);
+    s = __builtin_amdgcn_mfma_f64_4x4x4f64(a[3], r3, s, 0, 0, 0);
+}
+
 template <int V>
 __global__ __launch_bounds__(256) void ub(const double *F, double *out, int reps) {
     __shared__ double Tc[4096];
