@@ -8,8 +8,11 @@ systems nx=12, nu=4, Np=30 per GPU, reference-default tolerances (eps_abs=eps_re
 pyMPC/mpc.py:80), synthetic data, FP64, all inputs resident in HBM when the timed region starts.
 
     python bench.py --gpus 1 --steps 100 --warmup 20
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N ...                   # WORLD_SIZE unset: re-executes itself under torch.distributed.run with N ranks
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...      # what the driver runs
     python bench.py --workload cfg5                # BASELINE configs[4]: 512 x (20,8,100), Delta-u + slack rows active
+    python bench.py --workload cfg2                # BASELINE configs[1]: ONE cart-pole controller (4,1,20), latency per update()
+    python bench.py --workload notebook            # examples/example_inverted_pendulum_kalman.ipynb shape (4,1,150,75), one controller
     ... bench.py --gpus N --total-batch 1024       # BASELINE configs[3] read as strong scaling: the SAME 1024 instances over N GPUs
 
 Two ways through the same library, both measured, `--path` chooses which one is `value` (the other is `other_path`):
@@ -19,12 +22,14 @@ Two ways through the same library, both measured, `--path` chooses which one is 
 Both give bit-identical trajectories (tests/test_gpu_parity.py::test_device_loop_*).
 
 Rank 0 prints ONE JSON line.  With N > 1 the instances are sharded over ranks (weak scaling: `--batch` per GPU; strong
-scaling with --total-batch); RCCL is used only to scatter the problem data from rank 0 and to all-gather u*.
+scaling with --total-batch); RCCL is used only to scatter the problem data from rank 0 and to all-gather u*; every rank
+reports (rank, device identity) and the line carries `ranks_seen` / `devices_seen` (the run fails if either is < N).
 """
 import argparse
 import json
-import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,42 +38,164 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-NX, NU, NP = 12, 4, 30
-XBOX = 10.0
 HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md chip-level parameters (achievable: ~6.3e12)
+INFINITY_CACHE = 256 << 20  # bytes, MI355X_MICROARCH.md (memory-side cache in front of HBM)
 U_ERR_SAMPLE = 32          # instances whose u* is compared with the tight-tolerance CPU reference
+WORKLOADS = {              # name -> (nx, nu, Np, state box, default instances per GPU)
+    'cfg3': (12, 4, 30, 10.0, 1024),
+    'cfg5': (20, 8, 100, 1.0, 512),
+}
 
 
-def make_instances(first, count):
+# ----------------------------------------------------------------------------------------------------------------------
+# launching: one process per GPU
+# ----------------------------------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch_if_needed(args):
+    """`python bench.py --gpus N` with N > 1 outside torch.distributed.run: start the N ranks ourselves (same interpreter,
+    same flags, rendezvous on 127.0.0.1) and hand back their exit code.  Inside a launcher (WORLD_SIZE set) this is a no-op."""
+    if args.gpus <= 1 or 'WORLD_SIZE' in os.environ:
+        return
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC: RCCL needs it on this host driver
+    sys.exit(subprocess.call(cmd, env=env))
+
+
+def device_identity(torch, dev):
+    """Something that distinguishes physical GPUs: the device UUID if this torch exposes it, else the PCI address."""
+    if dev.type != 'cuda':
+        return 'cpu:%s:%d' % (socket.gethostname(), os.getpid())
+    p = torch.cuda.get_device_properties(dev)
+    uuid = getattr(p, 'uuid', None)
+    if uuid is not None:
+        return 'uuid:%s' % uuid
+    pci = tuple(getattr(p, k, None) for k in ('pci_domain_id', 'pci_bus_id', 'pci_device_id'))
+    if any(v is not None for v in pci):
+        return 'pci:%s:%s:%s' % pci
+    return 'index:%d:%s' % (dev.index, p.name)
+
+
+def init_distributed(args, torch, dist):
+    """Process group + the proof that N ranks on N distinct devices are in it.  Returns (rank, world, local_rank, dev, seen)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    backend = os.environ.get('MPCQP_BENCH_BACKEND', 'nccl')     # ('gloo': the CPU test of this plumbing, with --dry-run)
+    if args.dry_run and backend == 'gloo':
+        dev = torch.device('cpu')
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit('bench.py needs an AMD GPU; pympc_amd has no CPU fallback')
+        if world > 1 and torch.cuda.device_count() < world:
+            raise SystemExit('bench.py --gpus %d: only %d GPU(s) visible' % (world, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
+        dev = torch.device('cuda', local_rank)
+    if args.gpus != world and rank == 0:
+        print('bench.py: --gpus %d but WORLD_SIZE=%d; running with %d rank(s)' % (args.gpus, world, world), file=sys.stderr)
+    seen = [(rank, device_identity(torch, dev))]
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        if backend == 'nccl':
+            dist.init_process_group(backend='nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
+        got = [None] * world
+        dist.all_gather_object(got, seen[0])
+        seen = sorted(tuple(g) for g in got)
+    ranks_seen = len({r for r, _ in seen})
+    devices_seen = len({d for _, d in seen})
+    if ranks_seen < world or devices_seen < world:
+        raise SystemExit('bench.py: %d rank(s) on %d distinct device(s) in the process group, expected %d of each: %r'
+                         % (ranks_seen, devices_seen, world, seen))
+    return rank, world, local_rank, dev, dict(ranks_seen=ranks_seen, devices_seen=devices_seen,
+                                              backend=backend if world > 1 else None, devices=[d for _, d in seen])
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# workload
+# ----------------------------------------------------------------------------------------------------------------------
+def make_instances(dims, first, count):
     from pympc_amd import fixtures
-    kws = [fixtures.random_lti(first + i, nx=NX, nu=NU, Np=NP, xbox=XBOX) for i in range(count)]
+    nx, nu, Np, xbox = dims
+    kws = [fixtures.random_lti(first + i, nx=nx, nu=nu, Np=Np, xbox=xbox) for i in range(count)]
     return {k: np.stack([np.asarray(kw[k], dtype=float) for kw in kws]) for k in ('Ad', 'Bd', 'x0')}
 
 
-def algorithmic_bytes_8d(n, m, nnzL, iters, checks, solves):
+def algorithmic_bytes_8d(dims, n, m, nnzL, iters, checks, solves):
     """a generic sparse-LDL' ADMM, FP64 values only.  per iteration 8(2 nnzL_strict + 6n + 10m); per
     residual evaluation 8(nnz(triu P) + 2 nnz(A)); per solve 8(4n + 6m).  Kept beside the design figure: it charges the
     iterate and metric vectors to HBM every iteration, which this implementation keeps in LDS/registers."""
+    NX, NU, NP, _ = dims
     nnz_triuP = (NP + 1) * NX * 2 + NP * NU + (NP - 1) * NU     # diagonal weights: diag + upper QDu coupling
     nnzA = (NP + 1) * NX + NP * NX * NX + NP * NX * NU + 2 * (NP + 1) * NX + NP * NU + NU + 2 * NP * NU - 1
     b_it = 8 * (2 * (nnzL - n) + 6 * n + 10 * m)
     return iters * b_it + checks * 8 * (nnz_triuP + 2 * nnzA) + solves * 8 * (4 * n + 6 * m), b_it
 
 
-def pmc_bytes_per_iter(workload, path, kernel):
-    """Measured memory-side bytes per ADMM iteration per instance of `kernel`, from the committed rocprofv3 PMC passes of
-    this same command (profiles/pmc_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE collected in separate runs, FETCH_SIZE
-    doubled as MI355X_MICROARCH.md prescribes for gfx950, divided by the ADMM iterations of the profiled launches).
-    Counters cannot be read from inside the process; scaling the per-iteration figure by this run's iteration count
-    gives the per-launch traffic for whatever launch length the caller chose."""
+def pmc_entry(workload, path, kernel):
+    """The committed rocprofv3 PMC summary of this same command (profiles/pmc_hbm_traffic.json: FETCH_SIZE and WRITE_SIZE
+    collected in separate runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, divided by the ADMM
+    iterations of the profiled launches).  Counters cannot be read from inside the process; the entry records the batch it
+    was profiled with and is only used for a run of the same shape."""
     try:
         with open(os.path.join(ROOT, 'profiles', 'pmc_hbm_traffic.json')) as f:
-            return json.load(f)[workload][path][kernel]['hbm_bytes_per_iter_per_qp']
+            return json.load(f)[workload][path][kernel]
     except Exception:
         return None
 
 
-def cpu_legs(eps, samples, want_baseline, seconds_budget=12.0, inst=400, steps=100):
+def osqp_available():
+    try:
+        import osqp  # noqa: F401
+        return True
+    except Exception:
+        return False
+
+
+def real_osqp_pin():
+    """If the REAL solver the reference calls (PyPI `osqp`, pyMPC/mpc.py:4) is importable on this box, run the comparisons of
+    tests/test_real_osqp.py inline (oracle vs osqp at the default tolerance: status / iterations / iterate; osqp vs the
+    certified optimum goldens at 1e-10) and report -- the first box that has the wheel pins the oracle without code changes."""
+    if not osqp_available():
+        return {'osqp_available': False}
+    out = {'osqp_available': True}
+    try:
+        import osqp
+        import scipy.sparse as sp
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+        from util import golden_names, load_golden, golden_csc
+        from oracle.osqp_oracle import OSQP as Oracle
+        out['osqp_version'] = getattr(osqp, '__version__', '?')
+        res = {}
+        for name in golden_names():
+            g = load_golden(name)
+            P, A = golden_csc(g, 'P'), golden_csc(g, 'A')
+            pr = osqp.OSQP()
+            pr.setup(sp.triu(P, format='csc'), np.array(g['q']), A.tocsc(), np.array(g['l']), np.array(g['u']), verbose=False,
+                     eps_abs=1e-3, eps_rel=1e-3, adaptive_rho_interval=100)
+            r = pr.solve()
+            o = Oracle()
+            o.setup(P, g['q'], A, g['l'], g['u'], eps_abs=1e-3, eps_rel=1e-3, adaptive_rho_interval=100)
+            ro = o.solve()
+            res[name] = dict(status_equal=ro.info.status == r.info.status, iter_oracle=int(ro.info.iter), iter_osqp=int(r.info.iter),
+                             x_err=float(np.abs(ro.x - r.x).max()) if r.x is not None and r.x[0] is not None else None)
+        out['oracle_vs_osqp_eps1e-3'] = res
+        out['all_equal'] = all(v['status_equal'] and v['iter_oracle'] == v['iter_osqp'] for v in res.values())
+    except Exception as e:
+        out['error'] = repr(e)
+    return out
+
+
+def cpu_legs(dims, eps, samples, want_baseline, seconds_budget=12.0, inst=400, steps=100):
     """Everything that needs the CPU oracle (test infrastructure; the only place bench.py touches oracle/):
     (1) cpu_baseline -- the reference-style CPU path on this box's host cores: the C port of the OSQP algorithm
         (oracle/osqp_ref.c, rebuilt here with -O3 -march=native) driven by its C closed-loop driver like the reference
@@ -76,6 +203,7 @@ def cpu_legs(eps, samples, want_baseline, seconds_budget=12.0, inst=400, steps=1
         (`value`, what pyMPC does today), and the same on every usable core at once;
     (2) u*_ref of the sampled QPs at tolerance 1e-10, for 'max |u* - u*_ref|'."""
     from oracle import cpu_bench
+    NX, NU, NP, XBOX = dims
     out, refs = None, []
     if want_baseline:
         cpu_bench.build_native()
@@ -95,93 +223,71 @@ def cpu_legs(eps, samples, want_baseline, seconds_budget=12.0, inst=400, steps=1
     return out, refs
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=100, help='timed MPC steps (SURVEY 8d cfg-3: 100-step receding horizon)')
-    ap.add_argument('--warmup', type=int, default=20)
-    ap.add_argument('--batch', type=int, default=None, help='instances per GPU (weak scaling; default 1024, cfg5: 512)')
-    ap.add_argument('--total-batch', type=int, default=None, help='instances in total, split evenly over the GPUs (strong scaling)')
-    ap.add_argument('--eps', type=float, default=1e-3)
-    ap.add_argument('--chunk', type=int, default=None, help='device loop: steps per kernel launch (default: the timed steps in equal launches of at most 25)')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-other-path', action='store_true', help='skip the secondary measurements (other path, parity setting)')
-    ap.add_argument('--no-refactor-timing', action='store_true', help='skip the timing of the factorization alone (profiling runs: its launches carry the solve kernel\'s name)')
-    ap.add_argument('--path', default='device_loop', choices=['stepwise', 'device_loop'],
-                    help='stepwise: update()/solve()/output() per step from the host (the reference call pattern); '
-                         'device_loop: the same K steps inside mpcqp_mpc_loop (SURVEY 8f-1)')
-    ap.add_argument('--workload', default='cfg3', choices=['cfg3', 'cfg5'],
-                    help='cfg3: 1024 x (12,4,30) (headline); cfg5: 512 x (20,8,100), tight state box (SURVEY 8d)')
-    args = ap.parse_args()
-    global NX, NU, NP, XBOX
-    if args.workload == 'cfg5':
-        NX, NU, NP, XBOX = 20, 8, 100, 1.0
+class Shard:
+    """One rank's share of the batch: B instances set up on this GPU, and the two measured ways through the library."""
 
-    import torch
-    import torch.distributed as dist
-    from pympc_amd.solver import BatchProblem
+    def __init__(self, args, dims, B, rank, world, dev, first_instance, torch, dist):
+        from pympc_amd.solver import BatchProblem
+        from pympc_amd import sharding
+        self.args, self.dims, self.B, self.rank, self.world, self.dev = args, dims, B, rank, world, dev
+        self.torch, self.dist, self.sharding = torch, dist, sharding
+        NX, NU, NP, XBOX = dims
+        f64 = torch.float64
+        # ---- problem data: generated on rank 0, scattered over RCCL (north_star: scatter problem data)
+        full = None
+        if rank == 0:
+            full = {k: torch.from_numpy(v).to(dev) for k, v in make_instances(dims, first_instance, B * world).items()}
+        loc = sharding.scatter_instances(full, {'Ad': (NX, NX), 'Bd': (NX, NU), 'x0': (NX,)}, B, dev)
+        self.Ad, self.Bd, self.x = loc['Ad'], loc['Bd'], loc['x0'].clone()
+        stream = torch.cuda.current_stream(dev)
+        self.prob = prob = BatchProblem(B, NX, NU, NP, device=dev.index, stream=stream.cuda_stream,
+                                        eps_abs=args.eps, eps_rel=args.eps, warm_start=1)
+        eye = lambda k, s: (s * torch.eye(k, dtype=f64, device=dev)).expand(B, k, k).contiguous()
+        ones = lambda k, s: torch.full((B, k), s, dtype=f64, device=dev)
+        # SURVEY 8(d) measurement (i): cold setup() + first solve (pyMPC/mpc.py:254-269), timed with events on the stream
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        torch.cuda.synchronize()
+        ev[0].record()
+        prob.setup(self.Ad, self.Bd, eye(NX, 1.0), eye(NX, 1.0), eye(NU, 0.1), eye(NU, 0.1),
+                   ones(NX, -XBOX), ones(NX, XBOX), ones(NU, -1.0), ones(NU, 1.0), ones(NU, -0.5), ones(NU, 0.5),
+                   ones(NU, 0.0), torch.full((B, 1), 1e6, dtype=f64, device=dev),
+                   self.x, ones(NU, 0.0), torch.zeros((B, NX), dtype=f64, device=dev))
+        ev[1].record()
+        prob.solve_async()                        # cold solve (setup(solve=True))
+        ev[2].record()
+        self.u = torch.empty((B, NU), dtype=f64, device=dev)
+        prob.u0(out=self.u)
+        torch.cuda.synchronize()
+        st = prob.stats(reset=True)
+        self.cold = dict(setup_ms=ev[0].elapsed_time(ev[1]), first_solve_ms=ev[1].elapsed_time(ev[2]),
+                         iters_per_instance=st[0] / B, refactorizations_per_instance=st[2] / B, instances=B,
+                         note='mpc.py:254-269: setup() = upload + QP build + 10 Ruiz passes + first factorization of every instance '
+                              '(host upload included), first_solve = cold-started ADMM solve incl. its rho-update refactorizations')
+        # whole-process work per kernel (for the profile scripts: counter totals / these = bytes per iteration): 'solve' =
+        # k_mpc_run<..,false> (mpcqp_solve), 'loop' = k_mpc_run<..,true> (mpcqp_mpc_loop)
+        self.totals = {'solve': [0, 0, 0], 'loop': [0, 0, 0]}
+        self.account('solve', st)
+        self.gen = torch.Generator(device=dev)
+        self.gen.manual_seed(1234 + rank)
+        self.u_all = torch.empty((world * B, NU), dtype=f64, device=dev) if world > 1 else None
 
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an AMD GPU; pympc_amd has no CPU fallback')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
-    if world > 1:
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', device_id=dev)
-    if args.total_batch is not None:
-        if args.total_batch % world:
-            raise SystemExit('--total-batch must be divisible by the number of GPUs')
-        B, scaling = args.total_batch // world, 'strong'
-    else:
-        B, scaling = (args.batch if args.batch is not None else (1024 if args.workload == 'cfg3' else 512)), 'weak'
-    f64 = torch.float64
-
-    # ---- problem data: generated on rank 0, scattered over RCCL (north_star: scatter problem data)
-    from pympc_amd import sharding
-    full = None
-    if rank == 0:
-        full = {k: torch.from_numpy(v).to(dev) for k, v in make_instances(0, B * world).items()}
-    loc = sharding.scatter_instances(full, {'Ad': (NX, NX), 'Bd': (NX, NU), 'x0': (NX,)}, B, dev)
-    Ad, Bd, x = loc['Ad'], loc['Bd'], loc['x0'].clone()
-
-    stream = torch.cuda.current_stream(dev)
-    prob = BatchProblem(B, NX, NU, NP, device=local_rank, stream=stream.cuda_stream,
-                        eps_abs=args.eps, eps_rel=args.eps, warm_start=1)
-    eye = lambda k, s: (s * torch.eye(k, dtype=f64, device=dev)).expand(B, k, k).contiguous()
-    ones = lambda k, s: torch.full((B, k), s, dtype=f64, device=dev)
-    prob.setup(Ad, Bd, eye(NX, 1.0), eye(NX, 1.0), eye(NU, 0.1), eye(NU, 0.1),
-               ones(NX, -XBOX), ones(NX, XBOX), ones(NU, -1.0), ones(NU, 1.0), ones(NU, -0.5), ones(NU, 0.5),
-               ones(NU, 0.0), torch.full((B, 1), 1e6, dtype=f64, device=dev),
-               x, ones(NU, 0.0), torch.zeros((B, NX), dtype=f64, device=dev))
-    prob.solve_async()                        # cold solve (setup(solve=True))
-    u = torch.empty((B, NU), dtype=f64, device=dev)
-    prob.u0(out=u)
-    # whole-process work per kernel (for the profile scripts: counter totals / these = bytes per iteration): 'solve' =
-    # k_mpc_run<..,false> (mpcqp_solve), 'loop' = k_mpc_run<..,true> (mpcqp_mpc_loop)
-    totals = {'solve': [0, 0, 0], 'loop': [0, 0, 0]}
-
-    def account(kind, st=None):
-        st = prob.stats(reset=True) if st is None else st
+    def account(self, kind, st=None):
+        st = self.prob.stats(reset=True) if st is None else st
         for i, v in enumerate((st[0], st[1], st[3])):
-            totals[kind][i] += v
+            self.totals[kind][i] += v
         return st
-    account('solve')
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + rank)
-    u_all = torch.empty((world * B, NU), dtype=f64, device=dev) if world > 1 else None
 
-    def plant(xc, uc):
-        w = 0.01 * torch.randn((B, NX), dtype=f64, device=dev, generator=gen)
-        return torch.baddbmm(w.unsqueeze(2), Ad, xc.unsqueeze(2)).add_(torch.bmm(Bd, uc.unsqueeze(2))).squeeze(2)
+    def plant(self, xc, uc):
+        torch = self.torch
+        w = 0.01 * torch.randn((self.B, self.dims[0]), dtype=torch.float64, device=self.dev, generator=self.gen)
+        return torch.baddbmm(w.unsqueeze(2), self.Ad, xc.unsqueeze(2)).add_(torch.bmm(self.Bd, uc.unsqueeze(2))).squeeze(2)
 
-    def timed(kind, run_warm, run_timed):
+    def timed(self, kind, run_warm, run_timed):
         """W untimed steps, then the timed K steps between barrier + synchronize; returns max-over-ranks seconds
         and the device-side accounting of the timed region."""
+        torch, dist, prob, world = self.torch, self.dist, self.prob, self.world
         run_warm()
-        account(kind)
+        self.account(kind)
         prob.profile(enable=True, reset=True)
         if world > 1:
             dist.barrier()
@@ -193,128 +299,321 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([elapsed], dtype=f64, device=dev)
+            t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
-        iters, checks, refacts, solves = account(kind)
+        iters, checks, refacts, solves = self.account(kind)
         run_ms, launches = prob.profile(enable=False)
         return dict(elapsed=elapsed, iters=iters, checks=checks, refacts=refacts, solves=solves, run_ms=run_ms, launches=launches)
 
-    def measure_stepwise(steps, warmup):
+    def measure_stepwise(self, steps, warmup):
         """The reference's call pattern: per step the host calls update(), solve(), output() (one kernel launch per
         solve); plant and disturbance are torch ops on the same stream; with N > 1 u* is all-gathered every step."""
-        nonlocal x
-
         def step():
-            nonlocal x
-            x = plant(x, u)
-            prob.update(x, u)
-            prob.solve_async()
-            prob.u0(out=u)
-            if world > 1:
-                sharding.gather_inputs(u, out=u_all)
+            self.x = self.plant(self.x, self.u)
+            self.prob.update(self.x, self.u)
+            self.prob.solve_async()
+            self.prob.u0(out=self.u)
+            if self.world > 1:
+                self.sharding.gather_inputs(self.u, out=self.u_all)
 
-        return timed('solve', lambda: [step() for _ in range(warmup)], lambda: [step() for _ in range(steps)])
+        return self.timed('solve', lambda: [step() for _ in range(warmup)], lambda: [step() for _ in range(steps)])
 
-    def measure_device_loop(steps, warmup):
+    def measure_device_loop(self, steps, warmup):
         """The same closed loop inside mpcqp_mpc_loop: launches of `chunk` steps each, so that every
         launch (warm-up and timed) does the same work; the disturbance sequence is synthetic input generated before
         the timed region; with N > 1 the applied inputs of a chunk are all-gathered after it."""
-        nonlocal x
+        torch, B, dev, world = self.torch, self.B, self.dev, self.world
+        NX, NU = self.dims[0], self.dims[1]
+        f64 = torch.float64
         # steps per launch: a launch ends when its slowest instance has finished its steps (no instance can run ahead of its
         # own closed loop), so short launches pay the spread of the per-instance iteration counts more often -- at cfg-3,
         # 5-step launches cost 8 % against 20-step ones.  Default: the whole timed region in launches of at most 25 steps.
-        if args.chunk:
-            chunk = args.chunk
+        if self.args.chunk:
+            chunk = self.args.chunk
         else:
             chunk = steps
             while chunk > 25:
                 chunk = next((chunk // d for d in (2, 3, 5, 7) if chunk % d == 0), 25)
-        w_all = 0.01 * torch.randn((warmup + steps, B, NX), dtype=f64, device=dev, generator=gen)
+        w_all = 0.01 * torch.randn((warmup + steps, B, NX), dtype=f64, device=dev, generator=self.gen)
         outs = (torch.empty((chunk + 1, B, NX), dtype=f64, device=dev), torch.empty((chunk, B, NU), dtype=f64, device=dev),
                 torch.empty((chunk, B), dtype=torch.int32, device=dev), torch.empty((chunk, B), dtype=torch.int32, device=dev))
         u_hist = torch.empty((world * chunk, B, NU), dtype=f64, device=dev) if world > 1 else None
 
         def run(first, count):
+            o = None
             for c in range(first, first + count, chunk):
                 k = min(chunk, first + count - c)
                 o = outs if k == chunk else tuple(t[:k + (1 if i == 0 else 0)] for i, t in enumerate(outs))
-                prob.mpc_run(k, w=w_all[c:c + k], out=o)
+                self.prob.mpc_run(k, w=w_all[c:c + k], out=o)
                 if world > 1 and k == chunk:
-                    sharding.gather_trajectory(outs[1], out=u_hist)
+                    self.sharding.gather_trajectory(outs[1], out=u_hist)
             return o
 
         last = {}
-        r = timed('loop', lambda: last.update(o=run(0, warmup)) if warmup else None, lambda: last.update(o=run(warmup, steps)))
-        x = last['o'][0][-1].clone()
-        u.copy_(last['o'][1][-1])
+        r = self.timed('loop', lambda: last.update(o=run(0, warmup)) if warmup else None, lambda: last.update(o=run(warmup, steps)))
+        self.x = last['o'][0][-1].clone()
+        self.u.copy_(last['o'][1][-1])
         r['chunk'] = chunk
         return r
 
-    def sample_point():
+    def measure(self, path, steps, warmup):
+        return {'stepwise': self.measure_stepwise, 'device_loop': self.measure_device_loop}[path](steps, warmup)
+
+    def sample_point(self):
         """One more (untimed) closed-loop step through the stepwise API: returns the sampled QPs (x0, u_{-1}) and the
         u* the device produced for them at the current tolerance.  Rank 0's instances only (global index = local)."""
-        nonlocal x
-        x = plant(x, u)
-        um1 = u.clone()
-        prob.update(x, um1)
-        prob.solve_async()
-        prob.u0(out=u)
+        torch, B = self.torch, self.B
+        self.x = self.plant(self.x, self.u)
+        um1 = self.u.clone()
+        self.prob.update(self.x, um1)
+        self.prob.solve_async()
+        self.prob.u0(out=self.u)
         torch.cuda.synchronize()
-        account('solve')
+        self.account('solve')
         idx = np.unique(np.linspace(0, B - 1, min(U_ERR_SAMPLE, B)).astype(int))
-        infos = prob.infos()
-        return dict(idx=idx, x0=x[idx].cpu().numpy(), um1=um1[idx].cpu().numpy(), u=u[idx].cpu().numpy(),
+        infos = self.prob.infos()
+        return dict(idx=idx, x0=self.x[idx].cpu().numpy(), um1=um1[idx].cpu().numpy(), u=self.u[idx].cpu().numpy(),
                     solved=np.array([infos[int(i)].status == 1 for i in idx]))
 
-    measure = {'stepwise': measure_stepwise, 'device_loop': measure_device_loop}
-    res = measure[args.path](args.steps, args.warmup)
-    elapsed, iters, checks, refacts, solves = res['elapsed'], res['iters'], res['checks'], res['refacts'], res['solves']
-    admm_ms, admm_launches = res['run_ms'], res['launches']
-    infos = prob.infos()
-    n_solved = sum(1 for i in infos if i.status == 1)
-    samples = [dict(sample_point(), eps=args.eps)]
-    other = None
-    if not args.no_other_path:
-        oname = 'stepwise' if args.path == 'device_loop' else 'device_loop'
-        o = measure[oname](args.steps, args.warmup)
-        other = {'path': oname, 'value': B * world * args.steps / o['elapsed'], 'ms_per_step': 1e3 * o['elapsed'] / args.steps,
-                 'mean_admm_iters': o['iters'] / max(1, o['solves'])}
-    parity = None
-    if not args.no_other_path and args.eps > 1e-8:
-        # SURVEY 8(d): the same loop at the parity setting eps = 1e-9 (the tolerance the u* comparison is made at)
-        prob.update_settings(eps_abs=1e-9, eps_rel=1e-9)
-        pr = measure[args.path](args.steps, args.warmup)
-        pinf = prob.infos()
-        parity = {'eps_abs': 1e-9, 'eps_rel': 1e-9, 'path': args.path, 'value': B * world * args.steps / pr['elapsed'],
-                  'ms_per_step': 1e3 * pr['elapsed'] / args.steps, 'mean_admm_iters': pr['iters'] / max(1, pr['solves']),
-                  'solved_fraction_last_step': sum(1 for i in pinf if i.status == 1) / B}
-        samples.append(dict(sample_point(), eps=1e-9))
-        prob.update_settings(eps_abs=args.eps, eps_rel=args.eps)
-    # what one rho update costs: the block factorization of every instance, timed alone (mpcqp_refactor rewrites the factor
-    # that is already in place); the steady-state loop above needs none, the cold solve a few per instance
-    refactor_ms = None
-    if not args.no_refactor_timing:
+    def refactor_ms(self):
+        torch, prob = self.torch, self.prob
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         prob.refactor(); torch.cuda.synchronize()
         ev0.record()
         for _ in range(3):
             prob.refactor()
         ev1.record(); torch.cuda.synchronize()
-        refactor_ms = ev0.elapsed_time(ev1) / 3
-    kname = prob.kernel_name(loop=args.path == 'device_loop')
-    lds_state = ',true,' in kname.split('<')[1][:9]            # second template argument: iterate resident in LDS
+        return ev0.elapsed_time(ev1) / 3
 
-    if rank == 0:
-        n, m, nnzL = prob.n, prob.m, prob.nnzL
+    def working_set_bytes(self):
+        """Bytes the timed loop touches per GPU: every instance's KKT factor, iterate, metric, model and step data."""
+        p = self.prob
+        per = 8 * (p.factor_doubles + 3 * p.n + 5 * p.m + 2 * (p.n + p.m)) + 8 * 1024
+        return int(per * self.B)
+
+    def roofline(self, res, path, workload_key):
+        """HBM roofline of the one kernel of the path, k_mpc_run (QP refresh, ADMM iterations, residual checks).  HIP events
+        bracket every launch on its stream (mpcqp_profile); `achieved` divides the bytes this implementation streams BY
+        DESIGN (mpcqp_get_stream_bytes x the device-side iteration / round / solve counters of the timed region) by that time."""
+        prob = self.prob
+        iters, checks, solves = res['iters'], res['checks'], res['solves']
+        admm_ms, launches = res['run_ms'], max(1, res['launches'])
         per_iter, per_round, per_solve = prob.stream_bytes()
-        # the one kernel of the path, k_mpc_run, does everything (QP refresh, ADMM iterations, residual checks).  HIP events
-        # bracket every launch on its stream (mpcqp_profile); the bytes are what this implementation streams by design.
         design_bytes = iters * per_iter + checks * per_round + solves * per_solve
         achieved = design_bytes / (admm_ms * 1e-3)
-        alg8d, b_it8d = algorithmic_bytes_8d(n, m, nnzL, iters, checks, solves)
-        pmc = pmc_bytes_per_iter(args.workload, args.path, kname)
-        traffic = pmc * iters / max(1, admm_launches) if pmc else None
+        alg8d, b_it8d = algorithmic_bytes_8d(self.dims, prob.n, prob.m, prob.nnzL, iters, checks, solves)
+        kname = prob.kernel_name(loop=path == 'device_loop')
+        lds_state = ',true,' in kname.split('<')[1][:9]            # second template argument: iterate resident in LDS
+        pmc = pmc_entry(workload_key, path, kname) if workload_key else None
+        pmc_batch = (pmc or {}).get('batch')
+        pmc_ok = pmc is not None and (pmc_batch is None or pmc_batch == self.B)
+        pmc_b = pmc['hbm_bytes_per_iter_per_qp'] if pmc_ok else None
+        traffic = pmc_b * iters / launches if pmc_b else None
+        ws = self.working_set_bytes()
+        NX, NU = self.dims[0], self.dims[1]
+        return {'bound': 'hbm', 'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+                'frac': achieved / HBM_PEAK, 'frac_is': 'model-based: design bytes (below) / HIP-event kernel time / 8 TB/s',
+                'traffic': traffic,
+                'traffic_source': ('from_profile: profiles/pmc_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE per ADMM iteration per QP, profiled at batch %s) x this run\'s iterations per launch'
+                                   % (pmc_batch if pmc_batch is not None else 'of the same command')) if pmc_b else None,
+                'traffic_GBps': (traffic / (admm_ms / launches * 1e-3) / 1e9) if traffic else None,
+                'working_set_bytes': ws, 'fits_infinity_cache': bool(ws <= INFINITY_CACHE),
+                'bytes_model': 'design: what k_mpc_run streams per instance (mpcqp_get_stream_bytes) -- per ADMM iteration the KKT factor '
+                               '(%s%s), per round the residual-evaluation inputs and the '
+                               'iterate in/out of LDS, per solve the QP refresh and the write-out'
+                               % ('forward matrices of N-1 stages, packed S^-1 of N stages and the stage tables once each, [G|G\'] once' if NX + NU <= 16
+                                  else 'packed S^-1 of N stages twice, one stage table per sweep, [G|G\'] by each sweeping wave',
+                                  '' if lds_state else '; iterate and metric vectors too: they do not fit LDS at this size'),
+                'design_bytes_per_iter_per_qp': per_iter, 'design_bytes_per_round_per_qp': per_round, 'design_bytes_per_solve_per_qp': per_solve,
+                'design_bytes_per_launch': design_bytes / launches,
+                'measured_bytes_per_iter_per_qp': pmc_b,
+                'kernel': kname, 'kernel_ms': admm_ms / launches, 'launches': res['launches'],
+                'steps_per_launch': res.get('chunk', 1),
+                'algorithmic_8d': {'bytes_per_launch': alg8d / launches, 'bytes_per_iter_per_qp': b_it8d, 'nnzL': prob.nnzL,
+                                   'GBps': alg8d / (admm_ms * 1e-3) / 1e9, 'frac_8d': alg8d / (admm_ms * 1e-3) / HBM_PEAK,
+                                   'note': 'SURVEY 8(d) generic sparse-LDL formula; charges 6n+10m vector doubles per iteration to HBM that this '
+                                           'kernel keeps in LDS/registers, so it exceeds the HBM peak BY CONSTRUCTION (frac_8d > 1 is not a '
+                                           'bandwidth claim) -- not used for frac'}}
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# single-controller latency legs (BASELINE configs[1] and the reference notebook's shape)
+# ----------------------------------------------------------------------------------------------------------------------
+def latency_leg(kind, nsim=300):
+    """One controller through the drop-in class, `MPCController.update()` per step (pyMPC/mpc.py:338-364), median microseconds;
+    beside it the CPU oracle on the same loop.  kind = 'cfg2': examples/example_inverted_pendulum.py:10-69 (4,1,20);
+    'notebook': examples/example_inverted_pendulum_kalman.ipynb cells 3/12/13/15 (4,1,Np=150,Nc=75; the notebook's own
+    timing cell reports about 1.05-1.2 ms per step for its OSQP-backed controller)."""
+    import warnings
+    from pympc_amd import MPCController, fixtures
+    kw = fixtures.cart_pole()
+    if kind == 'notebook':
+        kw.update(Np=150, Nc=75)
+
+    def loop(K):
+        x = np.array(kw['x0'], dtype=float)
+        ts, its = [], []
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            K.setup()
+            for _ in range(nsim):
+                u = K.output()
+                x = kw['Ad'] @ x + kw['Bd'] @ u
+                t = time.perf_counter(); K.update(x); ts.append(time.perf_counter() - t)
+                its.append(K.res.info.iter)
+        return 1e6 * np.array(ts), np.array(its)
+
+    K = MPCController(**kw)
+    ts, its = loop(K)
+    bp = K.prob.batch_problem
+    bp.profile(enable=True, reset=True)
+    x = np.array(K.x0_rh, dtype=float)
+    t0 = time.perf_counter()
+    for _ in range(200):
+        bp.update(x0=x[None, :]); bp.solve_async(); bp.u0()
+    raw_us = 1e6 * (time.perf_counter() - t0) / 200
+    ms, nl = bp.profile(enable=False)
+    out = dict(workload='%s: one cart-pole MPCController, nx=4 nu=1 Np=%d Nc=%d' % (kind, kw['Np'], kw.get('Nc', kw['Np'])),
+               update_us_median=float(np.median(ts)), update_us_p95=float(np.percentile(ts, 95)), mean_admm_iters=float(its.mean()),
+               raw_c_abi_step_us=raw_us, kernel_us=1e3 * ms / max(1, nl), kernel=bp.kernel_name(loop=False))
+    from oracle.osqp_oracle import OSQP
+    Ko = MPCController(**kw); Ko.prob = OSQP()
+    tso, _ = loop(Ko)
+    out['cpu_oracle_update_us_median'] = float(np.median(tso))
+    if kind == 'notebook':
+        out['reference_note'] = 'examples/example_inverted_pendulum_kalman.ipynb cell 17: about 1.05-1.2 ms per MPC step (OSQP, the author\'s laptop)'
+    return out
+
+
+def dry_run(args, rank, world, dev, seen, torch, dist):
+    """The distributed plumbing of the bench without the solver: scatter from rank 0, a stand-in per-shard result, all-gather,
+    one JSON line.  Used by the CPU test of `bench.py --gpus N` (gloo) -- nothing here is a measurement."""
+    from pympc_amd import sharding
+    B = 4
+    full = None
+    if rank == 0:
+        full = {'x0': torch.arange(B * world * 3, dtype=torch.float64, device=dev).reshape(B * world, 3)}
+    loc = sharding.scatter_instances(full, {'x0': (3,)}, B, dev)
+    u = 2.0 * loc['x0'][:, :2]
+    u_all = sharding.gather_inputs(u)
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        expect = 2.0 * torch.arange(B * world * 3, dtype=torch.float64).reshape(B * world, 3)[:, :2]
+        ok = bool(torch.equal(u_all.cpu(), expect))
+        print(json.dumps(dict(dry_run=True, n_gpus=world, gathered_ok=ok, **seen)))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=100, help='timed MPC steps (SURVEY 8d cfg-3: 100-step receding horizon)')
+    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--batch', type=int, default=None, help='instances per GPU (weak scaling; default 1024, cfg5: 512)')
+    ap.add_argument('--total-batch', type=int, default=None, help='instances in total, split evenly over the GPUs (strong scaling)')
+    ap.add_argument('--eps', type=float, default=1e-3)
+    ap.add_argument('--chunk', type=int, default=None, help='device loop: steps per kernel launch (default: the timed steps in equal launches of at most 25)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-other-path', action='store_true', help='skip the secondary measurements (other path, parity setting, strong-scaling / HBM / latency legs)')
+    ap.add_argument('--no-refactor-timing', action='store_true', help='skip the timing of the factorization alone (profiling runs: its launches carry the solve kernel\'s name)')
+    ap.add_argument('--path', default='device_loop', choices=['stepwise', 'device_loop'],
+                    help='stepwise: update()/solve()/output() per step from the host (the reference call pattern); '
+                         'device_loop: the same K steps inside mpcqp_mpc_loop (SURVEY 8f-1)')
+    ap.add_argument('--workload', default='cfg3', choices=['cfg3', 'cfg5', 'cfg2', 'notebook'],
+                    help='cfg3: 1024 x (12,4,30) (headline); cfg5: 512 x (20,8,100), tight state box (SURVEY 8d); '
+                         'cfg2 / notebook: single-controller latency legs only')
+    ap.add_argument('--hbm-leg-batch', type=int, default=4096, help='cfg3, 1 GPU: second leg with a working set beyond the Infinity Cache (0 = skip)')
+    ap.add_argument('--dry-run', action='store_true', help=argparse.SUPPRESS)
+    args = ap.parse_args()
+    self_launch_if_needed(args)
+
+    import torch
+    import torch.distributed as dist
+    rank, world, local_rank, dev, seen = init_distributed(args, torch, dist)
+    if args.dry_run:
+        return dry_run(args, rank, world, dev, seen, torch, dist)
+    if args.workload in ('cfg2', 'notebook'):
+        if rank == 0:
+            leg = latency_leg(args.workload)
+            print(json.dumps({'metric': 'MPCController.update() latency, one controller (BASELINE configs[1])', 'value': leg['update_us_median'], 'unit': 'us',
+                              'n_gpus': 1, 'higher_is_better': False, 'dtype': 'f64', 'data': 'synthetic', 'config': {'workload': leg['workload']}, 'latency': leg}))
+        if world > 1:
+            dist.barrier(); dist.destroy_process_group()
+        return
+    dims = WORKLOADS[args.workload][:4]
+    NX, NU, NP, XBOX = dims
+    if args.total_batch is not None:
+        if args.total_batch % world:
+            raise SystemExit('--total-batch must be divisible by the number of GPUs')
+        B, scaling = args.total_batch // world, 'strong'
+    else:
+        B, scaling = (args.batch if args.batch is not None else WORKLOADS[args.workload][4]), 'weak'
+
+    sh = Shard(args, dims, B, rank, world, dev, 0, torch, dist)
+    prob = sh.prob
+    res = sh.measure(args.path, args.steps, args.warmup)
+    elapsed, iters, refacts, solves = res['elapsed'], res['iters'], res['refacts'], res['solves']
+    infos = prob.infos()
+    n_solved = sum(1 for i in infos if i.status == 1)
+    samples = [dict(sh.sample_point(), eps=args.eps)]
+    other = None
+    if not args.no_other_path:
+        oname = 'stepwise' if args.path == 'device_loop' else 'device_loop'
+        o = sh.measure(oname, args.steps, args.warmup)
+        other = {'path': oname, 'value': B * world * args.steps / o['elapsed'], 'ms_per_step': 1e3 * o['elapsed'] / args.steps,
+                 'mean_admm_iters': o['iters'] / max(1, o['solves'])}
+    parity = None
+    if not args.no_other_path and args.eps > 1e-8:
+        # SURVEY 8(d): the same loop at the parity setting eps = 1e-9 (the tolerance the u* comparison is made at)
+        prob.update_settings(eps_abs=1e-9, eps_rel=1e-9)
+        pr = sh.measure(args.path, args.steps, args.warmup)
+        pinf = prob.infos()
+        parity = {'eps_abs': 1e-9, 'eps_rel': 1e-9, 'path': args.path, 'value': B * world * args.steps / pr['elapsed'],
+                  'ms_per_step': 1e3 * pr['elapsed'] / args.steps, 'mean_admm_iters': pr['iters'] / max(1, pr['solves']),
+                  'solved_fraction_last_step': sum(1 for i in pinf if i.status == 1) / B}
+        samples.append(dict(sh.sample_point(), eps=1e-9))
+        prob.update_settings(eps_abs=args.eps, eps_rel=args.eps)
+    # what one rho update costs: the block factorization of every instance, timed alone (mpcqp_refactor rewrites the factor
+    # that is already in place); the steady-state loop above needs none, the cold solve a few per instance
+    refactor_ms = None if args.no_refactor_timing else sh.refactor_ms()
+    roof = sh.roofline(res, args.path, args.workload) if rank == 0 else None
+    totals, cold, n, m = sh.totals, sh.cold, prob.n, prob.m
+    knames = {k: prob.kernel_name(loop=(k == 'loop')) for k in totals}
+
+    # ---- secondary legs (each on a problem set of its own; the headline shard is released first)
+    extra = {}
+    if not args.no_other_path:
+        del sh, prob
+        torch.cuda.empty_cache()
+        if world > 1 and scaling == 'weak' and args.workload == 'cfg3' and 1024 % world == 0:
+            # BASELINE configs[3] read literally: the SAME 1024 instances split over the N GPUs
+            s2 = Shard(args, dims, 1024 // world, rank, world, dev, 0, torch, dist)
+            r2 = s2.measure(args.path, args.steps, args.warmup)
+            extra['strong_scaling'] = {'scaling': 'strong', 'total_batch': 1024, 'batch_per_gpu': 1024 // world, 'path': args.path,
+                                       'value': 1024 * args.steps / r2['elapsed'], 'ms_per_step': 1e3 * r2['elapsed'] / args.steps,
+                                       'mean_admm_iters': r2['iters'] / max(1, r2['solves'])}
+            del s2
+            torch.cuda.empty_cache()
+        if world == 1 and args.workload == 'cfg3' and args.hbm_leg_batch and args.hbm_leg_batch != B:
+            # the same kernel on a working set beyond the 256 MiB Infinity Cache: an HBM-only roofline fraction
+            s3 = Shard(args, dims, args.hbm_leg_batch, rank, world, dev, 0, torch, dist)
+            r3 = s3.measure(args.path, min(args.steps, 25), min(args.warmup, 25) or 5)
+            ro3 = s3.roofline(r3, args.path, None)
+            extra['hbm_leg'] = {'batch': args.hbm_leg_batch, 'value': args.hbm_leg_batch * min(args.steps, 25) / r3['elapsed'], 'unit': 'QP-solves/s',
+                                'ms_per_step': 1e3 * r3['elapsed'] / min(args.steps, 25), 'mean_admm_iters': r3['iters'] / max(1, r3['solves']),
+                                'roofline': {k: ro3[k] for k in ('achieved', 'peak', 'unit', 'frac', 'working_set_bytes', 'fits_infinity_cache', 'kernel', 'kernel_ms', 'design_bytes_per_launch')}}
+            del s3
+            torch.cuda.empty_cache()
+        if rank == 0 and args.workload == 'cfg3':
+            try:
+                extra['latency'] = {'cfg2': latency_leg('cfg2', nsim=200), 'notebook': latency_leg('notebook', nsim=100)}
+            except Exception as e:
+                extra['latency'] = {'error': repr(e)}
+
+    if rank == 0:
         out = {
             'metric': 'QP-solves/sec (MPC steps/sec) at nx=%d nu=%d Np=%d; max |u*-u*_ref|' % (NX, NU, NP),
             'value': B * world * args.steps / elapsed,
@@ -323,6 +622,7 @@ def main():
             'ms_per_step': 1e3 * elapsed / args.steps,
             'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
+            'ranks_seen': seen['ranks_seen'], 'devices_seen': seen['devices_seen'], 'collective_backend': seen['backend'],
             'config': {'workload': '%s: %d random stable LTI MPC instances per GPU (nx=%d, nu=%d, Np=Nc=%d, n=%d, m=%d), '
                                    'warm-started receding horizon x+=Ad x+Bd u*+w' % ('cfg-3' if args.workload == 'cfg3' else 'cfg-5', B, NX, NU, NP, n, m),
                        'batch_per_gpu': B, 'total_batch': B * world, 'eps_abs': args.eps, 'eps_rel': args.eps, 'path': args.path,
@@ -333,30 +633,15 @@ def main():
             'refactorization': {'per_solve_timed_region': refacts / max(1, solves), 'ms_per_batch': refactor_ms, 'us_per_instance_amortised': (1e3 * refactor_ms / B) if refactor_ms else None,
                                 'note': 'block LDL factorization of all %d instances in one launch (one rho update each); 0 per solve in the warm '
                                         'receding-horizon loop, a few per instance during the cold solve' % B},
-            'roofline': {'bound': 'hbm', 'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK, 'traffic': traffic,
-                         'traffic_GBps': (traffic / (admm_ms / max(1, admm_launches) * 1e-3) / 1e9) if traffic else None,
-                         'bytes_model': 'design: what k_mpc_run streams per instance (mpcqp_get_stream_bytes) -- per ADMM iteration the KKT factor '
-                                        '(%s%s), per round the residual-evaluation inputs and the '
-                                        'iterate in/out of LDS, per solve the QP refresh and the write-out'
-                                        % ('forward matrices of N-1 stages, packed S^-1 of N stages and the stage tables once each, [G|G\'] once' if NX + NU <= 16
-                                           else 'packed S^-1 of N stages twice, one stage table per sweep, [G|G\'] by each sweeping wave',
-                                           '' if lds_state else '; iterate and metric vectors too: they do not fit LDS at this size'),
-                         'design_bytes_per_iter_per_qp': per_iter, 'design_bytes_per_round_per_qp': per_round, 'design_bytes_per_solve_per_qp': per_solve,
-                         'design_bytes_per_launch': design_bytes / max(1, admm_launches),
-                         'measured_bytes_per_iter_per_qp': pmc,
-                         'kernel': kname, 'kernel_ms': admm_ms / max(1, admm_launches), 'launches': admm_launches,
-                         'steps_per_launch': res.get('chunk', 1),
-                         'algorithmic_8d': {'bytes_per_launch': alg8d / max(1, admm_launches), 'bytes_per_iter_per_qp': b_it8d, 'nnzL': nnzL,
-                                            'GBps': alg8d / (admm_ms * 1e-3) / 1e9,
-                                            'note': 'SURVEY 8(d) generic sparse-LDL formula; charges 6n+10m vector doubles per iteration to HBM that this '
-                                                    'kernel keeps in LDS/registers, so it may exceed the HBM peak -- not used for frac'}},
-            'accounting': {'timed': {'iters': iters, 'rounds': checks, 'solves': solves, 'launches': admm_launches, 'kernel_ms_total': admm_ms},
-                           'process_totals': {prob.kernel_name(loop=(k == 'loop')): dict(iters=v[0], rounds=v[1], solves=v[2]) for k, v in totals.items()}},
+            'cold': cold,
+            'roofline': roof,
+            'accounting': {'timed': {'iters': iters, 'rounds': res['checks'], 'solves': solves, 'launches': res['launches'], 'kernel_ms_total': res['run_ms']},
+                           'process_totals': {knames[k]: dict(iters=v[0], rounds=v[1], solves=v[2]) for k, v in totals.items()}},
             'other_path': other,
             'parity_setting': parity,
         }
-        cpu, refs = cpu_legs(args.eps, samples if world == 1 else [], want_baseline=(not args.no_cpu_baseline and world == 1))
+        out.update(extra)
+        cpu, refs = cpu_legs(dims, args.eps, samples, want_baseline=not args.no_cpu_baseline)
         if cpu:
             out['cpu_baseline'] = cpu
         if refs:
@@ -369,6 +654,7 @@ def main():
             out['u_err'] = dict(err, definition='max over the sample of |u* - u*_ref|_inf; rel = / max |u*_ref|_inf',
                                 reference='oracle/osqp_ref.c at eps 1e-10 on the same (x0, u_-1): the QP the device solved in one more warm-started step',
                                 north_star_tolerance_rel=1e-6)
+        out['real_osqp'] = real_osqp_pin() if not args.no_cpu_baseline else {'osqp_available': osqp_available()}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -34,6 +34,7 @@ for name, d in sorted(res.items()):
          'hbm_bytes_per_launch': (2 * f + w) * 1024, 'mean_duration_us_under_pmc': d['FETCH_SIZE'][2] / nl / 1e3,
          'note': 'FETCH_SIZE doubled (gfx950 counts 128-B requests at 64 B for wide coalesced reads); includes Infinity-Cache hits'}
     if name in totals and totals[name]['iters']:
+        s['batch'] = bench.get('config', {}).get('batch_per_gpu')          # bench.py only applies the entry to runs of this batch
         s['admm_iters_all_launches'] = totals[name]['iters']
         s['hbm_bytes_per_iter_per_qp'] = s['hbm_bytes_per_launch'] * s['launches'] / totals[name]['iters']
     hit, miss = d.get('TCC_HIT_sum'), d.get('TCC_MISS_sum')

@@ -1,0 +1,36 @@
+"""`python bench.py --gpus 2` must start two ranks by itself (no torch.distributed.run around it), prove that two ranks on
+two distinct devices joined the process group, and go through scatter -> per-shard work -> all-gather.  Here on CPU: the
+same entry with the collective backend overridden to gloo and the solver left out (--dry-run); on the GPU box the driver
+runs the real thing."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(extra_env, *flags):
+    env = dict(os.environ, MPCQP_BENCH_BACKEND='gloo', **extra_env)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--dry-run'] + list(flags), env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout          # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus2_self_launches_two_ranks():
+    out = _run({}, '--gpus', '2')
+    assert out['n_gpus'] == 2 and out['ranks_seen'] == 2 and out['devices_seen'] == 2
+    assert out['backend'] == 'gloo' and out['gathered_ok'] is True
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus1_stays_in_process():
+    out = _run({}, '--gpus', '1')
+    assert out['n_gpus'] == 1 and out['ranks_seen'] == 1 and out['devices_seen'] == 1 and out['gathered_ok'] is True
