@@ -55,8 +55,10 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #include "mpcqp_qp.h"
 #include "mpcqp_factor.h"
 #include "mpcqp_sweeps.h"
+#include "mpcqp_dense.h"
 #include "mpcqp_border.h"
 #include "mpcqp_phases.h"
+#include "mpcqp_tiny.h"
 #include "mpcqp_kernels.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -147,6 +149,7 @@ static Lay make_layout(int nx, int nu, int Np, int Nc, int soft) {
     L.ffwd = L.NB == 16 ? FactorFmt<16>::FWD : FactorFmt<32>::FWD;
     L.ftab = L.NB == 16 ? FactorFmt<16>::TAB : FactorFmt<32>::TAB;
     L.tsz = L.m + L.N * L.NB;                          // [W (m) | Tc (N*NB)]; mpcqp_create widens it where the factorization needs more
+    L.NR = L.N * L.nb; L.dld = L.NR | 1;               // dense mode (decided in mpcqp_create): unknowns, odd LDS row stride
     return L;
 }
 
@@ -185,7 +188,16 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     const Lay &L = h->L;
     Ptrs &P = h->P; memset(&P, 0, sizeof(P));
     size_t B = (size_t)batch;
-    P.fsz = (long long)L.fhead + (long long)L.N * L.fstage;
+    // Small problems keep the iterate x, z, y in LDS behind the common block (four workgroups per CU: 40 KB each); larger
+    // ones keep it in L2/HBM.
+    const size_t state_doubles = (size_t)(L.n + 2 * L.m);
+    h->lds_state = sizeof(double) * ((size_t)smem_common_doubles(L) + state_doubles) <= 40 * 1024 && L.m <= 4 * NT && L.N * L.NB <= 2 * NT && L.n_u + L.nu <= NT;      // (the owner map of the parallel phases: two state elements and one input element per thread)
+    // The smallest ones (the reference's own examples) solve the KKT system with a register-resident dense inverse (mpcqp_dense.h).
+    bool dense = h->lds_state && L.NB == 16 && !L.border && L.NR <= DenseFmt::ROWS;
+    if (const char *e = getenv("MPCQP_DENSE")) dense = dense && atoi(e) != 0;      // development switch (A/B against the block sweeps)
+    h->L.dense = dense ? 1 : 0;
+    if (dense) h->L.tsz += DenseFmt::SCRATCH;
+    P.fsz = dense ? (long long)DenseFmt::DOUBLES : (long long)L.fhead + (long long)L.N * L.fstage;
     int rc = 0;
     rc |= dalloc(h, &P.model, B * L.model_sz); rc |= dalloc(h, &P.step, B * L.step_sz);
     rc |= dalloc(h, &P.D, B * L.n); rc |= dalloc(h, &P.E, B * L.m); rc |= dalloc(h, &P.c, B);
@@ -204,12 +216,9 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->ncu = prop.multiProcessorCount; }
     if (const char *e = getenv("MPCQP_BALANCE")) h->auto_balance = atoi(e) != 0;      // development switch
     if (rc) { std::string msg = g_err; mpcqp_destroy(h); return fail(MPCQP_ERR_HIP, msg); }
-    // Small problems keep the iterate x, z, y in LDS behind the common block (four workgroups per CU: 40 KB each); larger
-    // ones keep it in L2/HBM.  The factorization's workspace starts at the work area T, the last part of the common block,
+    // The factorization's workspace starts at the work area T, the last part of the common block,
     // and may run on into the iterate area (dead while a factorization runs); T is widened only where even that is short.
-    const int fws = L.NB == 16 ? FactorCfg<16>::WS : FactorCfg<32>::WS;
-    const size_t state_doubles = (size_t)(L.n + 2 * L.m);
-    h->lds_state = sizeof(double) * ((size_t)smem_common_doubles(L) + state_doubles) <= 40 * 1024 && L.m <= 4 * NT && L.N * L.NB <= 2 * NT && L.n_u + L.nu <= NT;      // (the owner map of the parallel phases: two state elements and one input element per thread)
+    const int fws = dense ? L.NR * L.dld + 2 * DenseFmt::ROWS : (L.NB == 16 ? FactorCfg<16>::WS : FactorCfg<32>::WS);
     const int avail = L.tsz + (h->lds_state ? (int)state_doubles : 0);
     if (avail < fws) h->L.tsz += fws - avail;
     h->smem_setup = sizeof(double) * ((size_t)smem_common_doubles(h->L) + (h->lds_state ? state_doubles : 0));      // every kernel gets the full block
@@ -402,21 +411,21 @@ extern "C" int mpcqp_update_settings(mpcqp_handle *h, const mpcqp_settings *s) {
     return MPCQP_OK;
 }
 
-template <int NB, bool LDSS, int NXT, int NUT, bool BORDER>
+template <int NB, bool LDSS, int NXT, int NUT, int MODE>
 static int launch_run_t(mpcqp_handle *h, const RunArgs &R) {
     RunKArgs A; A.L = h->L; A.P = h->P; A.S = h->S; A.R = R;
     if (R.nsteps > 0) {
-        if (set_smem(k_mpc_run<NB, LDSS, NXT, NUT, BORDER, true>, h->smem_solve)) return MPCQP_ERR_HIP;
-        hipLaunchKernelGGL((k_mpc_run<NB, LDSS, NXT, NUT, BORDER, true>), dim3(h->batch), dim3(NT), h->smem_solve, h->stream, A);
+        if (set_smem(k_mpc_run<NB, LDSS, NXT, NUT, MODE, true>, h->smem_solve)) return MPCQP_ERR_HIP;
+        hipLaunchKernelGGL((k_mpc_run<NB, LDSS, NXT, NUT, MODE, true>), dim3(h->batch), dim3(NT), h->smem_solve, h->stream, A);
     } else {
-        if (set_smem(k_mpc_run<NB, LDSS, NXT, NUT, BORDER, false>, h->smem_solve)) return MPCQP_ERR_HIP;
-        hipLaunchKernelGGL((k_mpc_run<NB, LDSS, NXT, NUT, BORDER, false>), dim3(h->batch), dim3(NT), h->smem_solve, h->stream, A);
+        if (set_smem(k_mpc_run<NB, LDSS, NXT, NUT, MODE, false>, h->smem_solve)) return MPCQP_ERR_HIP;
+        hipLaunchKernelGGL((k_mpc_run<NB, LDSS, NXT, NUT, MODE, false>), dim3(h->batch), dim3(NT), h->smem_solve, h->stream, A);
     }
     return 0;
 }
 template <int NB, bool LDSS>
 static int launch_run_generic(mpcqp_handle *h, const RunArgs &R) {
-    return h->L.border ? launch_run_t<NB, LDSS, 0, 0, true>(h, R) : launch_run_t<NB, LDSS, 0, 0, false>(h, R);
+    return h->L.border ? launch_run_t<NB, LDSS, 0, 0, MODE_BORDER>(h, R) : launch_run_t<NB, LDSS, 0, 0, MODE_CHAIN>(h, R);
 }
 
 // Load balancing across CUs.  All workgroups of a launch are resident at once (a few per CU) and an instance keeps its
@@ -475,8 +484,9 @@ static int launch_run(mpcqp_handle *h, RunArgs R, int plain_iters) {
         HIPCHK(hipEventRecord(h->ev0[e], h->stream));
     }
     int rc;
-    if (L.NB == 16 && h->lds_state && L.nx == 12 && L.nu == 4 && !L.border) rc = launch_run_t<16, true, 12, 4, false>(h, R);
-    else if (L.NB == 32 && !h->lds_state && L.nx == 20 && L.nu == 8 && !L.border) rc = launch_run_t<32, false, 20, 8, false>(h, R);
+    if (L.dense) rc = launch_run_t<16, true, 0, 0, MODE_DENSE>(h, R);
+    else if (L.NB == 16 && h->lds_state && L.nx == 12 && L.nu == 4 && !L.border) rc = launch_run_t<16, true, 12, 4, MODE_CHAIN>(h, R);
+    else if (L.NB == 32 && !h->lds_state && L.nx == 20 && L.nu == 8 && !L.border) rc = launch_run_t<32, false, 20, 8, MODE_CHAIN>(h, R);
     else if (L.NB == 16) rc = h->lds_state ? launch_run_generic<16, true>(h, R) : launch_run_generic<16, false>(h, R);
     else rc = h->lds_state ? launch_run_generic<32, true>(h, R) : launch_run_generic<32, false>(h, R);
     if (rc) return rc;
@@ -722,11 +732,12 @@ extern "C" int mpcqp_get_stream_bytes(mpcqp_handle *h, int64_t *per_iter, int64_
     const Lay &L = h->L;
     const int64_t n = L.n, m = L.m, nq = L.n_x + L.n_u, NB = L.NB;
     const int64_t sinv = L.fstage - L.ffwd - L.ftab;
-    int64_t it = !L.ffwd ? 2 * (int64_t)L.N * sinv + (int64_t)L.N * L.ftab + 2 * (int64_t)L.fhead   // S^-1-only build: S^-1 twice, one of the two tables per sweep, [G | G'] by each sweeping wave
+    int64_t it = L.dense ? 0 /* K^-1 sits in registers for the round */ : !L.ffwd ? 2 * (int64_t)L.N * sinv + (int64_t)L.N * L.ftab + 2 * (int64_t)L.fhead   // S^-1-only build: S^-1 twice, one of the two tables per sweep, [G | G'] by each sweeping wave
                          : (int64_t)(L.N - 1) * L.ffwd + (int64_t)L.N * sinv + (int64_t)(L.N - 1) * L.ftab + L.fhead;   // forward matrices once, S^-1 once, the tables, G / G' once each
     if (!h->lds_state) it += (2 * n + 4 * m) /* x, z, y read + written */ + (m + L.n_x) /* omega */ + (n + L.n_x) /* s */ + nq /* q */;
     if (L.border) it += 2 * (int64_t)L.nu * L.N * NB;
     int64_t rd = (L.model_sz - L.hot_sz) + 2 * n + 2 * m /* D, s, E, omega */ + n + m /* dx, dy */;
+    if (L.dense) rd += DenseFmt::DOUBLES;               // the round's load of K^-1 into registers
     rd += h->lds_state ? 2 * (n + 2 * m) /* iterate in and out of LDS */ + (m + L.n_x) + (n + L.n_x) + nq : (n + 2 * m);
     int64_t sv = L.hot_sz + L.step_sz + 3 * m /* E, types, omega */ + nq + 2 * (n + m) /* solution out, iterate read */;
     if (per_iter) *per_iter = 8 * it;
@@ -740,9 +751,9 @@ extern "C" int mpcqp_get_stream_bytes(mpcqp_handle *h, int64_t *per_iter, int64_
 extern "C" int mpcqp_kernel_name(mpcqp_handle *h, int loop, char *buf, int buflen) {
     if (!h || !buf || buflen < 1) return fail(MPCQP_ERR_ARG, "null argument");
     const Lay &L = h->L;
-    const bool spec = !L.border && ((L.NB == 16 && h->lds_state && L.nx == 12 && L.nu == 4) || (L.NB == 32 && !h->lds_state && L.nx == 20 && L.nu == 8));
-    snprintf(buf, (size_t)buflen, "k_mpc_run<%d,%s,%d,%d,%s,%s>", L.NB, h->lds_state ? "true" : "false", spec ? L.nx : 0, spec ? L.nu : 0,
-             L.border ? "true" : "false", loop ? "true" : "false");
+    const bool spec = !L.border && !L.dense && ((L.NB == 16 && h->lds_state && L.nx == 12 && L.nu == 4) || (L.NB == 32 && !h->lds_state && L.nx == 20 && L.nu == 8));
+    snprintf(buf, (size_t)buflen, "k_mpc_run<%d,%s,%d,%d,%d,%s>", L.NB, h->lds_state ? "true" : "false", spec ? L.nx : 0, spec ? L.nu : 0,
+             L.dense ? MODE_DENSE : L.border ? MODE_BORDER : MODE_CHAIN, loop ? "true" : "false");
     return MPCQP_OK;
 }
 

@@ -121,7 +121,8 @@ __device__ void kkt_solve(const Ctx &c, const double *om, const double *sv, doub
     }
     __syncthreads();
     if (L.border) border_pre<NB>(L, bp.Bb, bp.Zb, bp.Sig, Tc, ubar, bp.red);
-    kkt_core<NB>(core_args(L, F, om), Tc);
+    if (L.dense) dense_core<NB>(L, F, Tc, Tc + L.N * NB, dense_slot<NB>(L));
+    else kkt_core<NB>(core_args(L, F, om), Tc);
     if (L.border) border_post(L, NB, Tc, ubar);
     for (int idx = threadIdx.x; idx < L.N * NB; idx += NT) {
         int k = idx / NB, a = idx % NB;

@@ -1,0 +1,145 @@
+// mpcqp_dense.h -- part of libmpcqp_hip (included by mpcqp.hip, one translation unit).
+// Small problems (the reference's own examples: point mass, cart-pole -- N (nx+nu) <= 128): the KKT solve of an ADMM iteration
+// as ONE dense mat-vec with the explicit inverse of the reduced KKT matrix, held in REGISTERS for a whole round.
+//
+// Why: the block-tridiagonal sweeps are a chain of N dependent stage steps (~250 shader cycles each, twice per iteration);
+// a single small QP therefore spends 8 us per ADMM iteration on one CU while 255 CUs idle -- three times slower than one CPU
+// core.  For NR = N (nx + nu) <= 128 unknowns the inverse K^-1 is NR^2 <= 16384 doubles = 64 per thread: every thread keeps one
+// half-row of K^-1 in 128 VGPRs, the right-hand side is read from LDS (wave-uniform addresses: broadcasts), and the "solve" is
+// 64 FMAs per thread plus one exchange of the two half-row sums -- a few hundred cycles, no dependent chain, no factor stream.
+// Per round the instance reads its K^-1 once (128 KB); per iteration nothing.
+//
+// Variable order of the dense system: stage-major COMPACT, v = k (nx + nu) + a (the padded order of Tc without the padding).
+// Factor record (DenseFmt): F[j * NT + t] = K^-1[row(t)][64 half(t) + j],  row(t) = t >> 1, half(t) = t & 1, j < 64 --
+// the order the threads load it in (coalesced), zero beyond NR and in rows/columns of absent inputs (stages >= NcT carry no u).
+// The two halves of a row sit in NEIGHBOURING LANES: their sums meet through one DPP swap, not through LDS and a barrier.
+#pragma once
+
+struct DenseFmt {
+    static constexpr int ROWS = 128, JW = 64;                 // row slots, columns per thread
+    static constexpr int DOUBLES = JW * NT;                   // doubles per instance
+    static constexpr int HPAD = 2;                            // the second half of the compact vector starts HPAD doubles late: lanes
+                                                              // of the two halves read cv[j] and cv[64 + HPAD + j] in one instruction -- other banks
+    static constexpr int CV = ROWS + HPAD + 6;                // compact right-hand side (16-byte multiples)
+    static constexpr int SCRATCH = 4 * ROWS + 64;             // LDS doubles: rhs | solution | two exchange vectors of the small-problem iteration
+};
+__device__ __forceinline__ int dense_cv_index(int v) { return v + (v >= DenseFmt::JW ? DenseFmt::HPAD : 0); }
+// swap with the neighbouring lane (lane ^ 1): DPP quad_perm [1,0,3,2]
+__device__ __forceinline__ double lane_swap1(double x) {
+    const long long xi = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_mov_dpp((int)xi, 0xB1, 0xF, 0xF, false), hi = __builtin_amdgcn_mov_dpp((int)(xi >> 32), 0xB1, 0xF, 0xF, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+static_assert(NT == 256, "the dense path maps 128 rows x 2 column halves onto 256 threads");
+
+__device__ __forceinline__ bool dense_dead(const Lay &L, int v) {       // variable slot v = (k, a) without a variable
+    const int k = v / L.nb, a = v - k * L.nb;
+    return a >= L.nx && k >= L.NcT;
+}
+
+// K (dense, SPD) assembled entry by entry from the stage blocks, inverted in place by Gauss-Jordan sweeps in LDS (NR steps, the
+// pivot row and column copied out first so that every entry updates in place), written out in register order.
+// W: LDS, NR * ld + 2 * ROWS doubles (ld = L.dld, odd: column accesses are bank-conflict free).  Returns 1 on a non-positive pivot.
+__device__ int factor_dense(const Ctx &c, const double *om, const double *sv, double cc, double *F, double *W, int *iflag) {
+    const Lay &L = c.L;
+    const int tid = threadIdx.x, NR = L.NR, ld = L.dld, nb = L.nb;
+    double *prow = W + NR * ld, *pcol = prow + DenseFmt::ROWS;
+    if (tid == 0) *iflag = 0;
+    __syncthreads();
+    for (int e = tid; e < NR * NR; e += NT) {
+        const int i = e / NR, j = e - i * NR;
+        const int ki = i / nb, ai = i - ki * nb, kj = j / nb, aj = j - kj * nb;
+        double v = 0.0;
+        if (ki == kj) v = kkt_diag_entry(c, om, sv, cc, ki, ai, aj);
+        else if (ki == kj + 1) v = kkt_sub_entry(c, om, cc, kj, ai, aj);
+        else if (kj == ki + 1) v = kkt_sub_entry(c, om, cc, ki, aj, ai);
+        W[i * ld + j] = v;
+    }
+    __syncthreads();
+    const int i = tid & (DenseFmt::ROWS - 1), h = tid >> 7;
+    const int j0 = DenseFmt::JW * h, j1 = min(j0 + DenseFmt::JW, NR);
+    for (int pv = 0; pv < NR; ++pv) {
+        if (tid < NR) { prow[tid] = W[pv * ld + tid]; pcol[tid] = W[tid * ld + pv]; }
+        __syncthreads();
+        double d = prow[pv];
+        if (!(d > 0.0)) { if (tid == 0) *iflag = 1; d = 1e-300; }
+        const double inv = 1.0 / d;
+        if (i < NR) {
+            double *row = W + i * ld;
+            if (i == pv) { for (int j = j0; j < j1; ++j) row[j] = (j == pv) ? inv : prow[j] * inv; }
+            else {
+                const double f = pcol[i] * inv;
+                for (int j = j0; j < j1; ++j) row[j] = (j == pv) ? -f : row[j] - f * prow[j];
+            }
+        }
+        __syncthreads();
+    }
+    const int ro = tid >> 1, co = DenseFmt::JW * (tid & 1);   // register order: row, first column of this thread
+    const bool dead_r = ro >= NR || dense_dead(L, ro);
+    for (int j = 0; j < DenseFmt::JW; ++j) {
+        const int cidx = co + j;
+        double v = 0.0;
+        if (!dead_r && cidx < NR && !dense_dead(L, cidx)) v = 0.5 * (W[ro * ld + cidx] + W[cidx * ld + ro]);
+        F[(size_t)j * NT + tid] = v;
+    }
+    __syncthreads();
+    return *iflag;
+}
+
+// This thread's half-row of K^-1 (the round's resident copy).
+__device__ __forceinline__ void dense_load(const double *F, double *Kreg) {
+    cgdouble *Fg = (cgdouble *)F;
+#pragma unroll
+    for (int j = 0; j < DenseFmt::JW; ++j) Kreg[j] = Fg[(size_t)j * NT + threadIdx.x];
+}
+
+// The half-row dot product of this thread with the compact vector cvec (LDS), both halves summed: every lane pair (2v, 2v+1)
+// returns row v of K^-1 cvec.  REGS: K^-1 from the registers loaded by dense_load; else streamed from F.
+template <bool REGS>
+__device__ __forceinline__ double dense_row(const double *Kreg, const double *F, const double *cvec) {
+    constexpr int BATCH = 16;                                 // LDS values in flight
+    const int tid = threadIdx.x;
+    const double *cv = cvec + (tid & 1) * (DenseFmt::JW + DenseFmt::HPAD);
+    cgdouble *Fg = (cgdouble *)F;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    // The reads are issued in groups and fenced: left alone, a scheduler that is short of registers (the inverse takes 128 of
+    // them) waits for every single read before the two FMAs that use it -- 32 LDS round trips per mat-vec instead of 4.
+    // 8-byte reads on purpose: every lane of a half reads the SAME address, which the LDS serves as a broadcast for 4- and 8-byte
+    // reads; 16-byte reads of one address by 32 lanes are serialised (measured: 260 cycles per instruction).
+#pragma unroll
+    for (int jb = 0; jb < DenseFmt::JW; jb += BATCH) {
+        double c[BATCH];
+#pragma unroll
+        for (int q = 0; q < BATCH; ++q) c[q] = cv[jb + q];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < BATCH; q += 4) {
+            const int j = jb + q;
+            const double k0 = REGS ? Kreg[j] : Fg[(size_t)j * NT + tid], k1 = REGS ? Kreg[j + 1] : Fg[(size_t)(j + 1) * NT + tid];
+            const double k2 = REGS ? Kreg[j + 2] : Fg[(size_t)(j + 2) * NT + tid], k3 = REGS ? Kreg[j + 3] : Fg[(size_t)(j + 3) * NT + tid];
+            a0 = fma(k0, c[q], a0); a1 = fma(k1, c[q + 1], a1); a2 = fma(k2, c[q + 2], a2); a3 = fma(k3, c[q + 3], a3);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    const double part = (a0 + a1) + (a2 + a3);
+    return part + lane_swap1(part);
+}
+
+// Tc <- K^-1 Tc on the padded stage-major vector Tc (stride NB): gather to compact order, row dot products, scatter
+// (verification kernel).  myidx: Tc index of compact slot threadIdx.x (threads < NR).  scr: LDS, DenseFmt::CV doubles.
+template <int NB>
+__device__ __forceinline__ void dense_core(const Lay &L, const double *F, double *Tc, double *scr, int myidx) {
+    const int tid = threadIdx.x;
+    if (tid < DenseFmt::ROWS) scr[dense_cv_index(tid)] = tid < L.NR ? Tc[myidx] : 0.0;
+    __syncthreads();
+    const double r = dense_row<false>(nullptr, F, scr);
+    const int v = tid >> 1, k = v / L.nb;
+    if (!(tid & 1) && v < L.NR) Tc[k * NB + (v - k * L.nb)] = r;
+    __syncthreads();
+}
+template <int NB>
+__device__ __forceinline__ int dense_slot(const Lay &L) {    // Tc index of this thread's compact slot
+    const int t = threadIdx.x < L.NR ? (int)threadIdx.x : 0;
+    const int k = t / L.nb;
+    return k * NB + (t - k * L.nb);
+}

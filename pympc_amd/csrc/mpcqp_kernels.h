@@ -82,18 +82,19 @@ __device__ __noinline__ void run_factor_phase() {
     RunSmem r = run_smem<false>(L, P);                       // (the common LDS area comes first in both layouts)
     const int b = inst_of(P.perm);
     Ctx c{L, r.S.hot, P.model + (size_t)b * L.model_sz + L.hot_sz};
-    factor_all<NB>(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], P.F + (size_t)b * P.fsz, r.S.T, r.S.iflag,
-                   border_ptrs(L, P, r.S));
+    if (L.dense) factor_dense(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], P.F + (size_t)b * P.fsz, r.S.T, r.S.iflag);
+    else factor_all<NB>(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], P.F + (size_t)b * P.fsz, r.S.T, r.S.iflag,
+                        border_ptrs(L, P, r.S));
 }
 
-template <int NB, bool LDSSTATE, int NXT, int NUT, bool BORDER>
+template <int NB, bool LDSSTATE, int NXT, int NUT, int MODE>
 __device__ __noinline__ void run_admm_phase(int iters) {
     const RunKArgs &A = run_kargs();
     const Lay &L = A.L; const Ptrs &P = A.P;
     RunSmem r = run_smem<LDSSTATE>(L, P);
     HotPtrs hp; hp.model = P.model; hp.step = P.step; hp.omega = P.omega; hp.s = P.s; hp.qv = P.qv; hp.F = P.F; hp.c = P.c;
     hp.Bb = P.Bb; hp.Zb = P.Zb; hp.Sig = P.Sig; hp.x = P.x; hp.z = P.z; hp.y = P.y; hp.dx = P.dx; hp.dy = P.dy; hp.perm = P.perm; hp.fsz = P.fsz;
-    admm_body<NB, LDSSTATE, NXT, NUT, BORDER>(L, hp, r.S, r.X, r.Z, r.Y, A.S.alpha, __builtin_amdgcn_readfirstlane(iters));
+    admm_body<NB, LDSSTATE, NXT, NUT, MODE>(L, hp, r.S, r.X, r.Z, r.Y, A.S.alpha, __builtin_amdgcn_readfirstlane(iters));
 }
 
 template <int NB, bool LDSSTATE>
@@ -110,8 +111,8 @@ __device__ __noinline__ int run_check_phase(int iter, int mode) {
     return check_body<NB>(A.L, A.P, A.S, r.S, __builtin_amdgcn_readfirstlane(iter), __builtin_amdgcn_readfirstlane(mode), r.X, r.Z, r.Y);
 }
 
-template <int NB, bool LDSSTATE, int NXT, int NUT, bool BORDER, bool LOOP>
-__global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_mpc_run(RunKArgs A_) {
+template <int NB, bool LDSSTATE, int NXT, int NUT, int MODE, bool LOOP>
+__global__ __launch_bounds__(NT, (MODE == MODE_DENSE ? 1 : NB <= 16 ? 4 : 2)) void k_mpc_run(RunKArgs A_) {
     const RunKArgs &A = run_kargs();
     const Lay &L = A.L; const Ptrs &P = A.P; const RunArgs &R = A.R;
     if (!LOOP && R.part == 2 && (int)blockIdx.x >= *R.npending) return;
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(NT, (NB <= 16 ? 4 : 2)) void k_mpc_run(RunKArgs A_)
         PHASE_CLOCK(0)
         while (!term) {
             const int nxt = next_stop(iter, R.max_iter, R.chk, R.rho_every);
-            run_admm_phase<NB, LDSSTATE, NXT, NUT, BORDER>(nxt - iter);
+            run_admm_phase<NB, LDSSTATE, NXT, NUT, MODE>(nxt - iter);
             iter = nxt;
             __syncthreads();
             PHASE_CLOCK(1)

@@ -25,6 +25,8 @@ struct Lay {
     int fstage;                   // doubles per factor stage (FactorFmt<NB>::STAGE): [forward matrix | packed S^-1 | table]
     int fhead, ffwd, ftab;        // doubles of the per-instance factor header ([G | G']) / of a stage's forward matrix / of its off-diagonal table (hybrid)
     int tsz;                      // LDS work vector length: max(m, 4*NB*NB)
+    int dense;                    // 1: small problem -- the KKT solve is a dense mat-vec with K^-1 held in registers (mpcqp_dense.h)
+    int NR, dld;                  // dense: unknowns N*(nx+nu) of the reduced KKT system; LDS row stride of the inversion workspace (odd)
 };
 
 struct Ptrs {

@@ -118,7 +118,8 @@ __global__ __launch_bounds__(NT) void k_setup(Lay L, Ptrs P, mpcqp_settings S_) 
     for (int j = tid; j < L.n; j += NT) sv[j] = S_.sigma / (D[j] * D[j]);
     if (tid == 0) { P.c[b] = cc; P.rho[b] = rho; }
     __syncthreads();
-    int bad = factor_all<NB>(c, om, sv, cc, P.F + (size_t)b * P.fsz, S.T, S.iflag, border_ptrs(L, P, S));
+    int bad = L.dense ? factor_dense(c, om, sv, cc, P.F + (size_t)b * P.fsz, S.T, S.iflag)
+                      : factor_all<NB>(c, om, sv, cc, P.F + (size_t)b * P.fsz, S.T, S.iflag, border_ptrs(L, P, S));
     // cold start
     for (int j = tid; j < L.n; j += NT) { P.x[(size_t)b * L.n + j] = 0.0; P.xo[(size_t)b * L.n + j] = 0.0; }
     for (int r = tid; r < L.m; r += NT) { P.z[(size_t)b * L.m + r] = 0.0; P.y[(size_t)b * L.m + r] = 0.0; P.yo[(size_t)b * L.m + r] = 0.0; }
@@ -700,8 +701,13 @@ __device__ __forceinline__ void gown_update(const Lay &L, const double *hot, con
 
 // `iters` ADMM iterations of this workgroup's instance.  Expects the hot model prefix and the step data in LDS
 // (load_common) and, with LDSSTATE, X/Z/Y carved behind the common area.
-template <int NB, bool LDSSTATE, int NXT, int NUT, bool BORDER>
+// MODE: how the KKT system is solved -- block-tridiagonal sweeps (MODE_CHAIN), the same with the bordered correction of a
+// control horizon Nc < Np (MODE_BORDER), or the dense register-resident inverse of small problems (MODE_DENSE, mpcqp_dense.h).
+enum { MODE_CHAIN = 0, MODE_BORDER = 1, MODE_DENSE = 2 };
+template <int NB> __device__ __forceinline__ void admm_tiny(const Lay &, const HotPtrs &, Smem &, double *, double *, double *, double, int);      // mpcqp_tiny.h
+template <int NB, bool LDSSTATE, int NXT, int NUT, int MODE>
 __device__ __forceinline__ void admm_body(const Lay &L, const HotPtrs &P, Smem &S, double *X, double *Z, double *Y, double alpha, int iters) {
+    if constexpr (MODE == MODE_DENSE) { admm_tiny<NB>(L, P, S, X, Z, Y, alpha, iters); return; }      // register-resident iterate and inverse
     const int b = inst_of(P.perm), tid = threadIdx.x;
     double *gx = P.x + (size_t)b * L.n, *gz = P.z + (size_t)b * L.m, *gy = P.y + (size_t)b * L.m;
     double *W = S.T, *Tc = S.T + L.m;
@@ -714,6 +720,7 @@ __device__ __forceinline__ void admm_body(const Lay &L, const HotPtrs &P, Smem &
     gdouble *dxg = (gdouble *)(P.dx + (size_t)b * L.n), *dyg = (gdouble *)(P.dy + (size_t)b * L.m);
     const double *F = P.F + (size_t)b * P.fsz;
     const double cc = P.c[b];
+    constexpr bool BORDER = MODE == MODE_BORDER;
     OwnRegs hr;
     if (LDSSTATE) own_load<NB, NXT, NUT>(L, gom, gsv, gqv, cc, hr);
 #ifndef MPCQP_ABL_NOPAR

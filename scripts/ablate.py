@@ -9,8 +9,7 @@ if os.environ.get('MPCQP_LIB'):            # ablation build: point the loader at
 from pympc_amd.solver import BatchProblem
 B = int(os.environ.get('B', 1024)); iters = int(os.environ.get('ITERS', 100))
 NX, NU, NP = (int(os.environ.get(k, v)) for k, v in (('NX', 12), ('NU', 4), ('NP', 30)))
-bench.NX, bench.NU, bench.NP = NX, NU, NP
-d = bench.make_instances(0, B)
+d = bench.make_instances((NX, NU, NP, float(os.environ.get('XBOX', 10.0))), 0, B)
 prob = BatchProblem(B, NX, NU, NP)
 eye = lambda k, s: np.broadcast_to(s * np.eye(k), (B, k, k))
 ones = lambda k, s: np.full((B, k), s)

@@ -4,7 +4,7 @@ import numpy as np, torch
 import bench
 from pympc_amd.solver import BatchProblem
 B, nx, nu, Np = 1024, 12, 4, 30
-d = bench.make_instances(0, B)
+d = bench.make_instances(bench.WORKLOADS['cfg3'][:4], 0, B)
 prob = BatchProblem(B, nx, nu, Np, eps_abs=1e-3, eps_rel=1e-3)
 eye = lambda k, s: np.broadcast_to(s * np.eye(k), (B, k, k))
 ones = lambda k, s: np.full((B, k), s)

@@ -1,0 +1,7 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT; O=gpurun_out
+timeout 300 python -m pytest tests/test_gpu_backends.py -m gpu -x -q 2>&1 | tail -15
+for f in cart_pole point_mass; do
+  MPCQP_LIB=scripts/diag/lib_timing.so timeout 120 python scripts/diag_small.py $f 200 2>&1 | grep -v amdgpu.ids | tail -3
+done
+timeout 300 python bench.py --workload cfg2 2>/dev/null

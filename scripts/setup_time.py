@@ -4,8 +4,7 @@ import numpy as np, torch
 import bench
 from pympc_amd.solver import BatchProblem
 for (nx, nu, Np, B, xb) in [(12, 4, 30, 1024, 10.0), (20, 8, 100, 512, 1.0)]:
-    bench.NX, bench.NU, bench.NP, bench.XBOX = nx, nu, Np, xb
-    d = bench.make_instances(0, B)
+    d = bench.make_instances((nx, nu, Np, xb), 0, B)
     prob = BatchProblem(B, nx, nu, Np)
     eye = lambda k, s: np.broadcast_to(s * np.eye(k), (B, k, k))
     ones = lambda k, s: np.full((B, k), s)

@@ -1,0 +1,150 @@
+"""The KKT system of an ADMM iteration has more than one solver on the device -- the block-tridiagonal sweeps (every size),
+the dense register-resident inverse (N (nx+nu) <= 128: the reference's own examples) -- and mpcqp_create picks one by problem
+size.  Everything must hold for EVERY backend a problem is eligible for: the same tests as tests/test_gpu_parity.py, with
+the development switches MPCQP_DENSE=0/1 forcing the choice, plus bit-level agreement of the paths that must not depend on it."""
+import os
+import warnings
+from contextlib import contextmanager
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from util import golden_names, load_golden, golden_kwargs, golden_csc, apply_attrs
+
+pytestmark = pytest.mark.gpu
+
+
+@contextmanager
+def backend(**env):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        yield
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _dense_eligible(name):
+    g = load_golden(name)
+    kw = golden_kwargs(g)
+    nx, nu = np.atleast_2d(kw['Bd']).shape if np.ndim(kw['Bd']) == 2 else (np.asarray(kw['Ad']).shape[0], 1)
+    Np = kw['Np']
+    return (Np + 1) * (nx + nu) <= 128 and kw.get('Nc', Np) in (None, Np)
+
+
+SMALL = [n for n in golden_names() if _dense_eligible(n)]
+BACKENDS = [dict(MPCQP_DENSE=0), dict(MPCQP_DENSE=1)]
+IDS = ['sweeps', 'dense']
+
+
+def _ctrl(kw, oracle=False, **settings):
+    from pympc_amd import MPCController
+    K = apply_attrs(MPCController(**kw), kw)
+    if oracle:
+        from oracle.osqp_oracle import OSQP
+        K.prob = OSQP()
+    K.solver_settings = dict(settings)
+    return K
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(1e-300, np.abs(b).max())
+
+
+def test_some_fixture_is_small_enough():
+    assert len(SMALL) >= 2, SMALL
+
+
+@pytest.mark.parametrize('env', BACKENDS, ids=IDS)
+@pytest.mark.parametrize('name', SMALL)
+def test_backend_is_the_one_asked_for(name, env):
+    with backend(**env):
+        K = _ctrl(golden_kwargs(load_golden(name))); K.setup(solve=False)
+        kn = K.prob.batch_problem.kernel_name(loop=False)
+    assert kn.split(',')[4] == ('2' if env['MPCQP_DENSE'] else '0'), kn
+
+
+@pytest.mark.parametrize('env', BACKENDS, ids=IDS)
+@pytest.mark.parametrize('name', SMALL)
+def test_kkt_solve_matches_dense_numpy(name, env):
+    g = load_golden(name)
+    with backend(**env):
+        K = _ctrl(golden_kwargs(g)); K.setup(solve=False)
+        bp = K.prob.batch_problem
+        D, E, c, rho = bp.scaling()
+        U = sp.triu(golden_csc(g, 'P')).toarray(); P = U + np.triu(U, 1).T
+        A = golden_csc(g, 'A').toarray()
+        l, u = np.clip(g['l'], -1e30, 1e30), np.clip(g['u'], -1e30, 1e30)
+        ls, us = E[0] * l, E[0] * u
+        rho_vec = np.where((ls < -1e26) & (us > 1e26), 1e-6, np.where(us - ls < 1e-4, 1e3 * rho[0], rho[0]))
+        Kmat = c[0] * P + np.diag(1e-6 / D[0] ** 2) + A.T @ np.diag(rho_vec * E[0] ** 2) @ A
+        rng = np.random.default_rng(5)
+        for _ in range(3):
+            rhs = rng.standard_normal(P.shape[0])
+            sol = bp.kkt_solve(rhs[None])[0]
+            assert _rel(sol, np.linalg.solve(Kmat, rhs)) < 1e-8
+
+
+@pytest.mark.parametrize('env', BACKENDS, ids=IDS)
+@pytest.mark.parametrize('iters', [1, 7, 40])
+@pytest.mark.parametrize('name', SMALL)
+def test_admm_iterates_match_oracle(name, iters, env):
+    kw = golden_kwargs(load_golden(name))
+    with backend(**env):
+        K = _ctrl(kw); K.setup(solve=False)
+        K.prob.batch_problem.iterate(iters)
+        x, z, y = K.prob.batch_problem.iterate_state()
+    Ko = _ctrl(kw, oracle=True); Ko.setup(solve=False)
+    Ko.prob.iterate(iters)
+    xo, zo, yo, _ = Ko.prob.iterate_state()
+    assert _rel(x[0], xo) < 1e-8 and _rel(z[0], zo) < 1e-8
+    assert np.abs(y[0] - yo).max() < 1e-8 * max(1.0, np.abs(yo).max())
+
+
+@pytest.mark.parametrize('env', BACKENDS, ids=IDS)
+@pytest.mark.parametrize('name', SMALL)
+def test_default_tolerance_solve_and_optimum(name, env):
+    """eps 1e-3 (mpc.py:80): status, iteration count, rho updates as the oracle; eps 1e-9: u* within 1e-6 of the certified optimum."""
+    g, opt = load_golden(name), load_golden(name, prefix='opt_')
+    kw = golden_kwargs(g)
+    with backend(**env), warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        K = _ctrl(kw); K.setup()
+        Ko = _ctrl(kw, oracle=True); Ko.setup()
+        assert K.res.info.status == Ko.res.info.status and K.res.info.iter == Ko.res.info.iter
+        assert K.res.info.rho_updates == Ko.res.info.rho_updates
+        kw2 = type(kw)(kw); kw2.attrs = kw.attrs
+        kw2.update(eps_abs=1e-9, eps_rel=1e-9)
+        K = _ctrl(kw2, max_iter=200000); K.setup()
+        assert K.res.info.status == 'solved'
+        assert np.abs(K.output() - opt['u0']).max() <= 1e-6 * max(1e-3, np.abs(opt['u0']).max())      # north-star tolerance
+
+
+@pytest.mark.parametrize('name', ['point_mass', 'cart_pole'])
+def test_closed_loop_is_the_same_on_both_backends(name):
+    """40 closed-loop steps stepwise and inside the device loop: the dense backend follows the sweeps to 1e-9 (two different
+    linear-algebra routes through the same ADMM iteration) and reproduces the reference-class trajectory to 1e-6."""
+    from pympc_amd import BatchMPCController, fixtures
+    kw = getattr(fixtures, name)()
+    kw.update(eps_abs=1e-9, eps_rel=1e-9)
+    out = {}
+    for env, tag in zip(BACKENDS, IDS):
+        with backend(**env), warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            st = lambda a: np.asarray(a, dtype=float)[None]
+            Kb = BatchMPCController(st(kw['Ad']), st(kw['Bd']), Np=kw['Np'], x0=st(kw['x0']), xref=st(kw['xref']), uref=st(kw['uref']),
+                                    uminus1=st(kw['uminus1']), Qx=st(kw['Qx']), QxN=st(kw['QxN']), Qu=st(kw['Qu']), QDu=st(kw['QDu']),
+                                    xmin=st(kw['xmin']), xmax=st(kw['xmax']), umin=st(kw['umin']), umax=st(kw['umax']),
+                                    Dumin=st(kw['Dumin']), Dumax=st(kw['Dumax']), eps_feas=kw.get('eps_feas', 1e6),
+                                    eps_abs=1e-9, eps_rel=1e-9, max_iter=200000)
+            Kb.setup()
+            out[tag] = Kb.run(40)
+    a, b = out['sweeps'], out['dense']
+    assert np.array_equal(a['status'], b['status'])
+    assert np.abs(a['u'] - b['u']).max() <= 1e-7 * max(1.0, np.abs(a['u']).max())
+    assert np.abs(a['x'] - b['x']).max() <= 1e-7 * max(1.0, np.abs(a['x']).max())
