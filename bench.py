@@ -471,12 +471,16 @@ def latency_leg(kind, nsim=300):
     x = np.array(K.x0_rh, dtype=float)
     t0 = time.perf_counter()
     for _ in range(200):
-        bp.update(x0=x[None, :]); bp.solve_async(); bp.u0()
+        bp.step_host(x0=x[None, :])                  # what the class calls: mpcqp_step_host (one launch, mapped host memory, no copies)
     raw_us = 1e6 * (time.perf_counter() - t0) / 200
     ms, nl = bp.profile(enable=False)
+    t0 = time.perf_counter()
+    for _ in range(200):
+        bp.update(x0=x[None, :]); bp.solve_async(); bp.u0()
+    raw3_us = 1e6 * (time.perf_counter() - t0) / 200
     out = dict(workload='%s: one cart-pole MPCController, nx=4 nu=1 Np=%d Nc=%d' % (kind, kw['Np'], kw.get('Nc', kw['Np'])),
                update_us_median=float(np.median(ts)), update_us_p95=float(np.percentile(ts, 95)), mean_admm_iters=float(its.mean()),
-               raw_c_abi_step_us=raw_us, kernel_us=1e3 * ms / max(1, nl), kernel=bp.kernel_name(loop=False))
+               raw_c_abi_step_us=raw_us, raw_c_abi_update_solve_u0_us=raw3_us, kernel_us=1e3 * ms / max(1, nl), kernel=bp.kernel_name(loop=False))
     from oracle.osqp_oracle import OSQP
     Ko = MPCController(**kw); Ko.prob = OSQP()
     tso, _ = loop(Ko)

@@ -15,7 +15,7 @@ SYMBOLS = [
     'mpcqp_default_settings', 'mpcqp_status_string', 'mpcqp_last_error', 'mpcqp_device_count',
     'mpcqp_create', 'mpcqp_destroy', 'mpcqp_set_stream', 'mpcqp_synchronize',
     'mpcqp_setup', 'mpcqp_setup_qp', 'mpcqp_update', 'mpcqp_update_vectors', 'mpcqp_warm_start', 'mpcqp_update_settings', 'mpcqp_solve',
-    'mpcqp_mpc_step', 'mpcqp_mpc_run', 'mpcqp_mpc_loop', 'mpcqp_get_solution', 'mpcqp_get_u0', 'mpcqp_get_dims', 'mpcqp_get_stream_bytes', 'mpcqp_kernel_name', 'mpcqp_get_stats', 'mpcqp_profile',
+    'mpcqp_mpc_step', 'mpcqp_step_host', 'mpcqp_mpc_run', 'mpcqp_mpc_loop', 'mpcqp_get_solution', 'mpcqp_get_u0', 'mpcqp_get_dims', 'mpcqp_get_stream_bytes', 'mpcqp_kernel_name', 'mpcqp_get_stats', 'mpcqp_profile',
     'mpcqp_export_qp', 'mpcqp_get_scaling', 'mpcqp_debug_kkt_solve', 'mpcqp_get_iterate', 'mpcqp_iterate', 'mpcqp_refactor',
 ]
 
@@ -87,6 +87,7 @@ def load():
     L.mpcqp_mpc_run.argtypes = [H, C.c_int] + [C.c_void_p] * 7
     L.mpcqp_mpc_step.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     L.mpcqp_mpc_loop.argtypes = [H, C.c_int, C.POINTER(Loop)]
+    L.mpcqp_step_host.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.mpcqp_get_solution.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p]
     L.mpcqp_get_u0.argtypes = [H, C.c_void_p]
     L.mpcqp_get_dims.argtypes = [H, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]

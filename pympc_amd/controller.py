@@ -220,6 +220,8 @@ class MPCController:
         self._update_QP_matrices_()
         if solve:
             self.solve()
+        elif hasattr(self.prob, 'flush'):
+            self.prob.flush()                 # (the device solver sends the step data with the solve; without one, now)
 
     def solve(self):
         """Warm-started solve (mpc.py:366-375)."""

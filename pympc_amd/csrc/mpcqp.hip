@@ -88,6 +88,9 @@ struct mpcqp_handle {
     long long run_launches;
     int nevents;                         // event pairs created so far (a partially built handle is destroyed cleanly)
     bool warm_x_pending;                 // mpcqp_warm_start replaced x: the next solve starts from z = A x (osqp_warm_start)
+    // mpcqp_step_host: mapped, coherent host memory the kernel reads its step data from and writes its results to
+    double *pin_in, *pin_out; void *pin_in_dev, *pin_out_dev;
+    unsigned *done_dev; unsigned long long host_seq; int pin_stride; bool pin_tried;
 };
 
 extern "C" void mpcqp_default_settings(mpcqp_settings *s) {
@@ -174,6 +177,7 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     h->device = device; h->batch = batch; h->is_setup = false; h->u0_dev = nullptr; h->run_buf = nullptr; h->run_bytes = 0; h->perm_dev = nullptr; h->solves_since_balance = 0; h->auto_balance = 1; h->ncu = 0;
     h->profiling = false; h->run_ms = 0.0; h->run_launches = 0; h->ev_count = 0; h->nevents = 0; h->stream = nullptr; h->own_stream = false;
     h->warm_x_pending = false;
+    h->pin_in = h->pin_out = nullptr; h->pin_in_dev = h->pin_out_dev = nullptr; h->done_dev = nullptr; h->host_seq = 0; h->pin_stride = 0; h->pin_tried = false;
     if (s) h->S = *s; else mpcqp_default_settings(&h->S);
     h->L = make_layout(nx, nu, Np, Nc, h->S.soft_constraints);
     // (every failure from here on releases what has been created so far: mpcqp_destroy copes with a partial handle)
@@ -234,6 +238,8 @@ extern "C" void mpcqp_destroy(mpcqp_handle *h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     for (void *p : h->allocs) hipFree(p);
     if (h->run_buf) hipFree(h->run_buf);
+    if (h->pin_in) hipHostFree(h->pin_in);
+    if (h->pin_out) hipHostFree(h->pin_out);
     for (int e = 0; e < h->nevents; ++e) { hipEventDestroy(h->ev0[e]); hipEventDestroy(h->ev1[e]); }
     if (h->own_stream && h->stream) hipStreamDestroy(h->stream);
     delete h;
@@ -671,6 +677,71 @@ extern "C" int mpcqp_mpc_step(mpcqp_handle *h, const double *x0, const double *u
     if (!due && is_device_ptr(u_out)) return MPCQP_OK;
     HIPCHK(hipStreamSynchronize(h->stream));
     return due ? rebalance(h) : MPCQP_OK;
+}
+
+// One control step with HOST data and the lowest latency the library can offer (the drop-in class's update(): mpc.py:338-375
+// = prob.update(l, u, q) + prob.solve() + reading res.x): x0 / u_{-1} / xref are placed in mapped host memory the kernel reads
+// itself, the solution comes back the same way, and the call waits on a flag in that memory -- ONE kernel launch, no copy calls, no
+// stream synchronisation.  Falls back to mpcqp_update + mpcqp_solve + mpcqp_get_solution where the batch is solved in two launches.
+static int ensure_pinned(mpcqp_handle *h) {
+    if (h->pin_tried) return h->pin_in && h->pin_out ? 0 : 1;
+    h->pin_tried = true;
+    const Lay &L = h->L; const size_t B = (size_t)h->batch;
+    h->pin_stride = L.nx + L.nu + L.N * L.nx;
+    const size_t in_bytes = sizeof(double) * B * h->pin_stride, out_bytes = sizeof(double) * B * (L.n + L.m) + sizeof(mpcqp_info) * B + 64;
+    const unsigned flags = hipHostMallocMapped | hipHostMallocCoherent;
+    if (hipHostMalloc((void **)&h->pin_in, in_bytes, flags) != hipSuccess) { h->pin_in = nullptr; (void)hipGetLastError(); return 1; }
+    if (hipHostMalloc((void **)&h->pin_out, out_bytes, flags) != hipSuccess) { hipHostFree(h->pin_in); h->pin_in = h->pin_out = nullptr; (void)hipGetLastError(); return 1; }
+    memset(h->pin_out, 0, out_bytes);
+    if (hipHostGetDevicePointer(&h->pin_in_dev, h->pin_in, 0) != hipSuccess || hipHostGetDevicePointer(&h->pin_out_dev, h->pin_out, 0) != hipSuccess) {
+        hipHostFree(h->pin_in); hipHostFree(h->pin_out); h->pin_in = h->pin_out = nullptr; (void)hipGetLastError(); return 1;
+    }
+    return 0;
+}
+
+extern "C" int mpcqp_step_host(mpcqp_handle *h, const double *x0, const double *uminus1, const double *xref, int xref_rows,
+                               double *x, double *y, mpcqp_info *info) {
+    if (!h) return fail(MPCQP_ERR_ARG, "null handle");
+    if (!h->is_setup) return fail(MPCQP_ERR_STATE, "mpcqp_step_host before mpcqp_setup");
+    if (xref && xref_rows != 1 && xref_rows != h->L.N) return fail(MPCQP_ERR_ARG, "xref_rows must be 1 or Np+1");
+    HIPCHK(hipSetDevice(h->device));
+    const bool split = h->auto_balance && h->ncu > 0 && h->batch > h->ncu;
+    if (split || ensure_pinned(h)) {
+        int rc = mpcqp_update(h, x0, uminus1, xref, xref_rows);
+        if (rc) return rc;
+        if ((rc = mpcqp_solve(h))) return rc;
+        return mpcqp_get_solution(h, x, y, info);
+    }
+    const Lay &L = h->L; const size_t B = (size_t)h->batch;
+    h->L.raw = 0;
+    if (xref) h->L.xref_rows = xref_rows;
+    const int nxr = xref ? xref_rows * L.nx : 0;
+    for (size_t b = 0; b < B; ++b) {
+        double *dst = h->pin_in + b * h->pin_stride;
+        if (x0) memcpy(dst, x0 + b * L.nx, sizeof(double) * L.nx);
+        if (uminus1) memcpy(dst + L.nx, uminus1 + b * L.nu, sizeof(double) * L.nu);
+        if (xref) memcpy(dst + L.nx + L.nu, xref + b * nxr, sizeof(double) * nxr);
+    }
+    RunArgs R; memset(&R, 0, sizeof(R));
+    R.pin_in = (x0 || uminus1 || xref) ? (const double *)h->pin_in_dev : nullptr;
+    R.pin_stride = h->pin_stride; R.pin_mask = (x0 ? 1 : 0) | (uminus1 ? 2 : 0) | (xref ? 4 : 0); R.pin_xref = nxr;
+    R.pub = (double *)h->pin_out_dev; R.done = (unsigned *)h->npending_dev + 2; R.seq = ++h->host_seq;
+    int rc = launch_run(h, R, 0);
+    if (rc) return rc;
+    volatile unsigned long long *flag = (volatile unsigned long long *)((char *)h->pin_out + sizeof(double) * B * (L.n + L.m) + sizeof(mpcqp_info) * B);
+    for (unsigned long long spins = 0; *flag != h->host_seq; ++spins) {
+        __builtin_ia32_pause();
+        if ((spins & 0xfffff) == 0xfffff) {                    // every ~million polls: has the stream died?
+            hipError_t e = hipStreamQuery(h->stream);
+            if (e != hipSuccess && e != hipErrorNotReady) return fail(MPCQP_ERR_HIP, std::string("mpcqp_step_host: ") + hipGetErrorString(e));
+            if (e == hipSuccess && *flag != h->host_seq) { HIPCHK(hipStreamSynchronize(h->stream)); break; }
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    if (x) memcpy(x, h->pin_out, sizeof(double) * B * L.n);
+    if (y) memcpy(y, h->pin_out + B * L.n, sizeof(double) * B * L.m);
+    if (info) memcpy(info, h->pin_out + B * (L.n + L.m), sizeof(mpcqp_info) * B);
+    return MPCQP_OK;
 }
 
 extern "C" int mpcqp_get_stats(mpcqp_handle *h, uint64_t *out4, int reset) {

@@ -35,6 +35,12 @@ struct RunArgs {
     double *u_traj;               // [nsteps][batch][nu]
     int *status_traj, *iter_traj; // [nsteps][batch]: outcome of the solve that follows step k's update
     int batch;
+    // host-resident exchange (mpcqp_step_host: one launch per control step, no copy calls, no stream synchronisation):
+    const double *pin_in;         // [batch][pin_stride] = [x0 | u_{-1} | xref] in mapped host memory, copied into the step blob first (null = off)
+    int pin_stride, pin_mask, pin_xref;   // mask: 1 x0, 2 u_{-1}, 4 xref (pin_xref doubles)
+    double *pub;                  // mapped host memory: [batch][n] x | [batch][m] y | [batch] info | flag; written when the solve is done (null = off)
+    unsigned *done;               // device counter of finished workgroups (the last one raises the flag)
+    unsigned long long seq;       // value the flag takes
 };
 
 __host__ __device__ inline int next_stop(int iter, int max_iter, int chk, int rho_every) {
@@ -120,6 +126,13 @@ __global__ __launch_bounds__(NT, (MODE == MODE_DENSE ? 1 : NB <= 16 ? 4 : 2)) vo
     Smem &S = rs.S;
     const int b = inst_of(P.perm), tid = threadIdx.x;
     double *step = P.step + (size_t)b * L.step_sz;
+    if (!LOOP && R.pin_in) {                     // update(x0, u_{-1}, xref) straight from the caller's (mapped) memory: one PCIe round trip
+        const double *src = R.pin_in + (size_t)b * R.pin_stride;
+        if (R.pin_mask & 1) for (int i = tid; i < L.nx; i += NT) step[i] = src[i];
+        if (R.pin_mask & 2) for (int i = tid; i < L.nu; i += NT) step[L.nx + i] = src[L.nx + i];
+        if (R.pin_mask & 4) for (int i = tid; i < R.pin_xref; i += NT) step[L.nx + L.nu + i] = src[L.nx + L.nu + i];
+        __syncthreads();
+    }
     load_common(L, P.model + (size_t)b * L.model_sz, step, S);
     if (!LOOP && R.part == 3) {                  // mpcqp_refactor: the factorization alone (what one rho update costs)
         __syncthreads();
@@ -213,6 +226,22 @@ __global__ __launch_bounds__(NT, (MODE == MODE_DENSE ? 1 : NB <= 16 ? 4 : 2)) vo
             R.iter_traj[(size_t)k * R.batch + b] = iter;
         }
         __syncthreads();
+    }
+    if (!LOOP && R.pub) {                        // results to the caller's (mapped) memory; the last workgroup raises the flag
+        double *px = R.pub + (size_t)b * L.n, *py = R.pub + (size_t)R.batch * L.n + (size_t)b * L.m;
+        for (int j = tid; j < L.n; j += NT) px[j] = P.xo[(size_t)b * L.n + j];
+        for (int r = tid; r < L.m; r += NT) py[r] = P.yo[(size_t)b * L.m + r];
+        mpcqp_info *pi = (mpcqp_info *)(R.pub + (size_t)R.batch * (L.n + L.m));
+        if (tid == 0) pi[b] = P.info[b];
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) {
+            if (atomicAdd(R.done, 1u) == gridDim.x - 1) {
+                *R.done = 0;
+                __threadfence_system();
+                *(volatile unsigned long long *)(pi + R.batch) = R.seq;
+            }
+        }
     }
     if (LOOP && tid < nx) {
         const size_t e = ((size_t)R.nsteps * R.batch + b) * nx + tid;

@@ -21,6 +21,9 @@ _IGNORED_SETTINGS = ('verbose', 'polish', 'linsys_solver', 'time_limit', 'scaled
                      'polish_refine_iter', 'adaptive_rho_fraction')
 
 
+_STATUS_STRINGS = {}       # status code -> OSQP's string (filled from mpcqp_status_string on first use)
+
+
 def _ptr(a):
     if a is None:
         return None
@@ -222,6 +225,21 @@ class BatchProblem:
         _lib.check(self._L.mpcqp_mpc_step(self._h, _ptr(a), _ptr(b), _ptr(c), rows, _ptr(out)), 'mpcqp_mpc_step')
         return out
 
+    def step_host(self, x0=None, uminus1=None, xref=None):
+        """update(x0, uminus1, xref) + warm-started solve + solution in ONE library call with host arrays (mpcqp_step_host):
+        the latency path of a single controller.  Returns ``(x [B,n], y [B,m], info[B])`` like ``solution()``."""
+        B, nx, nu = self.batch, self.nx, self.nu
+        a = None if x0 is None else np.ascontiguousarray(np.asarray(x0, dtype=np.float64).reshape(B, nx))
+        b = None if uminus1 is None else np.ascontiguousarray(np.asarray(uminus1, dtype=np.float64).reshape(B, nu))
+        c, rows = None, 1
+        if xref is not None:
+            rows = self._xref_rows(xref)
+            c = np.ascontiguousarray(np.asarray(xref, dtype=np.float64).reshape(B, rows * nx))
+        x, y = np.empty((B, self.n)), np.empty((B, self.m))
+        info = (_lib.Info * B)()
+        _lib.check(self._L.mpcqp_step_host(self._h, _ptr(a), _ptr(b), _ptr(c), rows, _ptr(x), _ptr(y), C.cast(info, C.c_void_p)), 'mpcqp_step_host')
+        return x, y, info
+
     def mpc_run(self, nsteps, w=None, Ap=None, Bp=None, out=None, xref_traj=None, estimator=None):
         """Device-side receding-horizon loop (mpcqp_mpc_loop): ``nsteps`` closed-loop steps
         ``u = output(); x = Ap x + Bp u + w[k]; update(x)`` of every instance without host round trips.
@@ -316,7 +334,10 @@ class BatchProblem:
         return ms.value, nl.value
 
     def status_string(self, code):
-        return self._L.mpcqp_status_string(int(code)).decode()
+        code = int(code)
+        if code not in _STATUS_STRINGS:
+            _STATUS_STRINGS[code] = self._L.mpcqp_status_string(code).decode()
+        return _STATUS_STRINGS[code]
 
     # -- verification surface -----------------------------------------------------------------
     def export_qp(self):
@@ -365,6 +386,7 @@ class DeviceProblem:
         self._bp = None
         self._hint = (nx, nu)
         self._model = None
+        self._pending = None              # step data of an update() that has not reached the device yet (sent with the solve)
 
     def _setup_from_matrices(self, P, q, A, l, u, **settings):
         from . import qp_recover
@@ -403,10 +425,17 @@ class DeviceProblem:
                        one(mpc['x0']), one(mpc['uminus1']), xref.reshape(1, -1))
         self.n, self.m = self._bp.n, self._bp.m
 
+    def flush(self):
+        """Send the step data of the last update() to the device now (it otherwise travels with the solve that follows)."""
+        if self._pending is not None:
+            pend, self._pending = self._pending, None
+            self._bp.update(*pend)
+
     def update(self, q=None, l=None, u=None, mpc_step=None, **unsupported):
         if unsupported:
             raise NotImplementedError('DeviceProblem.update supports q, l, u (what pyMPC updates, mpc.py:454); got %s' % sorted(unsupported))
         if mpc_step is None:                              # the caller's vectors, verbatim
+            self.flush()
             if self._model is None:
                 from . import qp_recover
                 raise qp_recover.NotAnMPCQP('update(q=, l=, u=) needs a problem set up from P, q, A, l, u')
@@ -417,21 +446,27 @@ class DeviceProblem:
             clip = lambda v: None if v is None else np.clip(np.asarray(v, dtype=float), -1e30, 1e30)[None]
             self._bp.update_vectors(None if q is None else np.asarray(q, dtype=float)[None], clip(l), clip(u))
             return
-        xref = np.asarray(mpc_step['xref'], dtype=float)
-        self._bp.update(np.asarray(mpc_step['x0'], dtype=float).reshape(1, -1),
-                        np.asarray(mpc_step['uminus1'], dtype=float).reshape(1, -1), xref.reshape(1, -1))
+        # kept on the host until the solve that follows (mpc.py:338-364: update() = refresh + solve): one library call, one launch
+        self._pending = (np.array(mpc_step['x0'], dtype=float).reshape(1, -1), np.array(mpc_step['uminus1'], dtype=float).reshape(1, -1),
+                         np.array(mpc_step['xref'], dtype=float).reshape(1, -1))
 
     def update_settings(self, **kw):
         self._bp.update_settings(**kw)
 
     def warm_start(self, x=None, y=None):
+        self.flush()
         self._bp.warm_start(None if x is None else np.asarray(x)[None], None if y is None else np.asarray(y)[None])
 
     def solve(self):
-        self._bp.solve_async()
-        x, y, info = self._bp.solution()
+        if self._pending is not None:
+            pend, self._pending = self._pending, None
+            x, y, info = self._bp.step_host(*pend)
+        else:
+            self._bp.solve_async()
+            x, y, info = self._bp.solution()
         return Result(x[0], y[0], info[0], self._bp.status_string(info[0].status))
 
     @property
     def batch_problem(self):
+        self.flush()
         return self._bp
