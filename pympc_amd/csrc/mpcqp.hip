@@ -55,15 +55,18 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #include "mpcqp_qp.h"
 #include "mpcqp_factor.h"
 #include "mpcqp_sweeps.h"
+#include "mpcqp_bcr.h"
 #include "mpcqp_dense.h"
 #include "mpcqp_border.h"
 #include "mpcqp_phases.h"
 #include "mpcqp_tiny.h"
+#include "mpcqp_lat.h"
 #include "mpcqp_kernels.h"
 
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+constexpr int BCR_STAGES = 31;      // the shape the register-resident cyclic reduction is instantiated for: Np = 30
 constexpr int BALANCE_EVERY = 16;  // stepwise API: solves between two rebuilds of the workgroup -> instance map
 
 struct mpcqp_handle {
@@ -201,7 +204,17 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     if (const char *e = getenv("MPCQP_DENSE")) dense = dense && atoi(e) != 0;      // development switch (A/B against the block sweeps)
     h->L.dense = dense ? 1 : 0;
     if (dense) h->L.tsz += DenseFmt::SCRATCH;
-    P.fsz = dense ? (long long)DenseFmt::DOUBLES : (long long)L.fhead + (long long)L.N * L.fstage;
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->ncu = prop.multiProcessorCount; }
+    // At most one instance per compute unit: the latency backend (block cyclic reduction, factor resident in registers) for the
+    // shape it is compiled for -- BASELINE (12, 4, 30).  Larger batches stream the chain format (the bandwidth backend).
+    bool bcr = !dense && h->lds_state && L.NB == 16 && !L.border && L.nx == 12 && L.nu == 4 && L.N == BCR_STAGES && h->ncu > 0 && batch <= h->ncu;
+    if (const char *e = getenv("MPCQP_BCR")) {      // development switch: 0 = never, 1 = whenever the shape allows (any batch)
+        if (atoi(e) == 0) bcr = false;
+        else bcr = !dense && h->lds_state && L.NB == 16 && !L.border && L.nx == 12 && L.nu == 4 && L.N == BCR_STAGES;
+    }
+    h->L.bcr = bcr ? 1 : 0;
+    if (bcr) h->L.tsz = std::max(h->L.tsz + L.N * L.NB, 5 * (L.N + 1) * L.NB + NT);      // the stage-major vectors of the latency round (mpcqp_lat.h); c_e of the streaming solve
+    P.fsz = dense ? (long long)DenseFmt::DOUBLES : bcr ? (long long)L.N * BcrFmt::REC : (long long)L.fhead + (long long)L.N * L.fstage;
     int rc = 0;
     rc |= dalloc(h, &P.model, B * L.model_sz); rc |= dalloc(h, &P.step, B * L.step_sz);
     rc |= dalloc(h, &P.D, B * L.n); rc |= dalloc(h, &P.E, B * L.m); rc |= dalloc(h, &P.c, B);
@@ -211,18 +224,18 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     rc |= dalloc(h, &P.xo, B * L.n); rc |= dalloc(h, &P.yo, B * L.m);
     rc |= dalloc(h, &P.dx, B * L.n); rc |= dalloc(h, &P.dy, B * L.m);
     rc |= dalloc(h, &P.qv, B * (size_t)(L.n_x + L.n_u));
+    if (bcr) rc |= dalloc(h, &P.bws, B * (size_t)L.N * BcrFmt::WSTAGE);
     if (L.border) { rc |= dalloc(h, &P.Bb, B * (size_t)L.nu * L.N * L.NB); rc |= dalloc(h, &P.Zb, B * (size_t)L.nu * L.N * L.NB); rc |= dalloc(h, &P.Sig, B * (size_t)L.nu * L.nu); }
     rc |= dalloc(h, &P.Dt, B * L.n); rc |= dalloc(h, &P.Et, B * L.m);
     rc |= dalloc(h, &P.ctype, B * L.m); rc |= dalloc(h, &P.info, B); rc |= dalloc(h, &P.stats, 8);
         rc |= dalloc(h, &h->u0_dev, B * L.nu);
     rc |= dalloc(h, &P.work, B); rc |= dalloc(h, &h->perm_dev, B);
     rc |= dalloc(h, &h->pending_dev, B); rc |= dalloc(h, &h->npending_dev, 4);
-    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->ncu = prop.multiProcessorCount; }
     if (const char *e = getenv("MPCQP_BALANCE")) h->auto_balance = atoi(e) != 0;      // development switch
     if (rc) { std::string msg = g_err; mpcqp_destroy(h); return fail(MPCQP_ERR_HIP, msg); }
     // The factorization's workspace starts at the work area T, the last part of the common block,
     // and may run on into the iterate area (dead while a factorization runs); T is widened only where even that is short.
-    const int fws = dense ? L.NR * L.dld + 2 * DenseFmt::ROWS : (L.NB == 16 ? FactorCfg<16>::WS : FactorCfg<32>::WS);
+    const int fws = dense ? L.NR * L.dld + 2 * DenseFmt::ROWS : bcr ? BcrFmt::LDSW : (L.NB == 16 ? FactorCfg<16>::WS : FactorCfg<32>::WS);
     const int avail = L.tsz + (h->lds_state ? (int)state_doubles : 0);
     if (avail < fws) h->L.tsz += fws - avail;
     h->smem_setup = sizeof(double) * ((size_t)smem_common_doubles(h->L) + (h->lds_state ? state_doubles : 0));      // every kernel gets the full block
@@ -491,6 +504,7 @@ static int launch_run(mpcqp_handle *h, RunArgs R, int plain_iters) {
     }
     int rc;
     if (L.dense) rc = launch_run_t<16, true, 0, 0, MODE_DENSE>(h, R);
+    else if (L.bcr) rc = launch_run_t<16, true, 12, 4, MODE_BCR + BCR_STAGES>(h, R);
     else if (L.NB == 16 && h->lds_state && L.nx == 12 && L.nu == 4 && !L.border) rc = launch_run_t<16, true, 12, 4, MODE_CHAIN>(h, R);
     else if (L.NB == 32 && !h->lds_state && L.nx == 20 && L.nu == 8 && !L.border) rc = launch_run_t<32, false, 20, 8, MODE_CHAIN>(h, R);
     else if (L.NB == 16) rc = h->lds_state ? launch_run_generic<16, true>(h, R) : launch_run_generic<16, false>(h, R);
@@ -751,9 +765,9 @@ extern "C" int mpcqp_get_stats(mpcqp_handle *h, uint64_t *out4, int reset) {
 #ifdef MPCQP_RUN_TIMING
     { uint64_t t[4]; hipMemcpy(t, h->P.stats + 4, sizeof(t), hipMemcpyDeviceToHost); fprintf(stderr, "phase wall-clock ticks: begin %llu admm %llu check %llu\n", (unsigned long long)t[0], (unsigned long long)t[1], (unsigned long long)t[2]);
       unsigned long long g[16]; hipMemcpyFromSymbol(g, HIP_SYMBOL(g_ticks), sizeof(g)); unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_ticks), z, sizeof(z));
-      { double tot = 0; for (int i = 0; i < 6; ++i) tot += (double)g[i]; if (tot <= 0) tot = 1;
-        fprintf(stderr, "iteration cycles (thread 0, summed over workgroups): rhs %.1f%% fwd %.1f%% middle %.1f%% bwd %.1f%% (unused) %.1f%% update %.1f%%  total %.3g\n",
-                100 * g[0] / tot, 100 * g[1] / tot, 100 * g[2] / tot, 100 * g[3] / tot, 100 * g[4] / tot, 100 * g[5] / tot, tot); } }
+      { double tot = 0; for (int i = 0; i < 7; ++i) tot += (double)g[i]; if (tot <= 0) tot = 1;
+        fprintf(stderr, "iteration cycles (thread 0, summed over workgroups): rhs %.1f%% fwd %.1f%% middle %.1f%% bwd %.1f%% t4 %.1f%% t5 %.1f%% t6 %.1f%% total %.3g\n",
+                100 * g[0] / tot, 100 * g[1] / tot, 100 * g[2] / tot, 100 * g[3] / tot, 100 * g[4] / tot, 100 * g[5] / tot, 100 * g[6] / tot, tot); } }
 #endif
     if (reset) HIPCHK(hipMemsetAsync(h->P.stats, 0, 8 * sizeof(uint64_t), h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
@@ -803,12 +817,13 @@ extern "C" int mpcqp_get_stream_bytes(mpcqp_handle *h, int64_t *per_iter, int64_
     const Lay &L = h->L;
     const int64_t n = L.n, m = L.m, nq = L.n_x + L.n_u, NB = L.NB;
     const int64_t sinv = L.fstage - L.ffwd - L.ftab;
-    int64_t it = L.dense ? 0 /* K^-1 sits in registers for the round */ : !L.ffwd ? 2 * (int64_t)L.N * sinv + (int64_t)L.N * L.ftab + 2 * (int64_t)L.fhead   // S^-1-only build: S^-1 twice, one of the two tables per sweep, [G | G'] by each sweeping wave
+    int64_t it = (L.dense || L.bcr) ? 0 /* the factor sits in registers for the round */ : !L.ffwd ? 2 * (int64_t)L.N * sinv + (int64_t)L.N * L.ftab + 2 * (int64_t)L.fhead   // S^-1-only build: S^-1 twice, one of the two tables per sweep, [G | G'] by each sweeping wave
                          : (int64_t)(L.N - 1) * L.ffwd + (int64_t)L.N * sinv + (int64_t)(L.N - 1) * L.ftab + L.fhead;   // forward matrices once, S^-1 once, the tables, G / G' once each
     if (!h->lds_state) it += (2 * n + 4 * m) /* x, z, y read + written */ + (m + L.n_x) /* omega */ + (n + L.n_x) /* s */ + nq /* q */;
     if (L.border) it += 2 * (int64_t)L.nu * L.N * NB;
     int64_t rd = (L.model_sz - L.hot_sz) + 2 * n + 2 * m /* D, s, E, omega */ + n + m /* dx, dy */;
     if (L.dense) rd += DenseFmt::DOUBLES;               // the round's load of K^-1 into registers
+    if (L.bcr) rd += (int64_t)L.N * BcrFmt::REC - 4 * BcrFmt::NN;      // ... of the cyclic-reduction fragments (the two end stages have one neighbour)
     rd += h->lds_state ? 2 * (n + 2 * m) /* iterate in and out of LDS */ + (m + L.n_x) + (n + L.n_x) + nq : (n + 2 * m);
     int64_t sv = L.hot_sz + L.step_sz + 3 * m /* E, types, omega */ + nq + 2 * (n + m) /* solution out, iterate read */;
     if (per_iter) *per_iter = 8 * it;
@@ -822,9 +837,9 @@ extern "C" int mpcqp_get_stream_bytes(mpcqp_handle *h, int64_t *per_iter, int64_
 extern "C" int mpcqp_kernel_name(mpcqp_handle *h, int loop, char *buf, int buflen) {
     if (!h || !buf || buflen < 1) return fail(MPCQP_ERR_ARG, "null argument");
     const Lay &L = h->L;
-    const bool spec = !L.border && !L.dense && ((L.NB == 16 && h->lds_state && L.nx == 12 && L.nu == 4) || (L.NB == 32 && !h->lds_state && L.nx == 20 && L.nu == 8));
+    const bool spec = L.bcr || !L.border && !L.dense && ((L.NB == 16 && h->lds_state && L.nx == 12 && L.nu == 4) || (L.NB == 32 && !h->lds_state && L.nx == 20 && L.nu == 8));
     snprintf(buf, (size_t)buflen, "k_mpc_run<%d,%s,%d,%d,%d,%s>", L.NB, h->lds_state ? "true" : "false", spec ? L.nx : 0, spec ? L.nu : 0,
-             L.dense ? MODE_DENSE : L.border ? MODE_BORDER : MODE_CHAIN, loop ? "true" : "false");
+             L.dense ? MODE_DENSE : L.bcr ? MODE_BCR + BCR_STAGES : L.border ? MODE_BORDER : MODE_CHAIN, loop ? "true" : "false");
     return MPCQP_OK;
 }
 

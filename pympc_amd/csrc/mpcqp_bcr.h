@@ -1,0 +1,206 @@
+// mpcqp_bcr.h -- part of libmpcqp_hip (included by mpcqp.hip, one translation unit).
+// Block cyclic reduction of the block-tridiagonal reduced KKT matrix: the latency backend for 16 x 16 stages.
+//
+// The twisted block LDL' (mpcqp_factor.h / mpcqp_sweeps.h) is a chain: N/2 dependent stage steps forward, N/2 backward, two of
+// the four waves busy -- 5.5 of the 9.7 us an ADMM iteration of ONE (12,4,30) instance takes on an otherwise idle CU.  Odd-even
+// (cyclic) reduction is the same block Gaussian elimination in nested-dissection order: level l eliminates every other stage of
+// what is left (stride h = 2^l), so the dependent depth is 2 ceil(log2 N) level steps instead of N stage steps, every level
+// step is a set of INDEPENDENT 16 x 16 mat-vecs, and all four waves work.  Elimination order changes nothing about
+// stability: the pivots are Schur complements of a symmetric positive definite matrix in either order.
+//
+//   level l, eliminated stages E_l = { e = h (2t+1) - 1 },  kept stages A_{l+1} = { i = 2h (t+1) - 1 },  neighbours e -+ h:
+//     factor   D_e^-1 = inv(K_ee);  Lb_{e,i} = D_e^-1 K_{e,i}  (i = e-h, e+h);
+//              K_ii -= K_{i,e} Lb_{e,i};   K_{e-h,e+h} = -K_{e-h,e} Lb_{e,e+h}          (the reduced chain of the next level)
+//     forward  c_e = D_e^-1 b_e;   b_i -= Lb_{e,i}' b_e            (kept i pulls from its two eliminated neighbours)
+//     backward x_e = c_e - Lb_{e,e-h} x_{e-h} - Lb_{e,e+h} x_{e+h}
+// Per stage the factor holds five MFMA fragments (operand order of v_mfma_f64_4x4x4_4b_f64, mpcqp_factor.h):
+//     [ D^-1 | -Lb_L | -Lb_R | -Lb_L' | -Lb_R' ]        (L / R: towards the neighbour e-h / e+h)
+// 31 stages: 143 fragments used per solve = 286 KB -- 2.5 x the bytes of the chain format, which is why this backend is chosen
+// for batches of at most one instance per compute unit: there the FOUR WAVES' REGISTER FILES hold the whole factor (each wave
+// the fragments of the tasks it always executes: 43 slots x 8 VGPRs of the 512 a wave may have at one workgroup per CU), loaded
+// once per round of check_termination iterations -- an iteration then reads no factor at all (mpcqp_lat.h).
+#pragma once
+#include <type_traits>
+
+struct BcrFmt {
+    static constexpr int NN = 256;                            // doubles per 16 x 16 fragment
+    static constexpr int REC = 5 * NN;                        // [ D^-1 | -LbL | -LbR | -LbL' | -LbR' ]
+    static constexpr int ODINV = 0, OLBL = NN, OLBR = 2 * NN, OLBLT = 3 * NN, OLBRT = 4 * NN;
+    static constexpr int WSTAGE = 4 * NN;                     // global workspace per stage of the factorization: K_ii | K_{i,next} | dK_L | dK_R
+    static constexpr int LDSW = 4 * 5 * NN;                   // LDS of the factorization: four groups x [ D | B_L | B_R | Lb_L | Lb_R ]
+};
+
+// ------------------------------------------------------------------------------------------------
+// Factorization (run time N).  Wg: this instance's global workspace, N * WSTAGE doubles; W: LDS, BcrFmt::LDSW doubles.
+// Four thread groups (one wave each) eliminate four stages of a level side by side; barriers are workgroup-wide, every
+// thread makes the same calls.  Returns 1 on a non-positive pivot.
+// ------------------------------------------------------------------------------------------------
+__device__ int factor_bcr(const Ctx &c, const double *om, const double *sv, double cc, double *F, double *Wg, double *W, int *iflag) {
+    constexpr int NN = BcrFmt::NN, G = 4, T = NT / G, EPT = NN / T, NB = 16;
+    const Lay &L = c.L;
+    const int N = L.N, tid = threadIdx.x, g = tid / T, lt = tid % T;
+    double *Kd = Wg, *Up = Wg + (size_t)N * NN, *dKL = Up + (size_t)N * NN, *dKR = dKL + (size_t)N * NN;
+    if (tid == 0) *iflag = 0;
+    for (int idx = tid; idx < N * NN; idx += NT) {
+        const int k = idx / NN, r = idx % NN, a = r / NB, b = r % NB;
+        Kd[idx] = kkt_diag_entry(c, om, sv, cc, k, a, b);
+        Up[idx] = (k + 1 < N) ? kkt_sub_entry(c, om, cc, k, b, a) : 0.0;      // K_{k,k+1}[a][b] = K_{k+1,k}[b][a]
+    }
+    __syncthreads();
+    double *D = W + g * 5 * NN, *BL = D + NN, *BR = D + 2 * NN, *LL = D + 3 * NN, *LR = D + 4 * NN;
+    for (int h = 1; h - 1 < N; h <<= 1) {
+        const int ne = (N + h) / (2 * h);                     // stages e = h (2t+1) - 1 < N
+        for (int t0 = 0; t0 < ne; t0 += G) {
+            const int t = t0 + g;
+            const bool on = t < ne;
+            const int e = h * (2 * t + 1) - 1, i1 = e - h, i2 = e + h;
+            const bool hasL = on && i1 >= 0, hasR = on && i2 < N;
+            if (on) {
+#pragma unroll
+                for (int u = 0; u < EPT; ++u) {
+                    const int idx = lt + T * u, a = idx / NB, b = idx % NB;
+                    D[idx] = Kd[(size_t)e * NN + idx];
+                    BL[idx] = hasL ? Up[(size_t)i1 * NN + b * NB + a] : 0.0;     // K_{e,i1} = K_{i1,e}'
+                    BR[idx] = hasR ? Up[(size_t)e * NN + idx] : 0.0;            // K_{e,i2}
+                }
+            }
+            __syncthreads();
+            // in-place Gauss-Jordan inversion of the SPD block (as in factor_all): step p uses the OLD pivot row and column
+            for (int pv = 0; pv < NB; ++pv) {
+                double rip[EPT], rpj[EPT], d = 1.0;
+                if (on) {
+                    d = D[pv * NB + pv];
+#pragma unroll
+                    for (int u = 0; u < EPT; ++u) { const int idx = lt + T * u; rip[u] = D[(idx / NB) * NB + pv]; rpj[u] = D[pv * NB + (idx % NB)]; }
+                }
+                if (on && !(d > 0.0)) { if (lt == 0) *iflag = 1; d = 1e-300; }
+                __syncthreads();
+                if (on) {
+                    const double inv = 1.0 / d;
+#pragma unroll
+                    for (int u = 0; u < EPT; ++u) {
+                        const int idx = lt + T * u, i = idx / NB, j = idx % NB;
+                        D[idx] = (i == pv) ? (j == pv ? inv : rpj[u] * inv) : (j == pv ? -rip[u] * inv : D[idx] - rip[u] * rpj[u] * inv);
+                    }
+                }
+                __syncthreads();
+            }
+            double sy[EPT];
+            if (on) {
+#pragma unroll
+                for (int u = 0; u < EPT; ++u) { const int idx = lt + T * u, a = idx / NB, b = idx % NB; sy[u] = 0.5 * (D[a * NB + b] + D[b * NB + a]); }
+            }
+            __syncthreads();
+            if (on) {
+#pragma unroll
+                for (int u = 0; u < EPT; ++u) D[lt + T * u] = sy[u];
+            }
+            __syncthreads();
+            if (on) {
+#pragma unroll
+                for (int u = 0; u < EPT; ++u) {              // Lb = D^-1 B
+                    const int idx = lt + T * u, a = idx / NB, b = idx % NB;
+                    double accL = 0.0, accR = 0.0;
+#pragma unroll 8
+                    for (int l = 0; l < NB; ++l) { const double dv = D[a * NB + l]; accL += dv * BL[l * NB + b]; accR += dv * BR[l * NB + b]; }
+                    LL[idx] = accL; LR[idx] = accR;
+                }
+            }
+            __syncthreads();
+            if (on) {
+                double *rec = F + (size_t)e * BcrFmt::REC;
+                const int nbk = (e < L.NcT) ? L.nb : L.nx;     // variables of this stage; the rest is padding (identity in K, zero in the factor)
+#pragma unroll
+                for (int u = 0; u < EPT; ++u) {
+                    const int idx = lt + T * u, a = idx / NB, b = idx % NB;
+                    const int fp = frag_pos<NB>(a, b);
+                    rec[BcrFmt::ODINV + fp] = (a >= nbk || b >= nbk) ? 0.0 : D[idx];
+                    rec[BcrFmt::OLBL + fp] = -LL[idx];
+                    rec[BcrFmt::OLBR + fp] = -LR[idx];
+                    rec[BcrFmt::OLBLT + fp] = -LL[b * NB + a];
+                    rec[BcrFmt::OLBRT + fp] = -LR[b * NB + a];
+                    double sL = 0.0, sR = 0.0, sU = 0.0;      // K_{i1,e} Lb_L,  K_{i2,e} Lb_R,  K_{i1,e} Lb_R
+#pragma unroll 8
+                    for (int l = 0; l < NB; ++l) {
+                        const double bl = BL[l * NB + a], br = BR[l * NB + a];
+                        sL += bl * LL[l * NB + b]; sR += br * LR[l * NB + b]; sU += bl * LR[l * NB + b];
+                    }
+                    dKL[(size_t)e * NN + idx] = sL;
+                    dKR[(size_t)e * NN + idx] = sR;
+                    if (hasL && hasR) Up[(size_t)i1 * NN + idx] = -sU;          // the coupling i1 <-> i2 of the next level
+                }
+            }
+            __syncthreads();
+        }
+        // kept stages: Schur updates from the (one or two) eliminated neighbours, in a fixed order
+        for (int idx = tid;; idx += NT) {
+            const int t = idx / NN, r = idx % NN, i = 2 * h * (t + 1) - 1;
+            if (i >= N) break;
+            double v = Kd[(size_t)i * NN + r] - dKR[(size_t)(i - h) * NN + r];
+            if (i + h < N) v -= dKL[(size_t)(i + h) * NN + r];
+            Kd[(size_t)i * NN + r] = v;
+        }
+        __syncthreads();
+    }
+    return *iflag;
+}
+
+// one accumulating 16 x 16 mat-vec on the matrix cores: (p, q) += A in, as two dependent MFMA pairs (frag_matvec)
+__device__ __forceinline__ void bcr_mv(const d4 a, double in, double &p, double &q) {
+    const double r1 = rot_blocks<1>(in), r2 = rot_blocks<2>(in), r3 = rot_blocks<3>(in);
+    p = __builtin_amdgcn_mfma_f64_4x4x4f64(a[0], in, p, 0, 0, 0);
+    q = __builtin_amdgcn_mfma_f64_4x4x4f64(a[2], r2, q, 0, 0, 0);
+    p = __builtin_amdgcn_mfma_f64_4x4x4f64(a[1], r1, p, 0, 0, 0);
+    q = __builtin_amdgcn_mfma_f64_4x4x4f64(a[3], r3, q, 0, 0, 0);
+}
+__device__ __forceinline__ d4 bcr_frag(const double *F, int stage, int off, int lane) {
+    return *(cgd4 *)(F + (size_t)stage * BcrFmt::REC + off + lane * 4);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Solve, streaming version (run time N; fragments read from memory as they are needed): the verification kernel and any caller
+// outside an ADMM round.  Tc <- K^-1 Tc, Cc: LDS, N * 16 doubles.  All threads call; barriers inside.
+// ------------------------------------------------------------------------------------------------
+__device__ void bcr_core_stream(const double *F, int N, double *Tc, double *Cc) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double *tb = Tc + vec_lane_offset(lane), *cb = Cc + vec_lane_offset(lane);
+    int top = 1;
+    for (int h = 1; h - 1 < N; h <<= 1) {
+        top = h;
+        const int ne = (N + h) / (2 * h), nk = N / (2 * h);
+        for (int t = wv; t < nk; t += NWAVES) {
+            const int i = 2 * h * (t + 1) - 1;
+            double p = tb[i * 16], q = 0.0;
+            bcr_mv(bcr_frag(F, i - h, BcrFmt::OLBRT, lane), tb[(i - h) * 16], p, q);
+            if (i + h < N) bcr_mv(bcr_frag(F, i + h, BcrFmt::OLBLT, lane), tb[(i + h) * 16], p, q);
+            tb[i * 16] = p + q;
+        }
+        for (int t = wv; t < ne; t += NWAVES) {
+            const int e = h * (2 * t + 1) - 1;
+            double p = 0.0, q = 0.0;
+            bcr_mv(bcr_frag(F, e, BcrFmt::ODINV, lane), tb[e * 16], p, q);
+            cb[e * 16] = p + q;
+        }
+        __syncthreads();
+    }
+    for (int h = top; h >= 1; h >>= 1) {
+        const int ne = (N + h) / (2 * h);
+        for (int t = wv; t < ne; t += NWAVES) {
+            const int e = h * (2 * t + 1) - 1;
+            double p = cb[e * 16], q = 0.0;
+            if (e - h >= 0) bcr_mv(bcr_frag(F, e, BcrFmt::OLBL, lane), tb[(e - h) * 16], p, q);
+            if (e + h < N) bcr_mv(bcr_frag(F, e, BcrFmt::OLBR, lane), tb[(e + h) * 16], p, q);
+            tb[e * 16] = p + q;
+        }
+        __syncthreads();
+    }
+}
+
+// compile-time helpers of the register-resident schedule (mpcqp_lat.h)
+template <int I, int END, class Fn>
+__device__ __forceinline__ void static_for(Fn &&f) {
+    if constexpr (I < END) { f(std::integral_constant<int, I>{}); static_for<I + 1, END>(f); }
+}
+constexpr int bcr_ne(int N, int h) { return (N + h) / (2 * h); }          // eliminated stages e = h (2t+1) - 1 < N of the level with stride h
+constexpr int bcr_nk(int N, int h) { return N / (2 * h); }                // kept stages i = 2h (t+1) - 1 < N
+constexpr int bcr_levels(int N) { int l = 0; for (int h = 1; h - 1 < N; h <<= 1) ++l; return l; }

@@ -89,6 +89,7 @@ __device__ __noinline__ void run_factor_phase() {
     const int b = inst_of(P.perm);
     Ctx c{L, r.S.hot, P.model + (size_t)b * L.model_sz + L.hot_sz};
     if (L.dense) factor_dense(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], P.F + (size_t)b * P.fsz, r.S.T, r.S.iflag);
+    else if (L.bcr) factor_bcr(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], P.F + (size_t)b * P.fsz, P.bws + (size_t)b * L.N * BcrFmt::WSTAGE, r.S.T, r.S.iflag);
     else factor_all<NB>(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], P.F + (size_t)b * P.fsz, r.S.T, r.S.iflag,
                         border_ptrs(L, P, r.S));
 }
@@ -118,7 +119,7 @@ __device__ __noinline__ int run_check_phase(int iter, int mode) {
 }
 
 template <int NB, bool LDSSTATE, int NXT, int NUT, int MODE, bool LOOP>
-__global__ __launch_bounds__(NT, (MODE == MODE_DENSE ? 1 : NB <= 16 ? 4 : 2)) void k_mpc_run(RunKArgs A_) {
+__global__ __launch_bounds__(NT, (MODE == MODE_DENSE || MODE >= MODE_BCR ? 1 : NB <= 16 ? 4 : 2)) void k_mpc_run(RunKArgs A_) {
     const RunKArgs &A = run_kargs();
     const Lay &L = A.L; const Ptrs &P = A.P; const RunArgs &R = A.R;
     if (!LOOP && R.part == 2 && (int)blockIdx.x >= *R.npending) return;

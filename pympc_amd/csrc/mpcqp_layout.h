@@ -26,6 +26,7 @@ struct Lay {
     int fhead, ffwd, ftab;        // doubles of the per-instance factor header ([G | G']) / of a stage's forward matrix / of its off-diagonal table (hybrid)
     int tsz;                      // LDS work vector length: max(m, 4*NB*NB)
     int dense;                    // 1: small problem -- the KKT solve is a dense mat-vec with K^-1 held in registers (mpcqp_dense.h)
+    int bcr;                      // 1: block cyclic reduction instead of the twisted sweeps (mpcqp_bcr.h; small batches of 16 x 16 stages)
     int NR, dld;                  // dense: unknowns N*(nx+nu) of the reduced KKT system; LDS row stride of the inversion workspace (odd)
 };
 
@@ -37,6 +38,7 @@ struct Ptrs {
     double *xo, *yo;              // reported solution
     double *dx, *dy;              // last primal / dual increments (infeasibility certificates)
     double *Bb, *Zb, *Sig;        // border (Nc < Np): K[:,ubar] and T^-1 K[:,ubar] in padded layout [nu][N*NB], Schur inverse [nu*nu]
+    double *bws;                  // block cyclic reduction: global workspace of the factorization, [batch][N * BcrFmt::WSTAGE]
     double *qv;                   // linear cost of the x,u variables [n_x+n_u] (rebuilt by every kernel prologue)
     double *Dt, *Et;              // Ruiz temporaries
     int *ctype;

@@ -119,6 +119,7 @@ __global__ __launch_bounds__(NT) void k_setup(Lay L, Ptrs P, mpcqp_settings S_) 
     if (tid == 0) { P.c[b] = cc; P.rho[b] = rho; }
     __syncthreads();
     int bad = L.dense ? factor_dense(c, om, sv, cc, P.F + (size_t)b * P.fsz, S.T, S.iflag)
+            : L.bcr ? factor_bcr(c, om, sv, cc, P.F + (size_t)b * P.fsz, P.bws + (size_t)b * L.N * BcrFmt::WSTAGE, S.T, S.iflag)
                       : factor_all<NB>(c, om, sv, cc, P.F + (size_t)b * P.fsz, S.T, S.iflag, border_ptrs(L, P, S));
     // cold start
     for (int j = tid; j < L.n; j += NT) { P.x[(size_t)b * L.n + j] = 0.0; P.xo[(size_t)b * L.n + j] = 0.0; }
@@ -703,11 +704,14 @@ __device__ __forceinline__ void gown_update(const Lay &L, const double *hot, con
 // (load_common) and, with LDSSTATE, X/Z/Y carved behind the common area.
 // MODE: how the KKT system is solved -- block-tridiagonal sweeps (MODE_CHAIN), the same with the bordered correction of a
 // control horizon Nc < Np (MODE_BORDER), or the dense register-resident inverse of small problems (MODE_DENSE, mpcqp_dense.h).
-enum { MODE_CHAIN = 0, MODE_BORDER = 1, MODE_DENSE = 2 };
+// MODE_BCR + N: block cyclic reduction with the factor of an N-stage problem resident in registers (mpcqp_bcr.h).
+enum { MODE_CHAIN = 0, MODE_BORDER = 1, MODE_DENSE = 2, MODE_BCR = 100 };
 template <int NB> __device__ __forceinline__ void admm_tiny(const Lay &, const HotPtrs &, Smem &, double *, double *, double *, double, int);      // mpcqp_tiny.h
+template <int NXT, int NUT, int NST> __device__ __forceinline__ void admm_lat(const Lay &, const HotPtrs &, Smem &, double *, double *, double *, double, int);      // mpcqp_lat.h
 template <int NB, bool LDSSTATE, int NXT, int NUT, int MODE>
 __device__ __forceinline__ void admm_body(const Lay &L, const HotPtrs &P, Smem &S, double *X, double *Z, double *Y, double alpha, int iters) {
     if constexpr (MODE == MODE_DENSE) { admm_tiny<NB>(L, P, S, X, Z, Y, alpha, iters); return; }      // register-resident iterate and inverse
+    if constexpr (MODE >= MODE_BCR) { admm_lat<NXT, NUT, MODE - MODE_BCR>(L, P, S, X, Z, Y, alpha, iters); return; }      // ... and cyclic-reduction factor
     const int b = inst_of(P.perm), tid = threadIdx.x;
     double *gx = P.x + (size_t)b * L.n, *gz = P.z + (size_t)b * L.m, *gy = P.y + (size_t)b * L.m;
     double *W = S.T, *Tc = S.T + L.m;

@@ -40,6 +40,10 @@ def _dense_eligible(name):
 SMALL = [n for n in golden_names() if _dense_eligible(n)]
 BACKENDS = [dict(MPCQP_DENSE=0), dict(MPCQP_DENSE=1)]
 IDS = ['sweeps', 'dense']
+# block cyclic reduction (register-resident factor) is instantiated for the BASELINE shape (12, 4, 30)
+BCR_NAMES = [n for n in golden_names() if n.startswith('random_12_4_30') and 'nc' not in n]
+CASES = [(n, e, i) for n in SMALL for e, i in zip(BACKENDS, IDS)] + [(n, e, i) for n in BCR_NAMES for e, i in ((dict(MPCQP_BCR=0), 'sweeps'), (dict(MPCQP_BCR=1), 'bcr'))]
+CASE_IDS = ['%s-%s' % (n, i) for n, e, i in CASES]
 
 
 def _ctrl(kw, oracle=False, **settings):
@@ -60,18 +64,16 @@ def test_some_fixture_is_small_enough():
     assert len(SMALL) >= 2, SMALL
 
 
-@pytest.mark.parametrize('env', BACKENDS, ids=IDS)
-@pytest.mark.parametrize('name', SMALL)
-def test_backend_is_the_one_asked_for(name, env):
+@pytest.mark.parametrize('name,env,tag', CASES, ids=CASE_IDS)
+def test_backend_is_the_one_asked_for(name, env, tag):
     with backend(**env):
         K = _ctrl(golden_kwargs(load_golden(name))); K.setup(solve=False)
         kn = K.prob.batch_problem.kernel_name(loop=False)
-    assert kn.split(',')[4] == ('2' if env['MPCQP_DENSE'] else '0'), kn
+    assert kn.split(',')[4] == {'sweeps': '0', 'dense': '2', 'bcr': '131'}[tag], kn
 
 
-@pytest.mark.parametrize('env', BACKENDS, ids=IDS)
-@pytest.mark.parametrize('name', SMALL)
-def test_kkt_solve_matches_dense_numpy(name, env):
+@pytest.mark.parametrize('name,env,tag', CASES, ids=CASE_IDS)
+def test_kkt_solve_matches_dense_numpy(name, env, tag):
     g = load_golden(name)
     with backend(**env):
         K = _ctrl(golden_kwargs(g)); K.setup(solve=False)
@@ -90,10 +92,9 @@ def test_kkt_solve_matches_dense_numpy(name, env):
             assert _rel(sol, np.linalg.solve(Kmat, rhs)) < 1e-8
 
 
-@pytest.mark.parametrize('env', BACKENDS, ids=IDS)
 @pytest.mark.parametrize('iters', [1, 7, 40])
-@pytest.mark.parametrize('name', SMALL)
-def test_admm_iterates_match_oracle(name, iters, env):
+@pytest.mark.parametrize('name,env,tag', CASES, ids=CASE_IDS)
+def test_admm_iterates_match_oracle(name, env, tag, iters):
     kw = golden_kwargs(load_golden(name))
     with backend(**env):
         K = _ctrl(kw); K.setup(solve=False)
@@ -106,9 +107,8 @@ def test_admm_iterates_match_oracle(name, iters, env):
     assert np.abs(y[0] - yo).max() < 1e-8 * max(1.0, np.abs(yo).max())
 
 
-@pytest.mark.parametrize('env', BACKENDS, ids=IDS)
-@pytest.mark.parametrize('name', SMALL)
-def test_default_tolerance_solve_and_optimum(name, env):
+@pytest.mark.parametrize('name,env,tag', CASES, ids=CASE_IDS)
+def test_default_tolerance_solve_and_optimum(name, env, tag):
     """eps 1e-3 (mpc.py:80): status, iteration count, rho updates as the oracle; eps 1e-9: u* within 1e-6 of the certified optimum."""
     g, opt = load_golden(name), load_golden(name, prefix='opt_')
     kw = golden_kwargs(g)
