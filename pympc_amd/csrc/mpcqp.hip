@@ -213,7 +213,7 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
         else bcr = !dense && h->lds_state && L.NB == 16 && !L.border && L.nx == 12 && L.nu == 4 && L.N == BCR_STAGES;
     }
     h->L.bcr = bcr ? 1 : 0;
-    if (bcr) h->L.tsz = std::max(h->L.tsz + L.N * L.NB, 5 * (L.N + 1) * L.NB + NT);      // the stage-major vectors of the latency round (mpcqp_lat.h); c_e of the streaming solve
+    if (bcr) h->L.tsz = std::max(h->L.tsz + L.N * L.NB, LAT_LDS_DOUBLES(L.N));      // the stage-major vectors of the latency round (mpcqp_lat.h); c_e of the streaming solve
     P.fsz = dense ? (long long)DenseFmt::DOUBLES : bcr ? (long long)L.N * BcrFmt::REC : (long long)L.fhead + (long long)L.N * L.fstage;
     int rc = 0;
     rc |= dalloc(h, &P.model, B * L.model_sz); rc |= dalloc(h, &P.step, B * L.step_sz);

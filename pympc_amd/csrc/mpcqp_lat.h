@@ -52,6 +52,7 @@ constexpr int lat_slot(int N, int W, int Lq, int kq, int tq) {
 constexpr int lat_slots(int N, int W) { return lat_slot(N, W, -1, -1, -1); }
 constexpr int lat_max_slots(int N) { int m = 0; for (int w = 0; w < 4; ++w) m = lat_slots(N, w) > m ? lat_slots(N, w) : m; return m; }
 
+#define LAT_LDS_DOUBLES(N) (5 * ((N) + 2) * 16 + NT)      /* LDS doubles of the latency round (five stage-major vectors + Wu) */
 #define LAT_DISPATCH(wv, CALL) switch (wv) { \
     case 0: { constexpr int W = 0; CALL; } break; case 1: { constexpr int W = 1; CALL; } break; \
     case 2: { constexpr int W = 2; CALL; } break; default: { constexpr int W = 3; CALL; } break; }
@@ -93,99 +94,57 @@ struct LatVecs { double *tb, *cb, *ab, *gb; };
 constexpr int lat_ord(int N, int W, int L, int kind, int tq) { int o = 0; for (int t = 0; t < tq; ++t) if (lat_owner(N, L, kind, t) == W) ++o; return o; }
 constexpr int lat_mine(int N, int W, int L, int kind) { return lat_ord(N, W, L, kind, lat_count(N, L, kind)); }
 
-// A wave issues in order: written task by task, every task would wait for its own LDS reads, rotations and dependent MFMA pair
-// (~350 cycles) before the next one starts.  The tasks of a phase are therefore executed in LOCKSTEP: all LDS reads, fence, all
-// rotations, the first MFMA of every chain, the second of every chain, sums and stores -- the matrix pipe stays busy and the
-// latencies are paid once per phase, not once per task.
-struct LatMv { double in, p, q; };                            // one mat-vec in flight: input vector, the two accumulator chains
-// NM mat-vecs in lockstep: m[o].(p, q) += frag(o) m[o].in.  The rotations are made where they are used (a rotated copy lives for one MFMA).
-template <int NM, class FragOf>
-__device__ __forceinline__ void lat_group(LatMv *m, FragOf frag) {
-    __builtin_amdgcn_sched_barrier(0);
-    static_for<0, NM>([&](auto oc) {
-        constexpr int o = decltype(oc)::value;
-        const d4 a = frag(oc);
-        m[o].p = __builtin_amdgcn_mfma_f64_4x4x4f64(a[0], m[o].in, m[o].p, 0, 0, 0);
-        m[o].q = __builtin_amdgcn_mfma_f64_4x4x4f64(a[2], rot_blocks<2>(m[o].in), m[o].q, 0, 0, 0);
-    });
-    __builtin_amdgcn_sched_barrier(0);
-    static_for<0, NM>([&](auto oc) {
-        constexpr int o = decltype(oc)::value;
-        const d4 a = frag(oc);
-        m[o].p = __builtin_amdgcn_mfma_f64_4x4x4f64(a[1], rot_blocks<1>(m[o].in), m[o].p, 0, 0, 0);
-        m[o].q = __builtin_amdgcn_mfma_f64_4x4x4f64(a[3], rot_blocks<3>(m[o].in), m[o].q, 0, 0, 0);
-    });
-    __builtin_amdgcn_sched_barrier(0);
+// (p, q) += A in: the two accumulator chains of a task run through ALL its mat-vecs (one addition per task at the end: a
+// double-precision vector add costs as much issue time as an MFMA here, see scripts/diag/mfma_rate.hip)
+__device__ __forceinline__ void lat_mv(const d4 a, double in, double &p, double &q) {
+    const double r1 = rot_blocks<1>(in), r2 = rot_blocks<2>(in), r3 = rot_blocks<3>(in);
+    p = __builtin_amdgcn_mfma_f64_4x4x4f64(a[0], in, p, 0, 0, 0);
+    q = __builtin_amdgcn_mfma_f64_4x4x4f64(a[2], r2, q, 0, 0, 0);
+    p = __builtin_amdgcn_mfma_f64_4x4x4f64(a[1], r1, p, 0, 0, 0);
+    q = __builtin_amdgcn_mfma_f64_4x4x4f64(a[3], r3, q, 0, 0, 0);
 }
-// t-th task (of a kind, at a level) that wave W owns -> its index among all tasks of that kind and level
-constexpr int lat_nth(int N, int W, int L, int kind, int o) { int c = 0; for (int t = 0; t < lat_count(N, L, kind); ++t) if (lat_owner(N, L, kind, t) == W) { if (c == o) return t; ++c; } return 0; }
 
 // forward tasks of level L that wave W owns.  ADD: the right-hand side is still split in two vectors (tb + ab).
 template <int N, int W, int L, bool ADD>
 __device__ __forceinline__ void lat_fwd(const d4 *fr, const LatVecs &v) {
-    constexpr int h = 1 << L, NK = lat_mine(N, W, L, 0), NE = lat_mine(N, W, L, 1);
+    constexpr int h = 1 << L;
     auto rd = [&](int s) { return ADD ? v.tb[s * 16] + v.ab[s * 16] : v.tb[s * 16]; };
-    if constexpr (NK > 0) {
-        LatMv ka[NK], kb[NK];
-        static_for<0, NK>([&](auto oc) {
-            constexpr int o = decltype(oc)::value, i = lat_stage(L, 0, lat_nth(N, W, L, 0, o));
-            ka[o].p = rd(i); ka[o].q = 0.0; ka[o].in = rd(i - h);
-            kb[o].p = 0.0; kb[o].q = 0.0; kb[o].in = rd(i + h < N ? i + h : i);
-        });
-        lat_group<NK>(ka, [&](auto oc) { constexpr int s = lat_slot(N, W, L, 0, lat_nth(N, W, L, 0, decltype(oc)::value)); return fr[s]; });
-        lat_group<NK>(kb, [&](auto oc) {
-            constexpr int t = lat_nth(N, W, L, 0, decltype(oc)::value), s = lat_slot(N, W, L, 0, t);
-            if constexpr (lat_stage(L, 0, t) + h < N) return fr[s + 1]; else return d4{0.0, 0.0, 0.0, 0.0};
-        });
-        static_for<0, NK>([&](auto oc) {
-            constexpr int o = decltype(oc)::value, i = lat_stage(L, 0, lat_nth(N, W, L, 0, o));
-            v.tb[i * 16] = (ka[o].p + ka[o].q) + (kb[o].p + kb[o].q);
-        });
-    }
-    if constexpr (NE > 0) {
-        LatMv ce[NE];
-        static_for<0, NE>([&](auto oc) {
-            constexpr int o = decltype(oc)::value, e = lat_stage(L, 1, lat_nth(N, W, L, 1, o));
-            ce[o].p = 0.0; ce[o].q = 0.0; ce[o].in = rd(e);
-        });
-        lat_group<NE>(ce, [&](auto oc) { constexpr int s = lat_slot(N, W, L, 1, lat_nth(N, W, L, 1, decltype(oc)::value)); return fr[s]; });
-        static_for<0, NE>([&](auto oc) {
-            constexpr int o = decltype(oc)::value, e = lat_stage(L, 1, lat_nth(N, W, L, 1, o));
-            v.cb[e * 16] = ce[o].p + ce[o].q;
-        });
-    }
+    static_for<0, lat_count(N, L, 0)>([&](auto tc) {
+        constexpr int t = decltype(tc)::value, i = lat_stage(L, 0, t);
+        if constexpr (lat_owner(N, L, 0, t) == W) {
+            constexpr int s = lat_slot(N, W, L, 0, t);
+            double p = v.tb[i * 16], q = ADD ? v.ab[i * 16] : 0.0;      // (the stage's own right-hand side starts the two chains)
+            lat_mv(fr[s], rd(i - h), p, q);
+            if constexpr (i + h < N) lat_mv(fr[s + 1], rd(i + h), p, q);
+            v.tb[i * 16] = p + q;
+        }
+    });
+    static_for<0, lat_count(N, L, 1)>([&](auto tc) {
+        constexpr int t = decltype(tc)::value, e = lat_stage(L, 1, t);
+        if constexpr (lat_owner(N, L, 1, t) == W) {
+            constexpr int s1 = lat_slot(N, W, L, 1, t);
+            double p = 0.0, q = 0.0;
+            lat_mv(fr[s1], rd(e), p, q);
+            v.cb[e * 16] = p + q;
+        }
+    });
 }
 // back-substitution tasks of level L that wave W owns; every solved stage e also leaves G v_e for stage e + 1
 template <int N, int W, int L>
 __device__ __forceinline__ void lat_bwd(const d4 *fr, const d4 Gf, const LatVecs &v) {
-    constexpr int h = 1 << L, NE = lat_mine(N, W, L, 2);
-    if constexpr (NE > 0) {
-        LatMv ma[NE], mb[NE];
-        static_for<0, NE>([&](auto oc) {
-            constexpr int o = decltype(oc)::value, e = lat_stage(L, 2, lat_nth(N, W, L, 2, o));
-            ma[o].p = v.cb[e * 16]; ma[o].q = 0.0; ma[o].in = v.tb[(e - h >= 0 ? e - h : e) * 16];
-            mb[o].p = 0.0; mb[o].q = 0.0; mb[o].in = v.tb[(e + h < N ? e + h : e) * 16];
-        });
-        lat_group<NE>(ma, [&](auto oc) {
-            constexpr int t = lat_nth(N, W, L, 2, decltype(oc)::value), s = lat_slot(N, W, L, 2, t);
-            if constexpr (lat_stage(L, 2, t) - h >= 0) return fr[s]; else return d4{0.0, 0.0, 0.0, 0.0};
-        });
-        lat_group<NE>(mb, [&](auto oc) {
-            constexpr int t = lat_nth(N, W, L, 2, decltype(oc)::value), e = lat_stage(L, 2, t), s = lat_slot(N, W, L, 2, t) + (e - h >= 0 ? 1 : 0);
-            if constexpr (e + h < N) return fr[s]; else return d4{0.0, 0.0, 0.0, 0.0};
-        });
-        static_for<0, NE>([&](auto oc) {
-            constexpr int o = decltype(oc)::value, e = lat_stage(L, 2, lat_nth(N, W, L, 2, o));
-            const double x = (ma[o].p + ma[o].q) + (mb[o].p + mb[o].q);
+    constexpr int h = 1 << L;
+    static_for<0, lat_count(N, L, 2)>([&](auto tc) {
+        constexpr int t = decltype(tc)::value, e = lat_stage(L, 2, t);
+        if constexpr (lat_owner(N, L, 2, t) == W) {
+            constexpr int s = lat_slot(N, W, L, 2, t), s2 = s + (e - h >= 0 ? 1 : 0);
+            double p = v.cb[e * 16], q = 0.0;
+            if constexpr (e - h >= 0) lat_mv(fr[s], v.tb[(e - h) * 16], p, q);
+            if constexpr (e + h < N) lat_mv(fr[s2], v.tb[(e + h) * 16], p, q);
+            const double x = p + q;
             v.tb[e * 16] = x;
-            ma[o].in = x; ma[o].p = 0.0; ma[o].q = 0.0;
-        });
-        lat_group<NE>(ma, [&](auto) { return Gf; });
-        static_for<0, NE>([&](auto oc) {
-            constexpr int o = decltype(oc)::value, e = lat_stage(L, 2, lat_nth(N, W, L, 2, o));
-            if constexpr (e + 1 < N) v.gb[(e + 1) * 16] = ma[o].p + ma[o].q;
-        });
-    }
+            if constexpr (e + 1 < N) { double g = 0.0, g2 = 0.0; lat_mv(Gf, x, g, g2); v.gb[(e + 1) * 16] = g + g2; }
+        }
+    });
 }
 
 // Tc <- K^-1 (Tc + AtW), and Gx.  All threads call; six barriers inside, none after the last phase (the caller's follows).
@@ -205,7 +164,7 @@ __device__ __forceinline__ void lat_solve(const d4 *fr, const d4 Gf, const LatVe
         constexpr int etop = lat_stage(LV - 1, 1, 0);
         const double x = v.cb[etop * 16];
         v.tb[etop * 16] = x;
-        if constexpr (etop + 1 < N) { double g = 0.0, g2 = 0.0; bcr_mv(Gf, x, g, g2); v.gb[(etop + 1) * 16] = g + g2; }
+        if constexpr (etop + 1 < N) { double g = 0.0, g2 = 0.0; lat_mv(Gf, x, g, g2); v.gb[(etop + 1) * 16] = g + g2; }
         static_for<0, LV - 3>([&](auto lc) { lat_bwd<N, 3, LV - 2 - decltype(lc)::value>(fr, Gf, v); });
     }
     __syncthreads();
@@ -217,19 +176,27 @@ __device__ __forceinline__ void lat_solve(const d4 *fr, const d4 Gf, const LatVe
 }
 
 // ---- the round ---------------------------------------------------------------------------------------------------------
-struct LatRow { double z, ys, om; };                          // a constraint row in registers: z, c y / omega, omega  (W = omega (z - ys))
+// A constraint row in registers: z, c y / omega, W = omega (z - c y / omega), omega.  Double-precision vector instructions are the
+// scarce resource of the element-wise phases (12 cycles of issue each with four waves on the CU: scripts/diag/mfma_rate.hip),
+// so a row step is written with as few of them as the arithmetic allows (seven; five for an equality row).
+struct LatRow { double z, ys, w, om; };
 __device__ __forceinline__ void lat_row_load(LatRow &r, cgdouble *gz, cgdouble *gy, cgdouble *om, double cc, int idx) {
-    r.om = om[idx]; r.z = gz[idx]; r.ys = cc * gy[idx] / r.om;
+    r.om = om[idx]; r.z = gz[idx]; r.ys = cc * gy[idx] / r.om; r.w = r.om * (r.z - r.ys);
 }
-__device__ __forceinline__ double lat_row_w(const LatRow &r) { return r.om * (r.z - r.ys); }
-// relaxation, projection on [lo, hi], dual step (own_update's `row`); returns the dual increment in y units
-__device__ __forceinline__ double lat_row_step(LatRow &r, double zt, double lo, double hi, double alpha, double beta, double cinv) {
-    lo = lo < -QP_INFTY ? -QP_INFTY : lo; hi = hi > QP_INFTY ? QP_INFTY : hi;
-    const double zr = alpha * zt + beta * r.z;
-    const double zn = fmin(fmax(zr + r.ys, lo), hi);
-    const double d = zr - zn;
-    r.ys += d; r.z = zn;
-    return (r.om * cinv) * d;
+// relaxation, projection on [lo, hi], dual step:  zr = alpha zt + beta z;  z+ = clamp(zr + ys);  ys+ = ys + (zr - z+)
+// returns the increment of ys (times omega / c: the dual increment the infeasibility certificates look at)
+__device__ __forceinline__ double lat_row_step(LatRow &r, double zt, double lo, double hi, double alpha, double beta) {
+    const double s = fma(alpha, zt, fma(beta, r.z, r.ys));
+    const double zn = fmin(fmax(s, lo), hi);
+    const double ysn = s - zn, d = ysn - r.ys;
+    r.z = zn; r.ys = ysn; r.w = r.om * (zn - ysn);
+    return d;
+}
+__device__ __forceinline__ double lat_row_step_eq(LatRow &r, double zt, double b0, double alpha, double beta) {
+    const double s = fma(alpha, zt, fma(beta, r.z, r.ys));
+    const double ysn = s - b0, d = ysn - r.ys;
+    r.z = b0; r.ys = ysn; r.w = r.om * (b0 - ysn);
+    return d;
 }
 
 // fragment of the 16 x 16 matrix whose entry (r, c) is f(r, c), built in registers (operand order: mpcqp_factor.h)
@@ -249,10 +216,10 @@ __device__ __forceinline__ void admm_lat(const Lay &L, const HotPtrs &P, Smem &S
     gdouble *dxg = (gdouble *)(P.dx + (size_t)b * L.n), *dyg = (gdouble *)(P.dy + (size_t)b * L.m);
     const double cc = P.c[b], cinv = 1.0 / cc, beta = 1.0 - alpha;
     const double *hot = S.hot;
-    // LDS: six stage-major vectors of (N + 1) stages and the flattened Delta-u row vector, in the work area T
-    constexpr int VS = (N + 1) * NB;
+    // LDS: five stage-major vectors of N + 2 stage slots and the flattened Delta-u row vector, in the work area T
+    constexpr int VS = (N + 2) * NB;
     double *Tc = S.T, *Cc = Tc + VS, *AtW = Cc + VS, *Gx = AtW + VS, *Wd = Gx + VS, *Wu = Wd + VS;
-    for (int i = tid; i < 5 * VS + NT; i += NT) S.T[i] = 0.0;
+    for (int i = tid; i < LAT_LDS_DOUBLES(N); i += NT) S.T[i] = 0.0;
     // ---- the factor: this wave's fragments, G = [Ad Bd] (rows: dynamics rows, columns: (x, u)) and G'
     d4 fr[lat_max_slots(N)];
     LAT_DISPATCH(wv, (lat_load<N, W>(P.F + (size_t)b * P.fsz, fr)))
@@ -262,73 +229,70 @@ __device__ __forceinline__ void admm_lat(const Lay &L, const HotPtrs &P, Smem &S
     const d4 GTf = lat_make_frag(lane, [&](int r, int c) { return gent(c, r); });
     const int lo16 = vec_lane_offset(lane);
     const LatVecs vec{Tc + lo16, Cc + lo16, AtW + lo16, Gx + lo16};
-    const double *wdb = Wd + lo16;
+    // G' W for FOUR stages per MFMA group: the B operand's four columns j carry four different stages' vectors (the matrix is the
+    // same for all of them) -- lane (k, b, j) reads element 4b + k of stage 4g + j + 1, the result for stage 4g + j lands in lane (i, b, j)
+    const int lk = lane >> 4, lb = (lane >> 2) & 3, lj = lane & 3;
+    const double *wd4 = Wd + (lj + 1) * NB + 4 * lb + lk;      // + 4 g NB
+    double *at4 = AtW + lj * NB + 4 * lb + lk;                  // (output: i takes the place of k)
     // ---- owner map (as own_*): state elements e = tid + NT j, input element cu = tid
     const double cef = cc * hot[L.oeps];
-    double x[2], ep[2], svx[2], cqx[2], sve[2], kap[2], te[2];
+    double x[2], ep[2], svx[2], ncq[2], sve[2], kap[2], okap[2], te[2], b0[2];
     LatRow rD[2], rS[2], rI, rU, r0;
-    int ek[2], ea[2];
+    int esl[2], ea[2];
     bool ev[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int e = tid + NT * j;
         ev[j] = e < NX;
-        const int ec = ev[j] ? e : 0;
-        ek[j] = ec / nx; ea[j] = ec - ek[j] * nx;
-        x[j] = gx[ec]; svx[j] = sv[ec]; cqx[j] = cc * qv[ec];
+        const int ec = ev[j] ? e : 0, k = ec / nx;
+        ea[j] = ec - k * nx; esl[j] = k * NB + ea[j];
+        x[j] = gx[ec]; svx[j] = sv[ec]; ncq[j] = -cc * qv[ec];
         ep[j] = L.soft ? gx[L.oe + ec] : 0.0; sve[j] = L.soft ? sv[L.oe + ec] : 0.0;
         lat_row_load(rD[j], gz, gy, om, cc, ec);
         lat_row_load(rS[j], gz, gy, om, cc, L.rs + ec);
-        kap[j] = 1.0 / (cef + sve[j] + rS[j].om);
+        kap[j] = L.soft ? 1.0 / (cef + sve[j] + rS[j].om) : 0.0; okap[j] = rS[j].om * kap[j];
         te[j] = 0.0;
+        b0[j] = k == 0 ? -S.x0s[ea[j]] : 0.0;
     }
     const bool uv = tid < NU, u0v = tid < nu;
     const int cu = uv ? tid : 0, uk = cu / nu, uj = cu - uk * nu;
     double u = gx[L.ou + cu];
-    const double svu = sv[L.ou + cu], cqu = cc * qv[L.n_x + cu];
+    const double svu = sv[L.ou + cu], ncqu = -cc * qv[L.n_x + cu];
     lat_row_load(rI, gz, gy, om, cc, L.ri + cu);
     lat_row_load(rU, gz, gy, om, cc, L.rdu + nu + cu);
     lat_row_load(r0, gz, gy, om, cc, L.rdu + (u0v ? tid : 0));
+    if (!u0v) r0.w = 0.0;
     const int uslot = uk * NB + nx + uj;                                          // this input's slot in the stage-major vectors
     const int unext = (uj + 1 < nu) ? uslot + 1 : (uk + 1) * NB + nx;             // next flattened input (cu + 1 < n_u)
     const bool has_unext = uv && cu + 1 < NU, has_uprev = uv && cu > 0;
+    const double s_uprev = has_uprev ? 1.0 : 0.0, s_unext = has_unext ? 1.0 : 0.0;
+    const double *uprevp = Wu + (has_uprev ? cu - 1 : 0), *unextp = Tc + (has_unext ? unext : 0);
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 2; ++j) if (ev[j]) Wd[ek[j] * NB + ea[j]] = lat_row_w(rD[j]);
-    if (uv) Wu[cu] = lat_row_w(rU);
+    for (int j = 0; j < 2; ++j) if (ev[j]) Wd[esl[j]] = rD[j].w;
+    if (uv) Wu[cu] = rU.w;
     __syncthreads();
     TICK_RESET
     for (int it = 1; it <= iters; ++it) {
         const bool keep_delta = it == iters;
         TICK_START
-        // ---- G' W_dyn of the next stage, for every stage but the last (30 independent mat-vecs over four waves) ...
+        // ---- G' W_dyn of the next stage for every stage: two groups of four stages per wave ...
         {
-            constexpr int NM = (N - 1 + NWAVES - 1) / NWAVES;
-            LatMv mm[NM];
-            static_for<0, NM>([&](auto uc) {
-                constexpr int uu = decltype(uc)::value;
-                const int k = min(wv + NWAVES * uu, N - 2);   // (a wave short of a task repeats the last one: same value, same place)
-                mm[uu].in = wdb[(k + 1) * NB]; mm[uu].p = 0.0; mm[uu].q = 0.0;
-            });
-            lat_group<NM>(mm, [&](auto) { return GTf; });
-            static_for<0, NM>([&](auto uc) {
-                constexpr int uu = decltype(uc)::value;
-                const int k = min(wv + NWAVES * uu, N - 2);
-                vec.ab[k * NB] = mm[uu].p + mm[uu].q;
-            });
+            double g0 = 0.0, h0 = 0.0, g1 = 0.0, h1 = 0.0;
+            lat_mv(GTf, wd4[4 * wv * NB], g0, h0);
+            lat_mv(GTf, wd4[4 * (wv + NWAVES) * NB], g1, h1);
+            at4[4 * wv * NB] = g0 + h0;
+            at4[4 * (wv + NWAVES) * NB] = g1 + h1;
         }
         // ---- ... and the rest of the right-hand side  s x - c q + (own rows' W)  with the slack eliminated (E1)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const double wS = lat_row_w(rS[j]);
-            te[j] = L.soft ? (sve[j] * ep[j] + wS) * kap[j] : 0.0;
-            const double rhs = svx[j] * x[j] - cqx[j] - lat_row_w(rD[j]) + (wS - rS[j].om * te[j]);
-            if (ev[j]) Tc[ek[j] * NB + ea[j]] = rhs;
+            te[j] = fma(sve[j], ep[j], rS[j].w) * kap[j];                          // (hard state box: kap = 0, no slack)
+            const double rhs = (fma(svx[j], x[j], ncq[j]) - rD[j].w) + fma(-rS[j].om, te[j], rS[j].w);
+            if (ev[j]) Tc[esl[j]] = rhs;
         }
         {
-            double rhs = svu * u - cqu + lat_row_w(rI) - lat_row_w(rU);
-            if (u0v) rhs += lat_row_w(r0);
-            if (has_uprev) rhs += Wu[cu - 1];
+            const double rhs = fma(s_uprev, *uprevp, fma(svu, u, ncqu) + (rI.w - rU.w)) + r0.w;
             if (uv) Tc[uslot] = rhs;
         }
         __syncthreads();
@@ -339,29 +303,30 @@ __device__ __forceinline__ void admm_lat(const Lay &L, const HotPtrs &P, Smem &S
         // ---- relaxation, projection, dual step of the owned rows (E2)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int sl = ek[j] * NB + ea[j];
-            const double xt = Tc[sl], gv = Gx[sl];
-            const double et = L.soft ? te[j] - (rS[j].om * kap[j]) * xt : 0.0;
-            const double xn = alpha * xt + beta * x[j], en = alpha * et + beta * ep[j];
-            const int e = tid + NT * j;
-            if (keep_delta && ev[j]) { dxg[e] = xn - x[j]; if (L.soft) dxg[L.oe + e] = en - ep[j]; }
+            const double xt = Tc[esl[j]], gv = Gx[esl[j]];
+            const double xlo = hot[L.oxmin + ea[j]], xhi = hot[L.oxmax + ea[j]];
+            const double et = fma(-okap[j], xt, te[j]);
+            const double xn = fma(alpha, xt, beta * x[j]), en = fma(alpha, et, beta * ep[j]);
+            const double dD = lat_row_step_eq(rD[j], gv - xt, b0[j], alpha, beta);
+            const double dS = lat_row_step(rS[j], xt + et, xlo, xhi, alpha, beta);
+            if (keep_delta && ev[j]) {
+                const int e = tid + NT * j;
+                dxg[e] = xn - x[j]; if (L.soft) dxg[L.oe + e] = en - ep[j];
+                dyg[e] = (rD[j].om * cinv) * dD; dyg[L.rs + e] = (rS[j].om * cinv) * dS;
+            }
             x[j] = xn; ep[j] = en;
-            const double b0 = ek[j] == 0 ? -S.x0s[ea[j]] : 0.0;
-            const double dD = lat_row_step(rD[j], gv - xt, b0, b0, alpha, beta, cinv);
-            const double dS = lat_row_step(rS[j], xt + et, hot[L.oxmin + ea[j]], hot[L.oxmax + ea[j]], alpha, beta, cinv);
-            if (keep_delta && ev[j]) { dyg[e] = dD; dyg[L.rs + e] = dS; }
-            if (ev[j]) Wd[sl] = lat_row_w(rD[j]);
+            if (ev[j]) Wd[esl[j]] = rD[j].w;
         }
         {
-            const double ut = Tc[uslot], un = has_unext ? Tc[unext] : 0.0;
-            const double unew = alpha * ut + beta * u;
-            if (keep_delta && uv) dxg[L.ou + cu] = unew - u;
+            const double ut = Tc[uslot], un = *unextp;
+            const double ulo = hot[L.oumin + uj], uhi = hot[L.oumax + uj], dlo = hot[L.oDumin + uj], dhi = hot[L.oDumax + uj];
+            const double unew = fma(alpha, ut, beta * u);
+            const double dI = lat_row_step(rI, ut, ulo, uhi, alpha, beta);
+            const double dU = lat_row_step(rU, fma(s_unext, un, -ut), dlo, dhi, alpha, beta);
+            if (keep_delta && uv) { dxg[L.ou + cu] = unew - u; dyg[L.ri + cu] = (rI.om * cinv) * dI; dyg[L.rdu + nu + cu] = (rU.om * cinv) * dU; }
             u = unew;
-            const double dI = lat_row_step(rI, ut, hot[L.oumin + uj], hot[L.oumax + uj], alpha, beta, cinv);
-            const double dU = lat_row_step(rU, (has_unext ? un : 0.0) - ut, hot[L.oDumin + uj], hot[L.oDumax + uj], alpha, beta, cinv);
-            if (keep_delta && uv) { dyg[L.ri + cu] = dI; dyg[L.rdu + nu + cu] = dU; }
-            if (u0v) { const double d0 = lat_row_step(r0, ut, S.du0[tid], S.du0[nu + tid], alpha, beta, cinv); if (keep_delta) dyg[L.rdu + tid] = d0; }
-            if (uv) Wu[cu] = lat_row_w(rU);
+            if (u0v) { const double d0 = lat_row_step(r0, ut, S.du0[tid], S.du0[nu + tid], alpha, beta); if (keep_delta) dyg[L.rdu + tid] = (r0.om * cinv) * d0; }
+            if (uv) Wu[cu] = rU.w;
         }
         __syncthreads();
         TICK(6)
