@@ -10,10 +10,13 @@
 //   * the KKT solve is 2 ceil(log2 N) - 1 level steps of independent mat-vecs; levels 0 and 1 run on all four waves with a
 //     barrier each, the levels above them (7 stages, a chain of 5 dependent steps) on ONE wave without barriers;
 //     which wave runs which task is fixed at compile time, so each wave keeps exactly the fragments it needs (<= 35 x 8 VGPRs);
-//   * every variable and constraint row has an owner thread that keeps it in registers for the round (as mpcqp_tiny.h);
-//   * A'W and A x -- the only neighbour couplings -- are 16 x 16 mat-vecs G' W_dyn and G v per stage, G = [Ad Bd]: on the matrix
-//     cores with G, G' resident (G v fused into the back substitution: the solution is in the producing wave's registers);
-//   * seven barriers per iteration:   E1 + G'W | level 0 | level 1 | upper levels | level 1 back | level 0 back + G v | E2.
+//   * every variable and constraint row has an owner lane that keeps it in registers for the round (as mpcqp_tiny.h), and the
+//     owner map IS the MFMA operand layout: lane (I, B, J) of group g owns slot a = 4B + I of stage s = 4g + J (x_s[a] with its
+//     slack, dynamics row and box row, or u_s[a - nx] with its box row and Delta-u row), two groups per wave;
+//   * A'W and A x -- the only neighbour couplings -- are 16 x 16 mat-vecs G' W_dyn(s+1) and G v(s-1), G = [Ad Bd]; the same G for
+//     every stage, so ONE MFMA group does FOUR stages (the B operand's four columns carry four stages' vectors) and its result
+//     lands exactly in the owner lanes: no LDS round trip between the products and the rows that consume them;
+//   * seven barriers per iteration:  G v + row updates | G'W + right-hand side | level 0 | level 1 | upper levels | level 1 back | level 0 back.
 #pragma once
 
 // ---- static schedule ---------------------------------------------------------------------------------------------------
@@ -52,7 +55,8 @@ constexpr int lat_slot(int N, int W, int Lq, int kq, int tq) {
 constexpr int lat_slots(int N, int W) { return lat_slot(N, W, -1, -1, -1); }
 constexpr int lat_max_slots(int N) { int m = 0; for (int w = 0; w < 4; ++w) m = lat_slots(N, w) > m ? lat_slots(N, w) : m; return m; }
 
-#define LAT_LDS_DOUBLES(N) (5 * ((N) + 2) * 16 + NT)      /* LDS doubles of the latency round (five stage-major vectors + Wu) */
+#define LAT_VS(N) ((4 * (((N) + 3) / 4) + 2) * 16)          /* doubles of one stage-major vector: stage slots -1 .. 4 ceil(N/4) */
+#define LAT_LDS_DOUBLES(N) (4 * LAT_VS(N) + 16)              /* LDS doubles of the latency round: right-hand side, c_e, W of the slots' two rows */
 #define LAT_DISPATCH(wv, CALL) switch (wv) { \
     case 0: { constexpr int W = 0; CALL; } break; case 1: { constexpr int W = 1; CALL; } break; \
     case 2: { constexpr int W = 2; CALL; } break; default: { constexpr int W = 3; CALL; } break; }
@@ -86,9 +90,8 @@ __device__ __forceinline__ void lat_load(const double *F, d4 *fr) {
 
 // LDS vectors of the round, all stage-major with stride 16 (element a of stage k at k * 16 + a), seen through the per-lane
 // base of the MFMA operand layout (vec_lane_offset):
-//   tb  right-hand side / solution      cb  c_e of the reduction       ab  G' W_dyn of the next stage (added to the right-hand side)
-//   gb  G v of the previous stage (stage k + 1's slot written by the wave that solved stage k)
-struct LatVecs { double *tb, *cb, *ab, *gb; };
+//   tb  right-hand side / solution      cb  c_e of the reduction
+struct LatVecs { double *tb, *cb; };
 
 // ordinal of a task among the tasks of its kind and level that wave W owns (compile time)
 constexpr int lat_ord(int N, int W, int L, int kind, int tq) { int o = 0; for (int t = 0; t < tq; ++t) if (lat_owner(N, L, kind, t) == W) ++o; return o; }
@@ -104,18 +107,17 @@ __device__ __forceinline__ void lat_mv(const d4 a, double in, double &p, double 
     q = __builtin_amdgcn_mfma_f64_4x4x4f64(a[3], r3, q, 0, 0, 0);
 }
 
-// forward tasks of level L that wave W owns.  ADD: the right-hand side is still split in two vectors (tb + ab).
-template <int N, int W, int L, bool ADD>
+// forward tasks of level L that wave W owns
+template <int N, int W, int L>
 __device__ __forceinline__ void lat_fwd(const d4 *fr, const LatVecs &v) {
     constexpr int h = 1 << L;
-    auto rd = [&](int s) { return ADD ? v.tb[s * 16] + v.ab[s * 16] : v.tb[s * 16]; };
     static_for<0, lat_count(N, L, 0)>([&](auto tc) {
         constexpr int t = decltype(tc)::value, i = lat_stage(L, 0, t);
         if constexpr (lat_owner(N, L, 0, t) == W) {
             constexpr int s = lat_slot(N, W, L, 0, t);
-            double p = v.tb[i * 16], q = ADD ? v.ab[i * 16] : 0.0;      // (the stage's own right-hand side starts the two chains)
-            lat_mv(fr[s], rd(i - h), p, q);
-            if constexpr (i + h < N) lat_mv(fr[s + 1], rd(i + h), p, q);
+            double p = v.tb[i * 16], q = 0.0;                 // (the stage's own right-hand side starts the chain)
+            lat_mv(fr[s], v.tb[(i - h) * 16], p, q);
+            if constexpr (i + h < N) lat_mv(fr[s + 1], v.tb[(i + h) * 16], p, q);
             v.tb[i * 16] = p + q;
         }
     });
@@ -124,14 +126,14 @@ __device__ __forceinline__ void lat_fwd(const d4 *fr, const LatVecs &v) {
         if constexpr (lat_owner(N, L, 1, t) == W) {
             constexpr int s1 = lat_slot(N, W, L, 1, t);
             double p = 0.0, q = 0.0;
-            lat_mv(fr[s1], rd(e), p, q);
+            lat_mv(fr[s1], v.tb[e * 16], p, q);
             v.cb[e * 16] = p + q;
         }
     });
 }
-// back-substitution tasks of level L that wave W owns; every solved stage e also leaves G v_e for stage e + 1
+// back-substitution tasks of level L that wave W owns
 template <int N, int W, int L>
-__device__ __forceinline__ void lat_bwd(const d4 *fr, const d4 Gf, const LatVecs &v) {
+__device__ __forceinline__ void lat_bwd(const d4 *fr, const LatVecs &v) {
     constexpr int h = 1 << L;
     static_for<0, lat_count(N, L, 2)>([&](auto tc) {
         constexpr int t = decltype(tc)::value, e = lat_stage(L, 2, t);
@@ -140,39 +142,34 @@ __device__ __forceinline__ void lat_bwd(const d4 *fr, const d4 Gf, const LatVecs
             double p = v.cb[e * 16], q = 0.0;
             if constexpr (e - h >= 0) lat_mv(fr[s], v.tb[(e - h) * 16], p, q);
             if constexpr (e + h < N) lat_mv(fr[s2], v.tb[(e + h) * 16], p, q);
-            const double x = p + q;
-            v.tb[e * 16] = x;
-            if constexpr (e + 1 < N) { double g = 0.0, g2 = 0.0; lat_mv(Gf, x, g, g2); v.gb[(e + 1) * 16] = g + g2; }
+            v.tb[e * 16] = p + q;
         }
     });
 }
 
-// Tc <- K^-1 (Tc + AtW), and Gx.  All threads call; six barriers inside, none after the last phase (the caller's follows).
+// Tc <- K^-1 Tc.  All threads call; four barriers inside, none after the last phase (the caller's follows).
 template <int N>
-__device__ __forceinline__ void lat_solve(const d4 *fr, const d4 Gf, const LatVecs &v, int wv) {
+__device__ __forceinline__ void lat_solve(const d4 *fr, const LatVecs &v, int wv) {
     constexpr int LV = bcr_levels(N);
     static_assert(LV >= 3, "levels 0 and 1 in parallel, the rest on one wave");
-    LAT_DISPATCH(wv, (lat_fwd<N, W, 0, true>(fr, v)))
+    LAT_DISPATCH(wv, (lat_fwd<N, W, 0>(fr, v)))
     __syncthreads();
     TICK(1)
-    LAT_DISPATCH(wv, (lat_fwd<N, W, 1, false>(fr, v)))
+    LAT_DISPATCH(wv, (lat_fwd<N, W, 1>(fr, v)))
     __syncthreads();
     TICK(2)
     if (wv == 3) {                 // the upper levels: a chain of dependent level steps, one wave, LDS in program order, no barriers
-        static_for<2, LV>([&](auto lc) { lat_fwd<N, 3, decltype(lc)::value, false>(fr, v); });
-        // the top level's only stage has no neighbours left: c is the solution
-        constexpr int etop = lat_stage(LV - 1, 1, 0);
-        const double x = v.cb[etop * 16];
-        v.tb[etop * 16] = x;
-        if constexpr (etop + 1 < N) { double g = 0.0, g2 = 0.0; lat_mv(Gf, x, g, g2); v.gb[(etop + 1) * 16] = g + g2; }
-        static_for<0, LV - 3>([&](auto lc) { lat_bwd<N, 3, LV - 2 - decltype(lc)::value>(fr, Gf, v); });
+        static_for<2, LV>([&](auto lc) { lat_fwd<N, 3, decltype(lc)::value>(fr, v); });
+        constexpr int etop = lat_stage(LV - 1, 1, 0);        // the top level's only stage has no neighbours left: c is the solution
+        v.tb[etop * 16] = v.cb[etop * 16];
+        static_for<0, LV - 3>([&](auto lc) { lat_bwd<N, 3, LV - 2 - decltype(lc)::value>(fr, v); });
     }
     __syncthreads();
     TICK(3)
-    LAT_DISPATCH(wv, (lat_bwd<N, W, 1>(fr, Gf, v)))
+    LAT_DISPATCH(wv, (lat_bwd<N, W, 1>(fr, v)))
     __syncthreads();
     TICK(4)
-    LAT_DISPATCH(wv, (lat_bwd<N, W, 0>(fr, Gf, v)))
+    LAT_DISPATCH(wv, (lat_bwd<N, W, 0>(fr, v)))
 }
 
 // ---- the round ---------------------------------------------------------------------------------------------------------
@@ -208,17 +205,17 @@ __device__ __forceinline__ d4 lat_make_frag(int lane, Fn f) {
 
 template <int NXT, int NUT, int NST>
 __device__ __forceinline__ void admm_lat(const Lay &L, const HotPtrs &P, Smem &S, double *Xl, double *Zl, double *Yl, double alpha, int iters) {
-    constexpr int NB = 16, nx = NXT, nu = NUT, N = NST, NX = N * nx, NU = (N - 1) * nu;
-    static_assert(NX <= 2 * NT && NU <= NT && nx + nu <= NB, "owner map: two state elements and one input element per thread");
+    constexpr int NB = 16, nx = NXT, nu = NUT, N = NST, NG = (N + 3) / 4;
+    static_assert(NG <= 2 * NWAVES && nx + nu <= NB, "owner map: two groups of four stages per wave");
     const int b = inst_of(P.perm), tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     gdouble *gx = (gdouble *)(P.x + (size_t)b * L.n), *gz = (gdouble *)(P.z + (size_t)b * L.m), *gy = (gdouble *)(P.y + (size_t)b * L.m);
     cgdouble *om = (cgdouble *)(P.omega + (size_t)b * L.m), *sv = (cgdouble *)(P.s + (size_t)b * L.n), *qv = (cgdouble *)S.Qv;
     gdouble *dxg = (gdouble *)(P.dx + (size_t)b * L.n), *dyg = (gdouble *)(P.dy + (size_t)b * L.m);
     const double cc = P.c[b], cinv = 1.0 / cc, beta = 1.0 - alpha;
     const double *hot = S.hot;
-    // LDS: five stage-major vectors of N + 2 stage slots and the flattened Delta-u row vector, in the work area T
-    constexpr int VS = (N + 2) * NB;
-    double *Tc = S.T, *Cc = Tc + VS, *AtW = Cc + VS, *Gx = AtW + VS, *Wd = Gx + VS, *Wu = Wd + VS;
+    // LDS: four stage-major vectors with stage slots -1 .. 4 NG (the slots outside 0 .. N-1 stay zero: neighbours of the ends)
+    constexpr int VS = LAT_VS(N);
+    double *Tc = S.T + NB, *Cc = Tc + VS, *WA = Cc + VS, *WB = WA + VS;      // right-hand side / solution, c_e, W of the first / second row of a slot
     for (int i = tid; i < LAT_LDS_DOUBLES(N); i += NT) S.T[i] = 0.0;
     // ---- the factor: this wave's fragments, G = [Ad Bd] (rows: dynamics rows, columns: (x, u)) and G'
     d4 fr[lat_max_slots(N)];
@@ -228,105 +225,96 @@ __device__ __forceinline__ void admm_lat(const Lay &L, const HotPtrs &P, Smem &S
     const d4 Gf = lat_make_frag(lane, gent);
     const d4 GTf = lat_make_frag(lane, [&](int r, int c) { return gent(c, r); });
     const int lo16 = vec_lane_offset(lane);
-    const LatVecs vec{Tc + lo16, Cc + lo16, AtW + lo16, Gx + lo16};
-    // G' W for FOUR stages per MFMA group: the B operand's four columns j carry four different stages' vectors (the matrix is the
-    // same for all of them) -- lane (k, b, j) reads element 4b + k of stage 4g + j + 1, the result for stage 4g + j lands in lane (i, b, j)
-    const int lk = lane >> 4, lb = (lane >> 2) & 3, lj = lane & 3;
-    const double *wd4 = Wd + (lj + 1) * NB + 4 * lb + lk;      // + 4 g NB
-    double *at4 = AtW + lj * NB + 4 * lb + lk;                  // (output: i takes the place of k)
-    // ---- owner map (as own_*): state elements e = tid + NT j, input element cu = tid
+    const LatVecs vec{Tc + lo16, Cc + lo16};
+    // ---- owner map: lane (I, B, J), group g = wv + 4 q  ->  slot a = 4B + I of stage s = 4g + J
+    const int a = 4 * ((lane >> 2) & 3) + (lane >> 4), J = lane & 3;
+    const bool is_x = a < nx;
+    const int jj = a - nx;
     const double cef = cc * hot[L.oeps];
-    double x[2], ep[2], svx[2], ncq[2], sve[2], kap[2], okap[2], te[2], b0[2];
-    LatRow rD[2], rS[2], rI, rU, r0;
-    int esl[2], ea[2];
-    bool ev[2];
+    double pv[2], pv2[2], svp[2], ncq[2], sve[2], kap[2], okap[2], te[2], loA[2], hiA[2], loB[2], hiB[2];
+    LatRow rA[2], rB[2], r0{0.0, 0.0, 0.0, 1.0};
+    int sl[2], pidx[2], aidx[2], bidx[2];
+    bool ok[2];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int e = tid + NT * j;
-        ev[j] = e < NX;
-        const int ec = ev[j] ? e : 0, k = ec / nx;
-        ea[j] = ec - k * nx; esl[j] = k * NB + ea[j];
-        x[j] = gx[ec]; svx[j] = sv[ec]; ncq[j] = -cc * qv[ec];
-        ep[j] = L.soft ? gx[L.oe + ec] : 0.0; sve[j] = L.soft ? sv[L.oe + ec] : 0.0;
-        lat_row_load(rD[j], gz, gy, om, cc, ec);
-        lat_row_load(rS[j], gz, gy, om, cc, L.rs + ec);
-        kap[j] = L.soft ? 1.0 / (cef + sve[j] + rS[j].om) : 0.0; okap[j] = rS[j].om * kap[j];
-        te[j] = 0.0;
-        b0[j] = k == 0 ? -S.x0s[ea[j]] : 0.0;
+    for (int q = 0; q < 2; ++q) {
+        const int s = 4 * (wv + NWAVES * q) + J;
+        sl[q] = s * NB + a;
+        ok[q] = is_x ? s < N : (a < nx + nu && s < N - 1);
+        const int e = s * nx + a, cu = s * nu + jj;
+        pidx[q] = is_x ? e : L.ou + cu; aidx[q] = is_x ? e : L.ri + cu; bidx[q] = is_x ? L.rs + e : L.rdu + nu + cu;
+        pv[q] = pv2[q] = svp[q] = ncq[q] = sve[q] = kap[q] = okap[q] = te[q] = 0.0;
+        loA[q] = hiA[q] = loB[q] = hiB[q] = 0.0;
+        rA[q] = LatRow{0.0, 0.0, 0.0, 1.0}; rB[q] = LatRow{0.0, 0.0, 0.0, 1.0};
+        if (ok[q]) {
+            pv[q] = gx[pidx[q]]; svp[q] = sv[pidx[q]]; ncq[q] = -cc * qv[is_x ? e : L.n_x + cu];
+            lat_row_load(rA[q], gz, gy, om, cc, aidx[q]);
+            lat_row_load(rB[q], gz, gy, om, cc, bidx[q]);
+            if (is_x) {
+                if (L.soft) { pv2[q] = gx[L.oe + e]; sve[q] = sv[L.oe + e]; kap[q] = 1.0 / (cef + sve[q] + rB[q].om); okap[q] = rB[q].om * kap[q]; }
+                loA[q] = hiA[q] = s == 0 ? -S.x0s[a] : 0.0;
+                loB[q] = hot[L.oxmin + a]; hiB[q] = hot[L.oxmax + a];
+            } else {
+                loA[q] = hot[L.oumin + jj]; hiA[q] = hot[L.oumax + jj]; loB[q] = hot[L.oDumin + jj]; hiB[q] = hot[L.oDumax + jj];
+            }
+        }
     }
-    const bool uv = tid < NU, u0v = tid < nu;
-    const int cu = uv ? tid : 0, uk = cu / nu, uj = cu - uk * nu;
-    double u = gx[L.ou + cu];
-    const double svu = sv[L.ou + cu], ncqu = -cc * qv[L.n_x + cu];
-    lat_row_load(rI, gz, gy, om, cc, L.ri + cu);
-    lat_row_load(rU, gz, gy, om, cc, L.rdu + nu + cu);
-    lat_row_load(r0, gz, gy, om, cc, L.rdu + (u0v ? tid : 0));
-    if (!u0v) r0.w = 0.0;
-    const int uslot = uk * NB + nx + uj;                                          // this input's slot in the stage-major vectors
-    const int unext = (uj + 1 < nu) ? uslot + 1 : (uk + 1) * NB + nx;             // next flattened input (cu + 1 < n_u)
-    const bool has_unext = uv && cu + 1 < NU, has_uprev = uv && cu > 0;
-    const double s_uprev = has_uprev ? 1.0 : 0.0, s_unext = has_unext ? 1.0 : 0.0;
-    const double *uprevp = Wu + (has_uprev ? cu - 1 : 0), *unextp = Tc + (has_unext ? unext : 0);
+    const bool u0v = wv == 0 && J == 0 && !is_x && a < nx + nu;      // the first-step rows u_0 - u_{-1} (mpc.py:574): stage 0's inputs
+    if (u0v) lat_row_load(r0, gz, gy, om, cc, L.rdu + jj);
+    // neighbours in the flattened input sequence (mpc.py:570): slot a + 1 / a - 1, across the stage boundary at the ends
+    const int onext = (jj + 1 < nu) ? 1 : NB - nu + 1, oprev = (jj > 0) ? -1 : -(NB - nu + 1);
+    const double selx = is_x ? 1.0 : 0.0, selu = is_x ? 0.0 : 1.0, sgnA = is_x ? -1.0 : 1.0;
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 2; ++j) if (ev[j]) Wd[esl[j]] = rD[j].w;
-    if (uv) Wu[cu] = rU.w;
+    for (int q = 0; q < 2; ++q) { WA[sl[q]] = rA[q].w; WB[sl[q]] = rB[q].w; }
     __syncthreads();
     TICK_RESET
     for (int it = 1; it <= iters; ++it) {
         const bool keep_delta = it == iters;
         TICK_START
-        // ---- G' W_dyn of the next stage for every stage: two groups of four stages per wave ...
+        // ---- right-hand side  s x - c q + A'W  with the slack eliminated; A'W = own rows' W + G' W_dyn of the next stage (MFMA, four stages a group)
         {
-            double g0 = 0.0, h0 = 0.0, g1 = 0.0, h1 = 0.0;
-            lat_mv(GTf, wd4[4 * wv * NB], g0, h0);
-            lat_mv(GTf, wd4[4 * (wv + NWAVES) * NB], g1, h1);
-            at4[4 * wv * NB] = g0 + h0;
-            at4[4 * (wv + NWAVES) * NB] = g1 + h1;
-        }
-        // ---- ... and the rest of the right-hand side  s x - c q + (own rows' W)  with the slack eliminated (E1)
+            double g[2] = {0.0, 0.0}, h2[2] = {0.0, 0.0};
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            te[j] = fma(sve[j], ep[j], rS[j].w) * kap[j];                          // (hard state box: kap = 0, no slack)
-            const double rhs = (fma(svx[j], x[j], ncq[j]) - rD[j].w) + fma(-rS[j].om, te[j], rS[j].w);
-            if (ev[j]) Tc[esl[j]] = rhs;
-        }
-        {
-            const double rhs = fma(s_uprev, *uprevp, fma(svu, u, ncqu) + (rI.w - rU.w)) + r0.w;
-            if (uv) Tc[uslot] = rhs;
+            for (int q = 0; q < 2; ++q) lat_mv(GTf, WA[sl[q] + NB], g[q], h2[q]);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const double wprev = WB[sl[q] + oprev];
+                te[q] = fma(sve[q], pv2[q], rB[q].w) * kap[q];                     // (inputs and a hard state box: kap = 0, no slack)
+                const double viaB = is_x ? fma(-rB[q].om, te[q], rB[q].w) : wprev - rB[q].w;
+                double rhs = fma(svp[q], pv[q], ncq[q]) + (g[q] + h2[q]);
+                rhs = fma(sgnA, rA[q].w, rhs) + viaB;
+                if (q == 0) rhs += r0.w;
+                Tc[sl[q]] = ok[q] ? rhs : 0.0;
+            }
         }
         __syncthreads();
         TICK(0)
-        lat_solve<N>(fr, Gf, vec, wv);
+        lat_solve<N>(fr, vec, wv);
         __syncthreads();
         TICK(5)
-        // ---- relaxation, projection, dual step of the owned rows (E2)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const double xt = Tc[esl[j]], gv = Gx[esl[j]];
-            const double xlo = hot[L.oxmin + ea[j]], xhi = hot[L.oxmax + ea[j]];
-            const double et = fma(-okap[j], xt, te[j]);
-            const double xn = fma(alpha, xt, beta * x[j]), en = fma(alpha, et, beta * ep[j]);
-            const double dD = lat_row_step_eq(rD[j], gv - xt, b0[j], alpha, beta);
-            const double dS = lat_row_step(rS[j], xt + et, xlo, xhi, alpha, beta);
-            if (keep_delta && ev[j]) {
-                const int e = tid + NT * j;
-                dxg[e] = xn - x[j]; if (L.soft) dxg[L.oe + e] = en - ep[j];
-                dyg[e] = (rD[j].om * cinv) * dD; dyg[L.rs + e] = (rS[j].om * cinv) * dS;
-            }
-            x[j] = xn; ep[j] = en;
-            if (ev[j]) Wd[esl[j]] = rD[j].w;
-        }
+        // ---- G v of the previous stage (MFMA), relaxation, projection, dual step of the owned rows
         {
-            const double ut = Tc[uslot], un = *unextp;
-            const double ulo = hot[L.oumin + uj], uhi = hot[L.oumax + uj], dlo = hot[L.oDumin + uj], dhi = hot[L.oDumax + uj];
-            const double unew = fma(alpha, ut, beta * u);
-            const double dI = lat_row_step(rI, ut, ulo, uhi, alpha, beta);
-            const double dU = lat_row_step(rU, fma(s_unext, un, -ut), dlo, dhi, alpha, beta);
-            if (keep_delta && uv) { dxg[L.ou + cu] = unew - u; dyg[L.ri + cu] = (rI.om * cinv) * dI; dyg[L.rdu + nu + cu] = (rU.om * cinv) * dU; }
-            u = unew;
-            if (u0v) { const double d0 = lat_row_step(r0, ut, S.du0[tid], S.du0[nu + tid], alpha, beta); if (keep_delta) dyg[L.rdu + tid] = (r0.om * cinv) * d0; }
-            if (uv) Wu[cu] = rU.w;
+            double g[2] = {0.0, 0.0}, h2[2] = {0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 2; ++q) lat_mv(Gf, Tc[sl[q] - NB], g[q], h2[q]);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const double xt = Tc[sl[q]], un = Tc[sl[q] + onext];
+                const double et = fma(-okap[q], xt, te[q]);
+                const double vn = fma(alpha, xt, beta * pv[q]), en = fma(alpha, et, beta * pv2[q]);
+                const double ztA = fma(selx, (g[q] + h2[q]) - xt - xt, xt);       // x: G v - xt;  u: ut
+                const double ztB = is_x ? xt + et : un - xt;
+                const double dA = lat_row_step(rA[q], ztA, loA[q], hiA[q], alpha, beta);
+                const double dB = lat_row_step(rB[q], ztB, loB[q], hiB[q], alpha, beta);
+                if (keep_delta && ok[q]) {
+                    dxg[pidx[q]] = vn - pv[q];
+                    if (is_x && L.soft) dxg[pidx[q] + L.oe] = en - pv2[q];
+                    dyg[aidx[q]] = (rA[q].om * cinv) * dA; dyg[bidx[q]] = (rB[q].om * cinv) * dB;
+                }
+                pv[q] = vn; pv2[q] = en;
+                if (q == 0 && u0v) { const double d0 = lat_row_step(r0, xt, S.du0[jj], S.du0[nu + jj], alpha, beta); if (keep_delta) dyg[L.rdu + jj] = (r0.om * cinv) * d0; }
+                WA[sl[q]] = ok[q] ? rA[q].w : 0.0; WB[sl[q]] = ok[q] ? rB[q].w : 0.0;      // (a slot without a variable -- beyond the last stage, the last stage's inputs -- contributes nothing)
+            }
         }
         __syncthreads();
         TICK(6)
@@ -335,14 +323,13 @@ __device__ __forceinline__ void admm_lat(const Lay &L, const HotPtrs &P, Smem &S
     // ---- end of the round: the iterate back to memory (global: next round / warm start; LDS copy: the residual evaluation)
     auto put_row = [&](const LatRow &r, int idx) { const double y = r.ys * (r.om * cinv); gz[idx] = r.z; gy[idx] = y; Zl[idx] = r.z; Yl[idx] = y; };
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int e = tid + NT * j;
-        if (ev[j]) {
-            gx[e] = x[j]; Xl[e] = x[j];
-            if (L.soft) { gx[L.oe + e] = ep[j]; Xl[L.oe + e] = ep[j]; }
-            put_row(rD[j], e); put_row(rS[j], L.rs + e);
+    for (int q = 0; q < 2; ++q) {
+        if (ok[q]) {
+            gx[pidx[q]] = pv[q]; Xl[pidx[q]] = pv[q];
+            if (is_x && L.soft) { gx[pidx[q] + L.oe] = pv2[q]; Xl[pidx[q] + L.oe] = pv2[q]; }
+            put_row(rA[q], aidx[q]); put_row(rB[q], bidx[q]);
         }
     }
-    if (uv) { gx[L.ou + cu] = u; Xl[L.ou + cu] = u; put_row(rI, L.ri + cu); put_row(rU, L.rdu + nu + cu); }
-    if (u0v) put_row(r0, L.rdu + tid);
+    if (u0v) put_row(r0, L.rdu + jj);
+    (void)selu;
 }
