@@ -91,7 +91,15 @@ __device__ __forceinline__ void lat_load(const double *F, d4 *fr) {
 // LDS vectors of the round, all stage-major with stride 16 (element a of stage k at k * 16 + a), seen through the per-lane
 // base of the MFMA operand layout (vec_lane_offset):
 //   tb  right-hand side / solution      cb  c_e of the reduction
-struct LatVecs { double *tb, *cb; };
+//   t1, t2, t3: tb seen through the lane bases of the three block rotations -- an input vector is read FOUR times from LDS
+//   (one 8-byte read per MFMA step) instead of once plus six cross-lane moves on the vector ALU, which is the busier unit here
+struct LatVecs { double *tb, *cb; const double *t1, *t2, *t3; };
+__device__ __forceinline__ void lat_mv_lds(const d4 a, const LatVecs &v, int off, double &p, double &q) {
+    p = __builtin_amdgcn_mfma_f64_4x4x4f64(a[0], v.tb[off], p, 0, 0, 0);
+    q = __builtin_amdgcn_mfma_f64_4x4x4f64(a[2], v.t2[off], q, 0, 0, 0);
+    p = __builtin_amdgcn_mfma_f64_4x4x4f64(a[1], v.t1[off], p, 0, 0, 0);
+    q = __builtin_amdgcn_mfma_f64_4x4x4f64(a[3], v.t3[off], q, 0, 0, 0);
+}
 
 // ordinal of a task among the tasks of its kind and level that wave W owns (compile time)
 constexpr int lat_ord(int N, int W, int L, int kind, int tq) { int o = 0; for (int t = 0; t < tq; ++t) if (lat_owner(N, L, kind, t) == W) ++o; return o; }
@@ -116,8 +124,8 @@ __device__ __forceinline__ void lat_fwd(const d4 *fr, const LatVecs &v) {
         if constexpr (lat_owner(N, L, 0, t) == W) {
             constexpr int s = lat_slot(N, W, L, 0, t);
             double p = v.tb[i * 16], q = 0.0;                 // (the stage's own right-hand side starts the chain)
-            lat_mv(fr[s], v.tb[(i - h) * 16], p, q);
-            if constexpr (i + h < N) lat_mv(fr[s + 1], v.tb[(i + h) * 16], p, q);
+            lat_mv_lds(fr[s], v, (i - h) * 16, p, q);
+            if constexpr (i + h < N) lat_mv_lds(fr[s + 1], v, (i + h) * 16, p, q);
             v.tb[i * 16] = p + q;
         }
     });
@@ -126,7 +134,7 @@ __device__ __forceinline__ void lat_fwd(const d4 *fr, const LatVecs &v) {
         if constexpr (lat_owner(N, L, 1, t) == W) {
             constexpr int s1 = lat_slot(N, W, L, 1, t);
             double p = 0.0, q = 0.0;
-            lat_mv(fr[s1], v.tb[e * 16], p, q);
+            lat_mv_lds(fr[s1], v, e * 16, p, q);
             v.cb[e * 16] = p + q;
         }
     });
@@ -140,8 +148,8 @@ __device__ __forceinline__ void lat_bwd(const d4 *fr, const LatVecs &v) {
         if constexpr (lat_owner(N, L, 2, t) == W) {
             constexpr int s = lat_slot(N, W, L, 2, t), s2 = s + (e - h >= 0 ? 1 : 0);
             double p = v.cb[e * 16], q = 0.0;
-            if constexpr (e - h >= 0) lat_mv(fr[s], v.tb[(e - h) * 16], p, q);
-            if constexpr (e + h < N) lat_mv(fr[s2], v.tb[(e + h) * 16], p, q);
+            if constexpr (e - h >= 0) lat_mv_lds(fr[s], v, (e - h) * 16, p, q);
+            if constexpr (e + h < N) lat_mv_lds(fr[s2], v, (e + h) * 16, p, q);
             v.tb[e * 16] = p + q;
         }
     });
@@ -225,7 +233,8 @@ __device__ __forceinline__ void admm_lat(const Lay &L, const HotPtrs &P, Smem &S
     const d4 Gf = lat_make_frag(lane, gent);
     const d4 GTf = lat_make_frag(lane, [&](int r, int c) { return gent(c, r); });
     const int lo16 = vec_lane_offset(lane);
-    const LatVecs vec{Tc + lo16, Cc + lo16};
+    const int lI = lane >> 4, lB = (lane >> 2) & 3;
+    const LatVecs vec{Tc + lo16, Cc + lo16, Tc + 4 * ((lB + 1) & 3) + lI, Tc + 4 * ((lB + 2) & 3) + lI, Tc + 4 * ((lB + 3) & 3) + lI};
     // ---- owner map: lane (I, B, J), group g = wv + 4 q  ->  slot a = 4B + I of stage s = 4g + J
     const int a = 4 * ((lane >> 2) & 3) + (lane >> 4), J = lane & 3;
     const bool is_x = a < nx;
