@@ -205,9 +205,9 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     h->L.dense = dense ? 1 : 0;
     if (dense) h->L.tsz += DenseFmt::SCRATCH;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->ncu = prop.multiProcessorCount; }
-    // At most one instance per compute unit: the latency backend (block cyclic reduction, factor resident in registers) for the
+    // Up to two instances per compute unit (one resident, one queued): the latency backend (block cyclic reduction, factor resident in registers) for the
     // shape it is compiled for -- BASELINE (12, 4, 30).  Larger batches stream the chain format (the bandwidth backend).
-    bool bcr = !dense && h->lds_state && L.NB == 16 && !L.border && L.nx == 12 && L.nu == 4 && L.N == BCR_STAGES && h->ncu > 0 && batch <= h->ncu;
+    bool bcr = !dense && h->lds_state && L.NB == 16 && !L.border && L.nx == 12 && L.nu == 4 && L.N == BCR_STAGES && h->ncu > 0 && batch <= 2 * h->ncu;      // (measured cross-over with the bandwidth kernel: between 512 and 768 instances)
     if (const char *e = getenv("MPCQP_BCR")) {      // development switch: 0 = never, 1 = whenever the shape allows (any batch)
         if (atoi(e) == 0) bcr = false;
         else bcr = !dense && h->lds_state && L.NB == 16 && !L.border && L.nx == 12 && L.nu == 4 && L.N == BCR_STAGES;

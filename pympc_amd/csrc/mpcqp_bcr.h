@@ -35,7 +35,7 @@ struct BcrFmt {
 // Four thread groups (one wave each) eliminate four stages of a level side by side; barriers are workgroup-wide, every
 // thread makes the same calls.  Returns 1 on a non-positive pivot.
 // ------------------------------------------------------------------------------------------------
-__device__ int factor_bcr(const Ctx &c, const double *om, const double *sv, double cc, double *F, double *Wg, double *W, int *iflag) {
+__device__ __forceinline__ int factor_bcr(const Ctx &c, const double *om, const double *sv, double cc, double *F, double *Wg, double *W, int *iflag) {
     constexpr int NN = BcrFmt::NN, G = 4, T = NT / G, EPT = NN / T, NB = 16;
     const Lay &L = c.L;
     const int N = L.N, tid = threadIdx.x, g = tid / T, lt = tid % T;

@@ -29,7 +29,7 @@ __device__ __forceinline__ int padded_var(const Lay &L, int k, int a) {
 }
 
 template <int NB>
-__device__ void border_factor(const Ctx &c, const double *om, const double *sv, double cc, const double *F,
+__device__ __forceinline__ void border_factor(const Ctx &c, const double *om, const double *sv, double cc, const double *F,
                               double *Bb, double *Zb, double *Sig, double *W, double *Tc, double *red) {
     const Lay &L = c.L;
     const int tid = threadIdx.x, nu = L.nu, NP = L.N * NB;

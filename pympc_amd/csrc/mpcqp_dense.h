@@ -40,7 +40,7 @@ __device__ __forceinline__ bool dense_dead(const Lay &L, int v) {       // varia
 // K (dense, SPD) assembled entry by entry from the stage blocks, inverted in place by Gauss-Jordan sweeps in LDS (NR steps, the
 // pivot row and column copied out first so that every entry updates in place), written out in register order.
 // W: LDS, NR * ld + 2 * ROWS doubles (ld = L.dld, odd: column accesses are bank-conflict free).  Returns 1 on a non-positive pivot.
-__device__ int factor_dense(const Ctx &c, const double *om, const double *sv, double cc, double *F, double *W, int *iflag) {
+__device__ __forceinline__ int factor_dense(const Ctx &c, const double *om, const double *sv, double cc, double *F, double *W, int *iflag) {
     const Lay &L = c.L;
     const int tid = threadIdx.x, NR = L.NR, ld = L.dld, nb = L.nb;
     double *prow = W + NR * ld, *pcol = prow + DenseFmt::ROWS;

@@ -100,7 +100,7 @@ __device__ __forceinline__ int frag_pos(int r, int cidx) {
 // W: LDS workspace of 6*NB*NB doubles.  Returns (uniformly) 0, or 1 if a pivot was not positive.
 struct BorderPtrs { double *Bb, *Zb, *Sig, *red; };
 
-template <int NB> __device__ void border_factor(const Ctx &, const double *, const double *, double, const double *, double *, double *, double *, double *, double *, double *);
+template <int NB> __device__ __forceinline__ void border_factor(const Ctx &, const double *, const double *, double, const double *, double *, double *, double *, double *, double *, double *);
 
 // The two half-chains are independent until the middle stage: for 16 x 16 stages each is factored by one half of the
 // workgroup, side by side (the stage count, not the arithmetic, is what a refactorization costs).  32 x 32 stages keep the
@@ -114,7 +114,7 @@ template <int NB> struct FactorCfg {
 };
 
 template <int NB>
-__device__ int factor_all(const Ctx &c, const double *om, const double *sv, double cc, double *F, double *W, int *iflag, BorderPtrs bp) {
+__device__ __forceinline__ int factor_all(const Ctx &c, const double *om, const double *sv, double cc, double *F, double *W, int *iflag, BorderPtrs bp) {
     const Lay &L = c.L;
     constexpr int G = FactorCfg<NB>::G, NN = NB * NB;
     const int tid = threadIdx.x;

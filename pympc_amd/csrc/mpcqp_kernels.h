@@ -81,7 +81,9 @@ __device__ __forceinline__ RunSmem run_smem(const Lay &L, const Ptrs &P) {
     return r;
 }
 
-template <int NB>
+// (OCC: workgroups per CU of the calling kernel -- a tag only: it keeps the phases of kernels with different launch bounds apart,
+//  so that the register budget of the one-workgroup-per-CU kernels does not leak into the four-per-CU ones through a shared callee)
+template <int NB, int OCC>
 __device__ __noinline__ void run_factor_phase() {
     const RunKArgs &A = run_kargs();
     const Lay &L = A.L; const Ptrs &P = A.P;
@@ -104,22 +106,24 @@ __device__ __noinline__ void run_admm_phase(int iters) {
     admm_body<NB, LDSSTATE, NXT, NUT, MODE>(L, hp, r.S, r.X, r.Z, r.Y, A.S.alpha, __builtin_amdgcn_readfirstlane(iters));
 }
 
-template <int NB, bool LDSSTATE>
+template <int NB, bool LDSSTATE, int OCC>
 __device__ __noinline__ void run_begin_phase(int plain, int warm_x) {
     const RunKArgs &A = run_kargs();
     RunSmem r = run_smem<LDSSTATE>(A.L, A.P);
-    begin_body<NB>(A.L, A.P, A.S, r.S, __builtin_amdgcn_readfirstlane(plain), __builtin_amdgcn_readfirstlane(warm_x));
+    begin_body<NB, OCC>(A.L, A.P, A.S, r.S, __builtin_amdgcn_readfirstlane(plain), __builtin_amdgcn_readfirstlane(warm_x));
 }
 
-template <int NB, bool LDSSTATE>
+template <int NB, bool LDSSTATE, int OCC>
 __device__ __noinline__ int run_check_phase(int iter, int mode) {
     const RunKArgs &A = run_kargs();
     RunSmem r = run_smem<LDSSTATE>(A.L, A.P);
-    return check_body<NB>(A.L, A.P, A.S, r.S, __builtin_amdgcn_readfirstlane(iter), __builtin_amdgcn_readfirstlane(mode), r.X, r.Z, r.Y);
+    return check_body<NB, OCC>(A.L, A.P, A.S, r.S, __builtin_amdgcn_readfirstlane(iter), __builtin_amdgcn_readfirstlane(mode), r.X, r.Z, r.Y);
 }
 
+constexpr int run_occupancy(int NB, int MODE) { return (MODE == MODE_DENSE || MODE >= MODE_BCR) ? 1 : NB <= 16 ? 4 : 2; }      // workgroups per CU
 template <int NB, bool LDSSTATE, int NXT, int NUT, int MODE, bool LOOP>
-__global__ __launch_bounds__(NT, (MODE == MODE_DENSE || MODE >= MODE_BCR ? 1 : NB <= 16 ? 4 : 2)) void k_mpc_run(RunKArgs A_) {
+__global__ __launch_bounds__(NT, run_occupancy(NB, MODE)) void k_mpc_run(RunKArgs A_) {
+    constexpr int OCC = run_occupancy(NB, MODE);
     const RunKArgs &A = run_kargs();
     const Lay &L = A.L; const Ptrs &P = A.P; const RunArgs &R = A.R;
     if (!LOOP && R.part == 2 && (int)blockIdx.x >= *R.npending) return;
@@ -137,7 +141,7 @@ __global__ __launch_bounds__(NT, (MODE == MODE_DENSE || MODE >= MODE_BCR ? 1 : N
     load_common(L, P.model + (size_t)b * L.model_sz, step, S);
     if (!LOOP && R.part == 3) {                  // mpcqp_refactor: the factorization alone (what one rho update costs)
         __syncthreads();
-        run_factor_phase<NB>();
+        run_factor_phase<NB, OCC>();
         return;
     }
     const int nx = L.nx, nu = L.nu;
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(NT, (MODE == MODE_DENSE || MODE >= MODE_BCR ? 1 : N
 #endif
         int iter = 0, term = 0;
         if (!LOOP && R.part == 2) iter = P.info[b].iter;      // resumed: the first round and its check are done
-        else run_begin_phase<NB, LDSSTATE>(R.plain, (R.warm_x && k == 0) ? 1 : 0);
+        else run_begin_phase<NB, LDSSTATE, OCC>(R.plain, (R.warm_x && k == 0) ? 1 : 0);
         __syncthreads();
         PHASE_CLOCK(0)
         while (!term) {
@@ -214,7 +218,7 @@ __global__ __launch_bounds__(NT, (MODE == MODE_DENSE || MODE >= MODE_BCR ? 1 : N
             iter = nxt;
             __syncthreads();
             PHASE_CLOCK(1)
-            term = run_check_phase<NB, LDSSTATE>(iter, stop_mode(iter, R.max_iter, R.chk, R.rho_every, R.plain != 0));
+            term = run_check_phase<NB, LDSSTATE, OCC>(iter, stop_mode(iter, R.max_iter, R.chk, R.rho_every, R.plain != 0));
             __syncthreads();
             PHASE_CLOCK(2)
             if (!LOOP && R.part == 1 && !term) {              // hand the instance over to the follow-up launch

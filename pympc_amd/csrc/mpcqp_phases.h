@@ -142,9 +142,9 @@ enum { COLD_CHECK = 1, COLD_RHO = 2, COLD_FINAL = 4, COLD_PLAIN = 8 };
 // Refactorization from inside a solve: a non-inlined function with a register allocation of its own (defined with the
 // other phases of k_mpc_run below), so that this rare, register-hungry path does not push the residual evaluation
 // and the per-solve prologue into scratch spills.
-template <int NB> __device__ void run_factor_phase();
+template <int NB, int OCC> __device__ void run_factor_phase();
 
-template <int NB>
+template <int NB, int OCC>
 __device__ __forceinline__ void begin_body(const Lay &L, const Ptrs &P, const mpcqp_settings &S_, Smem &S, int plain, int warm_x) {
     const int b = inst_of(P.perm), tid = threadIdx.x;
     const double *model = P.model + (size_t)b * L.model_sz, *step = P.step + (size_t)b * L.step_sz;
@@ -169,7 +169,7 @@ __device__ __forceinline__ void begin_body(const Lay &L, const Ptrs &P, const mp
         if (t != ctp[r]) { changed = 1; ctp[r] = t; om[r] = row_rho(t, rho) * E[r] * E[r]; }
     }
     changed = __syncthreads_or(changed);
-    if (changed) run_factor_phase<NB>();
+    if (changed) run_factor_phase<NB, OCC>();
     if (tid == 0) {
         mpcqp_info inf; inf.status = MPCQP_UNSOLVED; inf.iter = 0; inf.rho_updates = 0; inf.reserved = 0;
         inf.obj_val = 0.0; inf.pri_res = 0.0; inf.dua_res = 0.0; inf.rho = rho;
@@ -178,7 +178,7 @@ __device__ __forceinline__ void begin_body(const Lay &L, const Ptrs &P, const mp
 }
 
 // Returns 1 (to every thread) if the instance has terminated.
-template <int NB>
+template <int NB, int OCC>
 __device__ __forceinline__ int check_body(const Lay &L, const Ptrs &P, const mpcqp_settings &S_, Smem &S, int iter, int mode,
                                           const double *Xl, const double *Zl, const double *Yl) {
     const int b = inst_of(P.perm), tid = threadIdx.x;
@@ -312,7 +312,7 @@ __device__ __forceinline__ int check_body(const Lay &L, const Ptrs &P, const mpc
                 rho = rn;
                 for (int r = tid; r < L.m; r += NT) om[r] = row_rho(ctp[r], rho) * E[r] * E[r];
                 __syncthreads();
-                run_factor_phase<NB>();
+                run_factor_phase<NB, OCC>();
                 rho_upd = 1;
             }
         }

@@ -1,0 +1,50 @@
+"""The design counts on resident workgroups per compute unit: four for 16 x 16 stages (128 VGPRs: the bandwidth kernel of the
+headline batch), two for 32 x 32 stages, one for the latency kernels (register-resident factor).  A shared non-inlined phase
+once inherited the one-per-CU register budget and silently halved the headline throughput -- so the compiler's own
+resource remarks of the build (pympc_amd/libmpcqp_hip.kernel_resources.txt, written by csrc/build.sh) are checked."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PATH = os.path.join(ROOT, 'pympc_amd', 'libmpcqp_hip.kernel_resources.txt')
+
+
+def _kernels():
+    if not os.path.exists(PATH):
+        pytest.skip('no kernel_resources.txt next to the library (built without csrc/build.sh)')
+    out, cur = {}, None
+    for line in open(PATH):
+        m = re.match(r'\s*Function Name: (\S+)', line)
+        if m:
+            cur = out.setdefault(m.group(1), {})
+            continue
+        m = re.match(r'\s*([A-Za-z ]+?)(?: \[[^\]]*\])?: (\S+)', line)
+        if m and cur is not None:
+            cur[m.group(1).strip()] = m.group(2)
+    return out
+
+
+def _run_kernels(ks):
+    """k_mpc_run<NB, LDSSTATE, NXT, NUT, MODE, LOOP> instantiations by template arguments."""
+    res = {}
+    for name, v in ks.items():
+        m = re.match(r'_Z9k_mpc_runILi(\d+)ELb([01])ELi(\d+)ELi(\d+)ELi(\d+)ELb([01])EE', name)
+        if m:
+            res[tuple(int(g) for g in m.groups())] = v
+    return res
+
+
+def test_occupancy_of_the_solve_kernels():
+    rk = _run_kernels(_kernels())
+    assert rk, 'no k_mpc_run instantiation in the resource remarks'
+    for (nb, lds, nxt, nut, mode, loop), v in rk.items():
+        vg, occ = int(v['VGPRs']), int(v['Occupancy'])
+        if mode in (0, 1) and nb == 16:
+            assert vg <= 128 and occ >= 4, ('16 x 16 sweeps must keep four workgroups per CU', nb, mode, loop, v)
+        elif mode in (0, 1) and nb == 32:
+            assert vg + int(v['AGPRs']) <= 256 and occ >= 2, ('32 x 32 sweeps must keep two workgroups per CU', nb, mode, loop, v)
+        else:
+            assert occ >= 1
+    assert (16, 1, 12, 4, 0, 1) in rk and (32, 0, 20, 8, 0, 1) in rk          # the BASELINE specialisations exist
