@@ -135,6 +135,19 @@ int mpcqp_update(mpcqp_handle *h, const double *x0, const double *uminus1,
 int mpcqp_setup_qp(mpcqp_handle *h, const mpcqp_model *model, const double *q, const double *l, const double *u);
 int mpcqp_update_vectors(mpcqp_handle *h, const double *q, const double *l, const double *u);
 
+/* The same seam with the MATRICES themselves, bindable from any language (mpc.py:266 prob.setup(P, q, A, l, u, ...)):
+ *   mpcqp_create_csc  reads the controller's dimensions (nx, nu, Np, Nc) out of the sparsity patterns -- P: upper triangle or full
+ *                     symmetric, A: both CSC with int64 column pointers and int32 row indices, shared by the batch -- and creates
+ *                     the handle (nx_hint / nu_hint > 0 settle a pattern that does not determine them, e.g. an Ad with an empty first row);
+ *   mpcqp_setup_csc   reads (Ad, Bd, Qx, QxN, Qu, QDu, eps_feas) of every instance out of the values P_val [batch][nnz(P)],
+ *                     A_val [batch][nnz(A)], REBUILDS both matrices from them as pyMPC/mpc.py:456-608 would and compares entry for
+ *                     entry, checks q, l, u ([batch][n], [batch][m], HOST pointers) for pyMPC's structure, and continues as
+ *                     mpcqp_setup_qp.  A QP that is not pyMPC's is refused with MPCQP_ERR_UNSUPPORTED (mpcqp_last_error says
+ *                     which entries differ); nothing is approximated.  Afterwards: mpcqp_update_vectors / mpcqp_solve / ... */
+int mpcqp_create_csc(mpcqp_handle **h, int device, int batch, int n, int m, const int64_t *P_colptr, const int32_t *P_rowidx,
+                     const int64_t *A_colptr, const int32_t *A_rowidx, int nx_hint, int nu_hint, const mpcqp_settings *s);
+int mpcqp_setup_csc(mpcqp_handle *h, const double *P_val, const double *A_val, const double *q, const double *l, const double *u);
+
 /* Replace the iterate (osqp.warm_start(x=, y=)); x [batch][n], y [batch][m], NULL = keep. */
 int mpcqp_warm_start(mpcqp_handle *h, const double *x, const double *y);
 
@@ -218,6 +231,9 @@ int mpcqp_get_stats(mpcqp_handle *h, uint64_t *out4, int reset);
  * HIP events on the handle's stream: enable = 1/0 to switch, -1 to leave unchanged; returns accumulated
  * milliseconds and launch count (synchronises on the pending launches), optionally resets. */
 int mpcqp_profile(mpcqp_handle *h, int enable, double *run_ms, int64_t *run_launches, int reset);
+
+/* The controller's dimensions (what mpcqp_create was given, or what mpcqp_create_csc read out of the patterns). */
+int mpcqp_get_shape(mpcqp_handle *h, int *nx, int *nu, int *Np, int *Nc);
 
 /* Problem sizes: n, m of one instance, bytes of the KKT factor per instance, and nnz(L). */
 int mpcqp_get_dims(mpcqp_handle *h, int *n, int *m, int64_t *factor_doubles, int64_t *nnzL);

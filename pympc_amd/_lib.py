@@ -14,8 +14,8 @@ LIB_PATH = os.path.join(_HERE, 'libmpcqp_hip.so')     # the in-tree build, nothi
 SYMBOLS = [
     'mpcqp_default_settings', 'mpcqp_status_string', 'mpcqp_last_error', 'mpcqp_device_count',
     'mpcqp_create', 'mpcqp_destroy', 'mpcqp_set_stream', 'mpcqp_synchronize',
-    'mpcqp_setup', 'mpcqp_setup_qp', 'mpcqp_update', 'mpcqp_update_vectors', 'mpcqp_warm_start', 'mpcqp_update_settings', 'mpcqp_solve',
-    'mpcqp_mpc_step', 'mpcqp_step_host', 'mpcqp_mpc_run', 'mpcqp_mpc_loop', 'mpcqp_get_solution', 'mpcqp_get_u0', 'mpcqp_get_dims', 'mpcqp_get_stream_bytes', 'mpcqp_kernel_name', 'mpcqp_get_stats', 'mpcqp_profile',
+    'mpcqp_setup', 'mpcqp_setup_qp', 'mpcqp_create_csc', 'mpcqp_setup_csc', 'mpcqp_update', 'mpcqp_update_vectors', 'mpcqp_warm_start', 'mpcqp_update_settings', 'mpcqp_solve',
+    'mpcqp_mpc_step', 'mpcqp_step_host', 'mpcqp_mpc_run', 'mpcqp_mpc_loop', 'mpcqp_get_solution', 'mpcqp_get_u0', 'mpcqp_get_shape', 'mpcqp_get_dims', 'mpcqp_get_stream_bytes', 'mpcqp_kernel_name', 'mpcqp_get_stats', 'mpcqp_profile',
     'mpcqp_export_qp', 'mpcqp_get_scaling', 'mpcqp_debug_kkt_solve', 'mpcqp_get_iterate', 'mpcqp_iterate', 'mpcqp_refactor',
 ]
 
@@ -81,6 +81,8 @@ def load():
     L.mpcqp_update.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     L.mpcqp_setup_qp.argtypes = [H, C.POINTER(Model), C.c_void_p, C.c_void_p, C.c_void_p]
     L.mpcqp_update_vectors.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.mpcqp_create_csc.argtypes = [C.POINTER(H), C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(Settings)]
+    L.mpcqp_setup_csc.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.mpcqp_warm_start.argtypes = [H, C.c_void_p, C.c_void_p]
     L.mpcqp_update_settings.argtypes = [H, C.POINTER(Settings)]
     L.mpcqp_solve.argtypes = [H]
@@ -90,6 +92,7 @@ def load():
     L.mpcqp_step_host.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     L.mpcqp_get_solution.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p]
     L.mpcqp_get_u0.argtypes = [H, C.c_void_p]
+    L.mpcqp_get_shape.argtypes = [H] + [C.POINTER(C.c_int)] * 4
     L.mpcqp_get_dims.argtypes = [H, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.mpcqp_get_stream_bytes.argtypes = [H, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.mpcqp_kernel_name.argtypes = [H, C.c_int, C.c_char_p, C.c_int]

@@ -62,6 +62,7 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #include "mpcqp_tiny.h"
 #include "mpcqp_lat.h"
 #include "mpcqp_kernels.h"
+#include "mpcqp_csc.h"
 
 // ------------------------------------------------------------------------------------------------
 // host side
@@ -94,6 +95,7 @@ struct mpcqp_handle {
     // mpcqp_step_host: mapped, coherent host memory the kernel reads its step data from and writes its results to
     double *pin_in, *pin_out; void *pin_in_dev, *pin_out_dev;
     unsigned *done_dev; unsigned long long host_seq; int pin_stride; bool pin_tried;
+    CscSeam *csc;                        // patterns of P and A of a handle made by mpcqp_create_csc
 };
 
 extern "C" void mpcqp_default_settings(mpcqp_settings *s) {
@@ -180,6 +182,7 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     h->device = device; h->batch = batch; h->is_setup = false; h->u0_dev = nullptr; h->run_buf = nullptr; h->run_bytes = 0; h->perm_dev = nullptr; h->solves_since_balance = 0; h->auto_balance = 1; h->ncu = 0;
     h->profiling = false; h->run_ms = 0.0; h->run_launches = 0; h->ev_count = 0; h->nevents = 0; h->stream = nullptr; h->own_stream = false;
     h->warm_x_pending = false;
+    h->csc = nullptr;
     h->pin_in = h->pin_out = nullptr; h->pin_in_dev = h->pin_out_dev = nullptr; h->done_dev = nullptr; h->host_seq = 0; h->pin_stride = 0; h->pin_tried = false;
     if (s) h->S = *s; else mpcqp_default_settings(&h->S);
     h->L = make_layout(nx, nu, Np, Nc, h->S.soft_constraints);
@@ -251,6 +254,7 @@ extern "C" void mpcqp_destroy(mpcqp_handle *h) {
     if (h->stream) hipStreamSynchronize(h->stream);
     for (void *p : h->allocs) hipFree(p);
     if (h->run_buf) hipFree(h->run_buf);
+    delete h->csc;
     if (h->pin_in) hipHostFree(h->pin_in);
     if (h->pin_out) hipHostFree(h->pin_out);
     for (int e = 0; e < h->nevents; ++e) { hipEventDestroy(h->ev0[e]); hipEventDestroy(h->ev1[e]); }
@@ -418,6 +422,53 @@ extern "C" int mpcqp_setup_qp(mpcqp_handle *h, const mpcqp_model *M, const doubl
     });
     HIPCHK(hipGetLastError());
     h->is_setup = true;
+    return MPCQP_OK;
+}
+
+// ---- the seam with the caller's matrices (mpc.py:266), see mpcqp_csc.h
+extern "C" int mpcqp_create_csc(mpcqp_handle **out, int device, int batch, int n, int m, const int64_t *P_colptr, const int32_t *P_rowidx,
+                                const int64_t *A_colptr, const int32_t *A_rowidx, int nx_hint, int nu_hint, const mpcqp_settings *s) {
+    if (!out || !P_colptr || !P_rowidx || !A_colptr || !A_rowidx || n < 1 || m < 1) return fail(MPCQP_ERR_ARG, "mpcqp_create_csc: null argument");
+    CscSeam *seam = new CscSeam();
+    CscPattern &c = seam->pat;
+    c.n = n; c.m = m;
+    c.Pp.assign(P_colptr, P_colptr + n + 1); c.Ap.assign(A_colptr, A_colptr + n + 1);
+    if (c.Pp[0] != 0 || c.Ap[0] != 0 || c.Pp[n] < 0 || c.Ap[n] < 0) { delete seam; return fail(MPCQP_ERR_ARG, "mpcqp_create_csc: bad column pointers"); }
+    c.Pi.assign(P_rowidx, P_rowidx + c.Pp[n]); c.Ai.assign(A_rowidx, A_rowidx + c.Ap[n]);
+    for (int32_t r : c.Pi) if (r < 0 || r >= n) { delete seam; return fail(MPCQP_ERR_ARG, "mpcqp_create_csc: P row index out of range"); }
+    for (int32_t r : c.Ai) if (r < 0 || r >= m) { delete seam; return fail(MPCQP_ERR_ARG, "mpcqp_create_csc: A row index out of range"); }
+    int nx, nu, Np, Nc; std::string why;
+    if (csc_dims(c, nx_hint, nu_hint, &nx, &nu, &Np, &Nc, &why)) { delete seam; return fail(MPCQP_ERR_UNSUPPORTED, "mpcqp_create_csc: not an MPC QP of pyMPC: " + why); }
+    mpcqp_settings st; if (s) st = *s; else mpcqp_default_settings(&st);
+    st.soft_constraints = 1;                        // (the matrices carry slack columns: checked by csc_dims)
+    const int rc = mpcqp_create(out, device, batch, nx, nu, Np, Nc, &st);
+    if (rc) { delete seam; return rc; }
+    (*out)->csc = seam;
+    return MPCQP_OK;
+}
+
+extern "C" int mpcqp_setup_csc(mpcqp_handle *h, const double *P_val, const double *A_val, const double *q, const double *l, const double *u) {
+    if (!h || !P_val || !A_val || !q || !l || !u) return fail(MPCQP_ERR_ARG, "mpcqp_setup_csc: null argument");
+    if (!h->csc) return fail(MPCQP_ERR_STATE, "mpcqp_setup_csc: the handle was not made by mpcqp_create_csc");
+    const CscPattern &c = h->csc->pat; const Lay &L = h->L;
+    const size_t B = (size_t)h->batch, nnzP = (size_t)c.Pp[c.n], nnzA = (size_t)c.Ap[c.n];
+    const int nx = L.nx, nu = L.nu;
+    std::vector<double> Ad(B * nx * nx), Bd(B * nx * nu), Qx(B * nx * nx), QxN(B * nx * nx), Qu(B * nu * nu), QDu(B * nu * nu), ef(B), lc(B * c.m), uc(B * c.m);
+    for (size_t b = 0; b < B; ++b) {
+        MpcBlocks blk; std::string why;
+        if (csc_recover(c, nx, nu, L.Np, L.Nc, P_val + b * nnzP, A_val + b * nnzA, q + b * c.n, l + b * c.m, u + b * c.m, &blk, &why))
+            return fail(MPCQP_ERR_UNSUPPORTED, "mpcqp_setup_csc: instance " + std::to_string(b) + ": " + why);
+        std::copy(blk.Ad.begin(), blk.Ad.end(), Ad.begin() + b * nx * nx); std::copy(blk.Bd.begin(), blk.Bd.end(), Bd.begin() + b * nx * nu);
+        std::copy(blk.Qx.begin(), blk.Qx.end(), Qx.begin() + b * nx * nx); std::copy(blk.QxN.begin(), blk.QxN.end(), QxN.begin() + b * nx * nx);
+        std::copy(blk.Qu.begin(), blk.Qu.end(), Qu.begin() + b * nu * nu); std::copy(blk.QDu.begin(), blk.QDu.end(), QDu.begin() + b * nu * nu);
+        ef[b] = blk.eps_feas;
+    }
+    for (size_t i = 0; i < B * c.m; ++i) { lc[i] = std::min(std::max(l[i], -QP_INFTY), QP_INFTY); uc[i] = std::min(std::max(u[i], -QP_INFTY), QP_INFTY); }      // (osqp's wrapper clips to +-1e30)
+    mpcqp_model M; memset(&M, 0, sizeof(M));
+    M.Ad = Ad.data(); M.Bd = Bd.data(); M.Qx = Qx.data(); M.QxN = QxN.data(); M.Qu = Qu.data(); M.QDu = QDu.data(); M.eps_feas = ef.data();
+    const int rc = mpcqp_setup_qp(h, &M, q, lc.data(), uc.data());
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(h->stream));        // (the host staging vectors above die with this call)
     return MPCQP_OK;
 }
 
@@ -783,6 +834,15 @@ extern "C" int mpcqp_profile(mpcqp_handle *h, int enable, double *run_ms, int64_
     if (run_ms) *run_ms = h->run_ms;
     if (run_launches) *run_launches = h->run_launches;
     if (reset) { h->run_ms = 0.0; h->run_launches = 0; }
+    return MPCQP_OK;
+}
+
+extern "C" int mpcqp_get_shape(mpcqp_handle *h, int *nx, int *nu, int *Np, int *Nc) {
+    if (!h) return fail(MPCQP_ERR_ARG, "null handle");
+    if (nx) *nx = h->L.nx;
+    if (nu) *nu = h->L.nu;
+    if (Np) *Np = h->L.Np;
+    if (Nc) *Nc = h->L.Nc;
     return MPCQP_OK;
 }
 

@@ -100,6 +100,51 @@ class BatchProblem:
         if rc == -4:
             raise NotImplementedError(self._L.mpcqp_last_error().decode())
         _lib.check(rc, 'mpcqp_create')
+        self._finish_init(stream)
+
+    @classmethod
+    def from_matrices(cls, P, A, batch=1, device=0, stream=None, nx=None, nu=None, **settings):
+        """The seam of mpc.py:266 with the matrices themselves (mpcqp_create_csc): the LIBRARY reads nx, nu, Np, Nc out of
+        the sparsity patterns of P and A (scipy sparse, shared by the batch) and later, in ``setup_csc``, the controller
+        data out of their values -- refusing anything that is not pyMPC's QP (``NotAnMPCQP``)."""
+        import scipy.sparse as sp
+        from .qp_recover import NotAnMPCQP
+        self = cls.__new__(cls)
+        self._L = _lib.load()
+        self._h = C.c_void_p()
+        self.batch = int(batch)
+        self.settings = make_settings(**settings)
+        Pc, Ac = sp.csc_matrix(P), sp.csc_matrix(A)
+        Pc.sort_indices(); Ac.sort_indices()
+        self._csc = (Pc, Ac)
+        pp, pi = np.ascontiguousarray(Pc.indptr, dtype=np.int64), np.ascontiguousarray(Pc.indices, dtype=np.int32)
+        ap, ai = np.ascontiguousarray(Ac.indptr, dtype=np.int64), np.ascontiguousarray(Ac.indices, dtype=np.int32)
+        rc = self._L.mpcqp_create_csc(C.byref(self._h), int(device), self.batch, int(Pc.shape[0]), int(Ac.shape[0]), _ptr(pp), _ptr(pi), _ptr(ap), _ptr(ai),
+                                      int(nx or 0), int(nu or 0), C.byref(self.settings))
+        if rc == -4:
+            raise NotAnMPCQP(self._L.mpcqp_last_error().decode())
+        if rc == -3:
+            raise RuntimeError('pympc_amd needs an AMD GPU (no HIP device visible); there is no CPU fallback')
+        _lib.check(rc, 'mpcqp_create_csc')
+        d = [C.c_int() for _ in range(4)]
+        _lib.check(self._L.mpcqp_get_shape(self._h, *[C.byref(v) for v in d]), 'mpcqp_get_shape')
+        self.nx, self.nu, self.Np, self.Nc = (v.value for v in d)
+        self._finish_init(stream)
+        return self
+
+    def setup_csc(self, P_val, A_val, q, l, u):
+        """Values of P [B, nnz(P)] and A [B, nnz(A)] in the index order given to ``from_matrices`` (sorted CSC), q [B, n], l, u [B, m]
+        (host arrays): recovered, verified by a rebuild and set up by the library (mpcqp_setup_csc)."""
+        from .qp_recover import NotAnMPCQP
+        Pc, Ac = self._csc
+        pv = _prep(P_val, (self.batch, Pc.nnz), 'P_val'); av = _prep(A_val, (self.batch, Ac.nnz), 'A_val')
+        qa, la, ua = _prep(q, (self.batch, self.n), 'q'), _prep(l, (self.batch, self.m), 'l'), _prep(u, (self.batch, self.m), 'u')
+        rc = self._L.mpcqp_setup_csc(self._h, _ptr(pv), _ptr(av), _ptr(qa), _ptr(la), _ptr(ua))
+        if rc == -4:
+            raise NotAnMPCQP(self._L.mpcqp_last_error().decode())
+        _lib.check(rc, 'mpcqp_setup_csc')
+
+    def _finish_init(self, stream):
         n, m, fd, nnzL = C.c_int(), C.c_int(), C.c_int64(), C.c_int64()
         _lib.check(self._L.mpcqp_get_dims(self._h, C.byref(n), C.byref(m), C.byref(fd), C.byref(nnzL)), 'mpcqp_get_dims')
         self.n, self.m, self.factor_doubles, self.nnzL = n.value, m.value, fd.value, nnzL.value
@@ -389,15 +434,13 @@ class DeviceProblem:
         self._pending = None              # step data of an update() that has not reached the device yet (sent with the solve)
 
     def _setup_from_matrices(self, P, q, A, l, u, **settings):
-        from . import qp_recover
-        mdl = qp_recover.recover_model(P, A, l, u, *self._hint)        # raises unless P, A are pyMPC's matrices
-        self._check_q(mdl, q)
-        self._model = mdl
-        self._bp = BatchProblem(1, mdl['nx'], mdl['nu'], mdl['Np'], mdl['Nc'], device=self.device, **settings)
-        one = lambda a: np.asarray(a, dtype=float)[None]
-        clip = lambda v: np.clip(np.asarray(v, dtype=float), -1e30, 1e30)[None]
-        self._bp.setup_qp(one(mdl['Ad']), one(mdl['Bd']), one(mdl['Qx']), one(mdl['QxN']), one(mdl['Qu']), one(mdl['QDu']),
-                          np.array([[mdl['eps_feas']]]), one(q), clip(l), clip(u))
+        """setup(P, q, A, l, u) of mpc.py:266: the LIBRARY reads the controller out of the matrices and proves it by rebuilding them
+        (mpcqp_create_csc / mpcqp_setup_csc, csrc/mpcqp_csc.h); ``NotAnMPCQP`` if they are not pyMPC's."""
+        self._bp = BatchProblem.from_matrices(P, A, 1, device=self.device, nx=self._hint[0], nu=self._hint[1], **settings)
+        Pc, Ac = self._bp._csc
+        one = lambda v: np.asarray(v, dtype=float).reshape(1, -1)
+        self._bp.setup_csc(Pc.data[None], Ac.data[None], one(q), one(l), one(u))
+        self._model = dict(nx=self._bp.nx, nu=self._bp.nu, Np=self._bp.Np, Nc=self._bp.Nc)
         self.n, self.m = self._bp.n, self._bp.m
 
     @staticmethod
