@@ -128,10 +128,13 @@ int mpcqp_update(mpcqp_handle *h, const double *x0, const double *uminus1,
  *                         eps_feas: pympc_amd.qp_recover reads them back out of the reference-layout P and A and checks
  *                         that rebuilding reproduces both exactly); model->xmin..Dumax are ignored, uref may be NULL;
  *                         q [batch][n], l, u [batch][m] in the reference's layout.
- *   mpcqp_update_vectors  any of q, l, u may be NULL (= unchanged), like osqp.update.  l and u must have the reference's
- *                         structure (stage-periodic boxes, mpc.py:551-580) -- the host wrapper checks it.
+ *   mpcqp_update_vectors  q may be NULL (= unchanged), l and u both or neither (the equality rows l[:nx] == u[:nx] carry x0), like
+ *                         osqp.update as pyMPC calls it.  l and u must have the reference's structure (stage-periodic boxes,
+ *                         mpc.py:551-580) -- mpcqp_setup_csc and the host wrapper check it.  Host arrays go through a staging block the
+ *                         handle keeps; the call is stream-ordered and does not wait.
  * After either call the handle is in "raw vector" mode: solves use these vectors instead of rebuilding q, l, u from
- * (x0, u_{-1}, xref); mpcqp_update / mpcqp_mpc_step switch back, mpcqp_mpc_loop refuses (MPCQP_ERR_STATE). */
+ * (x0, u_{-1}, xref); mpcqp_update / mpcqp_mpc_step / mpcqp_step_host switch back -- on a handle that was set up from raw vectors they
+ * must then be given x0, u_{-1} AND xref (it holds none yet: MPCQP_ERR_STATE otherwise) --, mpcqp_mpc_loop refuses (MPCQP_ERR_STATE). */
 int mpcqp_setup_qp(mpcqp_handle *h, const mpcqp_model *model, const double *q, const double *l, const double *u);
 int mpcqp_update_vectors(mpcqp_handle *h, const double *q, const double *l, const double *u);
 

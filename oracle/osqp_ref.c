@@ -367,6 +367,15 @@ int oracle_update(oracle_work *w, const double *q, const double *l, const double
     return 0;
 }
 
+/* osqp.update_settings(): tolerances, iteration limits, alpha, the adaptive-rho rule -- what may change after setup
+ * (rho, sigma and the scaling shaped the factorization and stay). */
+void oracle_set_tolerances(oracle_work *w, const oracle_settings *s) {
+    const double rho = w->s.rho, sigma = w->s.sigma; const int scaling = w->s.scaling;
+    w->s = *s; w->s.rho = rho; w->s.sigma = sigma; w->s.scaling = scaling;
+    if (w->s.adaptive_rho && w->s.adaptive_rho_interval == 0)
+        w->s.adaptive_rho_interval = w->s.check_termination ? 4 * w->s.check_termination : 100;
+}
+
 void oracle_warm_start(oracle_work *w, const double *x, const double *y) {
     int64_t n = w->n, m = w->m;
     if (x) { for (int64_t j = 0; j < n; j++) w->x[j] = w->Dinv[j] * x[j]; mat_vec(m, n, w->Ap, w->Ai, w->Ax, w->x, w->z); }

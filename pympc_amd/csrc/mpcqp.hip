@@ -96,6 +96,8 @@ struct mpcqp_handle {
     double *pin_in, *pin_out; void *pin_in_dev, *pin_out_dev;
     unsigned *done_dev; unsigned long long host_seq; int pin_stride; bool pin_tried;
     CscSeam *csc;                        // patterns of P and A of a handle made by mpcqp_create_csc
+    double *vec_buf;                     // staging of mpcqp_update_vectors' host arrays [q | l | u], allocated on first use, kept
+    bool step_blank;                     // set up through mpcqp_setup_qp: the step blob holds no x0 / u_{-1} / xref yet
 };
 
 extern "C" void mpcqp_default_settings(mpcqp_settings *s) {
@@ -182,7 +184,7 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     h->device = device; h->batch = batch; h->is_setup = false; h->u0_dev = nullptr; h->run_buf = nullptr; h->run_bytes = 0; h->perm_dev = nullptr; h->solves_since_balance = 0; h->auto_balance = 1; h->ncu = 0;
     h->profiling = false; h->run_ms = 0.0; h->run_launches = 0; h->ev_count = 0; h->nevents = 0; h->stream = nullptr; h->own_stream = false;
     h->warm_x_pending = false;
-    h->csc = nullptr;
+    h->csc = nullptr; h->vec_buf = nullptr; h->step_blank = false;
     h->pin_in = h->pin_out = nullptr; h->pin_in_dev = h->pin_out_dev = nullptr; h->done_dev = nullptr; h->host_seq = 0; h->pin_stride = 0; h->pin_tried = false;
     if (s) h->S = *s; else mpcqp_default_settings(&h->S);
     h->L = make_layout(nx, nu, Np, Nc, h->S.soft_constraints);
@@ -255,6 +257,7 @@ extern "C" void mpcqp_destroy(mpcqp_handle *h) {
     for (void *p : h->allocs) hipFree(p);
     if (h->run_buf) hipFree(h->run_buf);
     delete h->csc;
+    if (h->vec_buf) hipFree(h->vec_buf);
     if (h->pin_in) hipHostFree(h->pin_in);
     if (h->pin_out) hipHostFree(h->pin_out);
     for (int e = 0; e < h->nevents; ++e) { hipEventDestroy(h->ev0[e]); hipEventDestroy(h->ev1[e]); }
@@ -352,37 +355,37 @@ extern "C" int mpcqp_setup(mpcqp_handle *h, const mpcqp_model *M, const double *
 extern "C" int mpcqp_update(mpcqp_handle *h, const double *x0, const double *um1, const double *xref, int xref_rows) {
     if (!h) return fail(MPCQP_ERR_ARG, "null handle");
     if (!h->is_setup) return fail(MPCQP_ERR_STATE, "mpcqp_update before mpcqp_setup");
+    if (h->step_blank && (!x0 || !um1 || !xref)) return fail(MPCQP_ERR_STATE, "mpcqp_update: the handle was set up from raw q, l, u and holds no x0 / u_{-1} / xref yet: give all three");
     HIPCHK(hipSetDevice(h->device));
+    h->step_blank = false;
     h->L.raw = 0;                                   // q, l, u are rebuilt from (x0, u_{-1}, xref) again
     return step_upload(h, x0, um1, xref, xref_rows);
 }
 
-// Stage a [batch][w] array on the device if it lives in host memory (the decode kernel reads it there).
-static int stage_in(mpcqp_handle *h, Scratch &sc, const double *src, size_t count, const double **dev) {
-    *dev = nullptr;
-    if (!src) return 0;
-    if (is_device_ptr(src)) { *dev = src; return 0; }
-    double *d = nullptr;
-    HIPCHK(sc.get(&d, count));
-    HIPCHK(hipMemcpyAsync(d, src, count * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    *dev = d;
-    return 0;
-}
-
+// The caller's q, l, u reach the decode kernel in place if they are device memory, else through the handle's staging block
+// (allocated once; copies and kernel are stream-ordered, so the next call may reuse it without waiting).
 static int upload_vectors(mpcqp_handle *h, const double *q, const double *l, const double *u) {
     const Lay &L = h->L; const size_t B = (size_t)h->batch;
-    Scratch sc;
-    const double *dq, *dl, *du;
-    if (stage_in(h, sc, q, B * L.n, &dq) || stage_in(h, sc, l, B * L.m, &dl) || stage_in(h, sc, u, B * L.m, &du)) return MPCQP_ERR_HIP;
-    hipLaunchKernelGGL(k_decode_vectors, dim3(h->batch), dim3(64), 0, h->stream, h->L, h->P, dq, dl, du, h->batch);
+    const double *src[3] = {q, l, u}; const size_t cnt[3] = {B * L.n, B * L.m, B * L.m};
+    const double *dev[3] = {nullptr, nullptr, nullptr};
+    size_t off = 0;
+    for (int i = 0; i < 3; ++i) {
+        if (src[i] && !is_device_ptr(src[i])) {
+            if (!h->vec_buf) HIPCHK(hipMalloc((void **)&h->vec_buf, sizeof(double) * B * (L.n + 2 * (size_t)L.m)));
+            HIPCHK(hipMemcpyAsync(h->vec_buf + off, src[i], cnt[i] * sizeof(double), hipMemcpyHostToDevice, h->stream));
+            dev[i] = h->vec_buf + off;
+        } else dev[i] = src[i];
+        off += cnt[i];
+    }
+    hipLaunchKernelGGL(k_decode_vectors, dim3(h->batch), dim3(64), 0, h->stream, h->L, h->P, dev[0], dev[1], dev[2], h->batch);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(h->stream));        // (the staging copies are freed on return)
     return MPCQP_OK;
 }
 
 extern "C" int mpcqp_update_vectors(mpcqp_handle *h, const double *q, const double *l, const double *u) {
     if (!h) return fail(MPCQP_ERR_ARG, "null handle");
     if (!h->is_setup) return fail(MPCQP_ERR_STATE, "mpcqp_update_vectors before setup");
+    if ((l == nullptr) != (u == nullptr)) return fail(MPCQP_ERR_ARG, "mpcqp_update_vectors: give l and u together (the equality rows l[:nx] == u[:nx] carry x0)");
     HIPCHK(hipSetDevice(h->device));
     if (!h->L.raw) {
         // entering raw mode: the vectors that are NOT given now must keep describing the current problem, so the
@@ -414,7 +417,7 @@ extern "C" int mpcqp_setup_qp(mpcqp_handle *h, const mpcqp_model *M, const doubl
     rc |= put(h, mb, ms, L.oQx, M->Qx, nx * nx); rc |= put(h, mb, ms, L.oQxN, M->QxN, nx * nx);
     rc |= put(h, mb, ms, L.oQu, M->Qu, nu * nu); rc |= put(h, mb, ms, L.oQDu, M->QDu, nu * nu);
     if (rc) return MPCQP_ERR_HIP;
-    h->L.raw = 1;
+    h->L.raw = 1; h->step_blank = true;
     if ((rc = upload_vectors(h, q, l, u))) return rc;
     DISPATCH_NB(L.NB, {
         if (set_smem(k_setup<NB>, h->smem_setup)) return MPCQP_ERR_HIP;
@@ -538,8 +541,8 @@ static int rebalance(mpcqp_handle *h) {
 static int launch_run(mpcqp_handle *h, RunArgs R, int plain_iters) {
     const Lay &L = h->L; const mpcqp_settings &S = h->S;
     R.plain = plain_iters > 0;
-    R.warm_x = (h->warm_x_pending && R.part != 2) ? 1 : 0;
-    if (R.part != 1) h->warm_x_pending = false;          // (a two-launch solve begins in its first launch only)
+    R.warm_x = (h->warm_x_pending && R.part != 2 && R.part != 3) ? 1 : 0;
+    if (R.part == 0 || R.part == 2) h->warm_x_pending = false;      // (a two-launch solve begins in its first launch only; mpcqp_refactor, part 3, is not a solve)
     R.max_iter = R.plain ? plain_iters : S.max_iter;
     R.chk = R.plain ? 0 : S.check_termination;
     R.rho_every = (!R.plain && S.adaptive_rho) ? (S.adaptive_rho_interval ? S.adaptive_rho_interval : (R.chk ? 4 * R.chk : 100)) : 0;
@@ -638,8 +641,8 @@ extern "C" int mpcqp_mpc_loop(mpcqp_handle *h, int nsteps, const mpcqp_loop *io)
     if (io->xref_traj && io->xref_rows != 0 && io->xref_rows != 1 && io->xref_rows != h->L.N)
         return fail(MPCQP_ERR_ARG, "mpcqp_mpc_loop: xref_rows must be 0 (as last uploaded), 1 or Np+1");
     HIPCHK(hipSetDevice(h->device));
-    if (io->xref_traj && io->xref_rows) h->L.xref_rows = io->xref_rows;     // update(x, u, xref_k) with this reference shape
     if (h->L.raw) return fail(MPCQP_ERR_STATE, "mpcqp_mpc_loop: the handle holds raw q, l, u (mpcqp_update_vectors); call mpcqp_update first");
+    if (io->xref_traj && io->xref_rows) h->L.xref_rows = io->xref_rows;     // update(x, u, xref_k) with this reference shape
     const Lay &L = h->L;
     const size_t B = (size_t)h->batch, K = (size_t)nsteps, nx = L.nx, nu = L.nu;
     const size_t xblk = (size_t)L.xref_rows * nx;
@@ -647,12 +650,12 @@ extern "C" int mpcqp_mpc_loop(mpcqp_handle *h, int nsteps, const mpcqp_loop *io)
     // stream-ordered and returns without waiting); host buffers go through one staging block on the device: inputs are
     // copied in before the launch, outputs copied out after it, and the call returns when they have arrived.
     struct Part { const void *src; void *dst; size_t bytes; size_t off; bool direct; };
-    Part parts[16]; int np = 0; size_t total = 0; bool any_host_out = false;
+    Part parts[16]; int np = 0; size_t total = 0; bool any_host = false;
     auto add = [&](const void *src, void *dst, size_t bytes) {
         const void *user = src ? src : dst;
         const bool direct = bytes && user && is_device_ptr(user);
         parts[np] = Part{src, dst, bytes, total, direct};
-        if (bytes && !direct) { total += (bytes + 15) & ~size_t(15); if (dst) any_host_out = true; }
+        if (bytes && !direct) { total += (bytes + 15) & ~size_t(15); any_host = true; }      // (a host INPUT must stay valid until its staged copy has been made: the call waits for that too)
         return np++;
     };
     const int iw = add(io->w, nullptr, io->w ? 8 * K * B * nx : 0);
@@ -691,7 +694,7 @@ extern "C" int mpcqp_mpc_loop(mpcqp_handle *h, int nsteps, const mpcqp_loop *io)
     for (int i = 0; i < np; ++i)
         if (parts[i].dst && parts[i].bytes && !parts[i].direct && get(h, parts[i].dst, dev(i), parts[i].bytes)) return MPCQP_ERR_HIP;
     const bool due = h->solves_since_balance >= BALANCE_EVERY;
-    if (!due && !any_host_out) return MPCQP_OK;               // everything the caller gets back is stream-ordered device memory
+    if (!due && !any_host) return MPCQP_OK;                   // every buffer is device memory: stream-ordered, nothing to wait for
     HIPCHK(hipStreamSynchronize(h->stream));
     return due ? rebalance(h) : MPCQP_OK;
 }
@@ -729,7 +732,9 @@ extern "C" int mpcqp_get_u0(mpcqp_handle *h, double *u0) {
 extern "C" int mpcqp_mpc_step(mpcqp_handle *h, const double *x0, const double *uminus1, const double *xref, int xref_rows, double *u_out) {
     if (!h || !x0 || !u_out) return fail(MPCQP_ERR_ARG, "mpcqp_mpc_step: null argument");
     if (!h->is_setup) return fail(MPCQP_ERR_STATE, "mpcqp_mpc_step before mpcqp_setup");
+    if (h->step_blank && (!uminus1 || !xref)) return fail(MPCQP_ERR_STATE, "mpcqp_mpc_step: the handle was set up from raw q, l, u and holds no u_{-1} / xref yet: give them");
     HIPCHK(hipSetDevice(h->device));
+    h->step_blank = false;
     h->L.raw = 0;
     int rc = step_upload(h, x0, uminus1, xref, xref_rows);
     if (rc) return rc;
@@ -769,7 +774,9 @@ extern "C" int mpcqp_step_host(mpcqp_handle *h, const double *x0, const double *
     if (!h) return fail(MPCQP_ERR_ARG, "null handle");
     if (!h->is_setup) return fail(MPCQP_ERR_STATE, "mpcqp_step_host before mpcqp_setup");
     if (xref && xref_rows != 1 && xref_rows != h->L.N) return fail(MPCQP_ERR_ARG, "xref_rows must be 1 or Np+1");
+    if (h->step_blank && (!x0 || !uminus1 || !xref)) return fail(MPCQP_ERR_STATE, "mpcqp_step_host: the handle was set up from raw q, l, u and holds no x0 / u_{-1} / xref yet: give all three");
     HIPCHK(hipSetDevice(h->device));
+    h->step_blank = false;
     const bool split = h->auto_balance && h->ncu > 0 && h->batch > h->ncu;
     if (split || ensure_pinned(h)) {
         int rc = mpcqp_update(h, x0, uminus1, xref, xref_rows);

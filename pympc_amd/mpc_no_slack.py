@@ -11,7 +11,6 @@ dimensionally inconsistent (one row for the first step, mpc_no_slack.py:270: the
 says so up front.
 """
 import numpy as np
-import scipy.sparse as sparse
 
 from .controller import MPCController as _Controller
 

@@ -308,6 +308,8 @@ class BatchProblem:
         io.w = inp(w, (K, B, nx), 'w'); io.Ap = inp(Ap, (B, nx, nx), 'Ap'); io.Bp = inp(Bp, (B, nx, nu), 'Bp')
         if xref_traj is not None:
             shp = tuple(xref_traj.shape)
+            if B == 1 and len(shp) == 2 and shp[0] == K:          # a single controller's [nsteps, nx] reference sequence
+                xref_traj = xref_traj.reshape(K, 1, shp[1]); shp = tuple(xref_traj.shape)
             if len(shp) < 3 or shp[0] != K or shp[1] != B:
                 raise ValueError('xref_traj must be [nsteps, batch, nx] or [nsteps, batch, Np+1, nx] (or flattened [nsteps, batch, (Np+1)*nx])')
             per = int(np.prod(shp[2:]))
@@ -459,6 +461,8 @@ class DeviceProblem:
         xref = np.asarray(mpc['xref'], dtype=float)
         if xref.ndim == 2 and xref.shape[0] != mpc['Np'] + 1:
             raise ValueError('a time-varying xref must have exactly Np+1 rows')
+        settings = dict(settings)
+        settings.pop('soft_constraints', None)            # (SOFT_ON of the controller is the single source of truth)
         self._bp = BatchProblem(1, mpc['nx'], mpc['nu'], mpc['Np'], mpc['Nc'], device=self.device,
                                 soft_constraints=int(bool(mpc.get('SOFT_ON', True))), **settings)
         one = lambda a: np.asarray(a, dtype=float)[None]
