@@ -1,0 +1,125 @@
+"""Driver-visible tests for what round 2 only printed in bench output or tested in a weakened form:
+  * the BENCH workloads themselves -- cfg-3 (1024 x (12,4,30)) and the UNMODIFIED cfg-5 batch (512 x (20,8,100), instance 276
+    included) -- run as bench.py runs them (eps 1e-3, 50 warm closed-loop steps in the device loop), then sampled instances'
+    u* at the parity tolerance against the oracle: the north-star criterion (1e-6 relative) on the benchmarked batches;
+  * the swapped eps kwargs of mpc.py:266 (eps_abs != eps_rel) through the drop-in class on the GPU, against the oracle;
+  * seam B (the caller's P, q, A, l, u and update(q, l, u) per step) inside a closed loop, against the reference-class trajectory."""
+import warnings
+
+import numpy as np
+import pytest
+
+from util import load_traj
+
+pytestmark = pytest.mark.gpu
+
+
+def _bench_batch(B, nx, nu, Np, xbox, eps):
+    from pympc_amd import BatchMPCController, fixtures
+    kws = [fixtures.random_lti(i, nx=nx, nu=nu, Np=Np, xbox=xbox) for i in range(B)]
+    stack = lambda k: np.stack([np.asarray(kw[k], dtype=float) for kw in kws])
+    K = BatchMPCController(stack('Ad'), stack('Bd'), Np=Np, x0=stack('x0'), Qx=np.eye(nx), QxN=np.eye(nx), Qu=0.1 * np.eye(nu), QDu=0.1 * np.eye(nu),
+                           xmin=-xbox * np.ones(nx), xmax=xbox * np.ones(nx), umin=-np.ones(nu), umax=np.ones(nu),
+                           Dumin=-0.5 * np.ones(nu), Dumax=0.5 * np.ones(nu), eps_feas=1e6, eps_abs=eps, eps_rel=eps)
+    return K, kws
+
+
+def _oracle_u(kw, x0, um1):
+    from pympc_amd import MPCController
+    from oracle.osqp_oracle import OSQP
+    kw = dict(kw); kw.update(x0=x0, uminus1=um1, eps_abs=1e-10, eps_rel=1e-10)
+    K = MPCController(**kw); K.prob = OSQP(); K.solver_settings = dict(max_iter=400000)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        K.setup()
+    return K.output(), K.res.info.status
+
+
+@pytest.mark.parametrize('cfg', ['cfg3', 'cfg5'])
+def test_benchmarked_batches_meet_the_north_star_tolerance(cfg):
+    B, nx, nu, Np, xbox, sample = (1024, 12, 4, 30, 10.0, 32) if cfg == 'cfg3' else (512, 20, 8, 100, 1.0, 6)
+    K, kws = _bench_batch(B, nx, nu, Np, xbox, 1e-3)
+    rng = np.random.default_rng(11)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        K.setup()
+        tr = K.run(50, w=0.01 * rng.standard_normal((50, B, nx)))            # the bench's regime: reference tolerance, warm receding horizon
+        assert (tr['status'][-25:] == 1).all(), np.argwhere(tr['status'][-25:] != 1)[:5]
+        assert tr['iter'].mean() < (45 if cfg == 'cfg3' else 35)
+        x, um1 = tr['x'][-1], tr['u'][-1]
+        K.prob.update_settings(eps_abs=1e-9, eps_rel=1e-9, max_iter=200000)
+        K.update(x, um1)
+        U, st = K.output(return_status=True)
+    idx = np.unique(np.linspace(0, B - 1, sample).astype(int))
+    if cfg == 'cfg5':
+        idx = np.unique(np.append(idx, 276))                               # the instance round 2's test replaced
+    worst = 0.0
+    for i in idx:
+        uo, so = _oracle_u(kws[int(i)], x[i], um1[i])
+        assert so == 'solved' and st['status'][int(i)] == 'solved', (i, so, st['status'][int(i)])
+        worst = max(worst, np.abs(U[i] - uo).max() / max(1e-3, np.abs(uo).max()))
+    assert worst <= 1e-6, worst                                            # north_star: u* within 1e-6 relative of the reference solver's
+
+
+@pytest.mark.parametrize('name', ['cart_pole', 'accel_brake', 'quadcopter'])
+def test_swapped_tolerance_kwargs_reach_the_device(name):
+    """mpc.py:266 passes eps_abs=self.eps_rel, eps_rel=self.eps_abs.  With eps_abs=1e-7, eps_rel=1e-3 the solver therefore runs with
+    (abs 1e-3, rel 1e-7): the GPU must terminate exactly where the oracle does with THOSE settings -- on these fixtures the
+    unswapped reading needs a different number of iterations (checked here too, so the test can tell the two apart)."""
+    from pympc_amd import MPCController, fixtures
+    from oracle.osqp_oracle import OSQP
+    kw = dict(fixtures.NAMED[name]()); kw.update(eps_abs=1e-7, eps_rel=1e-3)
+    K = MPCController(**kw)
+    Ko = MPCController(**kw); Ko.prob = OSQP()
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        K.setup(); Ko.setup()
+        assert (K.res.info.status, K.res.info.iter) == (Ko.res.info.status, Ko.res.info.iter)
+        assert np.abs(K.res.x - Ko.res.x).max() <= 1e-6 * max(1.0, np.abs(Ko.res.x).max())
+        O = OSQP(); O.setup(Ko.P, Ko.q, Ko.A, Ko.l, Ko.u, eps_abs=1e-7, eps_rel=1e-3)      # the UNswapped reading
+        ru = O.solve()
+    assert ru.info.iter != Ko.res.info.iter
+
+
+class _VectorsOnly:
+    """What pyMPC's own class sees of its solver (mpc.py:266,454,369): setup(P, q, A, l, u, **settings), update(q=, l=, u=), solve()."""
+
+    def __init__(self):
+        from pympc_amd.solver import DeviceProblem
+        self._d = DeviceProblem()
+
+    def setup(self, P, q, A, l, u, mpc=None, **settings):
+        self._d.setup(P, q, A, l, u, **settings)
+
+    def update(self, q=None, l=None, u=None, mpc_step=None):
+        self._d.update(q=q, l=l, u=u)
+
+    def solve(self):
+        return self._d.solve()
+
+
+@pytest.mark.parametrize('name', ['point_mass', 'accel_brake'])
+def test_seam_b_closed_loop_follows_the_reference_class(name):
+    """The one-line patch of INTEGRATION.md B (self.prob = DeviceProblem()) in a closed loop: host-built P, q, A, l, u go to the
+    library (mpcqp_create_csc / mpcqp_setup_csc), every step's q, l, u through mpcqp_update_vectors; the applied inputs follow
+    the trajectory the REFERENCE class produced (tests/golden/traj_*.npz) to 1e-6."""
+    from pympc_amd import MPCController, fixtures
+    g = load_traj(name)
+    kw = dict(fixtures.NAMED[str(g['fixture'])]())
+    kw.update(eps_abs=1e-9, eps_rel=1e-9)
+    K = MPCController(**kw); K.prob = _VectorsOnly(); K.solver_settings = dict(max_iter=400000)
+    xs, us = g['x'], g['u']
+    pattern = str(g['pattern'])
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        K.setup()
+        x, u = np.array(kw['x0'], dtype=float), np.array(kw['uminus1'], dtype=float)
+        for k in range(min(20, len(us))):
+            if pattern == 'update_output':
+                K.update(x, u); u = K.output()
+            else:
+                u = K.output()
+            assert np.abs(u - us[k]).max() <= 1e-6 * max(1e-3, np.abs(us).max()), (k, u, us[k])
+            x = xs[k + 1]
+            if pattern != 'update_output':
+                K.update(x)
