@@ -39,6 +39,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md chip-level parameters (achievable: ~6.3e12)
+MFMA_F64_PEAK = 78.6e12    # flop/s, FP64 matrix peak of MI355X (AMD datasheet; scripts/diag/mfma_rate.hip: 17 cycles per v_mfma_f64_4x4x4_4b = 74e12 measured)
 INFINITY_CACHE = 256 << 20  # bytes, MI355X_MICROARCH.md (memory-side cache in front of HBM)
 U_ERR_SAMPLE = 32          # instances whose u* is compared with the tight-tolerance CPU reference
 WORKLOADS = {              # name -> (nx, nu, Np, state box, default instances per GPU)
@@ -412,6 +413,21 @@ class Shard:
         traffic = pmc_b * iters / launches if pmc_b else None
         ws = self.working_set_bytes()
         NX, NU = self.dims[0], self.dims[1]
+        mode = int(kname.split('<')[1].split(',')[4])
+        if mode >= 100:
+            # the latency backend (at most two instances per CU): factor and iterate live in registers, an iteration reads nothing from
+            # memory -- the kernel is bound by the matrix cores' issue rate and the dependent level steps, not by HBM
+            mfma = prob.mfma_per_iter()
+            flops = 512.0 * mfma * iters
+            return {'bound': 'mfma', 'achieved': flops / (admm_ms * 1e-3) / 1e12, 'peak': MFMA_F64_PEAK / 1e12, 'unit': 'TFLOP/s',
+                    'frac': flops / (admm_ms * 1e-3) / MFMA_F64_PEAK, 'traffic': None,
+                    'frac_is': 'executed v_mfma_f64_4x4x4_4b_f64 flops (512 per instruction, mpcqp_get_work x the device-side iteration count) / HIP-event kernel '
+                               'time / the FP64 matrix peak; a mat-vec uses one of the four B-operand columns, so a quarter of these flops is useful',
+                    'useful_frac': 0.25 * flops / (admm_ms * 1e-3) / MFMA_F64_PEAK, 'mfma_per_iter_per_qp': mfma,
+                    'occupancy_note': '%d instances on %d CUs: %s' % (self.B, 256, 'one workgroup per CU, one wave per SIMD: no latency hiding by design' if self.B <= 256 else 'two rounds of workgroups'),
+                    'hbm_design_bytes_per_launch': design_bytes / launches, 'hbm_frac': achieved / HBM_PEAK,
+                    'working_set_bytes': ws, 'fits_infinity_cache': bool(ws <= INFINITY_CACHE),
+                    'kernel': kname, 'kernel_ms': admm_ms / launches, 'launches': res['launches'], 'steps_per_launch': res.get('chunk', 1)}
         return {'bound': 'hbm', 'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK, 'frac_is': 'model-based: design bytes (below) / HIP-event kernel time / 8 TB/s',
                 'traffic': traffic,

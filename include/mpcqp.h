@@ -248,6 +248,9 @@ int mpcqp_get_dims(mpcqp_handle *h, int *n, int *m, int64_t *factor_doubles, int
  * sparse LDL' solve behind pyMPC/mpc.py:369). */
 int mpcqp_get_stream_bytes(mpcqp_handle *h, int64_t *per_iter, int64_t *per_round, int64_t *per_solve);
 
+/* Matrix-core instructions (v_mfma_f64_4x4x4_4b_f64: 512 flop each) one instance issues per ADMM iteration with this handle's backend. */
+int mpcqp_get_work(mpcqp_handle *h, int64_t *mfma_per_iter);
+
 /* Name of the solve-kernel instantiation this handle launches (loop = 0: mpcqp_solve; 1: mpcqp_mpc_loop), as profilers print it. */
 int mpcqp_kernel_name(mpcqp_handle *h, int loop, char *buf, int buflen);
 

@@ -899,6 +899,25 @@ extern "C" int mpcqp_get_stream_bytes(mpcqp_handle *h, int64_t *per_iter, int64_
     return MPCQP_OK;
 }
 
+// Matrix-core instructions (v_mfma_f64_4x4x4_4b_f64, 512 flop each, a quarter of them useful in a mat-vec) one instance issues per
+// ADMM iteration with this handle's backend -- the numerator of the MFMA roofline bench.py reports for the latency backend.
+extern "C" int mpcqp_get_work(mpcqp_handle *h, int64_t *mfma_per_iter) {
+    if (!h || !mfma_per_iter) return fail(MPCQP_ERR_ARG, "null argument");
+    const Lay &L = h->L;
+    int64_t mv = 0;                                  // 16 x 16 mat-vecs (four MFMAs each)
+    if (L.dense) mv = 0;                             // vector ALU only
+    else if (L.bcr) {
+        for (int l = 0; l < bcr_levels(L.N); ++l)
+            for (int kind = 0; kind < 3; ++kind) for (int t = 0; t < lat_count(L.N, l, kind); ++t) mv += lat_nfr(L.N, l, kind, t);
+        mv += 2 * ((L.N + 3) / 4);                   // G v and G'W: one group per four stages each
+    } else {
+        const int64_t blk = (L.NB / 16) * (L.NB / 16);
+        mv = L.ffwd ? (int64_t)(L.N - 1) * blk * 3 + 3 * blk : (int64_t)(L.N - 1) * blk * 4 + 3 * blk;      // forward 1 (or 2) + backward 2 mat-vecs per stage, the middle stage
+    }
+    *mfma_per_iter = 4 * mv;
+    return MPCQP_OK;
+}
+
 // Name of the k_mpc_run instantiation the handle's solves (loop = 0) or closed-loop runs (loop = 1) launch, spelled as
 // rocprofv3 prints it (without spaces) -- so that bench.py and the profile summaries name the same kernel.
 extern "C" int mpcqp_kernel_name(mpcqp_handle *h, int loop, char *buf, int buflen) {

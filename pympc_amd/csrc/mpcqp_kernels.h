@@ -97,7 +97,7 @@ __device__ __noinline__ void run_factor_phase() {
 }
 
 template <int NB, bool LDSSTATE, int NXT, int NUT, int MODE>
-__device__ __noinline__ void run_admm_phase(int iters) {
+__device__ __forceinline__ void run_admm_phase_body(int iters) {
     const RunKArgs &A = run_kargs();
     const Lay &L = A.L; const Ptrs &P = A.P;
     RunSmem r = run_smem<LDSSTATE>(L, P);
@@ -105,6 +105,14 @@ __device__ __noinline__ void run_admm_phase(int iters) {
     hp.Bb = P.Bb; hp.Zb = P.Zb; hp.Sig = P.Sig; hp.x = P.x; hp.z = P.z; hp.y = P.y; hp.dx = P.dx; hp.dy = P.dy; hp.perm = P.perm; hp.fsz = P.fsz;
     admm_body<NB, LDSSTATE, NXT, NUT, MODE>(L, hp, r.S, r.X, r.Z, r.Y, A.S.alpha, __builtin_amdgcn_readfirstlane(iters));
 }
+template <int NB, bool LDSSTATE, int NXT, int NUT, int MODE>
+__device__ __noinline__ void run_admm_phase(int iters) { run_admm_phase_body<NB, LDSSTATE, NXT, NUT, MODE>(iters); }
+// (Measured for the latency kernels, whose phase saves and restores ~480 callee-saved registers per call -- 1 MB of scratch traffic per
+//  workgroup and round, 46 KB per iteration and instance in the write counters of a kernel that by design reads nothing: taking
+//  the phase INLINE removes that traffic but makes the allocator spill inside the iteration loop, 914 k -> 885 k solves/s at 256
+//  instances.  The call stays.)
+template <int NB, bool LDSSTATE, int NXT, int NUT, int MODE, int OCC>
+__device__ __forceinline__ void run_admm(int iters) { run_admm_phase<NB, LDSSTATE, NXT, NUT, MODE>(iters); }
 
 template <int NB, bool LDSSTATE, int OCC>
 __device__ __noinline__ void run_begin_phase(int plain, int warm_x) {
@@ -214,7 +222,7 @@ __global__ __launch_bounds__(NT, run_occupancy(NB, MODE)) void k_mpc_run(RunKArg
         PHASE_CLOCK(0)
         while (!term) {
             const int nxt = next_stop(iter, R.max_iter, R.chk, R.rho_every);
-            run_admm_phase<NB, LDSSTATE, NXT, NUT, MODE>(nxt - iter);
+            run_admm<NB, LDSSTATE, NXT, NUT, MODE, OCC>(nxt - iter);
             iter = nxt;
             __syncthreads();
             PHASE_CLOCK(1)

@@ -369,6 +369,12 @@ class BatchProblem:
         _lib.check(self._L.mpcqp_get_stream_bytes(self._h, C.byref(a), C.byref(b), C.byref(c)), 'mpcqp_get_stream_bytes')
         return a.value, b.value, c.value
 
+    def mfma_per_iter(self):
+        """Matrix-core instructions one instance issues per ADMM iteration (mpcqp_get_work)."""
+        v = C.c_int64()
+        _lib.check(self._L.mpcqp_get_work(self._h, C.byref(v)), 'mpcqp_get_work')
+        return v.value
+
     def kernel_name(self, loop):
         buf = C.create_string_buffer(128)
         _lib.check(self._L.mpcqp_kernel_name(self._h, int(bool(loop)), buf, 128), 'mpcqp_kernel_name')
