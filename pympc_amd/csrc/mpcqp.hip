@@ -56,6 +56,7 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #include "mpcqp_factor.h"
 #include "mpcqp_sweeps.h"
 #include "mpcqp_bcr.h"
+#include "mpcqp_wide.h"
 #include "mpcqp_dense.h"
 #include "mpcqp_border.h"
 #include "mpcqp_phases.h"
@@ -138,7 +139,7 @@ static Lay make_layout(int nx, int nu, int Np, int Nc, int soft) {
     L.n = (L.soft ? 2 : 1) * L.n_x + L.n_u; L.m = 2 * L.n_x + L.n_u + (Nc + 1) * nu;
     L.ou = L.n_x; L.oe = L.n_x + L.n_u;
     L.rs = L.n_x; L.ri = 2 * L.n_x; L.rdu = 2 * L.n_x + L.n_u;
-    L.NB = L.nb <= 16 ? 16 : 32;
+    L.NB = L.nb <= 16 ? 16 : L.nb <= 32 ? 32 : 64;
     L.border = Nc < Np ? 1 : 0;
     L.NcT = L.border ? Nc - 1 : Nc;
     L.rnx = 1.0f / (float)nx; L.rnu = 1.0f / (float)nu;
@@ -154,11 +155,11 @@ static Lay make_layout(int nx, int nu, int Np, int Nc, int soft) {
     L.step_sz = L.odu0 + 2 * nu;
     L.raw = 0;
     L.xref_rows = 1;
-    L.fstage = L.NB == 16 ? FactorFmt<16>::STAGE : FactorFmt<32>::STAGE;
-    L.fhead = L.NB == 16 ? FactorFmt<16>::HEAD : FactorFmt<32>::HEAD;
-    L.ffwd = L.NB == 16 ? FactorFmt<16>::FWD : FactorFmt<32>::FWD;
-    L.ftab = L.NB == 16 ? FactorFmt<16>::TAB : FactorFmt<32>::TAB;
-    L.tsz = L.m + L.N * L.NB;                          // [W (m) | Tc (N*NB)]; mpcqp_create widens it where the factorization needs more
+    L.fstage = L.NB == 16 ? FactorFmt<16>::STAGE : L.NB == 32 ? FactorFmt<32>::STAGE : WideFmt::STAGE;
+    L.fhead = L.NB == 16 ? FactorFmt<16>::HEAD : L.NB == 32 ? FactorFmt<32>::HEAD : 0;
+    L.ffwd = L.NB == 16 ? FactorFmt<16>::FWD : L.NB == 32 ? FactorFmt<32>::FWD : WideFmt::NN;      // (non-zero: the factor starts at the stages)
+    L.ftab = L.NB == 16 ? FactorFmt<16>::TAB : L.NB == 32 ? FactorFmt<32>::TAB : 0;
+    L.tsz = L.m + L.N * L.NB * (L.NB == 64 ? 2 : 1);   // [W (m) | Tc (N*NB)] (+ the second stage-major vector of the wide solve); mpcqp_create widens it where the factorization needs more
     L.NR = L.N * L.nb; L.dld = L.NR | 1;               // dense mode (decided in mpcqp_create): unknowns, odd LDS row stride
     return L;
 }
@@ -175,7 +176,7 @@ static int dalloc(mpcqp_handle *h, T **p, size_t count) {
 
 extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, int nu, int Np, int Nc, const mpcqp_settings *s) {
     if (!out || batch < 1 || nx < 1 || nu < 1 || Np < 2 || Nc < 1 || Nc > Np) return fail(MPCQP_ERR_ARG, "mpcqp_create: bad dimensions");
-    if (nx + nu > 32) return fail(MPCQP_ERR_UNSUPPORTED, "mpcqp_create: nx+nu > 32 is not implemented");
+    if (nx + nu > 64) return fail(MPCQP_ERR_UNSUPPORTED, "mpcqp_create: nx+nu > 64 is not implemented");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MPCQP_ERR_NO_DEVICE, "no HIP device available");
     if (device < 0 || device >= ndev) return fail(MPCQP_ERR_ARG, "mpcqp_create: bad device index");
@@ -203,7 +204,7 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     // Small problems keep the iterate x, z, y in LDS behind the common block (four workgroups per CU: 40 KB each); larger
     // ones keep it in L2/HBM.
     const size_t state_doubles = (size_t)(L.n + 2 * L.m);
-    h->lds_state = sizeof(double) * ((size_t)smem_common_doubles(L) + state_doubles) <= 40 * 1024 && L.m <= 4 * NT && L.N * L.NB <= 2 * NT && L.n_u + L.nu <= NT;      // (the owner map of the parallel phases: two state elements and one input element per thread)
+    h->lds_state = L.NB <= 32 && sizeof(double) * ((size_t)smem_common_doubles(L) + state_doubles) <= 40 * 1024 && L.m <= 4 * NT && L.N * L.NB <= 2 * NT && L.n_u + L.nu <= NT;      // (the owner map of the parallel phases: two state elements and one input element per thread)
     // The smallest ones (the reference's own examples) solve the KKT system with a register-resident dense inverse (mpcqp_dense.h).
     bool dense = h->lds_state && L.NB == 16 && !L.border && L.NR <= DenseFmt::ROWS;
     if (const char *e = getenv("MPCQP_DENSE")) dense = dense && atoi(e) != 0;      // development switch (A/B against the block sweeps)
@@ -240,7 +241,7 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     if (rc) { std::string msg = g_err; mpcqp_destroy(h); return fail(MPCQP_ERR_HIP, msg); }
     // The factorization's workspace starts at the work area T, the last part of the common block,
     // and may run on into the iterate area (dead while a factorization runs); T is widened only where even that is short.
-    const int fws = dense ? L.NR * L.dld + 2 * DenseFmt::ROWS : bcr ? BcrFmt::LDSW : (L.NB == 16 ? FactorCfg<16>::WS : FactorCfg<32>::WS);
+    const int fws = dense ? L.NR * L.dld + 2 * DenseFmt::ROWS : bcr ? BcrFmt::LDSW : (L.NB == 16 ? FactorCfg<16>::WS : L.NB == 32 ? FactorCfg<32>::WS : WideFmt::WS);
     const int avail = L.tsz + (h->lds_state ? (int)state_doubles : 0);
     if (avail < fws) h->L.tsz += fws - avail;
     h->smem_setup = sizeof(double) * ((size_t)smem_common_doubles(h->L) + (h->lds_state ? state_doubles : 0));      // every kernel gets the full block
@@ -306,7 +307,8 @@ static int put(mpcqp_handle *h, double *dst, int stride, int off, const double *
 
 #define DISPATCH_NB(NBV, EXPR) switch (NBV) { \
     case 16: { constexpr int NB = 16; EXPR; } break; \
-    default: { constexpr int NB = 32; EXPR; } break; }
+    case 32: { constexpr int NB = 32; EXPR; } break; \
+    default: { constexpr int NB = 64; EXPR; } break; }
 
 template <class K>
 static int set_smem(K kernel, size_t bytes) {
@@ -562,7 +564,8 @@ static int launch_run(mpcqp_handle *h, RunArgs R, int plain_iters) {
     else if (L.NB == 16 && h->lds_state && L.nx == 12 && L.nu == 4 && !L.border) rc = launch_run_t<16, true, 12, 4, MODE_CHAIN>(h, R);
     else if (L.NB == 32 && !h->lds_state && L.nx == 20 && L.nu == 8 && !L.border) rc = launch_run_t<32, false, 20, 8, MODE_CHAIN>(h, R);
     else if (L.NB == 16) rc = h->lds_state ? launch_run_generic<16, true>(h, R) : launch_run_generic<16, false>(h, R);
-    else rc = h->lds_state ? launch_run_generic<32, true>(h, R) : launch_run_generic<32, false>(h, R);
+    else if (L.NB == 32) rc = h->lds_state ? launch_run_generic<32, true>(h, R) : launch_run_generic<32, false>(h, R);
+    else rc = launch_run_generic<64, false>(h, R);
     if (rc) return rc;
     HIPCHK(hipGetLastError());
     if (h->profiling) { HIPCHK(hipEventRecord(h->ev1[e], h->stream)); h->ev_count += 1; }
@@ -636,7 +639,7 @@ extern "C" int mpcqp_mpc_loop(mpcqp_handle *h, int nsteps, const mpcqp_loop *io)
     if (!h->is_setup) return fail(MPCQP_ERR_STATE, "mpcqp_mpc_loop before mpcqp_setup");
     if ((io->Ap == nullptr) != (io->Bp == nullptr)) return fail(MPCQP_ERR_ARG, "mpcqp_mpc_loop: give both Ap and Bp or neither");
     const int ny = io->ny;
-    if (ny < 0 || ny > 32) return fail(MPCQP_ERR_ARG, "mpcqp_mpc_loop: ny must be in 0..32");
+    if (ny < 0 || ny > 64) return fail(MPCQP_ERR_ARG, "mpcqp_mpc_loop: ny must be in 0..64");
     if (ny && (!io->C || !io->Lgain || !io->x_true)) return fail(MPCQP_ERR_ARG, "mpcqp_mpc_loop: output feedback needs C, Lgain and x_true");
     if (io->xref_traj && io->xref_rows != 0 && io->xref_rows != 1 && io->xref_rows != h->L.N)
         return fail(MPCQP_ERR_ARG, "mpcqp_mpc_loop: xref_rows must be 0 (as last uploaded), 1 or Np+1");
@@ -886,6 +889,7 @@ extern "C" int mpcqp_get_stream_bytes(mpcqp_handle *h, int64_t *per_iter, int64_
     const int64_t sinv = L.fstage - L.ffwd - L.ftab;
     int64_t it = (L.dense || L.bcr) ? 0 /* the factor sits in registers for the round */ : !L.ffwd ? 2 * (int64_t)L.N * sinv + (int64_t)L.N * L.ftab + 2 * (int64_t)L.fhead   // S^-1-only build: S^-1 twice, one of the two tables per sweep, [G | G'] by each sweeping wave
                          : (int64_t)(L.N - 1) * L.ffwd + (int64_t)L.N * sinv + (int64_t)(L.N - 1) * L.ftab + L.fhead;   // forward matrices once, S^-1 once, the tables, G / G' once each
+    if (L.NB == 64) it = (3 * (int64_t)L.N - 2) * WideFmt::NN;      // wide stages: S^-1 of every stage, M and M' of all but the last
     if (!h->lds_state) it += (2 * n + 4 * m) /* x, z, y read + written */ + (m + L.n_x) /* omega */ + (n + L.n_x) /* s */ + nq /* q */;
     if (L.border) it += 2 * (int64_t)L.nu * L.N * NB;
     int64_t rd = (L.model_sz - L.hot_sz) + 2 * n + 2 * m /* D, s, E, omega */ + n + m /* dx, dy */;
@@ -905,7 +909,7 @@ extern "C" int mpcqp_get_work(mpcqp_handle *h, int64_t *mfma_per_iter) {
     if (!h || !mfma_per_iter) return fail(MPCQP_ERR_ARG, "null argument");
     const Lay &L = h->L;
     int64_t mv = 0;                                  // 16 x 16 mat-vecs (four MFMAs each)
-    if (L.dense) mv = 0;                             // vector ALU only
+    if (L.dense || L.NB == 64) mv = 0;               // vector ALU only
     else if (L.bcr) {
         for (int l = 0; l < bcr_levels(L.N); ++l)
             for (int kind = 0; kind < 3; ++kind) for (int t = 0; t < lat_count(L.N, l, kind); ++t) mv += lat_nfr(L.N, l, kind, t);

@@ -257,3 +257,4 @@ __device__ __forceinline__ int factor_all(const Ctx &c, const double *om, const 
     if (L.border) border_factor<NB>(c, om, sv, cc, F, bp.Bb, bp.Zb, bp.Sig, W, W + L.m, bp.red);
     return *iflag;
 }
+template <> __device__ __forceinline__ int factor_all<64>(const Ctx &, const double *, const double *, double, double *, double *, int *, BorderPtrs);      // mpcqp_wide.h

@@ -90,8 +90,8 @@ __device__ __noinline__ void run_factor_phase() {
     RunSmem r = run_smem<false>(L, P);                       // (the common LDS area comes first in both layouts)
     const int b = inst_of(P.perm);
     Ctx c{L, r.S.hot, P.model + (size_t)b * L.model_sz + L.hot_sz};
-    if (L.dense) factor_dense(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], P.F + (size_t)b * P.fsz, r.S.T, r.S.iflag);
-    else if (L.bcr) factor_bcr(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], P.F + (size_t)b * P.fsz, P.bws + (size_t)b * L.N * BcrFmt::WSTAGE, r.S.T, r.S.iflag);
+    if (NB == 16 && L.dense) factor_dense(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], P.F + (size_t)b * P.fsz, r.S.T, r.S.iflag);      // (the register-resident backends: 16 x 16 stages only)
+    else if (NB == 16 && L.bcr) factor_bcr(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], P.F + (size_t)b * P.fsz, P.bws + (size_t)b * L.N * BcrFmt::WSTAGE, r.S.T, r.S.iflag);
     else factor_all<NB>(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], P.F + (size_t)b * P.fsz, r.S.T, r.S.iflag,
                         border_ptrs(L, P, r.S));
 }
@@ -128,7 +128,7 @@ __device__ __noinline__ int run_check_phase(int iter, int mode) {
     return check_body<NB, OCC>(A.L, A.P, A.S, r.S, __builtin_amdgcn_readfirstlane(iter), __builtin_amdgcn_readfirstlane(mode), r.X, r.Z, r.Y);
 }
 
-constexpr int run_occupancy(int NB, int MODE) { return (MODE == MODE_DENSE || MODE >= MODE_BCR) ? 1 : NB <= 16 ? 4 : 2; }      // workgroups per CU
+constexpr int run_occupancy(int NB, int MODE) { return (MODE == MODE_DENSE || MODE >= MODE_BCR || NB > 32) ? 1 : NB <= 16 ? 4 : 2; }      // workgroups per CU
 template <int NB, bool LDSSTATE, int NXT, int NUT, int MODE, bool LOOP>
 __global__ __launch_bounds__(NT, run_occupancy(NB, MODE)) void k_mpc_run(RunKArgs A_) {
     constexpr int OCC = run_occupancy(NB, MODE);
@@ -156,8 +156,8 @@ __global__ __launch_bounds__(NT, run_occupancy(NB, MODE)) void k_mpc_run(RunKArg
     const int nrun = LOOP ? R.nsteps : 1;        // LOOP = false: one solve of the current data (mpcqp_solve)
     for (int k = 0; k < nrun; ++k) {
         if (LOOP) {
-            // scratch in the (idle) work area: un | xn | xt | ym | inn | xu, 32 doubles each (nx + nu <= 32)
-            double *un = S.T, *xn = S.T + 32, *xt = S.T + 64, *ym = S.T + 96, *inn = S.T + 128, *xu = S.T + 160;
+            // scratch in the (idle) work area: un | xn | xt | ym | inn | xu, 64 doubles each (nx + nu <= 64)
+            double *un = S.T, *xn = S.T + 64, *xt = S.T + 128, *ym = S.T + 192, *inn = S.T + 256, *xu = S.T + 320;
             const size_t kb = (size_t)k * R.batch + b;
             const int ny = R.ny;
             // ---- output(): first input of the current solution, or u_failure

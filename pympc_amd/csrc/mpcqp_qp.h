@@ -173,6 +173,9 @@ __device__ void block_reduce(double *vmax, double *vsum, double *red) {
 // Reduced KKT matrix  K = c P + diag(s) + A' diag(omega) A  with eps eliminated: stage blocks.
 // Stage k holds v_k = (x_k, u_k) (u absent in the last stage); blocks are NB x NB, identity padded.
 // ------------------------------------------------------------------------------------------------
+// (DYN = false leaves out G' diag(om_dyn) G, G = [Ad Bd], om_dyn = the weights of the dynamics rows of stage k+1 -- the one term every
+//  entry sums nx products for; mpcqp_wide.h forms it as a matrix product)
+template <bool DYN = true>
 __device__ __forceinline__ double kkt_diag_entry(const Ctx &c, const double *om, const double *sv, double cc, int k, int a, int b) {
     const Lay &L = c.L;
     const int nbk = (k < L.NcT) ? L.nb : L.nx;
@@ -183,7 +186,7 @@ __device__ __forceinline__ double kkt_diag_entry(const Ctx &c, const double *om,
     if (a < L.nx && b < L.nx) {
         const double *Q = (k < L.Np) ? c.Qx() : c.QxN();
         v = cc * Q[min(a, b) * L.nx + max(a, b)];
-        if (k < L.Np) for (int r = 0; r < L.nx; ++r) v += Ad[r * L.nx + a] * omd[r] * Ad[r * L.nx + b];
+        if (DYN && k < L.Np) for (int r = 0; r < L.nx; ++r) v += Ad[r * L.nx + a] * omd[r] * Ad[r * L.nx + b];
         if (a == b) {
             int e = k * L.nx + a;
             double ws = om[L.rs + e];
@@ -196,7 +199,7 @@ __device__ __forceinline__ double kkt_diag_entry(const Ctx &c, const double *om,
         double dk = (k == L.Nc - 1) ? 1.0 : 2.0;
         int lo = min(ja, jb), hi = max(ja, jb);
         v = cc * (iu * c.Qu()[lo * L.nu + hi] + dk * c.QDu()[lo * L.nu + hi]);
-        for (int r = 0; r < L.nx; ++r) v += Bd[r * L.nu + ja] * omd[r] * Bd[r * L.nu + jb];
+        if (DYN) for (int r = 0; r < L.nx; ++r) v += Bd[r * L.nu + ja] * omd[r] * Bd[r * L.nu + jb];
         int ca = k * L.nu + ja;
         const double *omdiff = om + L.rdu + L.nu;
         if (ja == jb) {
@@ -208,7 +211,7 @@ __device__ __forceinline__ double kkt_diag_entry(const Ctx &c, const double *om,
         }
     } else {
         int xa = a < L.nx ? a : b, ju = (a < L.nx ? b : a) - L.nx;
-        for (int r = 0; r < L.nx; ++r) v += Ad[r * L.nx + xa] * omd[r] * Bd[r * L.nu + ju];
+        if (DYN) for (int r = 0; r < L.nx; ++r) v += Ad[r * L.nx + xa] * omd[r] * Bd[r * L.nu + ju];
     }
     return v;
 }

@@ -603,3 +603,4 @@ __device__ __forceinline__ void kkt_core(const CoreArgs &a, double *Tc) {
     __syncthreads();
 #endif
 }
+template <> __device__ __forceinline__ void kkt_core<64>(const CoreArgs &, double *);      // mpcqp_wide.h (stages wider than 32)

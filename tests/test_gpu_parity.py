@@ -423,7 +423,7 @@ def test_device_loop_output_feedback_matches_reference_style_loop():
                                   (4, 1, 150, 75), (2, 2, 64, 64), (3, 12, 20, 20), (3, 12, 22, 22)])
 def test_boundary_dimensions_match_oracle(dims):
     """Shapes at the edges of the device code paths: smallest problem (nx=nu=1, Np=2), nx+nu = 16/17 (block size switch),
-    nx+nu = 32 (largest supported), Nc = 1, long horizons with Nc < Np (the reference's Kalman example uses Np=150, Nc=75),
+    nx+nu = 32 (largest 32-wide stage), Nc = 1, long horizons with Nc < Np (the reference's Kalman example uses Np=150, Nc=75),
     LDS-resident and global-memory iterate, and the two sides of the owner map's limit (one input element per thread:
     (3,12,20) has 252 input elements and rows, (3,12,22) 276 and falls back to the global-memory passes although it would fit
     LDS).  u* against the oracle at tight tolerance, plus one warm step."""
@@ -451,7 +451,7 @@ def test_boundary_dimensions_match_oracle(dims):
 
 def test_unsupported_dimensions_fail_loudly():
     from pympc_amd import fixtures
-    kw = dict(fixtures.random_lti(1, nx=25, nu=8, Np=3))
+    kw = dict(fixtures.random_lti(1, nx=60, nu=8, Np=3))        # nx + nu > 64 (32 < nx + nu <= 64: tests/test_gpu_wide.py)
     K = _gpu_controller(kw)
     with pytest.raises(NotImplementedError):
         K.setup()
