@@ -120,6 +120,7 @@ __device__ __forceinline__ int factor_all(const Ctx &c, const double *om, const 
     const int tid = threadIdx.x;
     const int N = L.N, mid = N / 2;
     if (tid == 0) *iflag = 0;
+    TICK_RESET
     double *SnA, *SnB;                                   // S^-1 of the stage eliminated last in the top / bottom half
     if (G == 2) { SnA = W + 3 * NN; SnB = W + 7 * NN; } else { SnA = W + 3 * NN; SnB = W + 4 * NN; }
     // One stage by the T threads lt = 0..T-1 of a group (barriers are workgroup-wide: every thread makes the same calls;
@@ -127,9 +128,28 @@ __device__ __forceinline__ int factor_all(const Ctx &c, const double *om, const 
     // below to eliminate (null = none); SnOut receives S_k^-1.
     auto stage = [&](bool on, int k, int T, int lt, double *Ws, const double *SnU, const double *SnD, double *SnOut) {
         double *S = Ws, *Ks = Ws + NN, *Mh = Ws + 2 * NN;
+        // K_kk.  Its one dense term, G' diag(om_dyn) G with G = [Ad Bd] (nx rows) and om_dyn the weights of the dynamics rows of stage k+1, is
+        // formed as a product from LDS, with the same control flow for every entry: G zero-padded to NB columns in Ks, om_dyn in Mh (both idle
+        // here).  Entry by entry (kkt_diag_entry<true>) it is three divergent nx-long loops and a global fetch per term.
+        const int nbk = (k < L.NcT) ? L.nb : L.nx;
+        const bool dyn = k < L.Np;
+        if (on && dyn) {
+            for (int e = lt; e < L.nx * NB; e += T) {
+                const int r = e / NB, q = e % NB;
+                Ks[e] = q < L.nx ? c.Ad()[r * L.nx + q] : (q < nbk ? c.Bd()[r * L.nu + (q - L.nx)] : 0.0);
+            }
+            if (lt < L.nx) Mh[lt] = om[(k + 1) * L.nx + lt];
+        }
         __syncthreads();
+        TICK_START
         if (on) for (int e = lt; e < NN; e += T) {
-            S[e] = kkt_diag_entry(c, om, sv, cc, k, e / NB, e % NB);
+            const int a = e / NB, b = e % NB;
+            double v = kkt_diag_entry<false>(c, om, sv, cc, k, a, b);
+            if (dyn) {
+#pragma unroll 4
+                for (int r = 0; r < L.nx; ++r) v = fma(Ks[r * NB + a] * Mh[r], Ks[r * NB + b], v);
+            }
+            S[e] = v;
             if constexpr (!FactorFmt<NB>::SONLY) { if (k == N - 1) F[(size_t)k * L.fstage + e] = 0.0; }     // the last stage has no forward matrix (stage 0's slot holds the middle's second one)
         }
         for (int side = 0; side < 2; ++side) {           // S -= (Ks Sn) Ks' for the neighbour above (side 0) / below (side 1)
@@ -137,11 +157,13 @@ __device__ __forceinline__ int factor_all(const Ctx &c, const double *om, const 
             const bool has = on && Sn != nullptr;
             const bool up = side == 0;
             __syncthreads();
+            TICK(0)
             if (has) for (int e = lt; e < NN; e += T) {
                 const int a = e / NB, b = e % NB;
                 Ks[e] = up ? kkt_sub_entry(c, om, cc, k - 1, a, b) : kkt_sub_entry(c, om, cc, k, b, a);
             }
             __syncthreads();
+            TICK(1)
             if (has) for (int e = lt; e < NN; e += T) {      // Mh = Ks * Sn
                 const int a = e / NB, b = e % NB;
                 double acc = 0.0;
@@ -150,6 +172,7 @@ __device__ __forceinline__ int factor_all(const Ctx &c, const double *om, const 
                 Mh[e] = acc;
             }
             __syncthreads();
+            TICK(2)
             if (has) {
                 const int fwd_stage = (k == mid && !up) ? 0 : k;
                 for (int e = lt; e < NN; e += T) {           // S -= Mh * Ks'
@@ -164,14 +187,21 @@ __device__ __forceinline__ int factor_all(const Ctx &c, const double *om, const 
             }
         }
         __syncthreads();
+        TICK(3)
         // in-place Gauss-Jordan inversion of the SPD block: step p uses the OLD pivot row and column (read, barrier, write)
-        constexpr int EPT = (NN + NT / G - 1) / (NT / G);    // entries per thread (2 with two groups of 128, 4 for 32 x 32)
+        constexpr int EPT = NN / (NT / G);                   // entries per thread (2 with two groups of 128, 4 for 32 x 32), kept in registers through the NB steps
+        static_assert(NN % (NT / G) == 0, "whole entries per thread");
+        double cur[EPT];
+        if (on) {
+#pragma unroll
+            for (int u = 0; u < EPT; ++u) cur[u] = S[lt + u * T];
+        }
         for (int pv = 0; pv < NB; ++pv) {
             double rip[EPT], rpj[EPT], d = 1.0;
             if (on) {
                 d = S[pv * NB + pv];
 #pragma unroll
-                for (int u = 0; u < EPT; ++u) { const int e = lt + u * T; if (e < NN) { rip[u] = S[(e / NB) * NB + pv]; rpj[u] = S[pv * NB + (e % NB)]; } }
+                for (int u = 0; u < EPT; ++u) { const int e = lt + u * T; rip[u] = S[(e / NB) * NB + pv]; rpj[u] = S[pv * NB + (e % NB)]; }
             }
             if (on && !(d > 0.0)) { if (lt == 0) *iflag = 1; d = 1e-300; }
             __syncthreads();
@@ -179,15 +209,17 @@ __device__ __forceinline__ int factor_all(const Ctx &c, const double *om, const 
                 const double inv = 1.0 / d;
 #pragma unroll
                 for (int u = 0; u < EPT; ++u) {
-                    const int e = lt + u * T;
-                    if (e < NN) {
-                        const int i = e / NB, j = e % NB;
-                        S[e] = (i == pv) ? (j == pv ? inv : rpj[u] * inv) : (j == pv ? -rip[u] * inv : S[e] - rip[u] * rpj[u] * inv);
-                    }
+                    const int e = lt + u * T, i = e / NB, j = e % NB;
+                    const bool rowp = i == pv, colp = j == pv;
+                    const double t = rip[u] * inv;
+                    const double off = rowp ? rpj[u] * inv : fma(-t, rpj[u], cur[u]), onp = rowp ? inv : -t;
+                    cur[u] = colp ? onp : off;
+                    S[e] = cur[u];
                 }
             }
             __syncthreads();
         }
+        TICK(4)
         if (on) for (int e = lt; e < NN; e += T) {               // S now holds S_k^-1: symmetrise, keep, store in the factor's format
             const int a = e / NB, b = e % NB;
             const double acc = 0.5 * (S[a * NB + b] + S[b * NB + a]);
@@ -223,6 +255,7 @@ __device__ __forceinline__ int factor_all(const Ctx &c, const double *om, const 
                 else entry(k == mid ? -1 : (k < mid ? k + 1 : k - 1), tab);
             }
         }
+        TICK(5)
     };
     if (G == 2) {
         const int T = NT / 2, g = tid / T, lt = tid % T;
@@ -253,6 +286,7 @@ __device__ __forceinline__ int factor_all(const Ctx &c, const double *om, const 
         }
         (void)NBLK;
     }
+    TICK_FLUSH
     __syncthreads();
     if (L.border) border_factor<NB>(c, om, sv, cc, F, bp.Bb, bp.Zb, bp.Sig, W, W + L.m, bp.red);
     return *iflag;

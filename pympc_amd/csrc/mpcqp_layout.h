@@ -78,3 +78,19 @@ struct Ctx {
     __device__ __forceinline__ const double *QDu() const { return wts + (L.oQDu - L.hot_sz); }
     __device__ __forceinline__ double eps_feas() const { return hot[L.oeps]; }
 };
+
+#ifdef MPCQP_RUN_TIMING
+// Development build: shader-clock cycles between phase boundaries as seen by thread 0, summed in LDS and flushed to g_ticks once
+// per ADMM phase (an atomic per tick would perturb what it measures).
+__device__ unsigned long long g_ticks[16];
+__device__ __forceinline__ unsigned long long *tick_slots() { __shared__ unsigned long long s[16]; return s; }
+#define TICK(i) { if (threadIdx.x == 0) { unsigned long long *s_ = tick_slots(); const unsigned long long t_ = clock64(); s_[i] += t_ - s_[15]; s_[15] = t_; } }
+#define TICK_START { if (threadIdx.x == 0) tick_slots()[15] = clock64(); }
+#define TICK_RESET { if (threadIdx.x < 16) tick_slots()[threadIdx.x] = 0; __syncthreads(); }
+#define TICK_FLUSH { __syncthreads(); if (threadIdx.x < 15) atomicAdd(&g_ticks[threadIdx.x], tick_slots()[threadIdx.x]); }
+#else
+#define TICK(i)
+#define TICK_START
+#define TICK_RESET
+#define TICK_FLUSH
+#endif

@@ -175,13 +175,14 @@ __device__ void block_reduce(double *vmax, double *vsum, double *red) {
 // ------------------------------------------------------------------------------------------------
 // (DYN = false leaves out G' diag(om_dyn) G, G = [Ad Bd], om_dyn = the weights of the dynamics rows of stage k+1 -- the one term every
 //  entry sums nx products for; mpcqp_wide.h forms it as a matrix product)
+// (omd_copy: optional copy of om_dyn in LDS -- the one thing the nx-long sums would otherwise fetch from global memory entry by entry)
 template <bool DYN = true>
-__device__ __forceinline__ double kkt_diag_entry(const Ctx &c, const double *om, const double *sv, double cc, int k, int a, int b) {
+__device__ __forceinline__ double kkt_diag_entry(const Ctx &c, const double *om, const double *sv, double cc, int k, int a, int b, const double *omd_copy = nullptr) {
     const Lay &L = c.L;
     const int nbk = (k < L.NcT) ? L.nb : L.nx;
     if (a >= nbk || b >= nbk) return a == b ? 1.0 : 0.0;
     const double *Ad = c.Ad(), *Bd = c.Bd();
-    const double *omd = om + (k + 1) * L.nx;          // dynamics rows of stage k+1
+    const double *omd = omd_copy ? omd_copy : om + (k + 1) * L.nx;          // dynamics rows of stage k+1
     double v = 0.0;
     if (a < L.nx && b < L.nx) {
         const double *Q = (k < L.Np) ? c.Qx() : c.QxN();
