@@ -141,7 +141,8 @@ int mpcqp_update_vectors(mpcqp_handle *h, const double *q, const double *l, cons
 /* The same seam with the MATRICES themselves, bindable from any language (mpc.py:266 prob.setup(P, q, A, l, u, ...)):
  *   mpcqp_create_csc  reads the controller's dimensions (nx, nu, Np, Nc) out of the sparsity patterns -- P: upper triangle or full
  *                     symmetric, A: both CSC with int64 column pointers and int32 row indices, shared by the batch -- and creates
- *                     the handle (nx_hint / nu_hint > 0 settle a pattern that does not determine them, e.g. an Ad with an empty first row);
+ *                     the handle (nx_hint / nu_hint > 0 settle a pattern that does not determine them, e.g. an Ad with an empty first row).
+ *                     Slack columns or not (pyMPC's SOFT_ON, mpc.py:237) is read off the pattern too and overrides settings->soft_constraints;
  *   mpcqp_setup_csc   reads (Ad, Bd, Qx, QxN, Qu, QDu, eps_feas) of every instance out of the values P_val [batch][nnz(P)],
  *                     A_val [batch][nnz(A)], REBUILDS both matrices from them as pyMPC/mpc.py:456-608 would and compares entry for
  *                     entry, checks q, l, u ([batch][n], [batch][m], HOST pointers) for pyMPC's structure, and continues as

@@ -442,10 +442,10 @@ extern "C" int mpcqp_create_csc(mpcqp_handle **out, int device, int batch, int n
     c.Pi.assign(P_rowidx, P_rowidx + c.Pp[n]); c.Ai.assign(A_rowidx, A_rowidx + c.Ap[n]);
     for (int32_t r : c.Pi) if (r < 0 || r >= n) { delete seam; return fail(MPCQP_ERR_ARG, "mpcqp_create_csc: P row index out of range"); }
     for (int32_t r : c.Ai) if (r < 0 || r >= m) { delete seam; return fail(MPCQP_ERR_ARG, "mpcqp_create_csc: A row index out of range"); }
-    int nx, nu, Np, Nc; std::string why;
-    if (csc_dims(c, nx_hint, nu_hint, &nx, &nu, &Np, &Nc, &why)) { delete seam; return fail(MPCQP_ERR_UNSUPPORTED, "mpcqp_create_csc: not an MPC QP of pyMPC: " + why); }
+    int nx, nu, Np, Nc, soft; std::string why;
+    if (csc_dims(c, nx_hint, nu_hint, &nx, &nu, &Np, &Nc, &soft, &why)) { delete seam; return fail(MPCQP_ERR_UNSUPPORTED, "mpcqp_create_csc: not an MPC QP of pyMPC: " + why); }
     mpcqp_settings st; if (s) st = *s; else mpcqp_default_settings(&st);
-    st.soft_constraints = 1;                        // (the matrices carry slack columns: checked by csc_dims)
+    st.soft_constraints = soft;                     // (slack columns or not: read off the pattern by csc_dims)
     const int rc = mpcqp_create(out, device, batch, nx, nu, Np, Nc, &st);
     if (rc) { delete seam; return rc; }
     (*out)->csc = seam;
@@ -461,7 +461,7 @@ extern "C" int mpcqp_setup_csc(mpcqp_handle *h, const double *P_val, const doubl
     std::vector<double> Ad(B * nx * nx), Bd(B * nx * nu), Qx(B * nx * nx), QxN(B * nx * nx), Qu(B * nu * nu), QDu(B * nu * nu), ef(B), lc(B * c.m), uc(B * c.m);
     for (size_t b = 0; b < B; ++b) {
         MpcBlocks blk; std::string why;
-        if (csc_recover(c, nx, nu, L.Np, L.Nc, P_val + b * nnzP, A_val + b * nnzA, q + b * c.n, l + b * c.m, u + b * c.m, &blk, &why))
+        if (csc_recover(c, nx, nu, L.Np, L.Nc, L.soft, P_val + b * nnzP, A_val + b * nnzA, q + b * c.n, l + b * c.m, u + b * c.m, &blk, &why))
             return fail(MPCQP_ERR_UNSUPPORTED, "mpcqp_setup_csc: instance " + std::to_string(b) + ": " + why);
         std::copy(blk.Ad.begin(), blk.Ad.end(), Ad.begin() + b * nx * nx); std::copy(blk.Bd.begin(), blk.Bd.end(), Bd.begin() + b * nx * nu);
         std::copy(blk.Qx.begin(), blk.Qx.end(), Qx.begin() + b * nx * nx); std::copy(blk.QxN.begin(), blk.QxN.end(), QxN.begin() + b * nx * nx);

@@ -14,14 +14,31 @@ struct CscPattern {
 // (one per handle created by mpcqp_create_csc, owned by the handle)
 struct CscSeam { CscPattern pat; };
 
-static int csc_dims(const CscPattern &c, int nx_hint, int nu_hint, int *nx, int *nu, int *Np, int *Nc, std::string *why) {
+static int csc_dims(const CscPattern &c, int nx_hint, int nu_hint, int *nx, int *nu, int *Np, int *Nc, int *soft, std::string *why) {
     const int n = c.n, m = c.m;
     auto colcount = [&](int j) { return (int)(c.Ap[j + 1] - c.Ap[j]); };
     int n_x = 0;                                              // the slack columns: trailing columns with exactly one entry (their soft row)
     while (n_x < n && colcount(n - 1 - n_x) == 1) ++n_x;
-    const int n_u = n - 2 * n_x;
-    if (n_x < 2 || n_u < 1) { *why = "A does not end in a block of slack columns (SOFT_ON = False problems go through mpcqp_setup)"; return 1; }
-    int u = nu_hint > 0 ? nu_hint : m - n - n_u;              // m = 2 n_x + n_u + (Nc + 1) nu
+    int n_u = n - 2 * n_x;
+    *soft = 1;
+    if (n_x == 0) {
+        // SOFT_ON = False (mpc.py:237,530-597): no slack columns, n = n_x + n_u (an input column always has its box row and a Delta-u
+        // row, so it never counts as one above).  The state box and the input box are then ONE identity block over all n columns,
+        // rows n_x .. n_x + n - 1, and n_x is where it starts: the first row R >= 1 such that row R + i holds exactly the entry (R + i, i)
+        // for every i (R = 0 -- the -1 of the x_0 rows -- stops at row nx, the first with entries of Ad and Bd).
+        *soft = 0;
+        std::vector<int> cnt(m, 0), col(m, -1);
+        for (int j = 0; j < n; ++j) for (int64_t p = c.Ap[j]; p < c.Ap[j + 1]; ++p) { cnt[c.Ai[p]]++; col[c.Ai[p]] = j; }
+        int R = 0;
+        for (int r = 1; r + n <= m && !R; ++r) {
+            bool ok = true;
+            for (int i = 0; i < n && ok; ++i) ok = cnt[r + i] == 1 && col[r + i] == i;
+            if (ok) R = r;
+        }
+        n_x = R; n_u = n - n_x;
+    }
+    if (n_x < 2 || n_u < 1) { *why = "A has neither pyMPC's block of slack columns nor (SOFT_ON = False) its identity block of box rows"; return 1; }
+    int u = nu_hint > 0 ? nu_hint : m - 2 * n_x - 2 * n_u;    // m = 2 n_x + n_u + (Nc + 1) nu
     if (u < 1 || n_u % u) { *why = "row/column counts do not fit m = 2 (Np+1) nx + Nc nu + (Nc+1) nu"; return 1; }
     int x = nx_hint;
     if (x <= 0) {         // rows 0..nx-1 of the dynamics block hold only the -1 of x_0 (and whatever explicit zeros scipy's kron left there,
@@ -44,7 +61,7 @@ static double csc_at(const std::vector<int64_t> &cp, const std::vector<int32_t> 
     return 0.0;
 }
 
-struct MpcBlocks { int nx, nu, Np, Nc; std::vector<double> Ad, Bd, Qx, QxN, Qu, QDu; double eps_feas; };
+struct MpcBlocks { int nx, nu, Np, Nc, soft; std::vector<double> Ad, Bd, Qx, QxN, Qu, QDu; double eps_feas; };
 
 // what pyMPC's builder puts at (r, c) of A / of the upper triangle of P, from the blocks (the host twin of A_row / P_row in mpcqp_qp.h)
 static double A_expected(const MpcBlocks &b, int r, int c) {
@@ -59,7 +76,7 @@ static double A_expected(const MpcBlocks &b, int r, int c) {
         }
         return 0.0;
     }
-    if (r < ri) { const int j = r - rs; return (c == j || c == oe + j) ? 1.0 : 0.0; }
+    if (r < ri) { const int j = r - rs; return (c == j || (b.soft && c == oe + j)) ? 1.0 : 0.0; }
     if (r < rdu) return c == ou + (r - ri) ? 1.0 : 0.0;
     const int rr = r - rdu;
     if (rr < nu) return c == ou + rr ? 1.0 : 0.0;
@@ -89,9 +106,9 @@ static double P_expected_upper(const MpcBlocks &b, int r, int c) {      // r <= 
 }
 
 // blocks of one instance out of its values, verified by the rebuild; l, u checked for the stage-periodic structure of mpc.py:551-580
-static int csc_recover(const CscPattern &c, int nx, int nu, int Np, int Nc, const double *Pv, const double *Av, const double *q,
+static int csc_recover(const CscPattern &c, int nx, int nu, int Np, int Nc, int soft, const double *Pv, const double *Av, const double *q,
                        const double *l, const double *u, MpcBlocks *out, std::string *why) {
-    MpcBlocks b; b.nx = nx; b.nu = nu; b.Np = Np; b.Nc = Nc;
+    MpcBlocks b; b.nx = nx; b.nu = nu; b.Np = Np; b.Nc = Nc; b.soft = soft;
     const int n_x = (Np + 1) * nx, n_u = Nc * nu, n = c.n, m = c.m;
     auto Pf = [&](int r, int cc) { return r <= cc ? csc_at(c.Pp, c.Pi, Pv, r, cc) : csc_at(c.Pp, c.Pi, Pv, cc, r); };      // what a solver keeping triu(P) sees
     auto Aat = [&](int r, int cc) { return csc_at(c.Ap, c.Ai, Av, r, cc); };
@@ -107,7 +124,7 @@ static int csc_recover(const CscPattern &c, int nx, int nu, int Np, int Nc, cons
         if (Nc >= 2) { b.QDu[i * nu + j] = -Pf(n_x + i, n_x + nu + j); b.Qu[i * nu + j] = D0 - 2.0 * b.QDu[i * nu + j]; }
         else { b.QDu[i * nu + j] = 0.0; b.Qu[i * nu + j] = D0 / (double)Np; }      // one block iU Qu + QDu: any split gives the same P (q is the caller's)
     }
-    b.eps_feas = Pf(n_x + n_u, n_x + n_u);
+    b.eps_feas = soft ? Pf(n_x + n_u, n_x + n_u) : 1e6;      // (no slack block without soft constraints: the value is never used)
     // ---- the guarantee: rebuild and compare, both ways (stored nonzero -> expected value; expected nonzero -> stored)
     int badA = 0, badP = 0;
     for (int j = 0; j < n; ++j) for (int64_t p = c.Ap[j]; p < c.Ap[j + 1]; ++p) if (Av[p] != A_expected(b, c.Ai[p], j)) ++badA;
@@ -116,7 +133,7 @@ static int csc_recover(const CscPattern &c, int nx, int nu, int Np, int Nc, cons
         const int rs = n_x, ri = 2 * n_x, rdu = 2 * n_x + n_u;
         auto probe = [&](int cc) { if (cc >= 0 && cc < n) { const double e = A_expected(b, r, cc); if (e != 0.0 && Aat(r, cc) != e) ++badA; } };
         if (r < rs) { const int k = r / nx; probe(r); if (k > 0) { for (int t = 0; t < nx; ++t) probe((k - 1) * nx + t); for (int t = 0; t < nu; ++t) probe(n_x + std::min(k - 1, Nc - 1) * nu + t); } }
-        else if (r < ri) { probe(r - rs); probe(n_x + n_u + r - rs); }
+        else if (r < ri) { probe(r - rs); if (soft) probe(n_x + n_u + r - rs); }
         else if (r < rdu) probe(n_x + r - ri);
         else { const int rr = r - rdu; if (rr < nu) probe(n_x + rr); else { probe(n_x + rr - nu); probe(n_x + rr - nu + 1); } }
     }

@@ -28,11 +28,25 @@ def _dims(P, A, nx=None, nu=None):
     n_x = 0
     while n_x < n and per_col[n - 1 - n_x] == 1:
         n_x += 1
-    n_u = n - 2 * n_x
+    n_u, soft = n - 2 * n_x, True
+    if n_x == 0:
+        # SOFT_ON = False (mpc.py:237,530-597): no slack columns.  State box and input box are then one identity block over all n
+        # columns, rows n_x .. n_x + n - 1; n_x is the first row R >= 1 at which such a block starts
+        soft = False
+        Ar = sp.csr_matrix(Ac)
+        per_row, cols = np.diff(Ar.indptr), Ar.indices
+        single = np.full(m, -1)
+        one = per_row == 1
+        single[one] = cols[Ar.indptr[:-1][one]]
+        for R in range(1, m - n + 1):
+            if np.array_equal(single[R:R + n], np.arange(n)):
+                n_x = R
+                break
+        n_u = n - n_x
     if n_x < 2 or n_u < 1:
-        raise NotAnMPCQP('A does not end in a block of slack columns')
+        raise NotAnMPCQP("A has neither pyMPC's block of slack columns nor (SOFT_ON = False) its identity block of box rows")
     if nu is None:
-        nu = m - n - n_u                               # m = 2 n_x + n_u + (Nc+1) nu
+        nu = m - 2 * n_x - 2 * n_u                     # m = 2 n_x + n_u + (Nc+1) nu
     if nu < 1 or n_u % nu:
         raise NotAnMPCQP('row/column counts do not fit m = 2(Np+1)nx + Nc nu + (Nc+1) nu')
     if nx is None:
@@ -42,7 +56,7 @@ def _dims(P, A, nx=None, nu=None):
         nx = int(more[0]) if more.size else 0
     if nx < 1 or n_x % nx:
         raise NotAnMPCQP('could not determine nx from the dynamics rows')
-    return int(nx), int(nu), n_x // nx - 1, n_u // nu
+    return int(nx), int(nu), n_x // nx - 1, n_u // nu, soft
 
 
 def recover_model(P, A, l, u, nx=None, nu=None):
@@ -52,9 +66,9 @@ def recover_model(P, A, l, u, nx=None, nu=None):
     verbatim through update_vectors)."""
     P, A = sp.csc_matrix(P), sp.csc_matrix(A)
     l, u = np.asarray(l, dtype=float), np.asarray(u, dtype=float)
-    nx, nu, Np, Nc = _dims(P, A, nx, nu)
+    nx, nu, Np, Nc, soft = _dims(P, A, nx, nu)
     N, n_x, n_u = Np + 1, (Np + 1) * nx, Nc * nu
-    n, m = 2 * n_x + n_u, 2 * n_x + n_u + (Nc + 1) * nu
+    n, m = (2 if soft else 1) * n_x + n_u, 2 * n_x + n_u + (Nc + 1) * nu
     if P.shape != (n, n) or A.shape != (m, n) or l.shape != (m,) or u.shape != (m,) or Np < 2:
         raise NotAnMPCQP('shapes do not fit an MPC QP with nx=%d nu=%d Np=%d Nc=%d' % (nx, nu, Np, Nc))
     Pu = sp.triu(P).tocsc()
@@ -68,14 +82,14 @@ def recover_model(P, A, l, u, nx=None, nu=None):
         Qu = D0 - 2.0 * QDu
     else:                                              # one block iU Qu + QDu: any split gives the same P (q is the caller's)
         QDu, Qu = np.zeros((nu, nu)), D0 / float(Np)
-    eps_feas = float(Pf[n_x + n_u, n_x + n_u])
-    model = dict(nx=nx, nu=nu, Np=Np, Nc=Nc, Ad=Ad, Bd=Bd, Qx=Qx, QxN=QxN, Qu=Qu, QDu=QDu, eps_feas=eps_feas)
+    eps_feas = float(Pf[n_x + n_u, n_x + n_u]) if soft else 1e6      # (no slack block without soft constraints: the value is never used)
+    model = dict(nx=nx, nu=nu, Np=Np, Nc=Nc, Ad=Ad, Bd=Bd, Qx=Qx, QxN=QxN, Qu=Qu, QDu=QDu, eps_feas=eps_feas, SOFT_ON=soft)
 
     # ---- the guarantee: rebuild and compare
     ctrl = SimpleNamespace(Np=Np, Nc=Nc, nx=nx, nu=nu, Ad=Ad, Bd=Bd, Qx=Qx, QxN=QxN, Qu=Qu, QDu=QDu, Qeps=eps_feas * sp.eye(nx),
                            xref=np.zeros(nx), uref=np.zeros(nu), uminus1=np.zeros(nu), x0=np.zeros(nx),
                            xmin=np.zeros(nx), xmax=np.zeros(nx), umin=np.zeros(nu), umax=np.zeros(nu), Dumin=np.zeros(nu), Dumax=np.zeros(nu),
-                           JX_ON=True, JU_ON=True, JDU_ON=True, SOFT_ON=True, COMPUTE_J_CNST=False)
+                           JX_ON=True, JU_ON=True, JDU_ON=True, SOFT_ON=soft, COMPUTE_J_CNST=False)
     P2, _, A2, _, _, _, _ = qp_build.build_qp(ctrl)
     dA = (A - A2); dA.eliminate_zeros()
     P2u = sp.triu(P2).tocsc()

@@ -450,13 +450,14 @@ class DeviceProblem:
         self._bp.setup_csc(Pc.data[None], Ac.data[None], one(q), one(l), one(u))
         self._model = dict(nx=self._bp.nx, nu=self._bp.nu, Np=self._bp.Np, Nc=self._bp.Nc)
         self.n, self.m = self._bp.n, self._bp.m
+        self._model['SOFT_ON'] = self.n > (self._bp.Np + 1) * self._bp.nx + self._bp.Nc * self._bp.nu
 
     @staticmethod
     def _check_q(mdl, q):
         from . import qp_recover
         nq = (mdl['Np'] + 1) * mdl['nx'] + mdl['Nc'] * mdl['nu']
         q = np.asarray(q, dtype=float)
-        if q.shape != (nq + (mdl['Np'] + 1) * mdl['nx'],) or np.any(q[nq:] != 0.0):
+        if q.shape != (nq + ((mdl['Np'] + 1) * mdl['nx'] if mdl.get('SOFT_ON', True) else 0),) or np.any(q[nq:] != 0.0):
             raise qp_recover.NotAnMPCQP('q must have length n with a zero slack part (mpc.py:599)')
 
     def setup(self, P=None, q=None, A=None, l=None, u=None, mpc=None, **settings):

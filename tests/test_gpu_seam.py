@@ -23,7 +23,7 @@ def _both(g, **settings):
     return pd, po
 
 
-@pytest.mark.parametrize('name', [n for n in golden_names() if not n.endswith('_hard')])
+@pytest.mark.parametrize('name', golden_names())          # (the *_hard fixtures: SOFT_ON = False, recognised by the library from the pattern)
 def test_reference_shaped_calls_at_default_tolerance(name):
     """eps 1e-3 (mpc.py:80): same status, iteration count and iterate after setup and after every update(l, u, q)."""
     g = load_golden(name)
@@ -50,7 +50,7 @@ def test_reference_shaped_calls_at_default_tolerance(name):
         assert abs(rd.info.obj_val - ro.info.obj_val) <= 1e-3 * max(1.0, abs(ro.info.obj_val))
 
 
-@pytest.mark.parametrize('name', [n for n in golden_names() if not n.endswith('_hard')])
+@pytest.mark.parametrize('name', golden_names())
 def test_reference_shaped_calls_reach_the_certified_optimum(name):
     g, opt = load_golden(name), load_golden(name, prefix='opt_')
     pd, _ = _both(g, eps_abs=1e-11, eps_rel=1e-11, max_iter=400000)

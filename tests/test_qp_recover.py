@@ -9,10 +9,10 @@ from util import golden_names, load_golden, golden_kwargs, golden_csc, update_st
 from pympc_amd.qp_recover import recover_model, check_vectors, NotAnMPCQP
 
 
-SOFT = [n for n in golden_names() if not n.endswith('_hard')]          # (the seam covers the public SOFT_ON = True formulation)
+ALL = golden_names()          # (the public SOFT_ON = True formulation and the hidden SOFT_ON = False one, fixtures *_hard)
 
 
-@pytest.mark.parametrize('name', SOFT)
+@pytest.mark.parametrize('name', ALL)
 def test_model_is_recovered_from_reference_matrices(name):
     g = load_golden(name); kw = golden_kwargs(g)
     P, A = golden_csc(g, 'P'), golden_csc(g, 'A')
@@ -21,7 +21,9 @@ def test_model_is_recovered_from_reference_matrices(name):
     assert (m['nx'], m['nu'], m['Np'], m['Nc']) == (nx, nu, kw['Np'], kw.get('Nc', kw['Np']))
     assert np.array_equal(m['Ad'], kw['Ad']) and np.array_equal(m['Bd'], kw['Bd'])
     assert np.array_equal(m['Qx'], kw['Qx']) and np.array_equal(m['QxN'], kw.get('QxN', kw['Qx']))
-    assert m['eps_feas'] == kw.get('eps_feas', 1e6)
+    assert m['SOFT_ON'] == (not name.endswith('_hard'))
+    if m['SOFT_ON']:
+        assert m['eps_feas'] == kw.get('eps_feas', 1e6)
     if m['Nc'] >= 2:
         assert np.allclose(m['Qu'], kw['Qu'], rtol=0, atol=1e-15) and np.array_equal(m['QDu'], kw['QDu'])
     assert recover_model(sp.triu(P), A, g['l'], g['u'], nx=nx, nu=nu)['Np'] == kw['Np']      # upper triangle + hints
@@ -30,9 +32,10 @@ def test_model_is_recovered_from_reference_matrices(name):
 
 
 def test_foreign_qps_are_refused():
-    h = load_golden('point_mass_hard')                                # SOFT_ON = False: no slack columns -> not handled by the seam, loudly
+    h = load_golden('point_mass_hard')                                # SOFT_ON = False with one box row missing: no identity block
+    Ah = golden_csc(h, 'A').tolil(); Ah[Ah.shape[1] + 3, :] = 0.0
     with pytest.raises(NotAnMPCQP):
-        recover_model(golden_csc(h, 'P'), golden_csc(h, 'A'), h['l'], h['u'])
+        recover_model(golden_csc(h, 'P'), Ah.tocsc(), h['l'], h['u'])
     g = load_golden('point_mass')
     P, A, l, u = golden_csc(g, 'P').tolil(), golden_csc(g, 'A').tolil(), g['l'].copy(), g['u'].copy()
     with pytest.raises(NotAnMPCQP):
