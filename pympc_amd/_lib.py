@@ -64,6 +64,14 @@ def load():
         raise RuntimeError(
             "libmpcqp_hip.so is missing (%s). Build it with pympc_amd/csrc/build.sh; "
             "pympc_amd has no CPU fallback." % LIB_PATH)
+    # One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64 with the same sonames as /opt/rocm's, so
+    # whichever is mapped first serves both: this library works on top of torch's, torch on top of the system's reports "No HIP GPUs are
+    # available" at its first CUDA call.  Where torch is installed it therefore loads first (it is the package's plumbing for device
+    # buffers, streams and torch.distributed anyway).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     H = C.c_void_p
     L.mpcqp_default_settings.argtypes = [C.POINTER(Settings)]

@@ -827,8 +827,8 @@ extern "C" int mpcqp_get_stats(mpcqp_handle *h, uint64_t *out4, int reset) {
     { uint64_t t[4]; hipMemcpy(t, h->P.stats + 4, sizeof(t), hipMemcpyDeviceToHost); fprintf(stderr, "phase wall-clock ticks: begin %llu admm %llu check %llu\n", (unsigned long long)t[0], (unsigned long long)t[1], (unsigned long long)t[2]);
       unsigned long long g[16]; hipMemcpyFromSymbol(g, HIP_SYMBOL(g_ticks), sizeof(g)); unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_ticks), z, sizeof(z));
       { double tot = 0; for (int i = 0; i < 7; ++i) tot += (double)g[i]; if (tot <= 0) tot = 1;
-        fprintf(stderr, "iteration cycles (thread 0, summed over workgroups): rhs %.1f%% fwd %.1f%% middle %.1f%% bwd %.1f%% t4 %.1f%% t5 %.1f%% t6 %.1f%% total %.3g\n",
-                100 * g[0] / tot, 100 * g[1] / tot, 100 * g[2] / tot, 100 * g[3] / tot, 100 * g[4] / tot, 100 * g[5] / tot, 100 * g[6] / tot, tot); } }
+        fprintf(stderr, "iteration cycles (thread 0, summed over workgroups): rhs %.1f%% fwd %.1f%% middle %.1f%% bwd %.1f%% t4 %.1f%% t5 %.1f%% t6 %.1f%% total %.3g;  outside the iterations (same unit): t7 %.3g t8 %.3g t9 %.3g;  check: setup+tail %.3g rows %.3g vars %.3g reduce %.3g decide %.3g\n",
+                100 * g[0] / tot, 100 * g[1] / tot, 100 * g[2] / tot, 100 * g[3] / tot, 100 * g[4] / tot, 100 * g[5] / tot, 100 * g[6] / tot, tot, (double)g[7], (double)g[8], (double)g[9], (double)g[10], (double)g[11], (double)g[12], (double)g[13], (double)g[14]); } }
 #endif
     if (reset) HIPCHK(hipMemsetAsync(h->P.stats, 0, 8 * sizeof(uint64_t), h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));

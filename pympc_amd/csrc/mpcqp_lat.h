@@ -224,6 +224,8 @@ __device__ __forceinline__ void admm_lat(const Lay &L, const HotPtrs &P, Smem &S
     // LDS: four stage-major vectors with stage slots -1 .. 4 NG (the slots outside 0 .. N-1 stay zero: neighbours of the ends)
     constexpr int VS = LAT_VS(N);
     double *Tc = S.T + NB, *Cc = Tc + VS, *WA = Cc + VS, *WB = WA + VS;      // right-hand side / solution, c_e, W of the first / second row of a slot
+    TICK_RESET
+    TICK_START
     for (int i = tid; i < LAT_LDS_DOUBLES(N); i += NT) S.T[i] = 0.0;
     // ---- the factor: this wave's fragments, G = [Ad Bd] (rows: dynamics rows, columns: (x, u)) and G'
     d4 fr[lat_max_slots(N)];
@@ -232,6 +234,7 @@ __device__ __forceinline__ void admm_lat(const Lay &L, const HotPtrs &P, Smem &S
     auto gent = [&](int r, int c) { return r < nx ? (c < nx ? Ad[r * nx + c] : (c < nx + nu ? Bd[r * nu + (c - nx)] : 0.0)) : 0.0; };
     const d4 Gf = lat_make_frag(lane, gent);
     const d4 GTf = lat_make_frag(lane, [&](int r, int c) { return gent(c, r); });
+    TICK(7)
     const int lo16 = vec_lane_offset(lane);
     const int lI = lane >> 4, lB = (lane >> 2) & 3;
     const LatVecs vec{Tc + lo16, Cc + lo16, Tc + 4 * ((lB + 1) & 3) + lI, Tc + 4 * ((lB + 2) & 3) + lI, Tc + 4 * ((lB + 3) & 3) + lI};
@@ -276,7 +279,7 @@ __device__ __forceinline__ void admm_lat(const Lay &L, const HotPtrs &P, Smem &S
 #pragma unroll
     for (int q = 0; q < 2; ++q) { WA[sl[q]] = rA[q].w; WB[sl[q]] = rB[q].w; }
     __syncthreads();
-    TICK_RESET
+    TICK(8)
     for (int it = 1; it <= iters; ++it) {
         const bool keep_delta = it == iters;
         TICK_START
@@ -328,7 +331,7 @@ __device__ __forceinline__ void admm_lat(const Lay &L, const HotPtrs &P, Smem &S
         __syncthreads();
         TICK(6)
     }
-    TICK_FLUSH
+    TICK_START
     // ---- end of the round: the iterate back to memory (global: next round / warm start; LDS copy: the residual evaluation)
     auto put_row = [&](const LatRow &r, int idx) { const double y = r.ys * (r.om * cinv); gz[idx] = r.z; gy[idx] = y; Zl[idx] = r.z; Yl[idx] = y; };
 #pragma unroll
@@ -340,5 +343,7 @@ __device__ __forceinline__ void admm_lat(const Lay &L, const HotPtrs &P, Smem &S
         }
     }
     if (u0v) put_row(r0, L.rdu + jj);
+    TICK(9)
+    TICK_FLUSH
     (void)selu;
 }

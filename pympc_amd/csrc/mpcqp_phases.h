@@ -182,6 +182,8 @@ template <int NB, int OCC>
 __device__ __forceinline__ int check_body(const Lay &L, const Ptrs &P, const mpcqp_settings &S_, Smem &S, int iter, int mode,
                                           const double *Xl, const double *Zl, const double *Yl) {
     const int b = inst_of(P.perm), tid = threadIdx.x;
+    TICK_RESET
+    TICK_START
     const double *model = P.model + (size_t)b * L.model_sz;
     // the weight matrices (read entry by entry by P_row) go to the idle Tc area of the work vector if they fit
     const int nweights = L.model_sz - L.hot_sz;
@@ -211,6 +213,7 @@ __device__ __forceinline__ int check_body(const Lay &L, const Ptrs &P, const mpc
     double nrm[11], vsum[1] = {0.0};
 #pragma unroll
     for (int i = 0; i < 11; ++i) nrm[i] = 0.0;
+    TICK(10)
     for (int r = tid; r < L.m; r += NT) {
         double ax = 0.0;
         A_row(c, r, [&](double co, int idx) { ax += co * X[idx]; });
@@ -218,6 +221,7 @@ __device__ __forceinline__ int check_body(const Lay &L, const Ptrs &P, const mpc
         nrm[0] = fmax(nrm[0], fabs(d)); nrm[1] = fmax(nrm[1], fabs(ax)); nrm[2] = fmax(nrm[2], fabs(z));
         nrm[7] = fmax(nrm[7], fabs(e * d)); nrm[8] = fmax(nrm[8], fmax(fabs(e * ax), fabs(e * z)));
     }
+    TICK(11)
     for (int j = tid; j < L.n; j += NT) {
         double px = 0.0, aty = 0.0;
         P_row(c, j, [&](double co, int idx) { px += co * X[idx]; });
@@ -229,8 +233,10 @@ __device__ __forceinline__ int check_body(const Lay &L, const Ptrs &P, const mpc
         nrm[10] = fmax(nrm[10], fmax(fabs(cd * qj), fmax(fabs(cd * aty), fabs(cd * px))));
         vsum[0] += xj * (0.5 * px + qj);
     }
+    TICK(12)
     block_reduce<11, 1>(nrm, vsum, S.red);
     obj_val = vsum[0]; pri_res = nrm[0]; dua_res = nrm[3];
+    TICK(13)
 
     // ---- OSQP's infeasibility certificates (paper section 3.5) on the last increments, in unscaled terms
     auto primal_infeasible = [&](double eps) -> bool {
@@ -318,6 +324,7 @@ __device__ __forceinline__ int check_body(const Lay &L, const Ptrs &P, const mpc
         }
     }
     __syncthreads();
+    TICK(14)
     if (term) {      // solution, and the iterate the next warm start begins from
         const bool has_sol = !(status == MPCQP_PRIMAL_INFEASIBLE || status == MPCQP_PRIMAL_INFEASIBLE_INACCURATE ||
                                status == MPCQP_DUAL_INFEASIBLE || status == MPCQP_DUAL_INFEASIBLE_INACCURATE || status == MPCQP_NON_CVX);
@@ -338,6 +345,8 @@ __device__ __forceinline__ int check_body(const Lay &L, const Ptrs &P, const mpc
         }
         P.info[b] = inf;
     }
+    TICK(10)
+    TICK_FLUSH
     return term;
 }
 

@@ -146,14 +146,37 @@ __device__ void build_q(const Ctx &c, const double *step, double *Qv) {
 // ------------------------------------------------------------------------------------------------
 // Block reductions (4 waves of 64).  red: LDS scratch of >= 4*K doubles.
 // ------------------------------------------------------------------------------------------------
+// Within a wave: four DPP steps (lane ^ 1, lane ^ 2, row rotations by 4 and 8) leave every lane with the result of its row of 16, the four rows
+// are combined from their first lanes.  (__shfl_xor on a double is two ds_bpermute round trips per step: six dependent steps of those per value
+// made the 12-value reduction of the termination check cost as much as one of its operator passes.)
+template <int CTRL>
+__device__ __forceinline__ double dpp_move_f64(double x) {
+    const long long xi = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_mov_dpp((int)xi, CTRL, 0xF, 0xF, false), hi = __builtin_amdgcn_mov_dpp((int)(xi >> 32), CTRL, 0xF, 0xF, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double readlane_f64(double x, int l) {
+    const long long xi = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_readlane((int)xi, l), hi = __builtin_amdgcn_readlane((int)(xi >> 32), l);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+template <bool MAX>
+__device__ __forceinline__ double wave_reduce(double v) {
+    auto op = [](double a, double b) { return MAX ? fmax(a, b) : a + b; };
+    v = op(v, dpp_move_f64<0xB1>(v));            // quad_perm [1,0,3,2]
+    v = op(v, dpp_move_f64<0x4E>(v));            // quad_perm [2,3,0,1]
+    v = op(v, dpp_move_f64<0x124>(v));           // row_ror:4
+    v = op(v, dpp_move_f64<0x128>(v));           // row_ror:8
+    return op(op(readlane_f64(v, 0), readlane_f64(v, 16)), op(readlane_f64(v, 32), readlane_f64(v, 48)));
+}
 template <int KMAX, int KSUM>
 __device__ void block_reduce(double *vmax, double *vsum, double *red) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     constexpr int K = KMAX + KSUM;
 #pragma unroll
-    for (int i = 0; i < KMAX; ++i) { double v = vmax[i]; for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o)); vmax[i] = v; }
+    for (int i = 0; i < KMAX; ++i) vmax[i] = wave_reduce<true>(vmax[i]);
 #pragma unroll
-    for (int i = 0; i < KSUM; ++i) { double v = vsum[i]; for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); vsum[i] = v; }
+    for (int i = 0; i < KSUM; ++i) vsum[i] = wave_reduce<false>(vsum[i]);
     __syncthreads();
     if (lane == 0) {
 #pragma unroll
