@@ -16,8 +16,14 @@
 //     cores (v_mfma_f64_4x4x4_4b_f64, stage output registers = next stage's B operand), all waves run the
 //     stage-parallel parts.
 //
-// This file: host side and C ABI (include/mpcqp.h).  Device code: mpcqp_layout.h, mpcqp_qp.h, mpcqp_factor.h,
-// mpcqp_sweeps.h, mpcqp_border.h, mpcqp_phases.h, mpcqp_kernels.h (one translation unit).
+//   - that is the bandwidth backend (any size, large batches).  Three more KKT backends, chosen per handle at mpcqp_create (DESIGN.md
+//     section 3): an explicit K^-1 held in registers for the reference's own small examples (mpcqp_dense.h, mpcqp_tiny.h), block
+//     cyclic reduction with the whole factor resident in the register files for the BASELINE shape at small batches (mpcqp_bcr.h,
+//     mpcqp_lat.h), and a plain vector-ALU block LDL' for stages wider than 32 (mpcqp_wide.h).
+//
+// This file: host side and C ABI (include/mpcqp.h).  Device code: mpcqp_layout.h, mpcqp_qp.h, mpcqp_factor.h, mpcqp_sweeps.h,
+// mpcqp_bcr.h, mpcqp_wide.h, mpcqp_dense.h, mpcqp_border.h, mpcqp_phases.h, mpcqp_tiny.h, mpcqp_lat.h, mpcqp_kernels.h; host only:
+// mpcqp_csc.h (one translation unit).
 //
 // FP64 throughout.  No CPU fallback exists in this library.
 
