@@ -158,32 +158,43 @@ __device__ __forceinline__ int factor_all(const Ctx &c, const double *om, const 
             const bool up = side == 0;
             __syncthreads();
             TICK(0)
+            // The two block products run on the matrix cores (v_mfma_f64_16x16x4_f64: one 16 x 16 tile of C += A B per wave and instruction, four
+            // steps of K per instruction; lane l feeds A[l & 15][l >> 4] and B[l >> 4][l & 15] and receives C[(l >> 4) + 4 v][l & 15], v = 0..3).
+            // Both operands are read along their fast index: the coupling block is stored transposed (KsT[b][a] = K_{k,nbr}[a][b]), Sn is
+            // symmetric, and the first product leaves Mh transposed for the second.  One tile per wave: wave 0 of a 16 x 16 group, all four
+            // waves at 32 x 32.
             if (has) for (int e = lt; e < NN; e += T) {
-                const int a = e / NB, b = e % NB;
-                Ks[e] = up ? kkt_sub_entry(c, om, cc, k - 1, a, b) : kkt_sub_entry(c, om, cc, k, b, a);
+                const int a = e / NB, b = e % NB;              // KsT[a][b] = Ks[b][a]
+                Ks[e] = up ? kkt_sub_entry(c, om, cc, k - 1, b, a) : kkt_sub_entry(c, om, cc, k, a, b);
             }
             __syncthreads();
             TICK(1)
-            if (has) for (int e = lt; e < NN; e += T) {      // Mh = Ks * Sn
-                const int a = e / NB, b = e % NB;
-                double acc = 0.0;
-#pragma unroll 8
-                for (int l = 0; l < NB; ++l) acc += Ks[a * NB + l] * Sn[l * NB + b];
-                Mh[e] = acc;
+            constexpr int TW = NB / 16;
+            const int wg = lt >> 6, ln = lt & 63, ti = wg / TW, tj = wg % TW, lr = ln & 15, lk = ln >> 4;
+            const bool mm = has && wg < TW * TW;                 // (uniform per wave)
+            const int fwd_stage = (k == mid && !up) ? 0 : k;
+            if (mm) {                                            // Mh = Ks Sn
+                d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < NB / 4; ++kk)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ks[(4 * kk + lk) * NB + 16 * ti + lr], Sn[(4 * kk + lk) * NB + 16 * tj + lr], acc, 0, 0, 0);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int row = 16 * ti + lk + 4 * v, col = 16 * tj + lr;
+                    Mh[col * NB + row] = acc[v];                 // (transposed: the second product reads it as its A operand)
+                    // forward matrix of stage k; the middle stage's second forward matrix lives in the otherwise unused slot of stage 0
+                    if constexpr (!FactorFmt<NB>::SONLY) F[(size_t)fwd_stage * L.fstage + frag_pos<NB>(row, col)] = -acc[v];
+                }
             }
             __syncthreads();
             TICK(2)
-            if (has) {
-                const int fwd_stage = (k == mid && !up) ? 0 : k;
-                for (int e = lt; e < NN; e += T) {           // S -= Mh * Ks'
-                    const int a = e / NB, b = e % NB;
-                    double acc = 0.0;
-#pragma unroll 8
-                    for (int l = 0; l < NB; ++l) acc += Mh[a * NB + l] * Ks[b * NB + l];
-                    S[e] -= acc;
-                    // forward matrix of stage k; the middle stage's second forward matrix lives in the otherwise unused slot of stage 0
-                    if constexpr (!FactorFmt<NB>::SONLY) F[(size_t)fwd_stage * L.fstage + frag_pos<NB>(a, b)] = -Mh[e];
-                }
+            if (mm) {                                            // S -= Mh Ks'
+                d4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int kk = 0; kk < NB / 4; ++kk)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Mh[(4 * kk + lk) * NB + 16 * ti + lr], Ks[(4 * kk + lk) * NB + 16 * tj + lr], acc, 0, 0, 0);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) S[(16 * ti + lk + 4 * v) * NB + 16 * tj + lr] -= acc[v];
             }
         }
         __syncthreads();
@@ -196,15 +207,19 @@ __device__ __forceinline__ int factor_all(const Ctx &c, const double *om, const 
 #pragma unroll
             for (int u = 0; u < EPT; ++u) cur[u] = S[lt + u * T];
         }
+        static_assert(NB % 2 == 0, "the pivot steps alternate between two buffers and end in S");
         for (int pv = 0; pv < NB; ++pv) {
+            // (one barrier per step: step pv reads the matrix step pv - 1 wrote and writes the other buffer -- Mh is idle here -- so nobody
+            //  overwrites what a slower thread of the same step is still reading)
+            const double *Sr = (pv & 1) ? Mh : S;
+            double *Sw = (pv & 1) ? S : Mh;
             double rip[EPT], rpj[EPT], d = 1.0;
             if (on) {
-                d = S[pv * NB + pv];
+                d = Sr[pv * NB + pv];
 #pragma unroll
-                for (int u = 0; u < EPT; ++u) { const int e = lt + u * T; rip[u] = S[(e / NB) * NB + pv]; rpj[u] = S[pv * NB + (e % NB)]; }
+                for (int u = 0; u < EPT; ++u) { const int e = lt + u * T; rip[u] = Sr[(e / NB) * NB + pv]; rpj[u] = Sr[pv * NB + (e % NB)]; }
             }
             if (on && !(d > 0.0)) { if (lt == 0) *iflag = 1; d = 1e-300; }
-            __syncthreads();
             if (on) {
                 const double inv = 1.0 / d;
 #pragma unroll
@@ -214,7 +229,7 @@ __device__ __forceinline__ int factor_all(const Ctx &c, const double *om, const 
                     const double t = rip[u] * inv;
                     const double off = rowp ? rpj[u] * inv : fma(-t, rpj[u], cur[u]), onp = rowp ? inv : -t;
                     cur[u] = colp ? onp : off;
-                    S[e] = cur[u];
+                    Sw[e] = cur[u];
                 }
             }
             __syncthreads();

@@ -138,13 +138,15 @@ __device__ __forceinline__ int factor_wide(const Ctx &c, const double *om, const
 #pragma unroll
         for (int u = 0; u < E; ++u) cur[u] = A[a * LD + b0 + u];
         for (int pv = 0; pv < NB; ++pv) {
+            // (one barrier per step: the steps alternate between A and Bm, which is idle here, and end in A)
+            const double *Ar = (pv & 1) ? Bm : A;
+            double *Aw = (pv & 1) ? A : Bm;
             double rpj[E];
-            double d = A[pv * LD + pv];
-            const double rip = A[a * LD + pv];
+            double d = Ar[pv * LD + pv];
+            const double rip = Ar[a * LD + pv];
 #pragma unroll
-            for (int u = 0; u < E; ++u) rpj[u] = A[pv * LD + b0 + u];
+            for (int u = 0; u < E; ++u) rpj[u] = Ar[pv * LD + b0 + u];
             if (!(d > 0.0)) { if (tid == 0) *iflag = 1; d = 1e-300; }
-            __syncthreads();
             const double inv = 1.0 / d, t = rip * inv;
             const bool rowp = a == pv;
 #pragma unroll
@@ -152,7 +154,7 @@ __device__ __forceinline__ int factor_wide(const Ctx &c, const double *om, const
                 const bool colp = b0 + u == pv;
                 const double off = rowp ? rpj[u] * inv : fma(-t, rpj[u], cur[u]), on = rowp ? inv : -t;
                 cur[u] = colp ? on : off;
-                A[a * LD + b0 + u] = cur[u];
+                Aw[a * LD + b0 + u] = cur[u];
             }
             __syncthreads();
         }
