@@ -168,30 +168,45 @@ __device__ __forceinline__ int factor_wide(const Ctx &c, const double *om, const
         // Bm = K_{k+1,k} (rows: stage k+1);  M = Bm S^-1
         for (int u = 0; u < E; ++u) Bm[a * LD + b0 + u] = kkt_sub_entry(c, om, cc, k, a, b0 + u);
         __syncthreads();
+        // The two 64 x 64 x 64 products on the matrix cores (v_mfma_f64_16x16x4_f64, operand map in mpcqp_factor.h): wave w computes the four
+        // 16 x 16 tiles of block row w.  The odd row stride makes both access patterns -- down a column for A operands, along a row for B
+        // operands -- conflict free.
+        const int wv = tid >> 6, lr = tid & 15, lk = (tid >> 4) & 3;
+        d4 acc[4];
 #pragma unroll
-        for (int u = 0; u < E; ++u) reg[u] = 0.0;
-        for (int j = 0; j < NB; ++j) {
-            const double bj = Bm[a * LD + j];
+        for (int tj = 0; tj < 4; ++tj) acc[tj] = d4{0.0, 0.0, 0.0, 0.0};
+        for (int kk = 0; kk < NB / 4; ++kk) {
+            const double av = Bm[(16 * wv + lr) * LD + 4 * kk + lk];
 #pragma unroll
-            for (int u = 0; u < E; ++u) reg[u] = fma(bj, A[j * LD + b0 + u], reg[u]);
+            for (int tj = 0; tj < 4; ++tj) acc[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, A[(4 * kk + lk) * LD + 16 * tj + lr], acc[tj], 0, 0, 0);
         }
 #pragma unroll
-        for (int u = 0; u < E; ++u) { Fk[WideFmt::OM + wide_pos(a, b0 + u)] = reg[u]; Fk[WideFmt::OMT + wide_pos(b0 + u, a)] = reg[u]; }
+        for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const int row = 16 * wv + lk + 4 * v, col = 16 * tj + lr;
+                Fk[WideFmt::OM + wide_pos(row, col)] = acc[tj][v]; Fk[WideFmt::OMT + wide_pos(col, row)] = acc[tj][v];
+            }
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < E; ++u) A[a * LD + b0 + u] = reg[u];                 // A = M
+        for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) A[(16 * wv + lk + 4 * v) * LD + 16 * tj + lr] = acc[tj][v];      // A = M
         __syncthreads();
         // S_{k+1} = K_{k+1,k+1} - M Bm'
 #pragma unroll
-        for (int u = 0; u < E; ++u) reg[u] = 0.0;
-        for (int j = 0; j < NB; ++j) {
-            const double mj = A[a * LD + j];
+        for (int tj = 0; tj < 4; ++tj) acc[tj] = d4{0.0, 0.0, 0.0, 0.0};
+        for (int kk = 0; kk < NB / 4; ++kk) {
+            const double av = A[(16 * wv + lr) * LD + 4 * kk + lk];
 #pragma unroll
-            for (int u = 0; u < E; ++u) reg[u] = fma(mj, Bm[(b0 + u) * LD + j], reg[u]);
+            for (int tj = 0; tj < 4; ++tj) acc[tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Bm[(16 * tj + lr) * LD + 4 * kk + lk], acc[tj], 0, 0, 0);
         }
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < E; ++u) A[a * LD + b0 + u] = -reg[u];
+        for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) A[(16 * wv + lk + 4 * v) * LD + 16 * tj + lr] = -acc[tj][v];
+        __syncthreads();
         diag_block(k + 1, true);
     }
     __syncthreads();
