@@ -75,7 +75,8 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 // host side
 // ------------------------------------------------------------------------------------------------
 constexpr int BCR_STAGES = 31;      // the shape the register-resident cyclic reduction is instantiated for: Np = 30
-constexpr int BALANCE_EVERY = 16;  // stepwise API: solves between two rebuilds of the workgroup -> instance map
+constexpr int BALANCE_EVERY = 16;  // solves between two rebuilds of the workgroup -> instance map
+constexpr int BALANCE_FIRST = 4;   // ... before the first one (an instance shows its character within a few solves; a short run should not end unbalanced)
 
 struct mpcqp_handle {
     int device, batch;
@@ -516,6 +517,7 @@ static int launch_run_generic(mpcqp_handle *h, const RunArgs &R) {
 // snake order (blocks b, b + #CU, b + 2 #CU, ... share a CU: dispatch is round-robin over XCDs and CUs), so that every CU
 // gets a similar total.  Pure scheduling: which workgroup handles which instance never changes a result.
 // Must be called with the stream idle.
+static bool balance_due(const mpcqp_handle *h) { return h->solves_since_balance >= (h->work_ema.empty() ? BALANCE_FIRST : BALANCE_EVERY); }
 static int rebalance(mpcqp_handle *h) {
     const int B = h->batch, ncu = h->ncu;
     h->solves_since_balance = 0;
@@ -702,7 +704,7 @@ extern "C" int mpcqp_mpc_loop(mpcqp_handle *h, int nsteps, const mpcqp_loop *io)
     if (rc) return rc;
     for (int i = 0; i < np; ++i)
         if (parts[i].dst && parts[i].bytes && !parts[i].direct && get(h, parts[i].dst, dev(i), parts[i].bytes)) return MPCQP_ERR_HIP;
-    const bool due = h->solves_since_balance >= BALANCE_EVERY;
+    const bool due = balance_due(h);
     if (!due && !any_host) return MPCQP_OK;                   // every buffer is device memory: stream-ordered, nothing to wait for
     HIPCHK(hipStreamSynchronize(h->stream));
     return due ? rebalance(h) : MPCQP_OK;
@@ -732,7 +734,7 @@ extern "C" int mpcqp_get_u0(mpcqp_handle *h, double *u0) {
     hipLaunchKernelGGL(k_gather_u0, dim3((tot + 255) / 256), dim3(256), 0, h->stream, h->L, h->P.xo, h->u0_dev, h->batch);
     HIPCHK(hipGetLastError());
     if (get(h, u0, h->u0_dev, sizeof(double) * (size_t)tot)) return MPCQP_ERR_HIP;
-    const bool due = h->solves_since_balance >= BALANCE_EVERY;
+    const bool due = balance_due(h);
     if (!due && is_device_ptr(u0)) return MPCQP_OK;           // device destination: stream-ordered, no need to wait
     HIPCHK(hipStreamSynchronize(h->stream));
     return due ? rebalance(h) : MPCQP_OK;
@@ -752,7 +754,7 @@ extern "C" int mpcqp_mpc_step(mpcqp_handle *h, const double *x0, const double *u
     hipLaunchKernelGGL(k_output_u, dim3((tot + 255) / 256), dim3(256), 0, h->stream, h->L, h->P, h->u0_dev, h->batch, 1);
     HIPCHK(hipGetLastError());
     if (get(h, u_out, h->u0_dev, sizeof(double) * (size_t)tot)) return MPCQP_ERR_HIP;
-    const bool due = h->solves_since_balance >= BALANCE_EVERY;
+    const bool due = balance_due(h);
     if (!due && is_device_ptr(u_out)) return MPCQP_OK;
     HIPCHK(hipStreamSynchronize(h->stream));
     return due ? rebalance(h) : MPCQP_OK;
