@@ -178,6 +178,103 @@ __device__ __forceinline__ void begin_body(const Lay &L, const Ptrs &P, const mp
 }
 
 // Returns 1 (to every thread) if the instance has terminated.
+// Residual norms and objective of the termination check for an LDS-resident iterate, with the owner map of the parallel phases below:
+// thread t owns the state elements e = t, t + NT (the variable x_e, its slack, the dynamics row e and the state-box row) and the input
+// element cu = t (the variable, its box row, its Delta-u row and, for cu < nu, its first-step row).  Every pass handles ONE kind of item --
+// no tree over four row types and three variable kinds per visitor call -- and the thread's D, E, q values are fetched together up front
+// instead of one global round trip per item.  Terms are summed in the order the row visitors (mpcqp_qp.h) enumerate them.
+// nrm / vsum as in check_body.  Needs n_x <= 2 NT and n_u <= NT (what the LDS-resident mode is chosen by).
+__device__ __forceinline__ void check_norms_own(const Ctx &c, const double *X, const double *Z, const double *Y, const double *D, const double *E,
+                                                const double *Qv, double cc, double *nrm, double *vsum) {
+    const Lay &L = c.L;
+    const int tid = threadIdx.x, nx = L.nx, nu = L.nu;
+    const double *Ad = c.Ad(), *Bd = c.Bd();
+    auto row = [&](double ax, double z, double e) {
+        const double d = ax - z;
+        nrm[0] = fmax(nrm[0], fabs(d)); nrm[1] = fmax(nrm[1], fabs(ax)); nrm[2] = fmax(nrm[2], fabs(z));
+        nrm[7] = fmax(nrm[7], fabs(e * d)); nrm[8] = fmax(nrm[8], fmax(fabs(e * ax), fabs(e * z)));
+    };
+    auto var = [&](double px, double aty, double qj, double xj, double cd) {
+        const double d = px + qj + aty;
+        nrm[3] = fmax(nrm[3], fabs(d)); nrm[4] = fmax(nrm[4], fabs(px)); nrm[5] = fmax(nrm[5], fabs(aty)); nrm[6] = fmax(nrm[6], fabs(qj));
+        nrm[9] = fmax(nrm[9], fabs(cd * d));
+        nrm[10] = fmax(nrm[10], fmax(fabs(cd * qj), fmax(fabs(cd * aty), fabs(cd * px))));
+        vsum[0] += xj * (0.5 * px + qj);
+    };
+    double eDyn[2], eBox[2], dXe[2], dEe[2], qXe[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int e = tid + NT * j;
+        const bool v = e < L.n_x;
+        eDyn[j] = v ? E[e] : 0.0; eBox[j] = v ? E[L.rs + e] : 0.0; dXe[j] = v ? D[e] : 0.0; dEe[j] = (v && L.soft) ? D[L.oe + e] : 0.0; qXe[j] = v ? Qv[e] : 0.0;
+    }
+    const int cu = tid;
+    const bool vu = cu < L.n_u;
+    const double eIn = vu ? E[L.ri + cu] : 0.0, eDu = vu ? E[L.rdu + nu + cu] : 0.0, eD0 = cu < nu ? E[L.rdu + cu] : 0.0;
+    const double dU = vu ? D[L.ou + cu] : 0.0, qU = vu ? Qv[L.n_x + cu] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int e = tid + NT * j;
+        if (e < L.n_x) {
+            const int k = idiv(e, L.rnx), a = e - k * nx;
+            const double xe = X[e], ee = L.soft ? X[L.oe + e] : 0.0;
+            double ax = -xe;                                           // dynamics row e  (mpc.py:537-552)
+            if (k > 0) {
+                const double *xp = X + (k - 1) * nx, *up = X + L.ou + min(k - 1, L.Nc - 1) * nu;
+#pragma unroll 4
+                for (int i = 0; i < nx; ++i) ax += Ad[a * nx + i] * xp[i];
+#pragma unroll 4
+                for (int i = 0; i < nu; ++i) ax += Bd[a * nu + i] * up[i];
+            }
+            row(ax, Z[e], eDyn[j]);
+            row(L.soft ? xe + ee : xe, Z[L.rs + e], eBox[j]);          // state-box row: x_k (+ eps_k)
+            const double *Q = (k < L.Np) ? c.Qx() : c.QxN();
+            const double *xk = X + k * nx;
+            double px = 0.0, aty = -Y[e];
+#pragma unroll 4
+            for (int l = 0; l < nx; ++l) px += Q[min(a, l) * nx + max(a, l)] * xk[l];
+            if (k < L.Np) {
+                const double *y1 = Y + (k + 1) * nx;
+#pragma unroll 4
+                for (int r = 0; r < nx; ++r) aty += Ad[r * nx + a] * y1[r];
+            }
+            aty += Y[L.rs + e];
+            var(px, aty, qXe[j], xe, cc * dXe[j]);
+            if (L.soft) { double pe = 0.0, ae = 0.0; pe += c.eps_feas() * ee; ae += Y[L.rs + e]; var(pe, ae, 0.0, ee, cc * dEe[j]); }
+        }
+    }
+    if (vu) {
+        const int k = idiv(cu, L.rnu), jj = cu - k * nu;
+        const double ut = X[L.ou + cu];
+        row(ut, Z[L.ri + cu], eIn);                                    // input box
+        double ax = -ut;                                               // Delta-u row nu + cu (mpc.py:570)
+        if (cu + 1 < L.n_u) ax += X[L.ou + cu + 1];
+        row(ax, Z[L.rdu + nu + cu], eDu);
+        if (cu < nu) row(ut, Z[L.rdu + cu], eD0);                      // first step: u_0 (- u_{-1} in the bounds)
+        const double iu = (k == L.Nc - 1) ? (double)(L.Np - L.Nc + 1) : 1.0, dk = (k == L.Nc - 1) ? 1.0 : 2.0;
+        const double *Qu = c.Qu(), *QDu = c.QDu(), *uk = X + L.ou + k * nu;
+        double px = 0.0;
+        for (int l = 0; l < nu; ++l) {
+            const int lo = min(jj, l), hi = max(jj, l);
+            px += __dadd_rn(__dmul_rn(iu, Qu[lo * nu + hi]), __dmul_rn(dk, QDu[lo * nu + hi])) * uk[l];
+        }
+        if (k + 1 < L.Nc) for (int l = 0; l < nu; ++l) px += -QDu[jj * nu + l] * uk[nu + l];
+        if (k > 0) for (int l = 0; l < nu; ++l) px += -QDu[l * nu + jj] * uk[l - nu];
+        double aty = 0.0;
+        const int s_end = (k == L.Nc - 1) ? L.Np : k + 1;            // the last input is held to the end of the horizon
+        for (int s = k + 1; s <= s_end; ++s) {
+            const double *y1 = Y + s * nx;
+#pragma unroll 4
+            for (int r = 0; r < nx; ++r) aty += Bd[r * nu + jj] * y1[r];
+        }
+        aty += Y[L.ri + cu];
+        if (k == 0) aty += Y[L.rdu + jj];
+        aty += -Y[L.rdu + nu + cu];
+        if (cu > 0) aty += Y[L.rdu + nu + cu - 1];
+        var(px, aty, qU, ut, cc * dU);
+    }
+}
+
 template <int NB, int OCC>
 __device__ __forceinline__ int check_body(const Lay &L, const Ptrs &P, const mpcqp_settings &S_, Smem &S, int iter, int mode,
                                           const double *Xl, const double *Zl, const double *Yl) {
@@ -214,24 +311,27 @@ __device__ __forceinline__ int check_body(const Lay &L, const Ptrs &P, const mpc
 #pragma unroll
     for (int i = 0; i < 11; ++i) nrm[i] = 0.0;
     TICK(10)
-    for (int r = tid; r < L.m; r += NT) {
-        double ax = 0.0;
-        A_row(c, r, [&](double co, int idx) { ax += co * X[idx]; });
-        double z = Z[r], d = ax - z, e = E[r];
-        nrm[0] = fmax(nrm[0], fabs(d)); nrm[1] = fmax(nrm[1], fabs(ax)); nrm[2] = fmax(nrm[2], fabs(z));
-        nrm[7] = fmax(nrm[7], fabs(e * d)); nrm[8] = fmax(nrm[8], fmax(fabs(e * ax), fabs(e * z)));
-    }
-    TICK(11)
-    for (int j = tid; j < L.n; j += NT) {
-        double px = 0.0, aty = 0.0;
-        P_row(c, j, [&](double co, int idx) { px += co * X[idx]; });
-        AT_row(c, j, [&](double co, int row) { aty += co * Y[row]; });
-        double qj = (j < L.oe) ? S.Qv[j] : 0.0, xj = X[j];
-        double d = px + qj + aty, cd = cc * D[j];
-        nrm[3] = fmax(nrm[3], fabs(d)); nrm[4] = fmax(nrm[4], fabs(px)); nrm[5] = fmax(nrm[5], fabs(aty)); nrm[6] = fmax(nrm[6], fabs(qj));
-        nrm[9] = fmax(nrm[9], fabs(cd * d));
-        nrm[10] = fmax(nrm[10], fmax(fabs(cd * qj), fmax(fabs(cd * aty), fabs(cd * px))));
-        vsum[0] += xj * (0.5 * px + qj);
+    if (Xl) check_norms_own(c, X, Z, Y, D, E, S.Qv, cc, nrm, vsum);      // (LDS-resident iterate: owner-mapped passes)
+    else {
+        for (int r = tid; r < L.m; r += NT) {
+            double ax = 0.0;
+            A_row(c, r, [&](double co, int idx) { ax += co * X[idx]; });
+            double z = Z[r], d = ax - z, e = E[r];
+            nrm[0] = fmax(nrm[0], fabs(d)); nrm[1] = fmax(nrm[1], fabs(ax)); nrm[2] = fmax(nrm[2], fabs(z));
+            nrm[7] = fmax(nrm[7], fabs(e * d)); nrm[8] = fmax(nrm[8], fmax(fabs(e * ax), fabs(e * z)));
+        }
+        TICK(11)
+        for (int j = tid; j < L.n; j += NT) {
+            double px = 0.0, aty = 0.0;
+            P_row(c, j, [&](double co, int idx) { px += co * X[idx]; });
+            AT_row(c, j, [&](double co, int row) { aty += co * Y[row]; });
+            double qj = (j < L.oe) ? S.Qv[j] : 0.0, xj = X[j];
+            double d = px + qj + aty, cd = cc * D[j];
+            nrm[3] = fmax(nrm[3], fabs(d)); nrm[4] = fmax(nrm[4], fabs(px)); nrm[5] = fmax(nrm[5], fabs(aty)); nrm[6] = fmax(nrm[6], fabs(qj));
+            nrm[9] = fmax(nrm[9], fabs(cd * d));
+            nrm[10] = fmax(nrm[10], fmax(fabs(cd * qj), fmax(fabs(cd * aty), fabs(cd * px))));
+            vsum[0] += xj * (0.5 * px + qj);
+        }
     }
     TICK(12)
     block_reduce<11, 1>(nrm, vsum, S.red);
