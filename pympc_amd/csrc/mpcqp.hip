@@ -517,7 +517,10 @@ static int launch_run_generic(mpcqp_handle *h, const RunArgs &R) {
 // snake order (blocks b, b + #CU, b + 2 #CU, ... share a CU: dispatch is round-robin over XCDs and CUs), so that every CU
 // gets a similar total.  Pure scheduling: which workgroup handles which instance never changes a result.
 // Must be called with the stream idle.
-static bool balance_due(const mpcqp_handle *h) { return h->solves_since_balance >= (h->work_ema.empty() ? BALANCE_FIRST : BALANCE_EVERY); }
+static bool balance_due(const mpcqp_handle *h) {
+    if (!h->auto_balance || h->ncu <= 0 || h->batch <= h->ncu) return false;      // (nothing to balance: no call waits for the stream on this account)
+    return h->solves_since_balance >= (h->work_ema.empty() ? BALANCE_FIRST : BALANCE_EVERY);
+}
 static int rebalance(mpcqp_handle *h) {
     const int B = h->batch, ncu = h->ncu;
     h->solves_since_balance = 0;
@@ -557,7 +560,7 @@ static int launch_run(mpcqp_handle *h, RunArgs R, int plain_iters) {
     R.chk = R.plain ? 0 : S.check_termination;
     R.rho_every = (!R.plain && S.adaptive_rho) ? (S.adaptive_rho_interval ? S.adaptive_rho_interval : (R.chk ? 4 * R.chk : 100)) : 0;
     R.batch = h->batch;
-    h->solves_since_balance += R.nsteps > 0 ? R.nsteps : 1;
+    h->solves_since_balance = std::min(h->solves_since_balance + (R.nsteps > 0 ? R.nsteps : 1), 1 << 20);
     const int e = h->ev_count % MAXEV;
     if (h->profiling) {
         if (h->ev_count >= MAXEV) {                 // ring full: bank the oldest pair first
