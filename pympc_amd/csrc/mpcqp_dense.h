@@ -37,43 +37,79 @@ __device__ __forceinline__ bool dense_dead(const Lay &L, int v) {       // varia
     return a >= L.nx && k >= L.NcT;
 }
 
-// K (dense, SPD) assembled entry by entry from the stage blocks, inverted in place by Gauss-Jordan sweeps in LDS (NR steps, the
-// pivot row and column copied out first so that every entry updates in place), written out in register order.
-// W: LDS, NR * ld + 2 * ROWS doubles (ld = L.dld, odd: column accesses are bank-conflict free).  Returns 1 on a non-positive pivot.
+// K (dense, SPD) assembled from the stage blocks (only the block-tridiagonal band is evaluated; omega and s are read from an LDS copy: an
+// entry sums nx products of them), inverted in place by Gauss-Jordan sweeps (NR steps).  A thread keeps its half row -- up to 64 entries --
+// in registers through the steps: a step reads the pivot row (64 broadcast reads, issued together) and its one pivot-column entry from the
+// copies made before the barrier, updates the registers and writes the half row back for the next step's copies.
+// W: LDS, NR * ld + 2 * ROWS + m + n doubles (ld = L.dld, odd: column accesses are bank-conflict free).  Returns 1 on a non-positive pivot.
 __device__ __forceinline__ int factor_dense(const Ctx &c, const double *om, const double *sv, double cc, double *F, double *W, int *iflag) {
     const Lay &L = c.L;
     const int tid = threadIdx.x, NR = L.NR, ld = L.dld, nb = L.nb;
-    double *prow = W + NR * ld, *pcol = prow + DenseFmt::ROWS;
+    double *prow = W + NR * ld, *pcol = prow + DenseFmt::ROWS, *oml = pcol + DenseFmt::ROWS, *svl = oml + L.m;
     if (tid == 0) *iflag = 0;
+    TICK_RESET
+    TICK_START
+    for (int r = tid; r < L.m; r += NT) oml[r] = om[r];
+    for (int r = tid; r < L.n; r += NT) svl[r] = sv[r];
+    for (int e = tid; e < NR * ld; e += NT) W[e] = 0.0;
     __syncthreads();
-    for (int e = tid; e < NR * NR; e += NT) {
-        const int i = e / NR, j = e - i * NR;
-        const int ki = i / nb, ai = i - ki * nb, kj = j / nb, aj = j - kj * nb;
-        double v = 0.0;
-        if (ki == kj) v = kkt_diag_entry(c, om, sv, cc, ki, ai, aj);
-        else if (ki == kj + 1) v = kkt_sub_entry(c, om, cc, kj, ai, aj);
-        else if (kj == ki + 1) v = kkt_sub_entry(c, om, cc, ki, aj, ai);
-        W[i * ld + j] = v;
+    const int per = 3 * nb * nb;                              // entries of one block row of the band: [sub | diag | super]
+    for (int e = tid; e < L.N * per; e += NT) {
+        const int ki = e / per, r = e - ki * per, blk = r / (nb * nb), q = r - blk * nb * nb, ai = q / nb, aj = q - ai * nb;
+        const int kj = ki + blk - 1;
+        if (kj < 0 || kj >= L.N) continue;
+        double v;
+        if (blk == 1) v = kkt_diag_entry(c, oml, svl, cc, ki, ai, aj);
+        else if (blk == 0) v = kkt_sub_entry(c, oml, cc, kj, ai, aj);          // K_{ki,ki-1}
+        else v = kkt_sub_entry(c, oml, cc, ki, aj, ai);                        // K_{ki,ki+1} = K_{ki+1,ki}'
+        W[(ki * nb + ai) * ld + kj * nb + aj] = v;
     }
     __syncthreads();
+    TICK(0)
     const int i = tid & (DenseFmt::ROWS - 1), h = tid >> 7;
-    const int j0 = DenseFmt::JW * h, j1 = min(j0 + DenseFmt::JW, NR);
+    const int j0 = DenseFmt::JW * h;
+    const bool live = i < NR;
+    const int nvalid = __builtin_amdgcn_readfirstlane(min(DenseFmt::JW, NR - j0));      // columns of this half that exist (the same for a whole wave)
+    double cur[DenseFmt::JW];
+#pragma unroll
+    for (int u = 0; u < DenseFmt::JW; ++u) cur[u] = (live && j0 + u < NR) ? W[i * ld + j0 + u] : 0.0;
     for (int pv = 0; pv < NR; ++pv) {
         if (tid < NR) { prow[tid] = W[pv * ld + tid]; pcol[tid] = W[tid * ld + pv]; }
         __syncthreads();
         double d = prow[pv];
         if (!(d > 0.0)) { if (tid == 0) *iflag = 1; d = 1e-300; }
         const double inv = 1.0 / d;
-        if (i < NR) {
-            double *row = W + i * ld;
-            if (i == pv) { for (int j = j0; j < j1; ++j) row[j] = (j == pv) ? inv : prow[j] * inv; }
-            else {
-                const double f = pcol[i] * inv;
-                for (int j = j0; j < j1; ++j) row[j] = (j == pv) ? -f : row[j] - f * prow[j];
+        if (live) {
+            // (in chunks of 16 columns: the pivot-row values of a chunk are read together; chunks beyond NR are skipped; the two threads of the
+            //  pivot row take their own branch instead of a select per entry.  nvalid is wave-uniform: scalar branches, no exec masking)
+            const double f = pcol[i] * inv;
+#pragma unroll
+            for (int ch = 0; ch < DenseFmt::JW / 16; ++ch) {
+                if (16 * ch < nvalid) {
+                double pr[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) pr[u] = prow[j0 + 16 * ch + u];      // (entries beyond NR are never stored)
+                if (i == pv) {
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) cur[16 * ch + u] = (j0 + 16 * ch + u == pv) ? inv : pr[u] * inv;
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) cur[16 * ch + u] = (j0 + 16 * ch + u == pv) ? -f : fma(-f, pr[u], cur[16 * ch + u]);
+                }
+                double *wr = W + i * ld + j0 + 16 * ch;
+                if (16 * ch + 16 <= nvalid) {
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) wr[u] = cur[16 * ch + u];
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) if (16 * ch + u < nvalid) wr[u] = cur[16 * ch + u];
+                }
+                }
             }
         }
         __syncthreads();
     }
+    TICK(1)
     const int ro = tid >> 1, co = DenseFmt::JW * (tid & 1);   // register order: row, first column of this thread
     const bool dead_r = ro >= NR || dense_dead(L, ro);
     for (int j = 0; j < DenseFmt::JW; ++j) {
@@ -82,6 +118,8 @@ __device__ __forceinline__ int factor_dense(const Ctx &c, const double *om, cons
         if (!dead_r && cidx < NR && !dense_dead(L, cidx)) v = 0.5 * (W[ro * ld + cidx] + W[cidx * ld + ro]);
         F[(size_t)j * NT + tid] = v;
     }
+    TICK(2)
+    TICK_FLUSH
     __syncthreads();
     return *iflag;
 }
