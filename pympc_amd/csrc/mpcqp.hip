@@ -248,7 +248,7 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     if (rc) { std::string msg = g_err; mpcqp_destroy(h); return fail(MPCQP_ERR_HIP, msg); }
     // The factorization's workspace starts at the work area T, the last part of the common block,
     // and may run on into the iterate area (dead while a factorization runs); T is widened only where even that is short.
-    const int fws = dense ? L.NR * L.dld + 2 * DenseFmt::ROWS + L.m + L.n : bcr ? BcrFmt::LDSW : (L.NB == 16 ? FactorCfg<16>::WS : L.NB == 32 ? FactorCfg<32>::WS : WideFmt::WS);
+    const int fws = dense ? L.NR * L.dld + 2 * DenseFmt::ROWS + L.m + L.n : bcr ? BcrFmt::LDSW + L.m + L.n : (L.NB == 16 ? FactorCfg<16>::WS : L.NB == 32 ? FactorCfg<32>::WS : WideFmt::WS);
     const int avail = L.tsz + (h->lds_state ? (int)state_doubles : 0);
     if (avail < fws) h->L.tsz += fws - avail;
     h->smem_setup = sizeof(double) * ((size_t)smem_common_doubles(h->L) + (h->lds_state ? state_doubles : 0));      // every kernel gets the full block

@@ -41,10 +41,15 @@ __device__ __forceinline__ int factor_bcr(const Ctx &c, const double *om, const 
     const int N = L.N, tid = threadIdx.x, g = tid / T, lt = tid % T;
     double *Kd = Wg, *Up = Wg + (size_t)N * NN, *dKL = Up + (size_t)N * NN, *dKR = dKL + (size_t)N * NN;
     if (tid == 0) *iflag = 0;
+    // (omega and s through an LDS copy behind the workspace: every entry of a diagonal block sums nx products of them)
+    double *oml = W + BcrFmt::LDSW, *svl = oml + L.m;
+    for (int r = tid; r < L.m; r += NT) oml[r] = om[r];
+    for (int r = tid; r < L.n; r += NT) svl[r] = sv[r];
+    __syncthreads();
     for (int idx = tid; idx < N * NN; idx += NT) {
         const int k = idx / NN, r = idx % NN, a = r / NB, b = r % NB;
-        Kd[idx] = kkt_diag_entry(c, om, sv, cc, k, a, b);
-        Up[idx] = (k + 1 < N) ? kkt_sub_entry(c, om, cc, k, b, a) : 0.0;      // K_{k,k+1}[a][b] = K_{k+1,k}[b][a]
+        Kd[idx] = kkt_diag_entry(c, oml, svl, cc, k, a, b);
+        Up[idx] = (k + 1 < N) ? kkt_sub_entry(c, oml, cc, k, b, a) : 0.0;      // K_{k,k+1}[a][b] = K_{k+1,k}[b][a]
     }
     __syncthreads();
     double *D = W + g * 5 * NN, *BL = D + NN, *BR = D + 2 * NN, *LL = D + 3 * NN, *LR = D + 4 * NN;
