@@ -7,5 +7,6 @@ controllers of equal dimensions on one GPU, sharded over GPUs with torch.distrib
 """
 from .controller import MPCController
 from .batch import BatchMPCController
+from .unconstrained import unconstrained_gains
 
-__all__ = ['MPCController', 'BatchMPCController']
+__all__ = ['MPCController', 'BatchMPCController', 'unconstrained_gains']
