@@ -521,6 +521,30 @@ __device__ __forceinline__ void own_rows_w(const Lay &L, const OwnRegs &h, doubl
     }
     __syncthreads();
 }
+// Nc < Np: the last input u_{Nc-1} is held to the end of the horizon, so its column of A has entries in the dynamics rows of ALL later stages
+// and its part of A'W is a sum over Np - Nc + 1 stages.  One thread adding them up serially was a third of an iteration of the reference's
+// Kalman notebook (Np = 150, Nc = 75).  The per-stage terms Bd' W_s are formed in parallel, parked in the input slots of the stages that
+// carry no input (zero otherwise, and zero again before the solve), and the owner of (Nc - 1, jj) adds Np - Nc + 1 LDS values in a fixed order.
+template <int NB>
+__device__ __forceinline__ void held_input_terms(const Lay &L, int nx, int nu, const double *Bd, const double *W, double *Tc) {
+    const int npair = (L.Np - L.Nc + 1) * nu;
+    for (int p = threadIdx.x; p < npair; p += NT) {
+        const int so = p / nu, jj = p - so * nu, s = L.Nc + so;
+        const double *w1 = W + s * nx;
+        double t = 0.0;
+        for (int r = 0; r < nx; ++r) t += Bd[r * nu + jj] * w1[r];
+        Tc[s * NB + nx + jj] = t;
+    }
+}
+template <int NB>
+__device__ __forceinline__ double held_input_sum(const Lay &L, int nx, int jj, double *Tc) {
+    double a0 = 0.0, a1 = 0.0;
+    int s = L.Nc;
+    for (; s + 1 <= L.Np; s += 2) { a0 += Tc[s * NB + nx + jj]; a1 += Tc[(s + 1) * NB + nx + jj]; Tc[s * NB + nx + jj] = 0.0; Tc[(s + 1) * NB + nx + jj] = 0.0; }
+    if (s <= L.Np) { a0 += Tc[s * NB + nx + jj]; Tc[s * NB + nx + jj] = 0.0; }
+    return a0 + a1;
+}
+
 // rhs = s x - c q + A' W with the slack eliminated, into Tc
 template <int NB, int NXT, int NUT>
 __device__ __forceinline__ void own_rhs(const Lay &L, const double *hot, const OwnRegs &h, double cc, const double *X, double *W, double *Tc) {
@@ -528,6 +552,8 @@ __device__ __forceinline__ void own_rhs(const Lay &L, const double *hot, const O
     const int nx = hx<NXT>(L), nu = hu<NUT>(L);
     const double *Ad = hot + L.oAd, *Bd = hot + L.oBd;
     const double cef = cc * hot[L.oeps];
+    const bool held = L.Nc < L.Np;
+    if (held) held_input_terms<NB>(L, nx, nu, Bd, W, Tc);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int e = tid + NT * j;
@@ -546,14 +572,15 @@ __device__ __forceinline__ void own_rhs(const Lay &L, const double *hot, const O
             Tc[k * NB + a] = rx + wsoft - h.om_s[j] * te;
         }
     }
+    if (held) __syncthreads();
     if (tid < L.n_u) {
         const int cu = tid, k = divu<NUT>(L, cu), jj = cu - k * nu;
         double ru = h.sv_u * X[L.ou + cu] - h.cq_u + W[L.ri + cu] - W[L.rdu + nu + cu];
         if (k == 0) ru += W[L.rdu + jj];
         if (cu > 0) ru += W[L.rdu + nu + cu - 1];
-        const int s_end = (k == L.Nc - 1) ? L.Np : k + 1;
-        for (int s = k + 1; s <= s_end; ++s) {
-            const double *w1 = W + s * nx;
+        if (held && k == L.Nc - 1) ru += held_input_sum<NB>(L, nx, jj, Tc);               // the last input acts on every later stage (mpc.py:540-543)
+        else {
+            const double *w1 = W + (k + 1) * nx;
 #pragma unroll
             for (int r = 0; r < (NXT ? NXT : 1); ++r) if (NXT) ru += Bd[r * nu + jj] * w1[r];
             if (!NXT) for (int r = 0; r < nx; ++r) ru += Bd[r * nu + jj] * w1[r];
@@ -673,6 +700,8 @@ __device__ __forceinline__ void gown_rhs(const Lay &L, const double *hot, cgdoub
     const double *Ad = hot + L.oAd, *Bd = hot + L.oBd;
     const double cef = cc * hot[L.oeps];
     cgdouble *Xg = (cgdouble *)X;
+    const bool held = L.Nc < L.Np;
+    if (held) held_input_terms<NB>(L, nx, nu, Bd, W, Tc);
     for (int e0 = tid; e0 < L.n_x; e0 += GU * NT) {
         double svx[GU], qx[GU], oms[GU], xv[GU], sve[GU], xe[GU];
 #pragma unroll
@@ -700,6 +729,7 @@ __device__ __forceinline__ void gown_rhs(const Lay &L, const double *hot, cgdoub
             }
         }
     }
+    if (held) __syncthreads();
     for (int c0 = tid; c0 < L.n_u; c0 += GU * NT) {
         double svu[GU], qu[GU], uv[GU];
 #pragma unroll
@@ -712,9 +742,9 @@ __device__ __forceinline__ void gown_rhs(const Lay &L, const double *hot, cgdoub
                 double ru = svu[u] * uv[u] - cc * qu[u] + W[L.ri + cu] - W[L.rdu + nu + cu];
                 if (k == 0) ru += W[L.rdu + jj];
                 if (cu > 0) ru += W[L.rdu + nu + cu - 1];
-                const int s_end = (k == L.Nc - 1) ? L.Np : k + 1;
-                for (int s = k + 1; s <= s_end; ++s) {
-                    const double *w1 = W + s * nx;
+                if (held && k == L.Nc - 1) ru += held_input_sum<NB>(L, nx, jj, Tc);       // the last input acts on every later stage (mpc.py:540-543)
+                else {
+                    const double *w1 = W + (k + 1) * nx;
 #pragma unroll
                     for (int r = 0; r < (NXT ? NXT : 1); ++r) if (NXT) ru += Bd[r * nu + jj] * w1[r];
                     if (!NXT) for (int r = 0; r < nx; ++r) ru += Bd[r * nu + jj] * w1[r];
