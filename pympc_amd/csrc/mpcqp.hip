@@ -213,7 +213,7 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     const size_t state_doubles = (size_t)(L.n + 2 * L.m);
     h->lds_state = L.NB <= 32 && sizeof(double) * ((size_t)smem_common_doubles(L) + state_doubles) <= 40 * 1024 && L.m <= 4 * NT && L.N * L.NB <= 2 * NT && L.n_u + L.nu <= NT;      // (the owner map of the parallel phases: two state elements and one input element per thread)
     // The smallest ones (the reference's own examples) solve the KKT system with a register-resident dense inverse (mpcqp_dense.h).
-    bool dense = h->lds_state && L.NB == 16 && !L.border && L.NR <= DenseFmt::ROWS;
+    bool dense = h->lds_state && L.NB == 16 && L.NR <= DenseFmt::ROWS;      // (Nc < Np included: the dense inverse holds the held input's couplings itself)
     if (const char *e = getenv("MPCQP_DENSE")) dense = dense && atoi(e) != 0;      // development switch (A/B against the block sweeps)
     h->L.dense = dense ? 1 : 0;
     if (dense) h->L.tsz += DenseFmt::SCRATCH;

@@ -34,8 +34,10 @@ static_assert(NT == 256, "the dense path maps 128 rows x 2 column halves onto 25
 
 __device__ __forceinline__ bool dense_dead(const Lay &L, int v) {       // variable slot v = (k, a) without a variable
     const int k = v / L.nb, a = v - k * L.nb;
-    return a >= L.nx && k >= L.NcT;
+    return a >= L.nx && k >= L.Nc;                                      // (Nc < Np: the held input u_{Nc-1} is an ordinary unknown of the dense system)
 }
+
+__device__ double kkt_entry_generic(const Ctx &c, const double *om, const double *sv, double cc, int v, int w);      // mpcqp_border.h
 
 // K (dense, SPD) assembled from the stage blocks (only the block-tridiagonal band is evaluated; omega and s are read from an LDS copy: an
 // entry sums nx products of them), inverted in place by Gauss-Jordan sweeps (NR steps).  A thread keeps its half row -- up to 64 entries --
@@ -65,6 +67,19 @@ __device__ __forceinline__ int factor_dense(const Ctx &c, const double *om, cons
         W[(ki * nb + ai) * ld + kj * nb + aj] = v;
     }
     __syncthreads();
+    if (L.border) {
+        // Nc < Np: the held input u_{Nc-1} couples to every later stage (mpc.py:513-517,540-543).  The sweeps treat it by bordering; a dense K
+        // simply has those entries: its rows and columns, taken entry by entry from the matrix-free operators (the band pass above saw stage
+        // Nc-1 without an input).
+        const int vb0 = (L.Nc - 1) * nb + L.nx, ub0 = L.ou + (L.Nc - 1) * L.nu;
+        for (int e = tid; e < L.nu * NR; e += NT) {
+            const int jj = e / NR, w = e - jj * NR, kw = w / nb, aw = w - kw * nb;
+            const int var = aw < L.nx ? kw * L.nx + aw : (kw < L.Nc ? L.ou + kw * L.nu + (aw - L.nx) : -1);
+            const double v = var >= 0 ? kkt_entry_generic(c, oml, svl, cc, ub0 + jj, var) : 0.0;
+            W[(vb0 + jj) * ld + w] = v; W[w * ld + vb0 + jj] = v;
+        }
+        __syncthreads();
+    }
     TICK(0)
     const int i = tid & (DenseFmt::ROWS - 1), h = tid >> 7;
     const int j0 = DenseFmt::JW * h;
@@ -115,7 +130,13 @@ __device__ __forceinline__ int factor_dense(const Ctx &c, const double *om, cons
     for (int j = 0; j < DenseFmt::JW; ++j) {
         const int cidx = co + j;
         double v = 0.0;
-        if (!dead_r && cidx < NR && !dense_dead(L, cidx)) v = 0.5 * (W[ro * ld + cidx] + W[cidx * ld + ro]);
+        if (!dead_r && cidx < NR) {
+            // (Nc < Np: the column of an input slot behind the held input is a copy of the held input's column -- admm_tiny puts the slot's
+            //  share of the held input's A'W into the right-hand side there, the mat-vec adds the shares up)
+            const int kc = cidx / nb, ac = cidx - kc * nb;
+            const int src = (L.border && ac >= L.nx && kc > L.Nc) ? (L.Nc - 1) * nb + ac : cidx;
+            if (!dense_dead(L, src)) v = 0.5 * (W[ro * ld + src] + W[src * ld + ro]);
+        }
         F[(size_t)j * NT + tid] = v;
     }
     TICK(2)

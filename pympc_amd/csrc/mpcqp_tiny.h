@@ -95,6 +95,18 @@ __device__ __forceinline__ void admm_tiny(const Lay &L, const HotPtrs &P, Smem &
     }
     // what the coefficient vector multiplies: odd lanes the next stage's dynamics-row W (A'W), even lanes the previous stage's solution
     const double *nbr = odd ? Wd + min((k + 1) * nx, L.n_x) : Xt + max(k - 1, 0) * nb;
+    // Nc < Np (mpc.py:513-517,540-543): the last input is held to the end of the horizon.  (i) The dynamics row of a stage behind it takes its
+    // input part from slot Nc - 1.  (ii) The held input's A'W sums B' W_dyn over every later stage: the term of stage s > Nc is computed by the
+    // otherwise idle odd lane of the input slot of stage s (same instruction stream as every other A'W term) and lands in the right-hand side
+    // at ITS slot -- whose column of the stored inverse is a copy of the held input's column (factor_dense), so the mat-vec adds the terms up.
+    const bool held = L.Nc < L.Np;
+    const double *nbu = Xt + min(max(k - 1, 0), L.Nc - 1) * nb + nx;           // input part for the even x lanes
+    const bool hterm = held && live && odd && a >= nx && k > L.Nc;
+    if (hterm) {
+#pragma unroll
+        for (int i = 0; i < MAXB; ++i) if (i < nx) cvec[i] = hot[L.oBd + i * nu + jj];
+        nbr = Wd + k * nx;
+    }
     const int unext = (jj + 1 < nu) ? v + 1 : (k + 1) * nb + nx;      // slot of the next flattened input (cu + 1 < n_u)
     const bool has_unext = is_u && cu + 1 < L.n_u;
     const bool has_uprev = is_u && cu > 0;
@@ -103,10 +115,15 @@ __device__ __forceinline__ void admm_tiny(const Lay &L, const HotPtrs &P, Smem &
     if (is_x && !odd) Wd[e] = r1.w;
     if (is_u && odd) Wu[cu] = r1.w;
     __syncthreads();
-    auto dot = [&]() {                                        // cvec . nbr[0..MAXB): all reads issued together, then the FMAs
+    auto dot = [&](bool split_u) {                            // cvec . nbr[0..MAXB): all reads issued together, then the FMAs
         double t[MAXB];
+        if (split_u) {                                        // (Nc < Np, phase B: the input part of [x_prev | u_prev] may sit in another slot)
 #pragma unroll
-        for (int i = 0; i < MAXB; ++i) t[i] = nbr[i];
+            for (int i = 0; i < MAXB; ++i) t[i] = (odd || i < nx) ? nbr[i] : nbu[i - nx];
+        } else {
+#pragma unroll
+            for (int i = 0; i < MAXB; ++i) t[i] = nbr[i];
+        }
         __builtin_amdgcn_sched_barrier(0);
         double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
@@ -127,13 +144,13 @@ __device__ __forceinline__ void admm_tiny(const Lay &L, const HotPtrs &P, Smem &
         TICK_START
         // ---- (A) right-hand side  s x - c q + A'W  with the slack eliminated: the pair's two halves
         //   even x: s x - c q - W_dyn      odd x: A'W + (W_box - omega te)      even u: s u - c q + W_box (+ W_du0)      odd u: B'W - W_du + W_du(prev)
-        const double atw = dot();
+        const double atw = dot(false);
         const double wprev = *upp;
         const double te = slack ? (svp * pv + r1.w) * kap : 0.0;
         double part = odd ? atw : svp * pv - cq;
         part += odd_x ? r1.w - r1.om * te : (even_u ? r1.w + r2.w : -r1.w);
         part = fma(s_uprev, wprev, part);
-        part = any ? part : 0.0;
+        part = (any || hterm) ? part : 0.0;
         const double rhs = part + lane_swap1(part);
         if (!odd && live) Cv[cvi] = rhs;
         __syncthreads();
@@ -145,7 +162,7 @@ __device__ __forceinline__ void admm_tiny(const Lay &L, const HotPtrs &P, Smem &
         TICK(1)
         // ---- (B) relaxation, projection, dual step
         //   even x: x, dynamics row (zt = [Ad Bd] v_prev - xt)   odd x: eps, box row (zt = xt + et)   even u: u, box row (zt = ut), first-step row   odd u: Delta-u row
-        const double gv = dot();
+        const double gv = dot(held);
         const double un = *unp;
         const double et = slack ? te - okap * xt : 0.0;
         const double vt = odd ? et : xt;                      // the variable this lane updates moves towards vt
