@@ -32,6 +32,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <sched.h>
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -51,6 +52,17 @@
 #define RHO_MAX 1e6
 #define RHO_EQ_OVER_RHO_INEQ 1e3
 #define RHO_TOL 1e-4
+
+// one polite spin of a host-side busy wait
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    __asm__ __volatile__("yield");
+#else
+    __asm__ __volatile__("" ::: "memory");
+#endif
+}
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -445,7 +457,9 @@ extern "C" int mpcqp_create_csc(mpcqp_handle **out, int device, int batch, int n
     CscPattern &c = seam->pat;
     c.n = n; c.m = m;
     c.Pp.assign(P_colptr, P_colptr + n + 1); c.Ap.assign(A_colptr, A_colptr + n + 1);
-    if (c.Pp[0] != 0 || c.Ap[0] != 0 || c.Pp[n] < 0 || c.Ap[n] < 0) { delete seam; return fail(MPCQP_ERR_ARG, "mpcqp_create_csc: bad column pointers"); }
+    bool cp_ok = c.Pp[0] == 0 && c.Ap[0] == 0;
+    for (int j = 0; j < n && cp_ok; ++j) cp_ok = c.Pp[j] <= c.Pp[j + 1] && c.Ap[j] <= c.Ap[j + 1];      // non-decreasing from 0: every entry is within [0, colptr[n]]
+    if (!cp_ok) { delete seam; return fail(MPCQP_ERR_ARG, "mpcqp_create_csc: bad column pointers (must start at 0 and be non-decreasing)"); }
     c.Pi.assign(P_rowidx, P_rowidx + c.Pp[n]); c.Ai.assign(A_rowidx, A_rowidx + c.Ap[n]);
     for (int32_t r : c.Pi) if (r < 0 || r >= n) { delete seam; return fail(MPCQP_ERR_ARG, "mpcqp_create_csc: P row index out of range"); }
     for (int32_t r : c.Ai) if (r < 0 || r >= m) { delete seam; return fail(MPCQP_ERR_ARG, "mpcqp_create_csc: A row index out of range"); }
@@ -790,10 +804,9 @@ extern "C" int mpcqp_step_host(mpcqp_handle *h, const double *x0, const double *
     if (xref && xref_rows != 1 && xref_rows != h->L.N) return fail(MPCQP_ERR_ARG, "xref_rows must be 1 or Np+1");
     if (h->step_blank && (!x0 || !uminus1 || !xref)) return fail(MPCQP_ERR_STATE, "mpcqp_step_host: the handle was set up from raw q, l, u and holds no x0 / u_{-1} / xref yet: give all three");
     HIPCHK(hipSetDevice(h->device));
-    h->step_blank = false;
     const bool split = h->auto_balance && h->ncu > 0 && h->batch > h->ncu;
     if (split || ensure_pinned(h)) {
-        int rc = mpcqp_update(h, x0, uminus1, xref, xref_rows);
+        int rc = mpcqp_update(h, x0, uminus1, xref, xref_rows);      // (clears step_blank once the step data is in)
         if (rc) return rc;
         if ((rc = mpcqp_solve(h))) return rc;
         return mpcqp_get_solution(h, x, y, info);
@@ -814,9 +827,12 @@ extern "C" int mpcqp_step_host(mpcqp_handle *h, const double *x0, const double *
     R.pub = (double *)h->pin_out_dev; R.done = (unsigned *)h->npending_dev + 2; R.seq = ++h->host_seq;
     int rc = launch_run(h, R, 0);
     if (rc) return rc;
+    h->step_blank = false;                                     // the step data has been accepted (a failed launch leaves the handle demanding it again)
     volatile unsigned long long *flag = (volatile unsigned long long *)((char *)h->pin_out + sizeof(double) * B * (L.n + L.m) + sizeof(mpcqp_info) * B);
+    // Poll the flag: a short busy wait (a small solve is done within tens of microseconds), then yield the core between polls -- a long
+    // solve (iteration limit, a long horizon) does not keep a CPU core spinning.
     for (unsigned long long spins = 0; *flag != h->host_seq; ++spins) {
-        __builtin_ia32_pause();
+        if (spins < 20000) cpu_relax(); else sched_yield();
         if ((spins & 0xfffff) == 0xfffff) {                    // every ~million polls: has the stream died?
             hipError_t e = hipStreamQuery(h->stream);
             if (e != hipSuccess && e != hipErrorNotReady) return fail(MPCQP_ERR_HIP, std::string("mpcqp_step_host: ") + hipGetErrorString(e));

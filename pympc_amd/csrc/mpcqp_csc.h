@@ -137,11 +137,17 @@ static int csc_recover(const CscPattern &c, int nx, int nu, int Np, int Nc, int 
         else if (r < rdu) probe(n_x + r - ri);
         else { const int rr = r - rdu; if (rr < nu) probe(n_x + rr); else { probe(n_x + rr - nu); probe(n_x + rr - nu + 1); } }
     }
-    const double ptol = 4.0 * 2.220446049250313e-16 * std::max(1.0, d0max);      // the input-weight blocks are stored as sums (Qu + 2 QDu): re-adding may move the last bit
+    // The input-weight blocks are stored as sums (Qu + 2 QDu, mpc.py:505-526): Qu = D0 - 2 QDu carries D0's rounding error, and re-adding
+    // may move the last bit.  With Nc < Np the LAST input block is rebuilt as (Np - Nc + 1) Qu + QDu (mpc.py:513-517), which multiplies that
+    // error by Np - Nc + 1: the bound for that block is scaled by the same factor.
+    const double ptol = 4.0 * 2.220446049250313e-16 * std::max(1.0, d0max);
+    const double ptol_last = ptol * (double)(Np - Nc + 1);
     auto p_ok = [&](int r, int cc, double given) {
         const double e = P_expected_upper(b, r, cc);
         if (given == e) return true;
-        return r >= n_x && r < n_x + n_u && cc >= n_x && cc < n_x + n_u && fabs(given - e) <= ptol;
+        if (!(r >= n_x && r < n_x + n_u && cc >= n_x && cc < n_x + n_u)) return false;
+        const bool last = r >= n_x + (Nc - 1) * nu && cc >= n_x + (Nc - 1) * nu;      // the diagonal block of the held input
+        return fabs(given - e) <= (last ? ptol_last : ptol);
     };
     for (int j = 0; j < n; ++j) for (int64_t p = c.Pp[j]; p < c.Pp[j + 1]; ++p) if (c.Pi[p] <= j && !p_ok(c.Pi[p], j, Pv[p])) ++badP;
     for (int r = 0; r < n && !badP; ++r) {

@@ -96,7 +96,15 @@ def recover_model(P, A, l, u, nx=None, nu=None):
     dP = (Pu - P2u).tocsc(); dP.eliminate_zeros()
     # A must come back exactly.  P too, except that the input-weight blocks are stored as sums (Qu + 2 QDu, mpc.py:505-526):
     # splitting and re-adding them may move the last bit
-    bad_P = dP.nnz and (np.abs(dP.data).max() > 4 * np.finfo(float).eps * max(1.0, np.abs(D0).max()) or dP.indices.min() < n_x or dP.indices.max() >= n_x + n_u)
+    # ... and with Nc < Np the LAST input block is rebuilt as (Np - Nc + 1) Qu + QDu (mpc.py:513-517), which multiplies the rounding
+    # error Qu = D0 - 2 QDu inherited from D0 by Np - Nc + 1: that block's bound is scaled by the same factor
+    bad_P = False
+    if dP.nnz:
+        dPc = dP.tocoo()
+        ptol = 4 * np.finfo(float).eps * max(1.0, np.abs(D0).max())
+        last = (dPc.row >= n_x + (Nc - 1) * nu) & (dPc.col >= n_x + (Nc - 1) * nu)
+        inside = (dPc.row >= n_x) & (dPc.row < n_x + n_u) & (dPc.col >= n_x) & (dPc.col < n_x + n_u)
+        bad_P = bool((~inside).any() or (np.abs(dPc.data) > np.where(last, (Np - Nc + 1) * ptol, ptol)).any())
     if dA.nnz or bad_P:
         raise NotAnMPCQP('P, A are not the matrices pyMPC builds from their own blocks (%d / %d entries differ)' % (dP.nnz, dA.nnz))
     check_vectors(model, l, u)

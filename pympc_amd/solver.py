@@ -121,8 +121,11 @@ class BatchProblem:
         ap, ai = np.ascontiguousarray(Ac.indptr, dtype=np.int64), np.ascontiguousarray(Ac.indices, dtype=np.int32)
         rc = self._L.mpcqp_create_csc(C.byref(self._h), int(device), self.batch, int(Pc.shape[0]), int(Ac.shape[0]), _ptr(pp), _ptr(pi), _ptr(ap), _ptr(ai),
                                       int(nx or 0), int(nu or 0), C.byref(self.settings))
-        if rc == -4:
-            raise NotAnMPCQP(self._L.mpcqp_last_error().decode())
+        if rc == -4:        # MPCQP_ERR_UNSUPPORTED: either not pyMPC's QP, or a valid one beyond what the device path implements
+            msg = self._L.mpcqp_last_error().decode()
+            if msg.startswith('mpcqp_create_csc: not an MPC QP'):
+                raise NotAnMPCQP(msg)
+            raise NotImplementedError(msg)
         if rc == -3:
             raise RuntimeError('pympc_amd needs an AMD GPU (no HIP device visible); there is no CPU fallback')
         _lib.check(rc, 'mpcqp_create_csc')
@@ -208,7 +211,10 @@ class BatchProblem:
         return None if v is None else _prep(v, (self.batch, self.m), name)
 
     def update_vectors(self, q=None, l=None, u=None):
-        """osqp's update(q=, l=, u=) (mpc.py:454) with caller-built vectors; any of them may be None (unchanged)."""
+        """osqp's update(q=, l=, u=) (mpc.py:454) with caller-built vectors.  q may be None (unchanged); l and u go together --
+        both or neither: the equality rows l[:nx] == u[:nx] carry x0 (the library refuses one without the other)."""
+        if (l is None) != (u is None):
+            raise ValueError('update_vectors: give l and u together (the equality rows l[:nx] == u[:nx] carry x0)')
         qa = None if q is None else _prep(q, (self.batch, self.n), 'q')
         la, ua = self._bound(l, 'l'), self._bound(u, 'u')
         _lib.check(self._L.mpcqp_update_vectors(self._h, _ptr(qa), _ptr(la), _ptr(ua)), 'mpcqp_update_vectors')

@@ -82,3 +82,37 @@ def test_tampered_values_are_refused_by_the_library():
     q2 = np.array(g['q']); q2[-1] = 1.0                                        # a cost on a slack variable
     with pytest.raises(NotAnMPCQP):
         DeviceProblem().setup(P, q2, A, g['l'], g['u'])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('Np,Nc,Qu,QDu,nu', [(150, 75, 0.1, 0.3, 1), (20, 5, 3.3, 0.7, 1), (12, 3, 0.1, 0.3, 2)])
+def test_held_input_with_inexact_weights_through_the_c_seam(Np, Nc, Qu, QDu, nu):
+    """ADVICE r3 (mpcqp_csc.h): Nc < Np with input weights that are not exactly representable -- the library's rebuild-and-compare
+    accepts the genuine pyMPC matrices (the last input block carries Np - Nc + 1 times the rounding error of Qu) and solves them."""
+    from pympc_amd.solver import DeviceProblem
+    from oracle.osqp_oracle import OSQP
+    from test_qp_recover import _held_input_qp
+    K = _held_input_qp(Np, Nc, Qu, QDu, nu)
+    D = DeviceProblem(); D.setup(K.P, K.q, K.A, K.l, K.u, eps_abs=1e-9, eps_rel=1e-9, max_iter=200000)
+    r = D.solve()
+    O = OSQP(); O.setup(K.P, K.q, K.A, K.l, K.u, eps_abs=1e-9, eps_rel=1e-9, max_iter=200000)
+    ro = O.solve()
+    assert r.info.status == ro.info.status == 'solved'
+    assert np.abs(r.x - ro.x).max() <= 1e-6 * max(1.0, np.abs(ro.x).max())
+
+
+def test_bad_column_pointers_are_an_argument_error():
+    """non-monotone or out-of-range column pointers must come back as MPCQP_ERR_ARG, not as an out-of-bounds read."""
+    from pympc_amd import _lib
+    L = _lib.load()
+    g = load_golden('point_mass')
+    Pc, Ac = sp.csc_matrix(golden_csc(g, 'P')), sp.csc_matrix(golden_csc(g, 'A'))
+    Pc.sort_indices(); Ac.sort_indices()
+    for which in ('P', 'A'):
+        pp, ap = np.array(Pc.indptr, dtype=np.int64), np.array(Ac.indptr, dtype=np.int64)
+        bad = pp if which == 'P' else ap
+        bad[3] = bad[-1] + 5                           # an interior pointer beyond colptr[n]
+        arrs = [pp, np.ascontiguousarray(Pc.indices, dtype=np.int32), ap, np.ascontiguousarray(Ac.indices, dtype=np.int32)]
+        h = C.c_void_p()
+        rc = L.mpcqp_create_csc(C.byref(h), 0, 1, Pc.shape[0], Ac.shape[0], *[a.ctypes.data_as(C.c_void_p) for a in arrs], 0, 0, None)
+        assert rc == -1, (which, rc, L.mpcqp_last_error().decode())

@@ -53,3 +53,27 @@ def test_foreign_qps_are_refused():
     l3 = l.copy(); l3[3] = 1.0                                        # a dynamics row with a nonzero right-hand side
     with pytest.raises(NotAnMPCQP):
         check_vectors(m, l3, u)
+
+
+def _held_input_qp(Np, Nc, Qu, QDu, nu=1):
+    """pyMPC's QP with a control horizon Nc < Np and input weights that are not dyadic rationals: the stored blocks Qu + 2 QDu and
+    (Np - Nc + 1) Qu + QDu (mpc.py:505-526) are rounded sums, so Qu read back from the first one is off by an ulp or two."""
+    from pympc_amd import MPCController, fixtures
+    from test_qp_build import _NullProb
+    kw = fixtures.cart_pole() if nu == 1 else fixtures.random_lti(3, nx=5, nu=nu, Np=Np, xbox=10.0)
+    kw.update(Np=Np, Nc=Nc, Qu=Qu * np.eye(nu), QDu=QDu * np.eye(nu))
+    K = MPCController(**kw); K.prob = _NullProb(); K.setup(solve=False)
+    return K
+
+
+@pytest.mark.parametrize('Np,Nc,Qu,QDu,nu', [(150, 75, 0.1, 0.3, 1), (20, 5, 3.3, 0.7, 1), (12, 3, 0.1, 0.3, 2), (25, 10, 1e-3, 7.7, 2)])
+def test_held_input_with_inexact_weights_is_recovered(Np, Nc, Qu, QDu, nu):
+    """with Nc < Np the last input block is rebuilt as (Np - Nc + 1) Qu + QDu, which multiplies the rounding error
+    of Qu = D0 - 2 QDu by Np - Nc + 1 -- the genuine pyMPC QP used to be refused ('1 / 0 entries differ')."""
+    K = _held_input_qp(Np, Nc, Qu, QDu, nu)
+    m = recover_model(K.P, K.A, K.l, K.u)
+    assert (m['Np'], m['Nc'], m['nu']) == (Np, Nc, nu)
+    assert np.allclose(m['Qu'], Qu * np.eye(nu), rtol=0, atol=8 * np.finfo(float).eps * max(1.0, Qu + 2 * QDu))
+    P2 = K.P.tolil(); j = K.P.shape[0] - (Np + 1) * K.nx - 1; P2[j, j] *= 1.0 + 1e-9      # a last block that is NOT pyMPC's is still refused
+    with pytest.raises(NotAnMPCQP):
+        recover_model(P2.tocsc(), K.A, K.l, K.u)
