@@ -270,8 +270,11 @@ class Shard:
         # k_mpc_run<..,false> (mpcqp_solve), 'loop' = k_mpc_run<..,true> (mpcqp_mpc_loop)
         self.totals = {'solve': [0, 0, 0], 'loop': [0, 0, 0]}
         self.account('solve', st)
-        self.gen = torch.Generator(device=dev)
-        self.gen.manual_seed(1234 + rank)
+        # process noise w_k ~ N(0, 0.01^2): instance i draws from ITS OWN seed-pinned stream (fixtures.random_lti_noise_rng, SURVEY 8d:
+        # "w from the same rng" recipe) -- the same realisation the CPU baseline's closed loop uses (oracle/cpu_bench.py), whatever
+        # the batch size, the rank count or the path; rows are consumed in step order across all the measurements of this shard
+        from pympc_amd import fixtures
+        self.noise_rngs = [fixtures.random_lti_noise_rng(first_instance + rank * B + j) for j in range(B)]
         self.u_all = torch.empty((world * B, NU), dtype=f64, device=dev) if world > 1 else None
 
     def account(self, kind, st=None):
@@ -280,9 +283,14 @@ class Shard:
             self.totals[kind][i] += v
         return st
 
-    def plant(self, xc, uc):
+    def noise(self, count):
+        """[count, B, nx] device tensor: the next `count` rows of every instance's noise stream."""
+        nx = self.dims[0]
+        w = np.stack([0.01 * r.standard_normal((count, nx)) for r in self.noise_rngs], axis=1)
+        return self.torch.from_numpy(w).to(self.dev)
+
+    def plant(self, xc, uc, w):
         torch = self.torch
-        w = 0.01 * torch.randn((self.B, self.dims[0]), dtype=torch.float64, device=self.dev, generator=self.gen)
         return torch.baddbmm(w.unsqueeze(2), self.Ad, xc.unsqueeze(2)).add_(torch.bmm(self.Bd, uc.unsqueeze(2))).squeeze(2)
 
     def timed(self, kind, run_warm, run_timed):
@@ -312,8 +320,10 @@ class Shard:
     def measure_stepwise(self, steps, warmup):
         """The reference's call pattern: per step the host calls update(), solve(), output() (one kernel launch per
         solve); plant and disturbance are torch ops on the same stream; with N > 1 u* is all-gathered every step."""
+        w_all = iter(self.noise(warmup + steps))       # synthetic input, generated before the timed region
+
         def step():
-            self.x = self.plant(self.x, self.u)
+            self.x = self.plant(self.x, self.u, next(w_all))
             self.prob.update(self.x, self.u)
             self.prob.solve_async()
             self.prob.u0(out=self.u)
@@ -338,43 +348,61 @@ class Shard:
             chunk = steps
             while chunk > 25:
                 chunk = next((chunk // d for d in (2, 3, 5, 7) if chunk % d == 0), 25)
-        w_all = 0.01 * torch.randn((warmup + steps, B, NX), dtype=f64, device=dev, generator=self.gen)
+        w_all = self.noise(warmup + steps)
         outs = (torch.empty((chunk + 1, B, NX), dtype=f64, device=dev), torch.empty((chunk, B, NU), dtype=f64, device=dev),
                 torch.empty((chunk, B), dtype=torch.int32, device=dev), torch.empty((chunk, B), dtype=torch.int32, device=dev))
         u_hist = torch.empty((world * chunk, B, NU), dtype=f64, device=dev) if world > 1 else None
 
-        def run(first, count):
+        # per launch: an event pair on the launch stream (the handle's stream IS torch's current stream) and the instances' iteration
+        # counts, summed on the device (one tiny reduction per launch, inside the timed region: extra work, nothing skipped)
+        marks, it_sum = [], torch.zeros((B,), dtype=torch.int64, device=dev)
+
+        def run(first, count, record):
             o = None
             for c in range(first, first + count, chunk):
                 k = min(chunk, first + count - c)
                 o = outs if k == chunk else tuple(t[:k + (1 if i == 0 else 0)] for i, t in enumerate(outs))
+                if record:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                 self.prob.mpc_run(k, w=w_all[c:c + k], out=o)
+                if record:
+                    e1.record(); marks.append((e0, e1, k))
+                    it_sum.add_(o[3].sum(dim=0))
                 if world > 1 and k == chunk:
                     self.sharding.gather_trajectory(outs[1], out=u_hist)
             return o
 
         last = {}
-        r = self.timed('loop', lambda: last.update(o=run(0, warmup)) if warmup else None, lambda: last.update(o=run(warmup, steps)))
+        r = self.timed('loop', lambda: last.update(o=run(0, warmup, False)) if warmup else None, lambda: last.update(o=run(warmup, steps, True)))
         self.x = last['o'][0][-1].clone()
         self.u.copy_(last['o'][1][-1])
         r['chunk'] = chunk
+        ms = [e0.elapsed_time(e1) for e0, e1, _ in marks]
+        its = it_sum.cpu().numpy().astype(float)
+        med = float(np.median(its))
+        # a launch ends with its slowest instance (no instance can run ahead of its own closed loop): how uneven the work was
+        r['launch_spread'] = {'launches': len(ms), 'steps_per_launch': chunk, 'ms_min': min(ms), 'ms_max': max(ms), 'ms_mean': float(np.mean(ms)),
+                              'iters_per_instance_median': med, 'iters_per_instance_max': float(its.max()),
+                              'instances_above_1p5x_median': int((its > 1.5 * med).sum()),
+                              'critical_path_ratio': float(its.max() / max(1.0, med))}
         return r
 
     def measure(self, path, steps, warmup):
         return {'stepwise': self.measure_stepwise, 'device_loop': self.measure_device_loop}[path](steps, warmup)
 
-    def sample_point(self):
+    def sample_point(self, nsample=U_ERR_SAMPLE):
         """One more (untimed) closed-loop step through the stepwise API: returns the sampled QPs (x0, u_{-1}) and the
         u* the device produced for them at the current tolerance.  Rank 0's instances only (global index = local)."""
         torch, B = self.torch, self.B
-        self.x = self.plant(self.x, self.u)
+        self.x = self.plant(self.x, self.u, self.noise(1)[0])
         um1 = self.u.clone()
         self.prob.update(self.x, um1)
         self.prob.solve_async()
         self.prob.u0(out=self.u)
         torch.cuda.synchronize()
         self.account('solve')
-        idx = np.unique(np.linspace(0, B - 1, min(U_ERR_SAMPLE, B)).astype(int))
+        idx = np.unique(np.linspace(0, B - 1, min(nsample, B)).astype(int))
         infos = self.prob.infos()
         return dict(idx=idx, x0=self.x[idx].cpu().numpy(), um1=um1[idx].cpu().numpy(), u=self.u[idx].cpu().numpy(),
                     solved=np.array([infos[int(i)].status == 1 for i in idx]))
@@ -408,7 +436,7 @@ class Shard:
         alg8d, b_it8d = algorithmic_bytes_8d(self.dims, prob.n, prob.m, prob.nnzL, iters, checks, solves)
         kname = prob.kernel_name(loop=path == 'device_loop')
         lds_state = ',true,' in kname.split('<')[1][:9]            # second template argument: iterate resident in LDS
-        pmc = pmc_entry(workload_key, path, kname) if workload_key else None
+        pmc = pmc_entry(workload_key, path, kname) if workload_key else None      # (keys: cfg3, cfg5, cfg3_b4096 -- one per profiled command)
         pmc_batch = (pmc or {}).get('batch')
         pmc_ok = pmc is not None and (pmc_batch is None or pmc_batch == self.B)
         pmc_b = pmc['hbm_bytes_per_iter_per_qp'] if pmc_ok else None
@@ -549,6 +577,7 @@ def main():
                     help='cfg3: 1024 x (12,4,30) (headline); cfg5: 512 x (20,8,100), tight state box (SURVEY 8d); '
                          'cfg2 / notebook: single-controller latency legs only')
     ap.add_argument('--hbm-leg-batch', type=int, default=4096, help='cfg3, 1 GPU: second leg with a working set beyond the Infinity Cache (0 = skip)')
+    ap.add_argument('--cfg5-leg-batch', type=int, default=512, help='cfg3, 1 GPU: BASELINE configs[4] (512 x (20,8,100)) as a leg of the default line (0 = skip)')
     ap.add_argument('--dry-run', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
     self_launch_if_needed(args)
@@ -607,7 +636,7 @@ def main():
     knames = {k: prob.kernel_name(loop=(k == 'loop')) for k in totals}
 
     # ---- secondary legs (each on a problem set of its own; the headline shard is released first)
-    extra = {}
+    extra, cfg5_samples = {}, None
     if not args.no_other_path:
         del sh, prob
         torch.cuda.empty_cache()
@@ -621,14 +650,62 @@ def main():
             del s2
             torch.cuda.empty_cache()
         if world == 1 and args.workload == 'cfg3' and args.hbm_leg_batch and args.hbm_leg_batch != B:
-            # the same kernel on a working set beyond the 256 MiB Infinity Cache: an HBM-only roofline fraction
+            # the same kernel on a working set beyond the 256 MiB Infinity Cache: an HBM-only roofline fraction; counter traffic from the
+            # profile of this very command shape (profiles/pmc_hbm_traffic.json, key cfg3_b<batch>: scripts/r4_profiles.sh)
             s3 = Shard(args, dims, args.hbm_leg_batch, rank, world, dev, 0, torch, dist)
             r3 = s3.measure(args.path, min(args.steps, 25), min(args.warmup, 25) or 5)
-            ro3 = s3.roofline(r3, args.path, None)
+            ro3 = s3.roofline(r3, args.path, 'cfg3_b%d' % args.hbm_leg_batch)
             extra['hbm_leg'] = {'batch': args.hbm_leg_batch, 'value': args.hbm_leg_batch * min(args.steps, 25) / r3['elapsed'], 'unit': 'QP-solves/s',
                                 'ms_per_step': 1e3 * r3['elapsed'] / min(args.steps, 25), 'mean_admm_iters': r3['iters'] / max(1, r3['solves']),
-                                'roofline': {k: ro3[k] for k in ('achieved', 'peak', 'unit', 'frac', 'frac_of_achievable', 'working_set_bytes', 'fits_infinity_cache', 'kernel', 'kernel_ms', 'design_bytes_per_launch')}}
+                                'launch_spread': r3.get('launch_spread'),
+                                'roofline': {k: ro3[k] for k in ('achieved', 'peak', 'unit', 'frac', 'frac_of_achievable', 'achievable_GBps', 'traffic', 'traffic_source', 'traffic_GBps',
+                                                                 'measured_bytes_per_iter_per_qp', 'design_bytes_per_iter_per_qp', 'working_set_bytes',
+                                                                 'fits_infinity_cache', 'kernel', 'kernel_ms', 'design_bytes_per_launch')},
+                                'note': 'frac_of_achievable compares with the guide\'s float4-COPY rate (6.29 TB/s: half reads, half writes, every byte from HBM); this '
+                                        'kernel is a read-only stream (writes < 5 %) of which the counters see every byte (FETCH_SIZE includes Infinity-Cache hits): a value '
+                                        'slightly above 1 says read-only streaming beats a copy, not that the HBM peak was exceeded -- frac (against 8 TB/s) is the claim'}
             del s3
+            torch.cuda.empty_cache()
+        if world == 1 and args.workload == 'cfg3' and args.cfg5_leg_batch:
+            # BASELINE configs[4] in the default line: 512 x (20,8,100), tight state box (slack rows active), 50 warm-started closed-loop
+            # steps after 25 warm-up steps, at the reference's default tolerance and at the parity setting
+            d5 = WORKLOADS['cfg5'][:4]
+            B5 = args.cfg5_leg_batch
+            s5 = Shard(args, d5, B5, rank, world, dev, 0, torch, dist)
+            r5 = s5.measure('device_loop', 50, 25)
+            ro5 = s5.roofline(r5, 'device_loop', 'cfg5')
+            inf5 = s5.prob.infos()
+            cfg5_samples = [dict(s5.sample_point(16), eps=args.eps)]
+            s5.prob.update_settings(eps_abs=1e-9, eps_rel=1e-9)
+            p5 = s5.measure('device_loop', 50, 25)
+            cfg5_samples.append(dict(s5.sample_point(16), eps=1e-9))
+            extra['cfg5_leg'] = {'workload': 'cfg-5: %d random stable LTI MPC instances (nx=%d, nu=%d, Np=Nc=%d, n=%d, m=%d), state box +-%g (slack active), '
+                                             'warm-started receding horizon' % (B5, d5[0], d5[1], d5[2], s5.prob.n, s5.prob.m, d5[3]),
+                                 'batch': B5, 'steps': 50, 'warmup': 25, 'eps_abs': args.eps, 'eps_rel': args.eps, 'path': 'device_loop',
+                                 'value': B5 * 50 / r5['elapsed'], 'unit': 'QP-solves/s', 'ms_per_step': 1e3 * r5['elapsed'] / 50,
+                                 'mean_admm_iters': r5['iters'] / max(1, r5['solves']), 'solved_fraction_last_step': sum(1 for i in inf5 if i.status == 1) / B5,
+                                 'launch_spread': r5.get('launch_spread'), 'cold': s5.cold,
+                                 'roofline': {k: ro5[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'frac_is', 'frac_of_achievable', 'traffic', 'traffic_source', 'traffic_GBps',
+                                                                  'measured_bytes_per_iter_per_qp', 'design_bytes_per_iter_per_qp', 'design_bytes_per_round_per_qp',
+                                                                  'design_bytes_per_solve_per_qp', 'working_set_bytes', 'fits_infinity_cache', 'kernel', 'kernel_ms',
+                                                                  'launches', 'steps_per_launch', 'design_bytes_per_launch')},
+                                 'parity_setting': {'eps_abs': 1e-9, 'eps_rel': 1e-9, 'value': B5 * 50 / p5['elapsed'], 'ms_per_step': 1e3 * p5['elapsed'] / 50,
+                                                    'mean_admm_iters': p5['iters'] / max(1, p5['solves']), 'launch_spread': p5.get('launch_spread')}}
+            del s5
+            torch.cuda.empty_cache()
+        if world == 1 and args.workload == 'cfg3' and scaling == 'weak' and B >= 8 and B % 8 == 0 and args.path == 'device_loop':
+            # BASELINE configs[3] read literally (the SAME batch split over 8 GPUs): what ONE GPU does with its eighth, measured here --
+            # the 8-GPU figure this projects to has no data-path collective to lose anything in (u* all-gather: 32 B per instance and step)
+            s8 = Shard(args, dims, B // 8, rank, world, dev, 0, torch, dist)
+            r8 = s8.measure(args.path, args.steps, args.warmup)
+            v8 = (B // 8) * args.steps / r8['elapsed']
+            extra['strong_scaling_projection'] = {'total_batch': B, 'batch_per_gpu_at_8': B // 8, 'measured_1gpu_value_at_that_batch': v8, 'kernel': s8.prob.kernel_name(loop=True),
+                                                  'projected_8gpu_value': 8 * v8, 'projected_vs_1gpu_full_batch': 8 * v8 / (B * world * args.steps / elapsed),
+                                                  'weak_scaling_projection_8gpu_value': 8 * B * world * args.steps / elapsed,
+                                                  'note': 'strong scaling (total batch fixed) leaves %d instances on 256 CUs per GPU: one workgroup (latency backend) per instance, half the '
+                                                          'CUs idle at 128; the >= 6x target at 8 GPUs is reachable as weak scaling (%d instances per GPU), which is what --gpus N measures; '
+                                                          '--total-batch measures the strong reading on real GPUs' % (B // 8, B)}
+            del s8
             torch.cuda.empty_cache()
         if rank == 0 and args.workload == 'cfg3':
             try:
@@ -658,6 +735,7 @@ def main():
                                         'receding-horizon loop, a few per instance during the cold solve' % B},
             'cold': cold,
             'roofline': roof,
+            'launch_spread': res.get('launch_spread'),
             'accounting': {'timed': {'iters': iters, 'rounds': res['checks'], 'solves': solves, 'launches': res['launches'], 'kernel_ms_total': res['run_ms']},
                            'process_totals': {knames[k]: dict(iters=v[0], rounds=v[1], solves=v[2]) for k, v in totals.items()}},
             'other_path': other,
@@ -667,16 +745,22 @@ def main():
         cpu, refs = cpu_legs(dims, args.eps, samples, want_baseline=not args.no_cpu_baseline)
         if cpu:
             out['cpu_baseline'] = cpu
-        if refs:
+        def u_err_block(samples, refs):
             err = {}
             for s, ref in zip(samples, refs):
                 ok = s['solved'] & np.isfinite(ref).all(axis=1)
                 d = np.abs(s['u'][ok] - ref[ok]).max() if ok.any() else float('nan')
                 sc = max(1e-3, np.abs(ref[ok]).max()) if ok.any() else 1.0
                 err['eps_%g' % s['eps']] = {'max_abs': float(d), 'max_rel': float(d / sc), 'instances': int(ok.sum())}
-            out['u_err'] = dict(err, definition='max over the sample of |u* - u*_ref|_inf; rel = / max |u*_ref|_inf',
-                                reference='oracle/osqp_ref.c at eps 1e-10 on the same (x0, u_-1): the QP the device solved in one more warm-started step',
-                                north_star_tolerance_rel=1e-6)
+            return dict(err, definition='max over the sample of |u* - u*_ref|_inf; rel = / max |u*_ref|_inf',
+                        reference='oracle/osqp_ref.c at eps 1e-10 on the same (x0, u_-1): the QP the device solved in one more warm-started step',
+                        north_star_tolerance_rel=1e-6)
+
+        if refs:
+            out['u_err'] = u_err_block(samples, refs)
+        if cfg5_samples and 'cfg5_leg' in out:
+            _, refs5 = cpu_legs(WORKLOADS['cfg5'][:4], args.eps, cfg5_samples, want_baseline=False)
+            out['cfg5_leg']['u_err'] = u_err_block(cfg5_samples, refs5)
         out['real_osqp'] = real_osqp_pin() if not args.no_cpu_baseline else {'osqp_available': osqp_available()}
         print(json.dumps(out))
     if world > 1:
