@@ -356,6 +356,7 @@ class Shard:
         # per launch: an event pair on the launch stream (the handle's stream IS torch's current stream) and the instances' iteration
         # counts, summed on the device (one tiny reduction per launch, inside the timed region: extra work, nothing skipped)
         marks, it_sum = [], torch.zeros((B,), dtype=torch.int64, device=dev)
+        it_sum.add_(outs[3].sum(dim=0)); it_sum.zero_()            # (torch loads a kernel the first time it is used, ~100 ms: not inside the timed region)
 
         def run(first, count, record):
             o = None

@@ -275,6 +275,123 @@ __device__ __forceinline__ void check_norms_own(const Ctx &c, const double *X, c
     }
 }
 
+// The same norms for an iterate that lives in GLOBAL memory (problems too large for the LDS-resident round: cfg-5, long horizons, wide
+// stages).  The row visitors used here before walk one row / variable at a time with a global load per term: 183 us of a 286 us check at
+// cfg-5 while all 512 instances stream (an ADMM iteration: 111 us).  Instead the (x, u) part of x and all of y -- everything a NEIGHBOUR
+// reads -- are staged once into the work vector T, which is idle during a check ([ Y (m) | X (n_x + n_u) ] fits: tsz >= m + N NB), with
+// coalesced, independent loads; then the owner map of check_norms_own, as many passes as it takes (state element e = t + NT j, input
+// element cu = t + NT j), two items per thread in flight with all their global operands (z, the slack, D, E, q) requested up front.
+// Terms are summed in the order the row visitors enumerate them.  wts: the weight matrices (LDS copy or global).
+__device__ __forceinline__ void check_norms_gown(const Ctx &c, const double *gX, const double *gZ, const double *gY, const double *D, const double *E,
+                                                 const double *Qv, double cc, double *T, double *nrm, double *vsum) {
+    constexpr int GU = 2;
+    const Lay &L = c.L;
+    const int tid = threadIdx.x, nx = L.nx, nu = L.nu;
+    const double *Ad = c.Ad(), *Bd = c.Bd();
+    cgdouble *Xg = (cgdouble *)gX, *Zg = (cgdouble *)gZ, *Yg = (cgdouble *)gY, *Dg = (cgdouble *)D, *Eg = (cgdouble *)E, *Qg = (cgdouble *)Qv;
+    double *Y = T, *X = T + L.m;                                        // X: the (x, u) part only; a slack is read by its owner alone
+    for (int i = tid; i < L.m; i += NT) Y[i] = Yg[i];
+    for (int i = tid; i < L.n_x + L.n_u; i += NT) X[i] = Xg[i];
+    __syncthreads();
+    auto row = [&](double ax, double z, double e) {
+        const double d = ax - z;
+        nrm[0] = fmax(nrm[0], fabs(d)); nrm[1] = fmax(nrm[1], fabs(ax)); nrm[2] = fmax(nrm[2], fabs(z));
+        nrm[7] = fmax(nrm[7], fabs(e * d)); nrm[8] = fmax(nrm[8], fmax(fabs(e * ax), fabs(e * z)));
+    };
+    auto var = [&](double px, double aty, double qj, double xj, double cd) {
+        const double d = px + qj + aty;
+        nrm[3] = fmax(nrm[3], fabs(d)); nrm[4] = fmax(nrm[4], fabs(px)); nrm[5] = fmax(nrm[5], fabs(aty)); nrm[6] = fmax(nrm[6], fabs(qj));
+        nrm[9] = fmax(nrm[9], fabs(cd * d));
+        nrm[10] = fmax(nrm[10], fmax(fabs(cd * qj), fmax(fabs(cd * aty), fabs(cd * px))));
+        vsum[0] += xj * (0.5 * px + qj);
+    };
+    for (int e0 = tid; e0 < L.n_x; e0 += GU * NT) {
+        double eDyn[GU], eBox[GU], dXe[GU], dEe[GU], qXe[GU], zD[GU], zB[GU], ee[GU];
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int e = min(e0 + u * NT, L.n_x - 1);
+            eDyn[u] = Eg[e]; eBox[u] = Eg[L.rs + e]; dXe[u] = Dg[e]; qXe[u] = Qg[e]; zD[u] = Zg[e]; zB[u] = Zg[L.rs + e];
+            dEe[u] = 0.0; ee[u] = 0.0;
+            if (L.soft) { dEe[u] = Dg[L.oe + e]; ee[u] = Xg[L.oe + e]; }
+        }
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int e = e0 + u * NT;
+            if (e < L.n_x) {
+                const int k = idiv(e, L.rnx), a = e - k * nx;
+                const double xe = X[e];
+                double ax = -xe;                                           // dynamics row e  (mpc.py:537-552)
+                if (k > 0) {
+                    const double *xp = X + (k - 1) * nx, *up = X + L.ou + min(k - 1, L.Nc - 1) * nu;
+#pragma unroll 4
+                    for (int i = 0; i < nx; ++i) ax += Ad[a * nx + i] * xp[i];
+#pragma unroll 4
+                    for (int i = 0; i < nu; ++i) ax += Bd[a * nu + i] * up[i];
+                }
+                row(ax, zD[u], eDyn[u]);
+                row(L.soft ? xe + ee[u] : xe, zB[u], eBox[u]);             // state-box row: x_k (+ eps_k)
+                const double *Q = (k < L.Np) ? c.Qx() : c.QxN();
+                const double *xk = X + k * nx;
+                double px = 0.0, aty = -Y[e];
+#pragma unroll 4
+                for (int l = 0; l < nx; ++l) px += Q[min(a, l) * nx + max(a, l)] * xk[l];
+                if (k < L.Np) {
+                    const double *y1 = Y + (k + 1) * nx;
+#pragma unroll 4
+                    for (int r = 0; r < nx; ++r) aty += Ad[r * nx + a] * y1[r];
+                }
+                aty += Y[L.rs + e];
+                var(px, aty, qXe[u], xe, cc * dXe[u]);
+                if (L.soft) { double pe = 0.0, ae = 0.0; pe += c.eps_feas() * ee[u]; ae += Y[L.rs + e]; var(pe, ae, 0.0, ee[u], cc * dEe[u]); }
+            }
+        }
+    }
+    for (int c0 = tid; c0 < L.n_u; c0 += GU * NT) {
+        double eIn[GU], eDu[GU], eD0[GU], dU[GU], qU[GU], zI[GU], zU[GU], z0[GU];
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int cu = min(c0 + u * NT, L.n_u - 1), r0 = L.rdu + min(cu, nu - 1);
+            eIn[u] = Eg[L.ri + cu]; eDu[u] = Eg[L.rdu + nu + cu]; eD0[u] = Eg[r0]; dU[u] = Dg[L.ou + cu]; qU[u] = Qg[L.n_x + cu];
+            zI[u] = Zg[L.ri + cu]; zU[u] = Zg[L.rdu + nu + cu]; z0[u] = Zg[r0];
+        }
+#pragma unroll
+        for (int u = 0; u < GU; ++u) {
+            const int cu = c0 + u * NT;
+            if (cu < L.n_u) {
+                const int k = idiv(cu, L.rnu), jj = cu - k * nu;
+                const double ut = X[L.ou + cu];
+                row(ut, zI[u], eIn[u]);                                    // input box
+                double ax = -ut;                                           // Delta-u row nu + cu (mpc.py:570)
+                if (cu + 1 < L.n_u) ax += X[L.ou + cu + 1];
+                row(ax, zU[u], eDu[u]);
+                if (cu < nu) row(ut, z0[u], eD0[u]);                       // first step: u_0 (- u_{-1} in the bounds)
+                const double iu = (k == L.Nc - 1) ? (double)(L.Np - L.Nc + 1) : 1.0, dk = (k == L.Nc - 1) ? 1.0 : 2.0;
+                const double *Qu = c.Qu(), *QDu = c.QDu(), *uk = X + L.ou + k * nu;
+                double px = 0.0;
+                for (int l = 0; l < nu; ++l) {
+                    const int lo = min(jj, l), hi = max(jj, l);
+                    px += __dadd_rn(__dmul_rn(iu, Qu[lo * nu + hi]), __dmul_rn(dk, QDu[lo * nu + hi])) * uk[l];
+                }
+                if (k + 1 < L.Nc) for (int l = 0; l < nu; ++l) px += -QDu[jj * nu + l] * uk[nu + l];
+                if (k > 0) for (int l = 0; l < nu; ++l) px += -QDu[l * nu + jj] * uk[l - nu];
+                double aty = 0.0;
+                const int s_end = (k == L.Nc - 1) ? L.Np : k + 1;        // the last input is held to the end of the horizon
+                for (int s = k + 1; s <= s_end; ++s) {
+                    const double *y1 = Y + s * nx;
+#pragma unroll 4
+                    for (int r = 0; r < nx; ++r) aty += Bd[r * nu + jj] * y1[r];
+                }
+                aty += Y[L.ri + cu];
+                if (k == 0) aty += Y[L.rdu + jj];
+                aty += -Y[L.rdu + nu + cu];
+                if (cu > 0) aty += Y[L.rdu + nu + cu - 1];
+                var(px, aty, qU[u], ut, cc * dU[u]);
+            }
+        }
+    }
+    __syncthreads();                                                       // (T is reused by the certificates and by the caller)
+}
+
 template <int NB, int OCC>
 __device__ __forceinline__ int check_body(const Lay &L, const Ptrs &P, const mpcqp_settings &S_, Smem &S, int iter, int mode,
                                           const double *Xl, const double *Zl, const double *Yl) {
@@ -282,11 +399,13 @@ __device__ __forceinline__ int check_body(const Lay &L, const Ptrs &P, const mpc
     TICK_RESET
     TICK_START
     const double *model = P.model + (size_t)b * L.model_sz;
-    // the weight matrices (read entry by entry by P_row) go to the idle Tc area of the work vector if they fit
+    // the weight matrices (read entry by entry) go to the idle part of the work vector if they fit: behind W for the LDS-resident
+    // iterate, behind the staged [ Y | X ] of check_norms_gown otherwise
     const int nweights = L.model_sz - L.hot_sz;
     const double *wts = model + L.hot_sz;
-    if (nweights <= L.tsz - L.m) {
-        double *wq = S.T + L.m;
+    const int wq_off = L.m + (Xl ? 0 : L.n_x + L.n_u);
+    if (nweights <= L.tsz - wq_off) {
+        double *wq = S.T + wq_off;
         for (int i = tid; i < nweights; i += NT) wq[i] = model[L.hot_sz + i];
         __syncthreads();
         wts = wq;
@@ -312,27 +431,7 @@ __device__ __forceinline__ int check_body(const Lay &L, const Ptrs &P, const mpc
     for (int i = 0; i < 11; ++i) nrm[i] = 0.0;
     TICK(10)
     if (Xl) check_norms_own(c, X, Z, Y, D, E, S.Qv, cc, nrm, vsum);      // (LDS-resident iterate: owner-mapped passes)
-    else {
-        for (int r = tid; r < L.m; r += NT) {
-            double ax = 0.0;
-            A_row(c, r, [&](double co, int idx) { ax += co * X[idx]; });
-            double z = Z[r], d = ax - z, e = E[r];
-            nrm[0] = fmax(nrm[0], fabs(d)); nrm[1] = fmax(nrm[1], fabs(ax)); nrm[2] = fmax(nrm[2], fabs(z));
-            nrm[7] = fmax(nrm[7], fabs(e * d)); nrm[8] = fmax(nrm[8], fmax(fabs(e * ax), fabs(e * z)));
-        }
-        TICK(11)
-        for (int j = tid; j < L.n; j += NT) {
-            double px = 0.0, aty = 0.0;
-            P_row(c, j, [&](double co, int idx) { px += co * X[idx]; });
-            AT_row(c, j, [&](double co, int row) { aty += co * Y[row]; });
-            double qj = (j < L.oe) ? S.Qv[j] : 0.0, xj = X[j];
-            double d = px + qj + aty, cd = cc * D[j];
-            nrm[3] = fmax(nrm[3], fabs(d)); nrm[4] = fmax(nrm[4], fabs(px)); nrm[5] = fmax(nrm[5], fabs(aty)); nrm[6] = fmax(nrm[6], fabs(qj));
-            nrm[9] = fmax(nrm[9], fabs(cd * d));
-            nrm[10] = fmax(nrm[10], fmax(fabs(cd * qj), fmax(fabs(cd * aty), fabs(cd * px))));
-            vsum[0] += xj * (0.5 * px + qj);
-        }
-    }
+    else check_norms_gown(c, X, Z, Y, D, E, S.Qv, cc, S.T, nrm, vsum);   // (iterate in global memory: staged, then the same passes)
     TICK(12)
     block_reduce<11, 1>(nrm, vsum, S.red);
     obj_val = vsum[0]; pri_res = nrm[0]; dua_res = nrm[3];
