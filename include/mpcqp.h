@@ -273,6 +273,17 @@ int mpcqp_iterate(mpcqp_handle *h, int iters);
  * costs per instance. */
 int mpcqp_refactor(mpcqp_handle *h);
 
+/* The EQUALITY-constrained part of the handle's QP -- minimise 1/2 w'P w + q'w subject to the dynamics rows alone, every other row
+ * ignored -- by sweeps of the method of multipliers in residual form, each one KKT solve with the handle's factor (one factorization,
+ * made by mpcqp_setup; give the handle a large rho: a sweep contracts the error by about |P| / (1e3 rho)).  This is what the gains of
+ * the law without inequality constraints need (test_scripts/alternative/unconstrained.py:170-183: k_x0, k_Xref, k_Uref, k_uminus1 --
+ * there a dense condensed solve); pympc_amd/unconstrained.py calls it on a batch of unit-vector problems.
+ * At most `sweeps` sweeps; an instance stops earlier once a correction is below tol * max(1, |w|_inf) (tol = 0: never).
+ * cold != 0: start from zero, else continue from the current iterate.  The result is read with mpcqp_get_solution (status 'solved',
+ * iter = sweeps done).  res (host or device, may be NULL): [batch][5] = |P w + q + A_e'y|, max(|P w|, |A_e'y|, |q|), |A_e w - b|,
+ * max(|A_e w|, |b|) (infinity norms, unscaled) after the last sweep, and the sweeps done.  Synchronous. */
+int mpcqp_eq_solve(mpcqp_handle *h, int sweeps, int cold, double tol, double *res);
+
 #ifdef __cplusplus
 }
 #endif

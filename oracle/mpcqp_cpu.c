@@ -541,4 +541,35 @@ int mpcqp_iterate(mpcqp_handle *h, int iters) {
     for (int b = 0; b < h->batch; ++b) oracle_iterate(h->w[b], iters);
     return MPCQP_OK;
 }
+/* the equality-constrained part by multiplier sweeps: with the settings the caller gives such a handle (alpha = 1, fixed rho, all
+ * inequality bounds infinite) one ADMM iteration of the oracle IS one sweep; an instance stops once a sweep moves x by less than
+ * tol * max(1, |x|); the residuals are not evaluated here (zeros) */
+int mpcqp_eq_solve(mpcqp_handle *h, int sweeps, int cold, double tol, double *res) {
+    if (!h || sweeps < 0) return fail(MPCQP_ERR_ARG, "mpcqp_eq_solve: bad argument");
+    if (!h->is_setup) return fail(MPCQP_ERR_STATE, "mpcqp_eq_solve before mpcqp_setup");
+    const size_t n = h->d.n, m = h->d.m;
+    double *D = dcalloc(n), *E = dcalloc(m), *xs = dcalloc(n), *zs = dcalloc(m), *ys = dcalloc(m), *xp = dcalloc(n), cc, rho;
+    for (int b = 0; b < h->batch; ++b) {
+        if (cold) { memset(xs, 0, sizeof(double) * n); memset(ys, 0, sizeof(double) * m); oracle_warm_start(h->w[b], xs, ys); }
+        oracle_get_scaling(h->w[b], D, E, &cc);
+        int done = 0;
+        for (int k = 0; k < sweeps; ++k) {
+            oracle_get_iterate(h->w[b], xp, zs, ys, &rho);
+            oracle_iterate(h->w[b], 1);
+            oracle_get_iterate(h->w[b], xs, zs, ys, &rho);
+            done = k + 1;
+            double dm = 0.0, xm = 0.0;
+            for (size_t j = 0; j < n; ++j) { dm = fmax(dm, fabs(D[j] * (xs[j] - xp[j]))); xm = fmax(xm, fabs(D[j] * xs[j])); }
+            if (k >= 2 && dm <= tol * fmax(1.0, xm)) break;      /* (an ADMM iteration sees the right-hand side b only through z: from a cold start the first one moves nothing) */
+        }
+        oracle_get_iterate(h->w[b], xs, zs, ys, &rho);
+        for (size_t j = 0; j < n; ++j) h->xs[(size_t)b * n + j] = D[j] * xs[j];
+        for (size_t i = 0; i < m; ++i) h->ys[(size_t)b * m + i] = E[i] * ys[i] / cc;
+        mpcqp_info *inf = &h->info[b];
+        inf->status = MPCQP_SOLVED; inf->iter = done; inf->rho_updates = 0; inf->reserved = 0; inf->obj_val = 0.0; inf->pri_res = 0.0; inf->dua_res = 0.0; inf->rho = rho;
+        if (res) { double *r = res + (size_t)b * 5; r[0] = 0.0; r[1] = 1.0; r[2] = 0.0; r[3] = 1.0; r[4] = (double)done; }
+    }
+    free(D); free(E); free(xs); free(zs); free(ys); free(xp);
+    return MPCQP_OK;
+}
 int mpcqp_refactor(mpcqp_handle *h) { return h && h->is_setup ? MPCQP_OK : fail(MPCQP_ERR_STATE, "mpcqp_refactor before mpcqp_setup"); }

@@ -236,13 +236,16 @@ class MPCController:
         self.update(x, u, xref=xref, solve=True)
         return self.output()
 
-    def unconstrained_gains(self, eps=1e-11):
+    def unconstrained_gains(self, tol=1e-13):
         """Gain matrices of this controller's law without inequality constraints, U* = K_x0 x0 + K_xref xref + K_uref uref + K_um1 u_{-1}
-        (test_scripts/alternative/unconstrained.py:170-183), computed on the device (pympc_amd/unconstrained.py).  An addition to the
-        reference's class; output() does not use it."""
-        from .unconstrained import unconstrained_gains
+        (test_scripts/alternative/unconstrained.py:170-183), computed on the device (pympc_amd/unconstrained.py: one KKT factorization, a
+        few batched solves).  An addition to the reference's class; output() does not use it."""
+        from .unconstrained import unconstrained_gains, GainSolver
         d = lambda M: np.asarray(M.toarray() if hasattr(M, 'toarray') else M, dtype=float)        # (scipy.sparse inputs are accepted like in the reference)
-        return unconstrained_gains(d(self.Ad), d(self.Bd), self.Np, self.Nc, Qx=d(self.Qx), QxN=d(self.QxN), Qu=d(self.Qu), QDu=d(self.QDu), eps=eps)
+        gs = getattr(self, '_gain_solver', None)
+        if gs is None or gs.tol != tol:
+            gs = self._gain_solver = GainSolver(self.nx, self.nu, self.Np, self.Nc, tol=tol)      # (kept: a second call allocates nothing)
+        return unconstrained_gains(d(self.Ad), d(self.Bd), self.Np, self.Nc, Qx=d(self.Qx), QxN=d(self.QxN), Qu=d(self.Qu), QDu=d(self.QDu), tol=tol, solver=gs)
 
     # ------------------------------------------------------------------------------------
     # q, l, u, J_CNST are public attributes of the reference (mpc.py:598-606).  The device solver rebuilds them itself from

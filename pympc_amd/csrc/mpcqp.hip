@@ -734,6 +734,24 @@ extern "C" int mpcqp_mpc_run(mpcqp_handle *h, int nsteps, const double *w, const
     return mpcqp_mpc_loop(h, nsteps, &io);
 }
 
+// The equality-constrained QP of the handle's problem (dynamics rows only) by at most `sweeps` multiplier sweeps in residual form, see k_eq_solve.
+extern "C" int mpcqp_eq_solve(mpcqp_handle *h, int sweeps, int cold, double tol, double *res) {
+    if (!h || sweeps < 0) return fail(MPCQP_ERR_ARG, "mpcqp_eq_solve: bad argument");
+    if (!h->is_setup) return fail(MPCQP_ERR_STATE, "mpcqp_eq_solve before mpcqp_setup");
+    HIPCHK(hipSetDevice(h->device));
+    double *dres = nullptr;
+    Scratch sc;
+    HIPCHK(sc.get(&dres, (size_t)h->batch * 5));
+    DISPATCH_NB(h->L.NB, {
+        if (set_smem(k_eq_solve<NB>, h->smem_setup)) return MPCQP_ERR_HIP;
+        hipLaunchKernelGGL(k_eq_solve<NB>, dim3(h->batch), dim3(NT), h->smem_setup, h->stream, h->L, h->P, sweeps, cold, tol, dres);
+    });
+    HIPCHK(hipGetLastError());
+    if (res) HIPCHK(hipMemcpyAsync(res, dres, sizeof(double) * 5 * (size_t)h->batch, hipMemcpyDefault, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MPCQP_OK;
+}
+
 extern "C" int mpcqp_get_solution(mpcqp_handle *h, double *x, double *y, mpcqp_info *info) {
     if (!h) return fail(MPCQP_ERR_ARG, "null handle");
     HIPCHK(hipSetDevice(h->device));

@@ -294,6 +294,92 @@ __global__ __launch_bounds__(NT) void k_kkt_solve(Lay L, Ptrs P, const double *r
     (void)tid;
 }
 
+// ------------------------------------------------------------------------------------------------
+// mpcqp_eq_solve: the EQUALITY-constrained QP (the dynamics rows alone; every other row ignored) by the method of multipliers in
+// RESIDUAL form, preconditioned by the handle's KKT factor:
+//     r  = -c (P x + q + A_e' y) - A_e' ( omega_e . (A_e x - b) )        (exact operators: the row visitors of mpcqp_qp.h)
+//     x += K^-1 r                                                         (kkt_solve: whatever backend the handle has)
+//     y += (omega_e / c) (A_e x - b)
+// K = c P + diag(s) + A' diag(omega) A is what the ADMM iteration solves with, so in exact arithmetic a sweep IS an ADMM iteration with
+// alpha = 1 on a problem whose other rows are free; written with the residual, the fixed point is the exact KKT point whatever the
+// rounding error of the stored factor (which only slows the contraction), so rho can be large and a sweep contracts by ~ |P| / rho_eq.
+// This is what the unconstrained gains of test_scripts/alternative/unconstrained.py:170-183 need: one factorization, a few solves.
+// At most `sweeps` sweeps; an instance stops earlier once a correction is below tol * max(1, |x|_inf) (tol = 0: never).
+// res [batch][5]: |P x + q + A_e'y|_inf, max(|P x|, |A_e'y|, |q|)_inf, |A_e x - b|_inf, max(|A_e x|, |b|)_inf after the last sweep, sweeps done.
+// Plain loops over the visitors: a utility on a handful of instances, not a hot path.
+// ------------------------------------------------------------------------------------------------
+template <int NB>
+__global__ __launch_bounds__(NT) void k_eq_solve(Lay L, Ptrs P, int sweeps, int cold, double tol, double *res) {
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    double *p = sh; Smem S; smem_common(L, P, p, S);
+    const int b = inst_of(P.perm), tid = threadIdx.x;
+    const double *model = P.model + (size_t)b * L.model_sz, *step = P.step + (size_t)b * L.step_sz;
+    load_common(L, model, step, S);
+    Ctx c{L, S.hot, model + L.hot_sz};
+    if (!L.raw) build_q(c, step, S.Qv);
+    double *x = P.x + (size_t)b * L.n, *y = P.y + (size_t)b * L.m, *z = P.z + (size_t)b * L.m;
+    double *r = P.dx + (size_t)b * L.n, *d = P.xo + (size_t)b * L.n;
+    const double *om = P.omega + (size_t)b * L.m, *sv = P.s + (size_t)b * L.n;
+    const double cc = P.c[b];
+    double *g = S.T;                                   // [n_x]: c y + omega (A x - b) of the dynamics rows (W's place in the work vector)
+    if (cold) { for (int j = tid; j < L.n; j += NT) x[j] = 0.0; for (int i = tid; i < L.m; i += NT) { y[i] = 0.0; z[i] = 0.0; } }
+    __syncthreads();
+    double nrm[4] = {0.0, 0.0, 0.0, 0.0}, dummy[1] = {0.0};
+    int done = 0;
+    bool settled = false;
+    for (int sw = 0; sw <= sweeps; ++sw) {
+        nrm[0] = nrm[1] = nrm[2] = nrm[3] = 0.0;
+        for (int i = tid; i < L.n_x; i += NT) {
+            double ax = 0.0, lo, hi;
+            A_row(c, i, [&](double co, int idx) { ax += co * x[idx]; });
+            row_bounds(c, S.x0s, S.du0, i, lo, hi);
+            g[i] = cc * y[i] + om[i] * (ax - lo);
+            nrm[2] = fmax(nrm[2], fabs(ax - lo)); nrm[3] = fmax(nrm[3], fmax(fabs(ax), fabs(lo)));
+        }
+        __syncthreads();
+        for (int j = tid; j < L.n; j += NT) {
+            double px = 0.0, atg = 0.0, aty = 0.0;
+            P_row(c, j, [&](double co, int idx) { px += co * x[idx]; });
+            AT_row(c, j, [&](double co, int row) { if (row < L.n_x) { atg += co * g[row]; aty += co * y[row]; } });
+            const double qj = (j < L.oe) ? S.Qv[j] : 0.0;
+            r[j] = -cc * (px + qj) - atg;
+            nrm[0] = fmax(nrm[0], fabs(px + qj + aty)); nrm[1] = fmax(nrm[1], fmax(fabs(px), fmax(fabs(aty), fabs(qj))));
+        }
+        __syncthreads();
+        if (sw == sweeps || settled) break;
+        kkt_solve<NB>(c, om, sv, cc, P.F + (size_t)b * P.fsz, r, S.T + L.m, d, border_ptrs(L, P, S), S.tv);
+        double mx[2] = {0.0, 0.0};
+        for (int j = tid; j < L.n; j += NT) { const double dj = d[j], xj = x[j] + dj; x[j] = xj; mx[0] = fmax(mx[0], fabs(dj)); mx[1] = fmax(mx[1], fabs(xj)); }
+        block_reduce<2, 1>(mx, dummy, S.red);
+        done = sw + 1;
+        settled = mx[0] <= tol * fmax(1.0, mx[1]);       // (the residuals of the settled iterate are evaluated by one more pass of the loop head)
+        for (int i = tid; i < L.n_x; i += NT) {
+            double ax = 0.0, lo, hi;
+            A_row(c, i, [&](double co, int idx) { ax += co * x[idx]; });
+            row_bounds(c, S.x0s, S.du0, i, lo, hi);
+            y[i] += (om[i] / cc) * (ax - lo);
+        }
+        __syncthreads();
+    }
+    block_reduce<4, 1>(nrm, dummy, S.red);
+    if (tid < 4) res[(size_t)b * 5 + tid] = nrm[tid];
+    if (tid == 4) res[(size_t)b * 5 + 4] = (double)done;
+    // the result as a solve reports it: solution, iterate (z = A x: what a warm start would begin from), info
+    double *xo = P.xo + (size_t)b * L.n, *yo = P.yo + (size_t)b * L.m;
+    for (int j = tid; j < L.n; j += NT) xo[j] = x[j];
+    for (int i = tid; i < L.m; i += NT) {
+        if (i >= L.n_x) y[i] = 0.0;
+        yo[i] = y[i];
+        double ax = 0.0; A_row(c, i, [&](double co, int idx) { ax += co * x[idx]; });
+        z[i] = ax;
+    }
+    if (tid == 0) {
+        mpcqp_info inf; inf.status = MPCQP_SOLVED; inf.iter = done; inf.rho_updates = 0; inf.reserved = 0;
+        inf.obj_val = 0.0; inf.pri_res = nrm[2]; inf.dua_res = nrm[0]; inf.rho = P.rho[b];
+        P.info[b] = inf;
+    }
+}
+
 __global__ void k_gather_u0(Lay L, const double *xo, double *u0, int batch) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < batch * L.nu) { int b = i / L.nu, j = i - b * L.nu; u0[i] = xo[(size_t)b * L.n + L.ou + j]; }

@@ -422,6 +422,14 @@ class BatchProblem:
         _lib.check(self._L.mpcqp_iterate(self._h, int(iters)), 'mpcqp_iterate')
         self.synchronize()
 
+    def eq_solve(self, sweeps, cold=True, tol=0.0):
+        """The equality-constrained part of the QP (dynamics rows only) by at most ``sweeps`` multiplier sweeps with the handle's KKT factor
+        (mpcqp_eq_solve); an instance stops once a correction is below ``tol * max(1, |w|)``.  Returns [B, 5]: the four residual norms
+        after the last sweep and the sweeps done; the solution is read with ``solution()``."""
+        res = np.empty((self.batch, 5))
+        _lib.check(self._L.mpcqp_eq_solve(self._h, int(sweeps), int(bool(cold)), float(tol), _ptr(res)), 'mpcqp_eq_solve')
+        return res
+
     def refactor(self):
         """Recompute every instance's KKT factor from its current rho (asynchronous; what one rho update costs)."""
         _lib.check(self._L.mpcqp_refactor(self._h), 'mpcqp_refactor')

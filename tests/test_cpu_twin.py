@@ -132,3 +132,20 @@ def test_batch_controller_stepwise_equals_closed_loop_call(twin):
             x = np.einsum('bij,bj->bi', st('Ad'), x) + np.einsum('bij,bj->bi', st('Bd'), u) + w[k]
             Kb.update(x)
     assert (tr['status'] == 1).all()
+
+
+def test_unconstrained_gains_host_logic_through_the_twin(twin):
+    """pympc_amd/unconstrained.py (unit-vector batch, mpcqp_eq_solve sweeps until the gains stop moving, slicing) through the ABI, the
+    twin's sweeps being the oracle's ADMM iterations on the same equality-constrained problems: against the condensed closed form."""
+    from pympc_amd import MPCController, fixtures
+    from closed_form import unconstrained_mpc
+    kw = fixtures.point_mass()
+    K = MPCController(**kw)
+    G = K.unconstrained_gains()
+    nx, nu, Np = 2, 1, kw['Np']
+    for which, key, size in (('x0', 'K_x0', nx), ('xref', 'K_xref', nx), ('uref', 'K_uref', nu), ('uminus1', 'K_um1', nu)):
+        for j in range(size):
+            args = dict(x0=np.zeros(nx), xref=np.zeros(nx), uref=np.zeros(nu), uminus1=np.zeros(nu))
+            args[which] = np.eye(size)[j]
+            u_seq, _ = unconstrained_mpc(kw['Ad'], kw['Bd'], Np, Qx=kw['Qx'], QxN=kw.get('QxN'), Qu=kw['Qu'], QDu=kw['QDu'], **args)
+            assert np.abs(G[key][:, j] - u_seq.ravel()).max() <= 1e-8 * max(1.0, np.abs(u_seq).max()), (key, j)

@@ -1,5 +1,5 @@
 """pympc_amd.unconstrained: the gains of the MPC law without inequality constraints (test_scripts/alternative/unconstrained.py:170-183),
-computed on the device by the ADMM / KKT backend, against the condensed closed form restated in tests/closed_form.py (dense normal
+computed on the device by multiplier sweeps with the KKT backend (mpcqp_eq_solve), against the condensed closed form restated in tests/closed_form.py (dense normal
 equations, shares nothing with the solver) -- and against the constrained controller itself where no constraint is active."""
 import warnings
 
@@ -38,7 +38,10 @@ def test_device_gains_equal_the_condensed_closed_form(case):
     R = _closed_form_gains(kw)
     for name in ('K_x0', 'K_xref', 'K_uref', 'K_um1'):
         assert G[name].shape == R[name].shape
-        assert np.abs(G[name] - R[name]).max() <= 1e-7 * max(1.0, np.abs(R[name]).max()), name
+        assert np.abs(G[name] - R[name]).max() <= 1e-9 * max(1.0, np.abs(R[name]).max()), name
+    assert K._gain_solver.sweeps <= 20, K._gain_solver.sweeps             # one factorization, a handful of KKT solves -- not an ADMM run
+    G2 = K.unconstrained_gains()                                           # the kept handle: same answer, no new allocation
+    assert K._gain_solver.prob is not None and all(np.array_equal(G[k], G2[k]) for k in G)
 
 
 def test_gains_reproduce_the_controller_where_no_constraint_is_active():
