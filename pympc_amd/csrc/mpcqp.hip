@@ -86,7 +86,10 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-constexpr int BCR_STAGES = 31;      // the shape the register-resident cyclic reduction is instantiated for: Np = 30
+constexpr int BCR_STAGES = 31;      // the largest stage count the register-resident cyclic reduction is instantiated for (Np = 30: the BASELINE shape)
+// The static schedule of mpcqp_lat.h exists for 11, 21 and 31 stages; a problem runs the smallest one that holds its N = Np + 1 stages (the rest
+// are identity padding: factor_bcr).  0: too long a horizon for this backend.
+static int bcr_schedule(int N) { return N <= 11 ? 11 : N <= 21 ? 21 : N <= BCR_STAGES ? BCR_STAGES : 0; }
 constexpr int BALANCE_EVERY = 16;  // solves between two rebuilds of the workgroup -> instance map
 constexpr int BALANCE_FIRST = 4;   // ... before the first one (an instance shows its character within a few solves; a short run should not end unbalanced)
 
@@ -230,16 +233,16 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     h->L.dense = dense ? 1 : 0;
     if (dense) h->L.tsz += DenseFmt::SCRATCH;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->ncu = prop.multiProcessorCount; }
-    // Up to two instances per compute unit (one resident, one queued): the latency backend (block cyclic reduction, factor resident in registers) for the
-    // shape it is compiled for -- BASELINE (12, 4, 30).  Larger batches stream the chain format (the bandwidth backend).
-    bool bcr = !dense && h->lds_state && L.NB == 16 && !L.border && L.nx == 12 && L.nu == 4 && L.N == BCR_STAGES && h->ncu > 0 && batch <= 2 * h->ncu;      // (measured cross-over with the bandwidth kernel: between 512 and 768 instances)
-    if (const char *e = getenv("MPCQP_BCR")) {      // development switch: 0 = never, 1 = whenever the shape allows (any batch)
-        if (atoi(e) == 0) bcr = false;
-        else bcr = !dense && h->lds_state && L.NB == 16 && !L.border && L.nx == 12 && L.nu == 4 && L.N == BCR_STAGES;
-    }
-    h->L.bcr = bcr ? 1 : 0;
-    if (bcr) h->L.tsz = std::max(h->L.tsz + L.N * L.NB, LAT_LDS_DOUBLES(L.N));      // the stage-major vectors of the latency round (mpcqp_lat.h); c_e of the streaming solve
-    P.fsz = dense ? (long long)DenseFmt::DOUBLES : bcr ? (long long)L.N * BcrFmt::REC : (long long)L.fhead + (long long)L.N * L.fstage;
+    // Up to two instances per compute unit (one resident, one queued): the latency backend (block cyclic reduction, factor resident in registers) for
+    // 16 x 16 stages and horizons of up to 30 steps -- the BASELINE shape (12, 4, 30) with compile-time dimensions, anything else with nx + nu <= 16 through
+    // the generic instantiations.  Larger batches stream the chain format (the bandwidth backend).
+    const bool bcr_shape = !dense && h->lds_state && L.NB == 16 && !L.border && bcr_schedule(L.N) > 0;
+    bool bcr = bcr_shape && h->ncu > 0 && batch <= 2 * h->ncu;      // (measured cross-over with the bandwidth kernel at (12,4,30): between 512 and 768 instances)
+    if (const char *e = getenv("MPCQP_BCR")) bcr = atoi(e) != 0 && bcr_shape;      // development switch: 0 = never, 1 = whenever the shape allows (any batch)
+    h->L.bcr = bcr ? bcr_schedule(L.N) : 0;
+    const int NS = h->L.bcr;                                        // stages of the schedule (>= L.N)
+    if (bcr) h->L.tsz = std::max(h->L.tsz + NS * L.NB, LAT_LDS_DOUBLES(NS));      // the stage-major vectors of the latency round (mpcqp_lat.h); c_e of the streaming solve
+    P.fsz = dense ? (long long)DenseFmt::DOUBLES : bcr ? (long long)NS * BcrFmt::REC : (long long)L.fhead + (long long)L.N * L.fstage;
     int rc = 0;
     rc |= dalloc(h, &P.model, B * L.model_sz); rc |= dalloc(h, &P.step, B * L.step_sz);
     rc |= dalloc(h, &P.D, B * L.n); rc |= dalloc(h, &P.E, B * L.m); rc |= dalloc(h, &P.c, B);
@@ -249,7 +252,7 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     rc |= dalloc(h, &P.xo, B * L.n); rc |= dalloc(h, &P.yo, B * L.m);
     rc |= dalloc(h, &P.dx, B * L.n); rc |= dalloc(h, &P.dy, B * L.m);
     rc |= dalloc(h, &P.qv, B * (size_t)(L.n_x + L.n_u));
-    if (bcr) rc |= dalloc(h, &P.bws, B * (size_t)L.N * BcrFmt::WSTAGE);
+    if (bcr) rc |= dalloc(h, &P.bws, B * (size_t)NS * BcrFmt::WSTAGE);
     if (L.border) { rc |= dalloc(h, &P.Bb, B * (size_t)L.nu * L.N * L.NB); rc |= dalloc(h, &P.Zb, B * (size_t)L.nu * L.N * L.NB); rc |= dalloc(h, &P.Sig, B * (size_t)L.nu * L.nu); }
     rc |= dalloc(h, &P.Dt, B * L.n); rc |= dalloc(h, &P.Et, B * L.m);
     rc |= dalloc(h, &P.ctype, B * L.m); rc |= dalloc(h, &P.info, B); rc |= dalloc(h, &P.stats, 8);
@@ -585,7 +588,10 @@ static int launch_run(mpcqp_handle *h, RunArgs R, int plain_iters) {
     }
     int rc;
     if (L.dense) rc = launch_run_t<16, true, 0, 0, MODE_DENSE>(h, R);
-    else if (L.bcr) rc = launch_run_t<16, true, 12, 4, MODE_BCR + BCR_STAGES>(h, R);
+    else if (L.bcr == 31 && L.nx == 12 && L.nu == 4) rc = launch_run_t<16, true, 12, 4, MODE_BCR + 31>(h, R);
+    else if (L.bcr == 31) rc = launch_run_t<16, true, 0, 0, MODE_BCR + 31>(h, R);
+    else if (L.bcr == 21) rc = launch_run_t<16, true, 0, 0, MODE_BCR + 21>(h, R);
+    else if (L.bcr == 11) rc = launch_run_t<16, true, 0, 0, MODE_BCR + 11>(h, R);
     else if (L.NB == 16 && h->lds_state && L.nx == 12 && L.nu == 4 && !L.border) rc = launch_run_t<16, true, 12, 4, MODE_CHAIN>(h, R);
     else if (L.NB == 32 && !h->lds_state && L.nx == 20 && L.nu == 8 && !L.border) rc = launch_run_t<32, false, 20, 8, MODE_CHAIN>(h, R);
     else if (L.NB == 16) rc = h->lds_state ? launch_run_generic<16, true>(h, R) : launch_run_generic<16, false>(h, R);
@@ -939,7 +945,7 @@ extern "C" int mpcqp_get_stream_bytes(mpcqp_handle *h, int64_t *per_iter, int64_
     if (L.border && !L.dense) it += 2 * (int64_t)L.nu * L.N * NB;      // (the dense inverse holds the held input's couplings itself)
     int64_t rd = (L.model_sz - L.hot_sz) + 2 * n + 2 * m /* D, s, E, omega */ + n + m /* dx, dy */;
     if (L.dense) rd += DenseFmt::DOUBLES;               // the round's load of K^-1 into registers
-    if (L.bcr) rd += (int64_t)L.N * BcrFmt::REC - 4 * BcrFmt::NN;      // ... of the cyclic-reduction fragments (the two end stages have one neighbour)
+    if (L.bcr) rd += (int64_t)L.bcr * BcrFmt::REC - 4 * BcrFmt::NN;      // ... of the cyclic-reduction fragments (the two end stages have one neighbour)
     rd += h->lds_state ? 2 * (n + 2 * m) /* iterate in and out of LDS */ + (m + L.n_x) + (n + L.n_x) + nq : (n + 2 * m);
     int64_t sv = L.hot_sz + L.step_sz + 3 * m /* E, types, omega */ + nq + 2 * (n + m) /* solution out, iterate read */;
     if (per_iter) *per_iter = 8 * it;
@@ -956,9 +962,9 @@ extern "C" int mpcqp_get_work(mpcqp_handle *h, int64_t *mfma_per_iter) {
     int64_t mv = 0;                                  // 16 x 16 mat-vecs (four MFMAs each)
     if (L.dense || L.NB == 64) mv = 0;               // vector ALU only
     else if (L.bcr) {
-        for (int l = 0; l < bcr_levels(L.N); ++l)
-            for (int kind = 0; kind < 3; ++kind) for (int t = 0; t < lat_count(L.N, l, kind); ++t) mv += lat_nfr(L.N, l, kind, t);
-        mv += 2 * ((L.N + 3) / 4);                   // G v and G'W: one group per four stages each
+        for (int l = 0; l < bcr_levels(L.bcr); ++l)
+            for (int kind = 0; kind < 3; ++kind) for (int t = 0; t < lat_count(L.bcr, l, kind); ++t) mv += lat_nfr(L.bcr, l, kind, t);
+        mv += 2 * ((L.bcr + 3) / 4);                 // G v and G'W: one group per four stages each
     } else {
         const int64_t blk = (L.NB / 16) * (L.NB / 16);
         mv = L.ffwd ? (int64_t)(L.N - 1) * blk * 3 + 3 * blk : (int64_t)(L.N - 1) * blk * 4 + 3 * blk;      // forward 1 (or 2) + backward 2 mat-vecs per stage, the middle stage
@@ -972,9 +978,10 @@ extern "C" int mpcqp_get_work(mpcqp_handle *h, int64_t *mfma_per_iter) {
 extern "C" int mpcqp_kernel_name(mpcqp_handle *h, int loop, char *buf, int buflen) {
     if (!h || !buf || buflen < 1) return fail(MPCQP_ERR_ARG, "null argument");
     const Lay &L = h->L;
-    const bool spec = L.bcr || !L.border && !L.dense && ((L.NB == 16 && h->lds_state && L.nx == 12 && L.nu == 4) || (L.NB == 32 && !h->lds_state && L.nx == 20 && L.nu == 8));
+    const bool spec = !L.border && !L.dense && (L.bcr ? (L.bcr == 31 && L.nx == 12 && L.nu == 4)
+                                                        : ((L.NB == 16 && h->lds_state && L.nx == 12 && L.nu == 4) || (L.NB == 32 && !h->lds_state && L.nx == 20 && L.nu == 8)));
     snprintf(buf, (size_t)buflen, "k_mpc_run<%d,%s,%d,%d,%d,%s>", L.NB, h->lds_state ? "true" : "false", spec ? L.nx : 0, spec ? L.nu : 0,
-             L.dense ? MODE_DENSE : L.bcr ? MODE_BCR + BCR_STAGES : L.border ? MODE_BORDER : MODE_CHAIN, loop ? "true" : "false");
+             L.dense ? MODE_DENSE : L.bcr ? MODE_BCR + L.bcr : L.border ? MODE_BORDER : MODE_CHAIN, loop ? "true" : "false");
     return MPCQP_OK;
 }
 

@@ -34,11 +34,13 @@ struct BcrFmt {
 // Factorization (run time N).  Wg: this instance's global workspace, N * WSTAGE doubles; W: LDS, BcrFmt::LDSW doubles.
 // Four thread groups (one wave each) eliminate four stages of a level side by side; barriers are workgroup-wide, every
 // thread makes the same calls.  Returns 1 on a non-positive pivot.
+// N = L.bcr >= L.N is the stage count of the elimination tree (the register-resident schedule of mpcqp_lat.h exists for a few sizes): the
+// stages beyond the problem's own are identity blocks without couplings -- they cost the schedule a few idle mat-vecs and change nothing.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int factor_bcr(const Ctx &c, const double *om, const double *sv, double cc, double *F, double *Wg, double *W, int *iflag) {
     constexpr int NN = BcrFmt::NN, G = 4, T = NT / G, EPT = NN / T, NB = 16;
     const Lay &L = c.L;
-    const int N = L.N, tid = threadIdx.x, g = tid / T, lt = tid % T;
+    const int N = L.bcr, NR = L.N, tid = threadIdx.x, g = tid / T, lt = tid % T;
     double *Kd = Wg, *Up = Wg + (size_t)N * NN, *dKL = Up + (size_t)N * NN, *dKR = dKL + (size_t)N * NN;
     if (tid == 0) *iflag = 0;
     // (omega and s through an LDS copy behind the workspace: every entry of a diagonal block sums nx products of them)
@@ -48,8 +50,8 @@ __device__ __forceinline__ int factor_bcr(const Ctx &c, const double *om, const 
     __syncthreads();
     for (int idx = tid; idx < N * NN; idx += NT) {
         const int k = idx / NN, r = idx % NN, a = r / NB, b = r % NB;
-        Kd[idx] = kkt_diag_entry(c, oml, svl, cc, k, a, b);
-        Up[idx] = (k + 1 < N) ? kkt_sub_entry(c, oml, cc, k, b, a) : 0.0;      // K_{k,k+1}[a][b] = K_{k+1,k}[b][a]
+        Kd[idx] = k < NR ? kkt_diag_entry(c, oml, svl, cc, k, a, b) : (a == b ? 1.0 : 0.0);
+        Up[idx] = (k + 1 < NR) ? kkt_sub_entry(c, oml, cc, k, b, a) : 0.0;     // K_{k,k+1}[a][b] = K_{k+1,k}[b][a]
     }
     __syncthreads();
     double *D = W + g * 5 * NN, *BL = D + NN, *BR = D + 2 * NN, *LL = D + 3 * NN, *LR = D + 4 * NN;
@@ -114,7 +116,7 @@ __device__ __forceinline__ int factor_bcr(const Ctx &c, const double *om, const 
             __syncthreads();
             if (on) {
                 double *rec = F + (size_t)e * BcrFmt::REC;
-                const int nbk = (e < L.NcT) ? L.nb : L.nx;     // variables of this stage; the rest is padding (identity in K, zero in the factor)
+                const int nbk = e >= NR ? 0 : (e < L.NcT) ? L.nb : L.nx;     // variables of this stage; the rest is padding (identity in K, zero in the factor)
 #pragma unroll
                 for (int u = 0; u < EPT; ++u) {
                     const int idx = lt + T * u, a = idx / NB, b = idx % NB;

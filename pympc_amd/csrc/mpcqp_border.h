@@ -123,7 +123,11 @@ __device__ void kkt_solve(const Ctx &c, const double *om, const double *sv, doub
     const bool bordered = L.border && !L.dense;            // (the dense inverse holds the held input's couplings itself)
     if (bordered) border_pre<NB>(L, bp.Bb, bp.Zb, bp.Sig, Tc, ubar, bp.red);
     if (NB == 16 && L.dense) dense_core<NB>(L, F, Tc, Tc + L.N * NB, dense_slot<NB>(L));
-    else if (NB == 16 && L.bcr) bcr_core_stream(F, L.N, Tc, Tc + L.N * NB);
+    else if (NB == 16 && L.bcr) {
+        for (int idx = L.N * NB + threadIdx.x; idx < L.bcr * NB; idx += NT) Tc[idx] = 0.0;      // (the schedule's padding stages)
+        __syncthreads();
+        bcr_core_stream(F, L.bcr, Tc, Tc + L.bcr * NB);
+    }
     else kkt_core<NB>(core_args(L, F, om), Tc);
     if (bordered) border_post(L, NB, Tc, ubar);
     for (int idx = threadIdx.x; idx < L.N * NB; idx += NT) {

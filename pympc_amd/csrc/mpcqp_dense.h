@@ -76,7 +76,11 @@ __device__ __forceinline__ int factor_dense(const Ctx &c, const double *om, cons
             const int jj = e / NR, w = e - jj * NR, kw = w / nb, aw = w - kw * nb;
             const int var = aw < L.nx ? kw * L.nx + aw : (kw < L.Nc ? L.ou + kw * L.nu + (aw - L.nx) : -1);
             const double v = var >= 0 ? kkt_entry_generic(c, oml, svl, cc, ub0 + jj, var) : 0.0;
-            W[(vb0 + jj) * ld + w] = v; W[w * ld + vb0 + jj] = v;
+            W[(vb0 + jj) * ld + w] = v;
+            // (the mirror entry -- except inside the held input's own nu x nu block, where the item (jj', w') of the other input writes it: two
+            //  threads storing sums formed in different orders to one address made the factor, and with it every iterate, depend on which store
+            //  landed last -- 1e-13 from handle to handle at nu = 2, found by scripts/fuzz_loop.py)
+            if (w < vb0 || w >= vb0 + L.nu) W[w * ld + vb0 + jj] = v;
         }
         __syncthreads();
     }

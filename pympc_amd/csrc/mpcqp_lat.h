@@ -1,5 +1,6 @@
 // mpcqp_lat.h -- part of libmpcqp_hip (included by mpcqp.hip, one translation unit).
-// The LATENCY round of 16 x 16 stages (MODE_BCR + N: at most one instance per compute unit, BASELINE shape (12, 4, 30)):
+// The LATENCY round of 16 x 16 stages (MODE_BCR + N: at most two instances per compute unit; any nx + nu <= 16 and up to 31 stages, the BASELINE
+// shape (12, 4, 30) with compile-time dimensions):
 // block cyclic reduction with the factor resident in registers (mpcqp_bcr.h), the iterate resident in registers, the
 // products with [Ad Bd] on the matrix cores.
 //
@@ -213,8 +214,10 @@ __device__ __forceinline__ d4 lat_make_frag(int lane, Fn f) {
 
 template <int NXT, int NUT, int NST>
 __device__ __forceinline__ void admm_lat(const Lay &L, const HotPtrs &P, Smem &S, double *Xl, double *Zl, double *Yl, double alpha, int iters) {
-    constexpr int NB = 16, nx = NXT, nu = NUT, N = NST, NG = (N + 3) / 4;
-    static_assert(NG <= 2 * NWAVES && nx + nu <= NB, "owner map: two groups of four stages per wave");
+    // NST: stage count of the static schedule (compile time), NR <= NST the problem's own (run time); NXT / NUT = 0: nx, nu from the layout
+    constexpr int NB = 16, N = NST, NG = (N + 3) / 4;
+    static_assert(NG <= 2 * NWAVES && NXT + NUT <= NB, "owner map: two groups of four stages per wave");
+    const int nx = NXT ? NXT : L.nx, nu = NUT ? NUT : L.nu, NR = L.N;
     const int b = inst_of(P.perm), tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     gdouble *gx = (gdouble *)(P.x + (size_t)b * L.n), *gz = (gdouble *)(P.z + (size_t)b * L.m), *gy = (gdouble *)(P.y + (size_t)b * L.m);
     cgdouble *om = (cgdouble *)(P.omega + (size_t)b * L.m), *sv = (cgdouble *)(P.s + (size_t)b * L.n), *qv = (cgdouble *)S.Qv;
@@ -249,9 +252,10 @@ __device__ __forceinline__ void admm_lat(const Lay &L, const HotPtrs &P, Smem &S
     bool ok[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        const int s = 4 * (wv + NWAVES * q) + J;
+        // (a group beyond the schedule's last -- shorter schedules have fewer than eight -- owns nothing: it is parked on the zero slot behind the last stage)
+        const int g = wv + NWAVES * q, s = g < NG ? 4 * g + J : 4 * NG;
         sl[q] = s * NB + a;
-        ok[q] = is_x ? s < N : (a < nx + nu && s < N - 1);
+        ok[q] = is_x ? s < NR : (a < nx + nu && s < NR - 1);
         const int e = s * nx + a, cu = s * nu + jj;
         pidx[q] = is_x ? e : L.ou + cu; aidx[q] = is_x ? e : L.ri + cu; bidx[q] = is_x ? L.rs + e : L.rdu + nu + cu;
         pv[q] = pv2[q] = svp[q] = ncq[q] = sve[q] = kap[q] = okap[q] = te[q] = 0.0;

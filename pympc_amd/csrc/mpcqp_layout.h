@@ -26,7 +26,8 @@ struct Lay {
     int fhead, ffwd, ftab;        // doubles of the per-instance factor header ([G | G']) / of a stage's forward matrix / of its off-diagonal table (hybrid)
     int tsz;                      // LDS work vector length: max(m, 4*NB*NB)
     int dense;                    // 1: small problem -- the KKT solve is a dense mat-vec with K^-1 held in registers (mpcqp_dense.h)
-    int bcr;                      // 1: block cyclic reduction instead of the twisted sweeps (mpcqp_bcr.h; small batches of 16 x 16 stages)
+    int bcr;                      // > 0: block cyclic reduction instead of the twisted sweeps (mpcqp_bcr.h; small batches of 16 x 16 stages); the value is the
+                                  // stage count of the schedule the handle runs (11, 21 or 31 >= N: stages N .. bcr-1 are identity padding)
     int NR, dld;                  // dense: unknowns N*(nx+nu) of the reduced KKT system; LDS row stride of the inversion workspace (odd)
 };
 

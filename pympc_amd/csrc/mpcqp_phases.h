@@ -119,7 +119,7 @@ __global__ __launch_bounds__(NT) void k_setup(Lay L, Ptrs P, mpcqp_settings S_) 
     if (tid == 0) { P.c[b] = cc; P.rho[b] = rho; }
     __syncthreads();
     int bad = NB == 16 && L.dense ? factor_dense(c, om, sv, cc, P.F + (size_t)b * P.fsz, S.T, S.iflag)
-            : NB == 16 && L.bcr ? factor_bcr(c, om, sv, cc, P.F + (size_t)b * P.fsz, P.bws + (size_t)b * L.N * BcrFmt::WSTAGE, S.T, S.iflag)
+            : NB == 16 && L.bcr ? factor_bcr(c, om, sv, cc, P.F + (size_t)b * P.fsz, P.bws + (size_t)b * L.bcr * BcrFmt::WSTAGE, S.T, S.iflag)
                       : factor_all<NB>(c, om, sv, cc, P.F + (size_t)b * P.fsz, S.T, S.iflag, border_ptrs(L, P, S));
     // cold start
     for (int j = tid; j < L.n; j += NT) { P.x[(size_t)b * L.n + j] = 0.0; P.xo[(size_t)b * L.n + j] = 0.0; }

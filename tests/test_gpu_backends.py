@@ -1,7 +1,7 @@
 """The KKT system of an ADMM iteration has more than one solver on the device -- the block-tridiagonal sweeps (every size),
-the dense register-resident inverse (N (nx+nu) <= 128: the reference's own examples) -- and mpcqp_create picks one by problem
-size.  Everything must hold for EVERY backend a problem is eligible for: the same tests as tests/test_gpu_parity.py, with
-the development switches MPCQP_DENSE=0/1 forcing the choice, plus bit-level agreement of the paths that must not depend on it."""
+the dense register-resident inverse (N (nx+nu) <= 128: the reference's own examples), block cyclic reduction with a register-resident
+factor (16 x 16 stages, up to 31 of them) -- and mpcqp_create picks one by problem size and batch.  Everything must hold for EVERY backend a problem is eligible for: the same tests as tests/test_gpu_parity.py, with
+the development switches MPCQP_DENSE / MPCQP_BCR forcing the choice, plus bit-level agreement of the paths that must not depend on it."""
 import os
 import warnings
 from contextlib import contextmanager
@@ -37,12 +37,25 @@ def _dense_eligible(name):
     return (Np + 1) * (nx + nu) <= 128 and kw.get('Nc', Np) in (None, Np)
 
 
+def _bcr_schedule(name):
+    """Stage count of the cyclic-reduction schedule mpcqp_create gives the fixture (11, 21 or 31 >= Np + 1), or 0: 16 x 16 stages,
+    no held input, at most 31 stages."""
+    kw = golden_kwargs(load_golden(name))
+    nx, nu = np.atleast_2d(kw['Bd']).shape if np.ndim(kw['Bd']) == 2 else (np.asarray(kw['Ad']).shape[0], 1)
+    Np = kw['Np']
+    if nx + nu > 16 or kw.get('Nc', Np) not in (None, Np) or Np + 1 > 31:
+        return 0
+    return 11 if Np + 1 <= 11 else 21 if Np + 1 <= 21 else 31
+
+
 SMALL = [n for n in golden_names() if _dense_eligible(n)]
-BACKENDS = [dict(MPCQP_DENSE=0), dict(MPCQP_DENSE=1)]
+SWEEPS, DENSE, BCR = dict(MPCQP_DENSE=0, MPCQP_BCR=0), dict(MPCQP_DENSE=1), dict(MPCQP_DENSE=0, MPCQP_BCR=1)
+BACKENDS = [SWEEPS, DENSE]
 IDS = ['sweeps', 'dense']
-# block cyclic reduction (register-resident factor) is instantiated for the BASELINE shape (12, 4, 30)
-BCR_NAMES = [n for n in golden_names() if n.startswith('random_12_4_30') and 'nc' not in n]
-CASES = [(n, e, i) for n in SMALL for e, i in zip(BACKENDS, IDS)] + [(n, e, i) for n in BCR_NAMES for e, i in ((dict(MPCQP_BCR=0), 'sweeps'), (dict(MPCQP_BCR=1), 'bcr'))]
+# block cyclic reduction (register-resident factor): any fixture with 16 x 16 stages, Nc = Np and at most 31 stages -- the BASELINE shape (12, 4, 30) with
+# compile-time dimensions, everything else (the reference's examples, the quadcopter, soft and hard state boxes) through the generic instantiations
+BCR_NAMES = [n for n in golden_names() if _bcr_schedule(n)]
+CASES = [(n, e, i) for n in SMALL for e, i in zip(BACKENDS, IDS)] + [(n, SWEEPS, 'sweeps') for n in BCR_NAMES if n not in SMALL] + [(n, BCR, 'bcr') for n in BCR_NAMES]
 CASE_IDS = ['%s-%s' % (n, i) for n, e, i in CASES]
 
 
@@ -62,6 +75,7 @@ def _rel(a, b):
 
 def test_some_fixture_is_small_enough():
     assert len(SMALL) >= 2, SMALL
+    assert {_bcr_schedule(n) for n in BCR_NAMES} == {11, 21, 31}, BCR_NAMES          # every schedule is exercised
 
 
 @pytest.mark.parametrize('name,env,tag', CASES, ids=CASE_IDS)
@@ -69,7 +83,7 @@ def test_backend_is_the_one_asked_for(name, env, tag):
     with backend(**env):
         K = _ctrl(golden_kwargs(load_golden(name))); K.setup(solve=False)
         kn = K.prob.batch_problem.kernel_name(loop=False)
-    assert kn.split(',')[4] == {'sweeps': '0', 'dense': '2', 'bcr': '131'}[tag], kn
+    assert kn.split(',')[4] == {'sweeps': '0', 'dense': '2', 'bcr': str(100 + _bcr_schedule(name))}[tag], kn
 
 
 @pytest.mark.parametrize('name,env,tag', CASES, ids=CASE_IDS)
@@ -148,3 +162,34 @@ def test_closed_loop_is_the_same_on_both_backends(name):
     assert np.array_equal(a['status'], b['status'])
     assert np.abs(a['u'] - b['u']).max() <= 1e-7 * max(1.0, np.abs(a['u']).max())
     assert np.abs(a['x'] - b['x']).max() <= 1e-7 * max(1.0, np.abs(a['x']).max())
+
+
+def test_held_multi_input_on_the_dense_backend_is_reproducible():
+    """Nc < Np with nu > 1 on the dense backend (random (4,2,10), Nc = 3, four controllers): the assembly of the held input's rows and
+    columns used to store two differently-ordered sums to the same entry of K from two threads, so the factor -- and every iterate
+    after it -- depended on which store landed last (1e-13 from handle to handle; found by scripts/fuzz_loop.py in round 4).  Two
+    handles must now agree bit for bit, and the device loop with the stepwise API as everywhere else."""
+    from pympc_amd import BatchMPCController, fixtures
+    nx, nu, Np, Nc, B = 4, 2, 10, 3, 4
+    kws = [fixtures.random_lti(53007 + i, nx=nx, nu=nu, Np=Np, xbox=4.0) for i in range(B)]
+    stack = lambda k: np.stack([np.asarray(kw[k], dtype=float) for kw in kws])
+    keys = ('x0', 'xref', 'uref', 'uminus1', 'Qx', 'QxN', 'Qu', 'QDu', 'xmin', 'xmax', 'umin', 'umax', 'Dumin', 'Dumax')
+
+    def make():
+        K = BatchMPCController(stack('Ad'), stack('Bd'), Np=Np, Nc=Nc, **{k: stack(k) for k in keys})
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            K.setup()
+        return K
+    Ka, Kb, Kc = make(), make(), make()
+    assert Ka.prob.kernel_name(loop=False).split(',')[4] == '2'               # the dense backend
+    xa, xb = Ka.prob.solution()[0], Kb.prob.solution()[0]
+    assert np.array_equal(xa, xb) and np.array_equal(xa, Kc.prob.solution()[0])
+    w = 0.01 * np.random.default_rng(3).standard_normal((6, B, nx))
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        tr = Ka.run(6, w=w)
+        for k in range(6):
+            assert np.array_equal(Kb.output(), tr['u'][k]), k
+            Kb.update(tr['x'][k + 1])
+            assert [i.iter for i in Kb.prob.infos()] == list(tr['iter'][k])
