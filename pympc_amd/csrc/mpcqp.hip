@@ -73,6 +73,7 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #include "mpcqp_qp.h"
 #include "mpcqp_factor.h"
 #include "mpcqp_sweeps.h"
+#include "mpcqp_group.h"
 #include "mpcqp_bcr.h"
 #include "mpcqp_wide.h"
 #include "mpcqp_dense.h"
@@ -240,9 +241,19 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     bool bcr = bcr_shape && h->ncu > 0 && batch <= 2 * h->ncu;      // (measured cross-over with the bandwidth kernel at (12,4,30): between 512 and 768 instances)
     if (const char *e = getenv("MPCQP_BCR")) bcr = atoi(e) != 0 && bcr_shape;      // development switch: 0 = never, 1 = whenever the shape allows (any batch)
     h->L.bcr = bcr ? bcr_schedule(L.N) : 0;
+    // Small stages (nx + nu <= 8) that neither of the register-resident backends takes: several stages per 16 x 16 block (mpcqp_group.h) -- the
+    // chain and the factor shrink by the group size.  (Worth it once the chain is long: at least three super-stages.)
+    int grp = (!dense && !bcr && L.NB == 16 && group_size(L.nb) >= 2 && group_count(L.N, group_size(L.nb)) >= 3) ? group_size(L.nb) : 0;
+    if (const char *e = getenv("MPCQP_GROUP")) { if (atoi(e) == 0) grp = 0; }      // development switch (A/B against one stage per block)
+    h->L.grp = grp;
+    if (grp) {
+        h->L.fstage = GroupFmt::REC; h->L.fhead = 0; h->L.ffwd = GroupFmt::NN; h->L.ftab = 0;
+        h->L.tsz += group_count(L.N, grp) * L.NB;          // the grouped vector Tg behind Tc
+    }
     const int NS = h->L.bcr;                                        // stages of the schedule (>= L.N)
     if (bcr) h->L.tsz = std::max(h->L.tsz + NS * L.NB, LAT_LDS_DOUBLES(NS));      // the stage-major vectors of the latency round (mpcqp_lat.h); c_e of the streaming solve
-    P.fsz = dense ? (long long)DenseFmt::DOUBLES : bcr ? (long long)NS * BcrFmt::REC : (long long)L.fhead + (long long)L.N * L.fstage;
+    P.fsz = dense ? (long long)DenseFmt::DOUBLES : bcr ? (long long)NS * BcrFmt::REC : grp ? (long long)(group_count(L.N, grp) + 1) * GroupFmt::REC
+                  : (long long)L.fhead + (long long)L.N * L.fstage;
     int rc = 0;
     rc |= dalloc(h, &P.model, B * L.model_sz); rc |= dalloc(h, &P.step, B * L.step_sz);
     rc |= dalloc(h, &P.D, B * L.n); rc |= dalloc(h, &P.E, B * L.m); rc |= dalloc(h, &P.c, B);
@@ -941,6 +952,7 @@ extern "C" int mpcqp_get_stream_bytes(mpcqp_handle *h, int64_t *per_iter, int64_
     int64_t it = (L.dense || L.bcr) ? 0 /* the factor sits in registers for the round */ : !L.ffwd ? 2 * (int64_t)L.N * sinv + (int64_t)L.N * L.ftab + 2 * (int64_t)L.fhead   // S^-1-only build: S^-1 twice, one of the two tables per sweep, [G | G'] by each sweeping wave
                          : (int64_t)(L.N - 1) * L.ffwd + (int64_t)L.N * sinv + (int64_t)(L.N - 1) * L.ftab + L.fhead;   // forward matrices once, S^-1 once, the tables, G / G' once each
     if (L.NB == 64) it = (3 * (int64_t)L.N - 2) * WideFmt::NN;      // wide stages: S^-1 of every stage, M and M' of all but the last
+    if (L.grp) it = (3 * (int64_t)group_count(L.N, L.grp) - 1) * GroupFmt::NN;      // grouped small stages: S^-1 of every super-stage, forward matrix and its transpose of all but the ends, the middle's second pair
     if (!h->lds_state) it += (2 * n + 4 * m) /* x, z, y read + written */ + (m + L.n_x) /* omega */ + (n + L.n_x) /* s */ + nq /* q */;
     if (L.border && !L.dense) it += 2 * (int64_t)L.nu * L.N * NB;      // (the dense inverse holds the held input's couplings itself)
     int64_t rd = (L.model_sz - L.hot_sz) + 2 * n + 2 * m /* D, s, E, omega */ + n + m /* dx, dy */;
@@ -965,7 +977,8 @@ extern "C" int mpcqp_get_work(mpcqp_handle *h, int64_t *mfma_per_iter) {
         for (int l = 0; l < bcr_levels(L.bcr); ++l)
             for (int kind = 0; kind < 3; ++kind) for (int t = 0; t < lat_count(L.bcr, l, kind); ++t) mv += lat_nfr(L.bcr, l, kind, t);
         mv += 2 * ((L.bcr + 3) / 4);                 // G v and G'W: one group per four stages each
-    } else {
+    } else if (L.grp) mv = 3 * (int64_t)group_count(L.N, L.grp) - 1;      // forward 1, backward 2 mat-vecs per super-stage, the middle stage
+    else {
         const int64_t blk = (L.NB / 16) * (L.NB / 16);
         mv = L.ffwd ? (int64_t)(L.N - 1) * blk * 3 + 3 * blk : (int64_t)(L.N - 1) * blk * 4 + 3 * blk;      // forward 1 (or 2) + backward 2 mat-vecs per stage, the middle stage
     }

@@ -83,10 +83,22 @@ __device__ __forceinline__ RunSmem run_smem(const Lay &L, const Ptrs &P) {
 
 // (OCC: workgroups per CU of the calling kernel -- a tag only: it keeps the phases of kernels with different launch bounds apart,
 //  so that the register budget of the one-workgroup-per-CU kernels does not leak into the four-per-CU ones through a shared callee)
+// (the grouped small stages' factorization: a function of its own, see factor_grouped in mpcqp_group.h)
+template <int OCC>
+__device__ __noinline__ void run_group_factor_phase() {
+    const RunKArgs &A = run_kargs();
+    const Lay &L = A.L; const Ptrs &P = A.P;
+    RunSmem r = run_smem<false>(L, P);
+    const int b = inst_of(P.perm);
+    Ctx c{L, r.S.hot, P.model + (size_t)b * L.model_sz + L.hot_sz};
+    factor_grouped(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], P.F + (size_t)b * P.fsz, r.S.T, r.S.iflag, border_ptrs(L, P, r.S));
+}
+
 template <int NB, int OCC>
 __device__ __noinline__ void run_factor_phase() {
     const RunKArgs &A = run_kargs();
     const Lay &L = A.L; const Ptrs &P = A.P;
+    if constexpr (NB == 16) { if (L.grp > 1) { run_group_factor_phase<OCC>(); return; } }
     RunSmem r = run_smem<false>(L, P);                       // (the common LDS area comes first in both layouts)
     const int b = inst_of(P.perm);
     Ctx c{L, r.S.hot, P.model + (size_t)b * L.model_sz + L.hot_sz};

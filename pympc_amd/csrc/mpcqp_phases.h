@@ -118,7 +118,8 @@ __global__ __launch_bounds__(NT) void k_setup(Lay L, Ptrs P, mpcqp_settings S_) 
     for (int j = tid; j < L.n; j += NT) sv[j] = S_.sigma / (D[j] * D[j]);
     if (tid == 0) { P.c[b] = cc; P.rho[b] = rho; }
     __syncthreads();
-    int bad = NB == 16 && L.dense ? factor_dense(c, om, sv, cc, P.F + (size_t)b * P.fsz, S.T, S.iflag)
+    int bad = NB == 16 && L.grp > 1 ? factor_grouped(c, om, sv, cc, P.F + (size_t)b * P.fsz, S.T, S.iflag, border_ptrs(L, P, S))
+            : NB == 16 && L.dense ? factor_dense(c, om, sv, cc, P.F + (size_t)b * P.fsz, S.T, S.iflag)
             : NB == 16 && L.bcr ? factor_bcr(c, om, sv, cc, P.F + (size_t)b * P.fsz, P.bws + (size_t)b * L.bcr * BcrFmt::WSTAGE, S.T, S.iflag)
                       : factor_all<NB>(c, om, sv, cc, P.F + (size_t)b * P.fsz, S.T, S.iflag, border_ptrs(L, P, S));
     // cold start
@@ -984,7 +985,7 @@ __device__ __forceinline__ void admm_body(const Lay &L, const HotPtrs &P, Smem &
             bp.Bb = (double *)P.Bb + b * npb; bp.Zb = (double *)P.Zb + b * npb; bp.Sig = (double *)P.Sig + (size_t)b * L.nu * L.nu;
         }
         if (BORDER) border_pre<NB>(L, bp.Bb, bp.Zb, bp.Sig, Tc, S.tv, S.red);
-        kkt_core<NB>(core_args(L, opaque_ptr(F), opaque_ptr((const double *)P.omega + (size_t)b * L.m)), Tc);
+        kkt_core<NB, NB == 16 && NXT == 0>(core_args(L, opaque_ptr(F), opaque_ptr((const double *)P.omega + (size_t)b * L.m)), Tc);
         if (BORDER) border_post(L, NB, Tc, S.tv);
 #ifndef MPCQP_ABL_NOPAR
         if (LDSSTATE) own_update<NB, NXT, NUT>(L, S.hot, S.x0s, S.du0, hr, cc, alpha, X, Z, Y, W, Tc, keep_delta, dxg, dyg);

@@ -190,9 +190,9 @@ __device__ __forceinline__ void chain_sweep(const int first, const int dir, cons
 
 // What the linear-system core needs to know about one instance.
 // F: the stages; G: the constant fragments [G | G'] (in front of the stages in the S^-1-only format, behind them otherwise).
-struct CoreArgs { int N, fstage, nx, nu, NcT, rdu; const double *F; const double *G; const double *om; };
+struct CoreArgs { int N, fstage, nx, nu, NcT, rdu, grp; const double *F; const double *G; const double *om; };
 __device__ __forceinline__ CoreArgs core_args(const Lay &L, const double *F, const double *om) {
-    CoreArgs a; a.N = L.N; a.fstage = L.fstage; a.nx = L.nx; a.nu = L.nu; a.NcT = L.NcT; a.rdu = L.rdu; a.om = om;
+    CoreArgs a; a.N = L.N; a.fstage = L.fstage; a.nx = L.nx; a.nu = L.nu; a.NcT = L.NcT; a.rdu = L.rdu; a.om = om; a.grp = L.grp;
     a.F = L.ffwd ? F : F + L.fhead;
     a.G = L.ffwd ? F + (size_t)L.N * L.fstage : F;
     return a;
@@ -578,13 +578,16 @@ __device__ __forceinline__ void kkt_core_fwd(const CoreArgs &a, double *Tc) {
 // half-chains of the twisted factorization concurrently.  Tc must be seen by the compiler as an LDS pointer
 // (a pointer laundered through an integer becomes FLAT: flat LDS accesses count on vmcnt AND lgkmcnt and force a
 // full s_waitcnt vmcnt(0) -- draining the factor prefetch -- before every stage).
-template <int NB>
+__device__ __forceinline__ void kkt_core_group(const CoreArgs &, double *);      // mpcqp_group.h: several small stages per 16 x 16 block
+// (GROUPABLE = false: an instantiation that can never meet grouped stages -- compile-time nx + nu = 16 -- does not carry that path)
+template <int NB, bool GROUPABLE = (NB == 16)>
 __device__ __forceinline__ void kkt_core(const CoreArgs &a, double *Tc) {
 #ifndef MPCQP_ABL_NOCHAIN
+    if constexpr (NB == 16 && GROUPABLE) { if (a.grp > 1) { kkt_core_group(a, Tc); return; } }
     if constexpr (FactorFmt<NB>::SONLY) kkt_core_so<NB>(a, Tc);
     else kkt_core_fwd<NB>(a, Tc);                 // (each of them ends with a barrier)
 #else
     __syncthreads();
 #endif
 }
-template <> __device__ __forceinline__ void kkt_core<64>(const CoreArgs &, double *);      // mpcqp_wide.h (stages wider than 32)
+template <> __device__ __forceinline__ void kkt_core<64, false>(const CoreArgs &, double *);      // mpcqp_wide.h (stages wider than 32)

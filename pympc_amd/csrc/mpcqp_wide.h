@@ -221,4 +221,4 @@ __device__ __forceinline__ int factor_all<64>(const Ctx &c, const double *om, co
     return bad;
 }
 template <>
-__device__ __forceinline__ void kkt_core<64>(const CoreArgs &a, double *Tc) { wide_core(a.F, a.N, Tc, Tc + a.N * WideFmt::NB); TICK(3) }
+__device__ __forceinline__ void kkt_core<64, false>(const CoreArgs &a, double *Tc) { wide_core(a.F, a.N, Tc, Tc + a.N * WideFmt::NB); TICK(3) }

@@ -11,6 +11,7 @@ from pympc_amd.solver import BatchProblem
 name = sys.argv[1] if len(sys.argv) > 1 else 'cart_pole'
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 kw = getattr(fixtures, name)()
+if os.environ.get('NP'): kw = dict(kw, Np=int(os.environ['NP']), Nc=int(os.environ.get('NC', os.environ['NP'])))
 nx, nu = np.asarray(kw['Bd']).reshape(np.asarray(kw['Ad']).shape[0], -1).shape
 Np = kw['Np']; Nc = kw.get('Nc') or Np
 one = lambda a, shp: np.asarray(a, dtype=float).reshape((1,) + shp)

@@ -1,0 +1,162 @@
+"""GROUPED stages (pympc_amd/csrc/mpcqp_group.h): long horizons of small stages -- nx + nu <= 8 -- put several stages into one 16 x 16 block of
+the KKT factor (the reference's published timing example, examples/example_inverted_pendulum_kalman.ipynb, is such a problem: nx = 4, nu = 1,
+Np = 150, Nc = 75).  The backend is chosen by mpcqp_create; everything the other backends are held to must hold here too: the reduced-KKT solve
+against dense numpy, ADMM iterates, status / iteration counts at the default tolerance and u* at the north-star tolerance against the oracle,
+the device loop against the stepwise API bit for bit, and agreement with the one-stage-per-block sweeps (development switch MPCQP_GROUP=0)."""
+import os
+import warnings
+from contextlib import contextmanager
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+# (nx, nu, Np, Nc, soft): g = 16 // (nx + nu) stages per block -- 3, 3, 8, 3, 2, 2, 4, 5; horizons that are and are not multiples of g; held
+# inputs (Nc < Np: the bordered correction around the grouped solve) with nu = 1 and nu = 2; a hard state box
+SHAPES = [(4, 1, 150, 75, True), (4, 1, 61, 61, True), (1, 1, 90, 90, True), (3, 2, 50, 20, True), (5, 3, 40, 40, True), (7, 1, 45, 45, False),
+          (3, 1, 64, 17, True), (2, 1, 77, 77, False)]
+IDS = ['%d_%d_%d_%d%s' % (s[0], s[1], s[2], s[3], '' if s[4] else '_hard') for s in SHAPES]
+
+
+@contextmanager
+def env(**kv):
+    old = {k: os.environ.get(k) for k in kv}
+    os.environ.update({k: str(v) for k, v in kv.items()})
+    try:
+        yield
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _kw(shape, seed=0, **more):
+    from pympc_amd import fixtures
+    nx, nu, Np, Nc, soft = shape
+    if (nx, nu) == (4, 1):
+        kw = dict(fixtures.cart_pole()); kw.update(Np=Np)                  # the notebook's plant (unstable: what makes long horizons hard)
+    else:
+        kw = dict(fixtures.random_lti(71000 + 13 * nx + nu + seed, nx=nx, nu=nu, Np=Np, xbox=4.0))
+        kw['x0'] = 0.4 * kw['x0']
+    kw.update(Nc=Nc)
+    kw.update(more)
+    return kw
+
+
+def _ctrl(shape, oracle=False, settings=None, **more):
+    from pympc_amd import MPCController
+    K = MPCController(**_kw(shape, **more))
+    K.SOFT_ON = shape[4]
+    if oracle:
+        from oracle.osqp_oracle import OSQP
+        K.prob = OSQP()
+    K.solver_settings = dict(settings or {})
+    return K
+
+
+def _grouped(bp, shape):
+    nx, nu, Np = shape[:3]
+    g = 16 // (nx + nu)
+    return bp.factor_doubles == (-(-(Np + 1) // g) + 1) * 768
+
+
+@pytest.mark.parametrize('shape', SHAPES, ids=IDS)
+def test_backend_and_kkt_solve(shape):
+    """mpcqp_create chooses the grouped factor for these shapes; K sol = rhs against dense numpy on the host-built matrices."""
+    K = _ctrl(shape)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        K.setup(solve=False)
+    bp = K.prob.batch_problem
+    assert _grouped(bp, shape), bp.factor_doubles
+    D, E, c, rho = bp.scaling()
+    U = sp.triu(K.P).toarray(); P = U + np.triu(U, 1).T
+    A = K.A.toarray()
+    l, u = np.clip(K.l, -1e30, 1e30), np.clip(K.u, -1e30, 1e30)
+    ls, us = E[0] * l, E[0] * u
+    rho_vec = np.where((ls < -1e26) & (us > 1e26), 1e-6, np.where(us - ls < 1e-4, 1e3 * rho[0], rho[0]))
+    Kmat = c[0] * P + np.diag(1e-6 / D[0] ** 2) + A.T @ np.diag(rho_vec * E[0] ** 2) @ A
+    rng = np.random.default_rng(5)
+    for _ in range(3):
+        rhs = rng.standard_normal(P.shape[0])
+        sol = bp.kkt_solve(rhs[None])[0]
+        ref = np.linalg.solve(Kmat, rhs)
+        assert np.abs(sol - ref).max() <= 1e-8 * np.abs(ref).max()
+
+
+@pytest.mark.parametrize('iters', [1, 7, 40])
+@pytest.mark.parametrize('shape', SHAPES, ids=IDS)
+def test_admm_iterates_match_oracle(shape, iters):
+    K, Ko = _ctrl(shape), _ctrl(shape, oracle=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        K.setup(solve=False); Ko.setup(solve=False)
+    K.prob.batch_problem.iterate(iters)
+    x, z, y = K.prob.batch_problem.iterate_state()
+    Ko.prob.iterate(iters)
+    xo, zo, yo, _ = Ko.prob.iterate_state()
+    rel = lambda a, b: np.abs(a - b).max() / max(1e-300, np.abs(b).max())
+    assert rel(x[0], xo) < 1e-8 and rel(z[0], zo) < 1e-8
+    assert np.abs(y[0] - yo).max() < 1e-8 * max(1.0, np.abs(yo).max())
+
+
+@pytest.mark.parametrize('shape', SHAPES, ids=IDS)
+def test_solves_like_the_oracle_and_like_one_stage_per_block(shape):
+    """Default tolerance (mpc.py:80): status, iteration count and rho updates of the oracle; parity tolerance: the whole input sequence within
+    1e-6 of the oracle's at 1e-10 (north-star criterion) and of the ungrouped sweeps' (MPCQP_GROUP=0); one warm step further."""
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        K, Ko = _ctrl(shape), _ctrl(shape, oracle=True)
+        K.setup(); Ko.setup()
+        assert (K.res.info.status, K.res.info.iter, K.res.info.rho_updates) == (Ko.res.info.status, Ko.res.info.iter, Ko.res.info.rho_updates)
+        tight = dict(eps_abs=1e-10, eps_rel=1e-10)
+        K, Ko = _ctrl(shape, settings=dict(max_iter=400000), **tight), _ctrl(shape, oracle=True, settings=dict(max_iter=400000), **tight)
+        K.setup(); Ko.setup()
+        assert K.res.info.status == Ko.res.info.status == 'solved'
+        (u, info), (uo, infoo) = K.output(return_u_seq=True), Ko.output(return_u_seq=True)
+        scale = max(1e-3, np.abs(infoo['u_seq']).max())
+        assert np.abs(info['u_seq'] - infoo['u_seq']).max() <= 1e-6 * scale
+        with env(MPCQP_GROUP=0):
+            Kp = _ctrl(shape, settings=dict(max_iter=400000), **tight); Kp.setup()
+            assert not _grouped(Kp.prob.batch_problem, shape)
+        assert np.abs(info['u_seq'] - Kp.output(return_u_seq=True)[1]['u_seq']).max() <= 1e-6 * scale
+        kw = _kw(shape)
+        x = np.asarray(kw['Ad']) @ np.asarray(kw['x0']) + np.asarray(kw['Bd']).reshape(len(kw['x0']), -1) @ uo
+        K.update(x, uo); Ko.update(x, uo)
+        assert K.res.info.status == Ko.res.info.status
+        assert np.abs(K.output() - Ko.output()).max() <= 1e-6 * scale
+
+
+@pytest.mark.parametrize('shape', SHAPES[:5], ids=IDS[:5])
+def test_device_loop_equals_stepwise(shape):
+    from pympc_amd import BatchMPCController
+    nx, nu, Np, Nc, soft = shape
+    B = 3
+    kws = [_kw(shape, seed=i) for i in range(B)]
+    for i, kw in enumerate(kws):
+        kw['x0'] = (1.0 + 0.1 * i) * np.asarray(kw['x0'], dtype=float)
+    keys = ('x0', 'xref', 'uref', 'uminus1', 'Qx', 'QxN', 'Qu', 'QDu', 'xmin', 'xmax', 'umin', 'umax', 'Dumin', 'Dumax')
+    stack = lambda k: np.stack([np.asarray(kw[k], dtype=float).reshape(np.asarray(kws[0][k], dtype=float).shape) for kw in kws])
+    Bd = np.stack([np.asarray(kw['Bd'], dtype=float).reshape(nx, nu) for kw in kws])
+
+    def make():
+        K = BatchMPCController(stack('Ad'), Bd, Np=Np, Nc=Nc, eps_feas=np.array([[kw.get('eps_feas', 1e6)] for kw in kws]), SOFT_ON=soft,
+                               **{k: stack(k) for k in keys})
+        K.setup()
+        return K
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        Kd, Ks = make(), make()
+        assert _grouped(Kd.prob, shape)
+        steps = 5
+        w = 0.002 * np.random.default_rng(9).standard_normal((steps, B, nx))
+        tr = Kd.run(steps, w=w)
+        for k in range(steps):
+            assert np.array_equal(Ks.output(), tr['u'][k]), k
+            Ks.update(tr['x'][k + 1])
+            infos = Ks.prob.infos()
+            assert [i.status for i in infos] == list(tr['status'][k]) and [i.iter for i in infos] == list(tr['iter'][k]), k
