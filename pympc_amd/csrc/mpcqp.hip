@@ -248,7 +248,7 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     h->L.grp = grp;
     if (grp) {
         h->L.fstage = GroupFmt::REC; h->L.fhead = 0; h->L.ffwd = GroupFmt::NN; h->L.ftab = 0;
-        h->L.tsz += group_count(L.N, grp) * L.NB;          // the grouped vector Tg behind Tc
+        h->L.tsz += (group_count(L.N, grp) + 2) * L.NB;    // the grouped vector Tg behind Tc (+ the two slots of the middle stage's inputs)
     }
     const int NS = h->L.bcr;                                        // stages of the schedule (>= L.N)
     if (bcr) h->L.tsz = std::max(h->L.tsz + NS * L.NB, LAT_LDS_DOUBLES(NS));      // the stage-major vectors of the latency round (mpcqp_lat.h); c_e of the streaming solve
@@ -278,6 +278,16 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     const int avail = L.tsz + (h->lds_state ? (int)state_doubles : 0);
     if (avail < fws) h->L.tsz += fws - avail;
     h->smem_setup = sizeof(double) * ((size_t)smem_common_doubles(h->L) + (h->lds_state ? state_doubles : 0));      // every kernel gets the full block
+    // At most one instance per compute unit and an iterate that does not qualify for the LDS-resident owner map: stage it (with the metric
+    // vectors, the linear cost and the border matrices) into LDS for the length of a round if one workgroup's LDS holds it (admm_round_global).
+    {
+        const size_t stage_doubles = 2 * (size_t)L.n + 3 * (size_t)L.m + (size_t)(L.n_x + L.n_u) + (L.border ? 2 * (size_t)L.nu * L.N * L.NB : 0);
+        const bool specialised = L.NB == 32 && L.nx == 20 && L.nu == 8 && !L.border;      // (the BASELINE cfg-5 instantiation has compile-time dimensions and no staged round)
+        bool lstage = !h->lds_state && !dense && !bcr && !specialised && h->ncu > 0 && batch <= h->ncu && h->smem_setup + sizeof(double) * stage_doubles <= 150 * 1024;
+        if (const char *e = getenv("MPCQP_LSTAGE")) lstage = lstage && atoi(e) != 0;      // development switch
+        h->L.lstage = lstage ? 1 : 0;
+        if (lstage) h->smem_setup += sizeof(double) * stage_doubles;
+    }
     h->smem_solve = h->smem_setup;
     if (h->smem_solve > 160 * 1024) { mpcqp_destroy(h); return fail(MPCQP_ERR_UNSUPPORTED, "problem too large for one workgroup's LDS"); }
     *out = h;
@@ -953,12 +963,13 @@ extern "C" int mpcqp_get_stream_bytes(mpcqp_handle *h, int64_t *per_iter, int64_
                          : (int64_t)(L.N - 1) * L.ffwd + (int64_t)L.N * sinv + (int64_t)(L.N - 1) * L.ftab + L.fhead;   // forward matrices once, S^-1 once, the tables, G / G' once each
     if (L.NB == 64) it = (3 * (int64_t)L.N - 2) * WideFmt::NN;      // wide stages: S^-1 of every stage, M and M' of all but the last
     if (L.grp) it = (3 * (int64_t)group_count(L.N, L.grp) - 1) * GroupFmt::NN;      // grouped small stages: S^-1 of every super-stage, forward matrix and its transpose of all but the ends, the middle's second pair
-    if (!h->lds_state) it += (2 * n + 4 * m) /* x, z, y read + written */ + (m + L.n_x) /* omega */ + (n + L.n_x) /* s */ + nq /* q */;
+    if (!h->lds_state && !L.lstage) it += (2 * n + 4 * m) /* x, z, y read + written */ + (m + L.n_x) /* omega */ + (n + L.n_x) /* s */ + nq /* q */;
     if (L.border && !L.dense) it += 2 * (int64_t)L.nu * L.N * NB;      // (the dense inverse holds the held input's couplings itself)
     int64_t rd = (L.model_sz - L.hot_sz) + 2 * n + 2 * m /* D, s, E, omega */ + n + m /* dx, dy */;
     if (L.dense) rd += DenseFmt::DOUBLES;               // the round's load of K^-1 into registers
     if (L.bcr) rd += (int64_t)L.bcr * BcrFmt::REC - 4 * BcrFmt::NN;      // ... of the cyclic-reduction fragments (the two end stages have one neighbour)
-    rd += h->lds_state ? 2 * (n + 2 * m) /* iterate in and out of LDS */ + (m + L.n_x) + (n + L.n_x) + nq : (n + 2 * m);
+    rd += (h->lds_state || L.lstage) ? 2 * (n + 2 * m) /* iterate in and out of LDS */ + (m + L.n_x) + (n + L.n_x) + nq : (n + 2 * m);
+    if (L.lstage && L.border) rd += 2 * (int64_t)L.nu * L.N * NB;      // the border matrices staged with it
     int64_t sv = L.hot_sz + L.step_sz + 3 * m /* E, types, omega */ + nq + 2 * (n + m) /* solution out, iterate read */;
     if (per_iter) *per_iter = 8 * it;
     if (per_round) *per_round = 8 * rd;

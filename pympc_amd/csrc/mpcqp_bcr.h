@@ -168,7 +168,7 @@ __device__ __forceinline__ d4 bcr_frag(const double *F, int stage, int off, int 
 // Solve, streaming version (run time N; fragments read from memory as they are needed): the verification kernel and any caller
 // outside an ADMM round.  Tc <- K^-1 Tc, Cc: LDS, N * 16 doubles.  All threads call; barriers inside.
 // ------------------------------------------------------------------------------------------------
-__device__ void bcr_core_stream(const double *F, int N, double *Tc, double *Cc) {
+__device__ __forceinline__ void bcr_core_stream(const double *F, int N, double *Tc, double *Cc) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     double *tb = Tc + vec_lane_offset(lane), *cb = Cc + vec_lane_offset(lane);
     int top = 1;

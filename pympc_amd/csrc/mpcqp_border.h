@@ -9,7 +9,11 @@
 // With Z = T^-1 B and Sigma = C - B'Z (computed at factor time):  ub = Sigma^-1 (r2 - Z' r1),  y = T^-1 (r1 - B ub).
 // B and C are taken entry by entry from the matrix-free operators (K = cP + diag(s) + A' diag(omega) A).
 // ------------------------------------------------------------------------------------------------
-__device__ double kkt_entry_generic(const Ctx &c, const double *om, const double *sv, double cc, int v, int w) {
+// (ALWAYS inlined.  As an ordinary function it was ONE callee shared by the factor phases of kernels with different launch bounds -- one, two
+//  and four workgroups per CU -- and by k_setup; when round 4 added a second caller inside the refactorization phase of the four-per-CU
+//  kernels, that phase began to return NaN factors for bordered 16 x 16 problems (or faulted), although no line on its path had changed:
+//  scripts/diag_refactor.py.  With internal linkage or inlined the same sources are correct; inlined, no callee is shared at all.)
+__device__ __forceinline__ double kkt_entry_generic(const Ctx &c, const double *om, const double *sv, double cc, int v, int w) {
     double acc = 0.0;
     P_row(c, v, [&](double co, int idx) { if (idx == w) acc += cc * co; });
     if (v == w) acc += sv[v];
@@ -75,7 +79,7 @@ __device__ __forceinline__ void border_factor(const Ctx &c, const double *om, co
 // Before the tridiagonal solve: Tc holds r1 in the padded slots and r2 in the (otherwise padding) u slots of stage
 // Nc-1.  Computes ub, leaves it in ubar[] (LDS, nu doubles) and replaces r1 by r1 - B ub.
 template <int NB>
-__device__ void border_pre(const Lay &L, const double *Bb, const double *Zb, const double *Sig, double *Tc, double *ubar, double *red) {
+__device__ __forceinline__ void border_pre(const Lay &L, const double *Bb, const double *Zb, const double *Sig, double *Tc, double *ubar, double *red) {
     const int tid = threadIdx.x, nu = L.nu, NP = L.N * NB;
     const int slot = (L.Nc - 1) * NB + L.nx;
     for (int j = 0; j < nu; ++j) {
@@ -103,7 +107,7 @@ __device__ __forceinline__ void border_post(const Lay &L, int NB, double *Tc, co
 // Generic front end (verification kernel): flat rhs (global) -> flat solution `out` (global, n doubles).
 // Tc: LDS, N*NB doubles.
 template <int NB>
-__device__ void kkt_solve(const Ctx &c, const double *om, const double *sv, double cc, const double *F,
+__device__ __forceinline__ void kkt_solve(const Ctx &c, const double *om, const double *sv, double cc, const double *F,
                           const double *rg, double *Tc, double *out, BorderPtrs bp, double *ubar) {
     const Lay &L = c.L;
     const double cef = cc * c.eps_feas();

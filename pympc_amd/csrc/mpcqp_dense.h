@@ -37,7 +37,7 @@ __device__ __forceinline__ bool dense_dead(const Lay &L, int v) {       // varia
     return a >= L.nx && k >= L.Nc;                                      // (Nc < Np: the held input u_{Nc-1} is an ordinary unknown of the dense system)
 }
 
-__device__ double kkt_entry_generic(const Ctx &c, const double *om, const double *sv, double cc, int v, int w);      // mpcqp_border.h
+__device__ __forceinline__ double kkt_entry_generic(const Ctx &c, const double *om, const double *sv, double cc, int v, int w);      // mpcqp_border.h
 
 // K (dense, SPD) assembled from the stage blocks (only the block-tridiagonal band is evaluated; omega and s are read from an LDS copy: an
 // entry sums nx products of them), inverted in place by Gauss-Jordan sweeps (NR steps).  A thread keeps its half row -- up to 64 entries --

@@ -12,10 +12,9 @@
 // The blocks are no longer "weights times a constant [Ad Bd]" (a diagonal block holds g - 1 stage couplings itself), so nothing is applied
 // matrix-free: per super-stage the factor keeps three full fragments
 //       [ -Mh_K | -Mh_K' | S_K^-1 ]      Mh_K = K_{K,nbr} S_nbr^-1 (nbr = K-1 in the top half, K+1 in the bottom half),  S_K = K_KK - Mh_K K_{K,nbr}'
-// and the solve is   forward  yh_K = b_K - Mh_K yh_nbr   (chain_sweep: one dependent mat-vec per step),
+// and the solve is   forward  yh_K = b_K - Mh_K yh_nbr,  w_K = S_K^-1 yh_K   (one dependent mat-vec per step; w_K rides in its shadow),
 //                    middle   x_m = S_m^-1 (b_m - Mh_m yh_{m-1} - Mt_m yh_{m+1})          (Mt_m: record N')
-//                    backward x_K = S_K^-1 yh_K - Mh_next' x_next   (next = the stage towards the middle; S_K^-1 yh_K does not wait for x_next:
-//                                                                    one dependent mat-vec per step).
+//                    backward x_K = w_K - Mh_next' x_next          (next = the stage towards the middle: one dependent mat-vec per step).
 // Everything around the solve -- the parallel phases, the bordered correction of a held input (Nc < Np), the residual evaluation -- keeps the
 // stage-major layout Tc[k * 16 + a]: kkt_core repacks into the grouped vector Tg[K * 16 + A] (behind Tc in the work area) and back, two LDS
 // passes over N (nx + nu) values.  Dead slots (block padding, sub-stages beyond the horizon, inputs beyond the control horizon) are identity in K
@@ -118,20 +117,23 @@ __device__ __forceinline__ int factor_group(const Ctx &c, const double *om, cons
     return *iflag;
 }
 
-// One half of the back substitution by ONE wave: for i = 1..nsteps, K = first + dir * i:   Tg[K] <- S_K^-1 Tg[K] + MhT(K - dir) Tg[K - dir]
-// (MhT(J): the transposed forward matrix stored with stage J; `extra` replaces J = first, the middle stage, where the bottom half needs -Mt_m').
-// Fragments of the next stages are prefetched into a register ring like chain_sweep's.
-__device__ __forceinline__ void group_back_sweep(const int first, const int dir, const int nsteps, const int extra, const double *F, double *Tg) {
-    constexpr int NB = 16, DEPTH = 2;
+// One half of the forward elimination by ONE wave, stages K = first + dir * i, i = 0..nsteps:
+//     yh_K = b_K + Fwd(K) yh_{K-dir}   (yh_first = b_first)         the dependent chain: one mat-vec per step
+//     w_K  = S_K^-1 yh_K  -> Tg[K]                                    what the back substitution starts from
+// and the last yh, which the middle stage needs, goes to Tg[ylast].  A wave issues in order: written right behind yh_K, the product for w_K would
+// make the chain wait for it.  It is therefore formed ONE STEP LATER, next to the chain's product for yh_{K+1} -- two independent MFMA
+// sequences in one block, which the scheduler interleaves: w rides in the latency of the chain.  Fragments of the next stages are prefetched
+// into a register ring (branch-free refills with clamped indices, like chain_sweep).
+__device__ __forceinline__ void group_fwd_sweep(const int first, const int dir, const int nsteps, const int ylast, const double *F, double *Tg) {
+    constexpr int NB = 16, DEPTH = 3;
     const int lane = opaque_lane(threadIdx.x & 63);
     double *tb = Tg + vec_lane_offset(lane);
-    if (nsteps < 1) return;
+    const bool writer = MPCQP_STORE_ALL ? true : vec_lane_writer(lane);
     auto stage_of = [&](int i) { return first + dir * (i < nsteps ? i : nsteps); };
-    auto src_of = [&](int i) { const int J = stage_of(i) - dir; return (J == first && extra >= 0) ? extra : J; };
-    d4 rs[DEPTH], rm[DEPTH];
+    d4 rf[DEPTH], rs[DEPTH];                              // ring slot d: forward matrix of stage i, S^-1 of stage i - 1
     auto ring_load = [&](int i, int d) {
-        rs[d] = *(cgd4 *)(F + (size_t)stage_of(i) * GroupFmt::REC + GroupFmt::OSINV + lane * 4);
-        rm[d] = *(cgd4 *)(F + (size_t)src_of(i) * GroupFmt::REC + GroupFmt::OMHT + lane * 4);
+        rf[d] = *(cgd4 *)(F + (size_t)stage_of(i) * GroupFmt::REC + GroupFmt::OMH + lane * 4);
+        rs[d] = *(cgd4 *)(F + (size_t)stage_of(i - 1) * GroupFmt::REC + GroupFmt::OSINV + lane * 4);
     };
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) ring_load(1 + d, d);
@@ -141,11 +143,54 @@ __device__ __forceinline__ void group_back_sweep(const int first, const int dir,
     auto step = [&](int i, int d) {
         const int K = stage_of(i);
         vec_load<NB>(tb, stage_of(i + 1), nxt);
-        double a[1] = {0.0}, b[1] = {0.0};
-        frag_matvec<NB>(&rs[d], own, a);                          // S_K^-1 yh_K: does not wait for the running vector
-        frag_matvec<NB>(&rm[d], run, b);
-        run[0] = a[0] + b[0];
-        vec_store<NB>(tb, K, run, true);
+        double y[1] = {own[0]}, w[1] = {0.0};
+        frag_matvec<NB>(&rf[d], run, y);                          // the chain: yh_K from yh_{K-dir}
+        frag_matvec<NB>(&rs[d], run, w);                          // beside it: w_{K-dir} = S^-1 yh_{K-dir}
+        vec_store<NB>(tb, K - dir, w, writer);
+        run[0] = y[0];
+        own[0] = nxt[0];
+    };
+    int i0 = 1;
+    for (; i0 + DEPTH - 1 <= nsteps; i0 += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) { step(i0 + d, d); ring_load(i0 + d + DEPTH, d); }
+    }
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) if (i0 + d <= nsteps) step(i0 + d, d);
+    {   // the last stage of the half: its yh for the middle stage, its w
+        const int K = stage_of(nsteps);
+        const d4 sl = *(cgd4 *)(F + (size_t)K * GroupFmt::REC + GroupFmt::OSINV + lane * 4);
+        double w[1] = {0.0};
+        frag_matvec<NB>(&sl, run, w);
+        vec_store<NB>(tb, ylast, run, writer);
+        vec_store<NB>(tb, K, w, writer);
+    }
+}
+
+// One half of the back substitution by ONE wave: for i = 1..nsteps, K = first + dir * i:   Tg[K] (= w_K) <- w_K + MhT(K - dir) Tg[K - dir]
+// (MhT(J): the transposed forward matrix stored with stage J; `extra` replaces J = first, the middle stage, where the bottom half needs -Mt_m').
+__device__ __forceinline__ void group_back_sweep(const int first, const int dir, const int nsteps, const int extra, const double *F, double *Tg) {
+    constexpr int NB = 16, DEPTH = 4;
+    const int lane = opaque_lane(threadIdx.x & 63);
+    double *tb = Tg + vec_lane_offset(lane);
+    const bool writer = MPCQP_STORE_ALL ? true : vec_lane_writer(lane);
+    if (nsteps < 1) return;
+    auto stage_of = [&](int i) { return first + dir * (i < nsteps ? i : nsteps); };
+    auto src_of = [&](int i) { const int J = stage_of(i) - dir; return (J == first && extra >= 0) ? extra : J; };
+    d4 rm[DEPTH];
+    auto ring_load = [&](int i, int d) { rm[d] = *(cgd4 *)(F + (size_t)src_of(i) * GroupFmt::REC + GroupFmt::OMHT + lane * 4); };
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) ring_load(1 + d, d);
+    double run[1], own[1], nxt[1];
+    vec_load<NB>(tb, first, run);
+    vec_load<NB>(tb, stage_of(1), own);
+    auto step = [&](int i, int d) {
+        const int K = stage_of(i);
+        vec_load<NB>(tb, stage_of(i + 1), nxt);
+        double x[1] = {own[0]};
+        frag_matvec<NB>(&rm[d], run, x);
+        run[0] = x[0];
+        vec_store<NB>(tb, K, run, writer);
         own[0] = nxt[0];
     };
     int i0 = 1;
@@ -157,7 +202,8 @@ __device__ __forceinline__ void group_back_sweep(const int first, const int dir,
     for (int d = 0; d < DEPTH; ++d) if (i0 + d <= nsteps) step(i0 + d, d);
 }
 
-// Tc <- K^-1 Tc through the grouped factor.  Tc: stage-major [N][16]; Tg: [N'][16] right behind it.  All threads call; barriers inside.
+// Tc <- K^-1 Tc through the grouped factor.  Tc: stage-major [N][16]; Tg: [N' + 2][16] right behind it (the two extra slots: the last yh of
+// either half, for the middle stage).  All threads call; barriers inside.
 __device__ __forceinline__ void kkt_core_group(const CoreArgs &a, double *Tc) {
     constexpr int NB = 16;
     const int g = a.grp, nb = a.nx + a.nu, N = a.N, NS = group_count(N, g), mid = NS / 2;
@@ -170,8 +216,8 @@ __device__ __forceinline__ void kkt_core_group(const CoreArgs &a, double *Tc) {
     }
     __syncthreads();
     TICK_START
-    if (wv == 0) chain_sweep<NB>(0, +1, mid - 1, GroupFmt::REC, F, Tg);
-    else if (wv == 1) chain_sweep<NB>(NS - 1, -1, NS - 2 - mid, GroupFmt::REC, F, Tg);
+    if (wv == 0) group_fwd_sweep(0, +1, mid - 1, NS, F, Tg);                // w_0 .. w_{mid-1};  yh_{mid-1} -> slot N'
+    else if (wv == 1) group_fwd_sweep(NS - 1, -1, NS - 2 - mid, NS + 1, F, Tg);      // w_{N'-1} .. w_{mid+1};  yh_{mid+1} -> slot N'+1
     __syncthreads();
     TICK(1)
     if (wv == 0) {
@@ -180,10 +226,8 @@ __device__ __forceinline__ void kkt_core_group(const CoreArgs &a, double *Tc) {
         frag_load<NB>(F + (size_t)mid * GroupFmt::REC + GroupFmt::OMH, lane, &fu);
         frag_load<NB>(F + (size_t)NS * GroupFmt::REC + GroupFmt::OMH, lane, &fd);
         frag_load<NB>(F + (size_t)mid * GroupFmt::REC + GroupFmt::OSINV, lane, &fs);
-        double up[1] = {0.0}, dn[1] = {0.0}, acc[1], out[1] = {0.0};
-        vec_load<NB>(tb, mid, acc);
-        if (mid > 0) vec_load<NB>(tb, mid - 1, up);
-        if (mid < NS - 1) vec_load<NB>(tb, mid + 1, dn);
+        double up[1], dn[1], acc[1], out[1] = {0.0};
+        vec_load<NB>(tb, mid, acc); vec_load<NB>(tb, NS, up); vec_load<NB>(tb, NS + 1, dn);
         frag_matvec<NB>(&fu, up, acc);
         frag_matvec<NB>(&fd, dn, acc);
         frag_matvec<NB>(&fs, acc, out);
@@ -191,8 +235,8 @@ __device__ __forceinline__ void kkt_core_group(const CoreArgs &a, double *Tc) {
     }
     __syncthreads();
     TICK(2)
-    if (wv == 0) group_back_sweep(mid, -1, mid, -1, F, Tg);                  // x_{mid-1} .. x_0:       x_K = S_K^-1 yh_K - Mh_{K+1}' x_{K+1}
-    else if (wv == 1) group_back_sweep(mid, +1, NS - 1 - mid, NS, F, Tg);    // x_{mid+1} .. x_{N'-1}:  x_K = S_K^-1 yh_K - Mt_{K-1}' x_{K-1}
+    if (wv == 0) group_back_sweep(mid, -1, mid, -1, F, Tg);                  // x_{mid-1} .. x_0:       x_K = w_K - Mh_{K+1}' x_{K+1}
+    else if (wv == 1) group_back_sweep(mid, +1, NS - 1 - mid, NS, F, Tg);    // x_{mid+1} .. x_{N'-1}:  x_K = w_K - Mt_{K-1}' x_{K-1}
     __syncthreads();
     TICK(3)
     for (int idx = threadIdx.x; idx < NS * NB; idx += NT) {

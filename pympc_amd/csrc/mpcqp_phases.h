@@ -31,20 +31,20 @@ __device__ __forceinline__ double *carve(double *&p, int n) { double *r = p; p +
 // [ X | Z | Y ] of small problems.  T comes last so that the factorization, which runs while the iterate copy is dead
 // (before a round loads it, after a check has read it), can let its workspace run on into that area.
 template <class PT>
-__device__ void smem_common(const Lay &L, const PT &P, double *&p, Smem &S) {
+__device__ __forceinline__ void smem_common(const Lay &L, const PT &P, double *&p, Smem &S) {
     S.Qv = (double *)P.qv + (size_t)inst_of(P.perm) * (L.n_x + L.n_u);
     S.hot = carve(p, L.hot_sz);
     S.x0s = carve(p, L.nx);
     S.um1s = carve(p, L.nu);
     S.du0 = carve(p, 2 * L.nu);
     S.red = carve(p, 64);
-    S.tv = carve(p, 64);
+    S.tv = carve(p, 128);          // the bordered solve's [ubar | reduced right-hand side] (2 nu <= 126 doubles); outside it, the held input's A'W sums (nu)
     S.iflag = (int *)carve(p, 2);
     S.T = carve(p, L.tsz);
 }
-__host__ __device__ inline int smem_common_doubles(const Lay &L) { return L.tsz + L.hot_sz + L.nx + 3 * L.nu + 64 + 64 + 2; }
+__host__ __device__ inline int smem_common_doubles(const Lay &L) { return L.tsz + L.hot_sz + L.nx + 3 * L.nu + 64 + 128 + 2; }
 
-__device__ void load_common(const Lay &L, const double *model, const double *step, Smem &S) {
+__device__ __forceinline__ void load_common(const Lay &L, const double *model, const double *step, Smem &S) {
     for (int i = threadIdx.x; i < L.hot_sz; i += NT) S.hot[i] = model[i];
     for (int i = threadIdx.x; i < L.nx; i += NT) S.x0s[i] = step[i];
     for (int i = threadIdx.x; i < L.nu; i += NT) {
@@ -490,7 +490,8 @@ __device__ __forceinline__ int check_body(const Lay &L, const Ptrs &P, const mpc
     };
     auto check_termination = [&](bool approx) -> bool {
         double ea = S_.eps_abs, er = S_.eps_rel, epi = S_.eps_prim_inf, edi = S_.eps_dual_inf;
-        if (pri_res > QP_INFTY || dua_res > QP_INFTY) { status = MPCQP_NON_CVX; obj_val = NAN; return true; }
+        // (fmax drops NaN operands, so a NaN iterate leaves both residuals at zero: the objective, a plain sum, carries it)
+        if (pri_res > QP_INFTY || dua_res > QP_INFTY || obj_val != obj_val) { status = MPCQP_NON_CVX; obj_val = NAN; return true; }
         if (approx) { ea *= 10; er *= 10; epi *= 10; edi *= 10; }
         bool pc = pri_res < ea + er * fmax(nrm[2], nrm[1]);
         bool dc = dua_res < ea + er * fmax(fmax(nrm[6], nrm[5]), nrm[4]);
@@ -636,18 +637,27 @@ __device__ __forceinline__ void held_input_terms(const Lay &L, int nx, int nu, c
         Tc[s * NB + nx + jj] = t;
     }
 }
+// The owner of (Nc - 1, jj) used to add the Np - Nc + 1 parked terms itself, one LDS read after the other (76 dependent reads at the notebook
+// shape: 2 us of a 15 us iteration, every other thread waiting at the barrier).  Now wave 0 sums them -- lane l takes stages Nc + l, Nc + l + 64, ...,
+// then a fixed-order butterfly over the lanes -- and leaves the nu sums in `out` (LDS, nu doubles); the parked slots are zeroed on the way.
+// All threads call (one barrier inside); the order of the additions is fixed, so results do not depend on timing.
 template <int NB>
-__device__ __forceinline__ double held_input_sum(const Lay &L, int nx, int jj, double *Tc) {
-    double a0 = 0.0, a1 = 0.0;
-    int s = L.Nc;
-    for (; s + 1 <= L.Np; s += 2) { a0 += Tc[s * NB + nx + jj]; a1 += Tc[(s + 1) * NB + nx + jj]; Tc[s * NB + nx + jj] = 0.0; Tc[(s + 1) * NB + nx + jj] = 0.0; }
-    if (s <= L.Np) { a0 += Tc[s * NB + nx + jj]; Tc[s * NB + nx + jj] = 0.0; }
-    return a0 + a1;
+__device__ __forceinline__ void held_input_reduce(const Lay &L, int nx, int nu, double *Tc, double *out) {
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        for (int jj = 0; jj < nu; ++jj) {
+            double a = 0.0;
+            for (int s = L.Nc + lane; s <= L.Np; s += 64) { a += Tc[s * NB + nx + jj]; Tc[s * NB + nx + jj] = 0.0; }
+            a = wave_reduce<false>(a);
+            if (lane == 0) out[jj] = a;
+        }
+    }
+    __syncthreads();
 }
 
 // rhs = s x - c q + A' W with the slack eliminated, into Tc
 template <int NB, int NXT, int NUT>
-__device__ __forceinline__ void own_rhs(const Lay &L, const double *hot, const OwnRegs &h, double cc, const double *X, double *W, double *Tc) {
+__device__ __forceinline__ void own_rhs(const Lay &L, const double *hot, const OwnRegs &h, double cc, const double *X, double *W, double *Tc, double *hsum) {
     const int tid = opaque_lane(threadIdx.x);        // (keeps the per-thread index arithmetic out of LICM's reach: hoisted, it spills)
     const int nx = hx<NXT>(L), nu = hu<NUT>(L);
     const double *Ad = hot + L.oAd, *Bd = hot + L.oBd;
@@ -672,13 +682,13 @@ __device__ __forceinline__ void own_rhs(const Lay &L, const double *hot, const O
             Tc[k * NB + a] = rx + wsoft - h.om_s[j] * te;
         }
     }
-    if (held) __syncthreads();
+    if (held) { __syncthreads(); held_input_reduce<NB>(L, nx, nu, Tc, hsum); }
     if (tid < L.n_u) {
         const int cu = tid, k = divu<NUT>(L, cu), jj = cu - k * nu;
         double ru = h.sv_u * X[L.ou + cu] - h.cq_u + W[L.ri + cu] - W[L.rdu + nu + cu];
         if (k == 0) ru += W[L.rdu + jj];
         if (cu > 0) ru += W[L.rdu + nu + cu - 1];
-        if (held && k == L.Nc - 1) ru += held_input_sum<NB>(L, nx, jj, Tc);               // the last input acts on every later stage (mpc.py:540-543)
+        if (held && k == L.Nc - 1) ru += hsum[jj];                                        // the last input acts on every later stage (mpc.py:540-543)
         else {
             const double *w1 = W + (k + 1) * nx;
 #pragma unroll
@@ -773,9 +783,14 @@ __device__ __forceinline__ void own_finish(const Lay &L, const OwnRegs &h, doubl
 // Against the flat loops this replaces (one over the padded variables, one over the variables again, one over the m rows with
 // a four-way branch per row): a third of the round trips and no divergent tree.
 // ------------------------------------------------------------------------------------------------
-template <int NB> struct GownCfg { static constexpr int U = 2; };      // items per thread in flight (ten operands per input item; 2 / 4 / 8 measured at cfg-5: 95.0 / 94.2 / 92.2 k solves/s)
-template <int NB>
-__device__ __forceinline__ void gown_rows_w(const Lay &L, cgdouble *om, double cc, const double *Z, double *Y, double *W, double *Tc) {
+template <int NB> struct GownCfg { static constexpr int U = 2; };
+// INL: the iterate and the metric vectors are LDS copies staged for the round (admm_body: at most one instance per compute unit, so the copies
+// fit) -- the same passes without the global round trips.  The pointer types say which: explicit global address space, or plain (LDS, inferred).
+template <bool INL> struct GPtr { typedef cgdouble c; typedef gdouble m; };
+template <> struct GPtr<true> { typedef const double c; typedef double m; };      // items per thread in flight (ten operands per input item; 2 / 4 / 8 measured at cfg-5: 95.0 / 94.2 / 92.2 k solves/s)
+template <int NB, bool INL = false>
+__device__ __forceinline__ void gown_rows_w(const Lay &L, typename GPtr<INL>::c *om, double cc, const double *Z, double *Y, double *W, double *Tc) {
+    typedef typename GPtr<INL>::c cgdouble; typedef typename GPtr<INL>::m gdouble;
     const int tid = opaque_lane(threadIdx.x);
     cgdouble *Zg = (cgdouble *)Z, *Yg = (cgdouble *)Y;
     for (int i = tid; i < L.N * NB; i += NT) Tc[i] = 0.0;      // (padding and absent inputs stay zero through the solves: the factor has zero rows there)
@@ -784,7 +799,9 @@ __device__ __forceinline__ void gown_rows_w(const Lay &L, cgdouble *om, double c
     __syncthreads();
 }
 // end of a round: y back from c y / omega
-__device__ __forceinline__ void gown_finish(const Lay &L, cgdouble *om, double cc, double *Y) {
+template <bool INL = false>
+__device__ __forceinline__ void gown_finish(const Lay &L, typename GPtr<INL>::c *om, double cc, double *Y) {
+    typedef typename GPtr<INL>::m gdouble;
     const int tid = opaque_lane(threadIdx.x);
     const double cinv = 1.0 / cc;
     gdouble *Yg = (gdouble *)Y;
@@ -792,8 +809,9 @@ __device__ __forceinline__ void gown_finish(const Lay &L, cgdouble *om, double c
     for (int r = tid; r < L.m; r += NT) Yg[r] = Yg[r] * (om[r] * cinv);
     __syncthreads();
 }
-template <int NB, int NXT, int NUT>
-__device__ __forceinline__ void gown_rhs(const Lay &L, const double *hot, cgdouble *om, cgdouble *sv, cgdouble *qv, double cc, const double *X, double *W, double *Tc) {
+template <int NB, int NXT, int NUT, bool INL = false>
+__device__ __forceinline__ void gown_rhs(const Lay &L, const double *hot, typename GPtr<INL>::c *om, typename GPtr<INL>::c *sv, typename GPtr<INL>::c *qv, double cc, const double *X, double *W, double *Tc, double *hsum) {
+    typedef typename GPtr<INL>::c cgdouble;
     constexpr int GU = GownCfg<NB>::U;
     const int tid = opaque_lane(threadIdx.x);
     const int nx = hx<NXT>(L), nu = hu<NUT>(L);
@@ -829,7 +847,7 @@ __device__ __forceinline__ void gown_rhs(const Lay &L, const double *hot, cgdoub
             }
         }
     }
-    if (held) __syncthreads();
+    if (held) { __syncthreads(); held_input_reduce<NB>(L, nx, nu, Tc, hsum); }
     for (int c0 = tid; c0 < L.n_u; c0 += GU * NT) {
         double svu[GU], qu[GU], uv[GU];
 #pragma unroll
@@ -842,7 +860,7 @@ __device__ __forceinline__ void gown_rhs(const Lay &L, const double *hot, cgdoub
                 double ru = svu[u] * uv[u] - cc * qu[u] + W[L.ri + cu] - W[L.rdu + nu + cu];
                 if (k == 0) ru += W[L.rdu + jj];
                 if (cu > 0) ru += W[L.rdu + nu + cu - 1];
-                if (held && k == L.Nc - 1) ru += held_input_sum<NB>(L, nx, jj, Tc);       // the last input acts on every later stage (mpc.py:540-543)
+                if (held && k == L.Nc - 1) ru += hsum[jj];                                // the last input acts on every later stage (mpc.py:540-543)
                 else {
                     const double *w1 = W + (k + 1) * nx;
 #pragma unroll
@@ -855,9 +873,10 @@ __device__ __forceinline__ void gown_rhs(const Lay &L, const double *hot, cgdoub
     }
     __syncthreads();
 }
-template <int NB, int NXT, int NUT>
-__device__ __forceinline__ void gown_update(const Lay &L, const double *hot, const double *x0s, const double *du0, cgdouble *om, cgdouble *sv, double cc, double alpha,
-                                            double *X, double *Z, double *Y, double *W, const double *Tc, bool keep_delta, gdouble *dxg, gdouble *dyg) {
+template <int NB, int NXT, int NUT, bool INL = false>
+__device__ __forceinline__ void gown_update(const Lay &L, const double *hot, const double *x0s, const double *du0, typename GPtr<INL>::c *om, typename GPtr<INL>::c *sv, double cc, double alpha,
+                                            double *X, double *Z, double *Y, double *W, const double *Tc, bool keep_delta, ::gdouble *dxg, ::gdouble *dyg) {
+    typedef typename GPtr<INL>::m gdouble;
     constexpr int GU = GownCfg<NB>::U;
     const int tid = opaque_lane(threadIdx.x);
     const int nx = hx<NXT>(L), nu = hu<NUT>(L);
@@ -947,17 +966,86 @@ __device__ __forceinline__ void gown_update(const Lay &L, const double *hot, con
 enum { MODE_CHAIN = 0, MODE_BORDER = 1, MODE_DENSE = 2, MODE_BCR = 100 };
 template <int NB> __device__ __forceinline__ void admm_tiny(const Lay &, const HotPtrs &, Smem &, double *, double *, double *, double, int);      // mpcqp_tiny.h
 template <int NXT, int NUT, int NST> __device__ __forceinline__ void admm_lat(const Lay &, const HotPtrs &, Smem &, double *, double *, double *, double, int);      // mpcqp_lat.h
+// The ADMM round of a problem whose iterate does not live in LDS for the owner-mapped phases above (n_x > 2 NT, or too large for four workgroups
+// per CU).  INL = false: x, z, y, omega, s, q in global memory (L2 / HBM), every pass pays its round trips -- right for batches, where other
+// workgroups fill them.  INL = true (the handle holds at most one instance per compute unit, Lay::lstage): everything the passes read is STAGED
+// into LDS behind the work area for the round -- iterate, metric vectors, linear cost and, with a held input, the two border matrices -- and the
+// iterate goes back when the round ends: the same code without a global access inside an iteration (a lone long-horizon controller spent
+// more than half of its iteration in those round trips).
+template <int NB, int NXT, int NUT, int MODE, bool INL>
+__device__ __forceinline__ void admm_round_global(const Lay &L, const HotPtrs &P, Smem &S, double alpha, int iters) {
+    typedef typename GPtr<INL>::c cptr;
+    const int b = inst_of(P.perm), tid = threadIdx.x;
+    double *gx = P.x + (size_t)b * L.n, *gz = P.z + (size_t)b * L.m, *gy = P.y + (size_t)b * L.m;
+    double *W = S.T, *Tc = S.T + L.m;
+    constexpr bool BORDER = MODE == MODE_BORDER;
+    const size_t npb = (size_t)L.nu * L.N * L.NB;
+    const double *Bg = BORDER ? P.Bb + b * npb : nullptr, *Zg = BORDER ? P.Zb + b * npb : nullptr;
+    double *X = gx, *Z = gz, *Y = gy;
+    const double *omp = P.omega + (size_t)b * L.m, *svp = P.s + (size_t)b * L.n, *qvp = S.Qv, *Bb = Bg, *Zb = Zg;
+    if constexpr (INL) {
+        double *p = S.T + L.tsz;                      // [ x | z | y | omega | s | q | Bb | Zb ] behind the work area
+        const int nq = L.n_x + L.n_u;
+        double *Xs = carve(p, L.n), *Zs = carve(p, L.m), *Ys = carve(p, L.m), *oms = carve(p, L.m), *svs = carve(p, L.n), *qvs = carve(p, nq);
+        for (int j = tid; j < L.n; j += NT) { Xs[j] = gx[j]; svs[j] = svp[j]; }
+        for (int r = tid; r < L.m; r += NT) { Zs[r] = gz[r]; Ys[r] = gy[r]; oms[r] = omp[r]; }
+        for (int j = tid; j < nq; j += NT) qvs[j] = qvp[j];
+        X = Xs; Z = Zs; Y = Ys; omp = oms; svp = svs; qvp = qvs;
+        if (BORDER) {
+            double *Bs = carve(p, (int)npb), *Zbs = carve(p, (int)npb);
+            for (int i = tid; i < (int)npb; i += NT) { Bs[i] = Bg[i]; Zbs[i] = Zg[i]; }
+            Bb = Bs; Zb = Zbs;
+        }
+    }
+    __syncthreads();
+    cptr *gom = (cptr *)omp, *gsv = (cptr *)svp, *gqv = (cptr *)qvp;
+    gdouble *dxg = (gdouble *)(P.dx + (size_t)b * L.n), *dyg = (gdouble *)(P.dy + (size_t)b * L.m);
+    const double *F = P.F + (size_t)b * P.fsz;
+    const double cc = P.c[b];
+#ifndef MPCQP_ABL_NOPAR
+    gown_rows_w<NB, INL>(L, gom, cc, Z, Y, W, Tc);
+#endif
+    TICK_RESET
+    for (int it = 1; it <= iters; ++it) {
+        const bool keep_delta = it == iters;         // the increments feed the infeasibility certificates of the check
+        TICK_START
+#ifndef MPCQP_ABL_NOPAR
+        gown_rhs<NB, NXT, NUT, INL>(L, S.hot, gom, gsv, gqv, cc, X, W, Tc, S.tv);
+#endif
+        TICK(0)
+        if (BORDER) border_pre<NB>(L, Bb, Zb, P.Sig + (size_t)b * L.nu * L.nu, Tc, S.tv, S.red);
+        kkt_core<NB, NB == 16 && NXT == 0>(core_args(L, opaque_ptr(F), opaque_ptr((const double *)P.omega + (size_t)b * L.m)), Tc);
+        if (BORDER) border_post(L, NB, Tc, S.tv);
+#ifndef MPCQP_ABL_NOPAR
+        gown_update<NB, NXT, NUT, INL>(L, S.hot, S.x0s, S.du0, gom, gsv, cc, alpha, X, Z, Y, W, Tc, keep_delta, dxg, dyg);
+#endif
+        TICK(5)
+    }
+    TICK_FLUSH
+#ifndef MPCQP_ABL_NOPAR
+    gown_finish<INL>(L, gom, cc, Y);
+#endif
+    if constexpr (INL) {
+        for (int j = tid; j < L.n; j += NT) gx[j] = X[j];
+        for (int r = tid; r < L.m; r += NT) { gz[r] = Z[r]; gy[r] = Y[r]; }
+    }
+}
+
 template <int NB, bool LDSSTATE, int NXT, int NUT, int MODE>
 __device__ __forceinline__ void admm_body(const Lay &L, const HotPtrs &P, Smem &S, double *X, double *Z, double *Y, double alpha, int iters) {
     if constexpr (MODE == MODE_DENSE) { admm_tiny<NB>(L, P, S, X, Z, Y, alpha, iters); return; }      // register-resident iterate and inverse
     if constexpr (MODE >= MODE_BCR) { admm_lat<NXT, NUT, MODE - MODE_BCR>(L, P, S, X, Z, Y, alpha, iters); return; }      // ... and cyclic-reduction factor
+    if constexpr (!LDSSTATE) {          // iterate in global memory -- or staged in LDS for the round (generic kernels of small batches)
+        if constexpr (NXT == 0) { if (L.lstage) { admm_round_global<NB, NXT, NUT, MODE, true>(L, P, S, alpha, iters); return; } }
+        admm_round_global<NB, NXT, NUT, MODE, false>(L, P, S, alpha, iters);
+        return;
+    }
+    // small-problem mode: the iterate x, z, y lives in LDS for the whole round, the owner-mapped phases above
     const int b = inst_of(P.perm), tid = threadIdx.x;
     double *gx = P.x + (size_t)b * L.n, *gz = P.z + (size_t)b * L.m, *gy = P.y + (size_t)b * L.m;
     double *W = S.T, *Tc = S.T + L.m;
-    if (LDSSTATE) {          // small-problem mode: the iterate x, z, y lives in LDS for the whole round
-        for (int j = tid; j < L.n; j += NT) X[j] = gx[j];
-        for (int r = tid; r < L.m; r += NT) { Z[r] = gz[r]; Y[r] = gy[r]; }
-    } else { X = gx; Z = gz; Y = gy; }
+    for (int j = tid; j < L.n; j += NT) X[j] = gx[j];
+    for (int r = tid; r < L.m; r += NT) { Z[r] = gz[r]; Y[r] = gy[r]; }
     __syncthreads();
     cgdouble *gom = (cgdouble *)(P.omega + (size_t)b * L.m), *gsv = (cgdouble *)(P.s + (size_t)b * L.n), *gqv = (cgdouble *)S.Qv;
     gdouble *dxg = (gdouble *)(P.dx + (size_t)b * L.n), *dyg = (gdouble *)(P.dy + (size_t)b * L.m);
@@ -965,18 +1053,16 @@ __device__ __forceinline__ void admm_body(const Lay &L, const HotPtrs &P, Smem &
     const double cc = P.c[b];
     constexpr bool BORDER = MODE == MODE_BORDER;
     OwnRegs hr;
-    if (LDSSTATE) own_load<NB, NXT, NUT>(L, gom, gsv, gqv, cc, hr);
+    own_load<NB, NXT, NUT>(L, gom, gsv, gqv, cc, hr);
 #ifndef MPCQP_ABL_NOPAR
-    if (LDSSTATE) own_rows_w<NB>(L, hr, cc, Z, Y, W, Tc);
-    else gown_rows_w<NB>(L, gom, cc, Z, Y, W, Tc);
+    own_rows_w<NB>(L, hr, cc, Z, Y, W, Tc);
 #endif
     TICK_RESET
     for (int it = 1; it <= iters; ++it) {
         const bool keep_delta = it == iters;         // the increments feed the infeasibility certificates of the check
         TICK_START
 #ifndef MPCQP_ABL_NOPAR
-        if (LDSSTATE) own_rhs<NB, NXT, NUT>(L, S.hot, hr, cc, X, W, Tc);
-        else gown_rhs<NB, NXT, NUT>(L, S.hot, gom, gsv, gqv, cc, X, W, Tc);
+        own_rhs<NB, NXT, NUT>(L, S.hot, hr, cc, X, W, Tc, S.tv);
 #endif
         TICK(0)
         BorderPtrs bp; bp.red = S.red;
@@ -988,18 +1074,14 @@ __device__ __forceinline__ void admm_body(const Lay &L, const HotPtrs &P, Smem &
         kkt_core<NB, NB == 16 && NXT == 0>(core_args(L, opaque_ptr(F), opaque_ptr((const double *)P.omega + (size_t)b * L.m)), Tc);
         if (BORDER) border_post(L, NB, Tc, S.tv);
 #ifndef MPCQP_ABL_NOPAR
-        if (LDSSTATE) own_update<NB, NXT, NUT>(L, S.hot, S.x0s, S.du0, hr, cc, alpha, X, Z, Y, W, Tc, keep_delta, dxg, dyg);
-        else gown_update<NB, NXT, NUT>(L, S.hot, S.x0s, S.du0, gom, gsv, cc, alpha, X, Z, Y, W, Tc, keep_delta, dxg, dyg);
+        own_update<NB, NXT, NUT>(L, S.hot, S.x0s, S.du0, hr, cc, alpha, X, Z, Y, W, Tc, keep_delta, dxg, dyg);
 #endif
         TICK(5)
     }
     TICK_FLUSH
 #ifndef MPCQP_ABL_NOPAR
-    if (LDSSTATE) own_finish(L, hr, cc, Y);
-    else gown_finish(L, gom, cc, Y);
+    own_finish(L, hr, cc, Y);
 #endif
-    if (LDSSTATE) {
-        for (int j = tid; j < L.n; j += NT) gx[j] = X[j];
-        for (int r = tid; r < L.m; r += NT) { gz[r] = Z[r]; gy[r] = Y[r]; }
-    }
+    for (int j = tid; j < L.n; j += NT) gx[j] = X[j];
+    for (int r = tid; r < L.m; r += NT) { gz[r] = Z[r]; gy[r] = Y[r]; }
 }

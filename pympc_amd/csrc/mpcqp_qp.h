@@ -118,7 +118,7 @@ __device__ __forceinline__ void row_bounds(const Ctx &c, const double *x0s, cons
 }
 
 // Linear cost of the x and u variables (eps part is zero): mpc.py:489-526 / 411-452.
-__device__ void build_q(const Ctx &c, const double *step, double *Qv) {
+__device__ __forceinline__ void build_q(const Ctx &c, const double *step, double *Qv) {
     const Lay &L = c.L;
     const double *um1 = step + L.nx, *xref = step + L.nx + L.nu;
     const double *uref = c.hot + L.ouref;
@@ -170,7 +170,7 @@ __device__ __forceinline__ double wave_reduce(double v) {
     return op(op(readlane_f64(v, 0), readlane_f64(v, 16)), op(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
 template <int KMAX, int KSUM>
-__device__ void block_reduce(double *vmax, double *vsum, double *red) {
+__device__ __forceinline__ void block_reduce(double *vmax, double *vsum, double *red) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     constexpr int K = KMAX + KSUM;
 #pragma unroll

@@ -123,7 +123,12 @@ def test_solves_like_the_oracle_and_like_one_stage_per_block(shape):
         with env(MPCQP_GROUP=0):
             Kp = _ctrl(shape, settings=dict(max_iter=400000), **tight); Kp.setup()
             assert not _grouped(Kp.prob.batch_problem, shape)
-        assert np.abs(info['u_seq'] - Kp.output(return_u_seq=True)[1]['u_seq']).max() <= 1e-6 * scale
+        # (the one-stage-per-block sweeps do not get every one of these to 1e-10 -- 151 blocks that are nine tenths padding around an unstable
+        #  plant, bordered: that is what this backend replaces -- so the comparison is made where they report 'solved')
+        if Kp.res.info.status == 'solved':
+            assert np.abs(info['u_seq'] - Kp.output(return_u_seq=True)[1]['u_seq']).max() <= 1e-6 * scale
+        else:
+            assert shape[3] < shape[2], (shape, Kp.res.info.status)          # only seen with a held input
         kw = _kw(shape)
         x = np.asarray(kw['Ad']) @ np.asarray(kw['x0']) + np.asarray(kw['Bd']).reshape(len(kw['x0']), -1) @ uo
         K.update(x, uo); Ko.update(x, uo)
@@ -160,3 +165,32 @@ def test_device_loop_equals_stepwise(shape):
             Ks.update(tr['x'][k + 1])
             infos = Ks.prob.infos()
             assert [i.status for i in infos] == list(tr['status'][k]) and [i.iter for i in infos] == list(tr['iter'][k]), k
+
+
+REFAC = {'notebook': (lambda f: dict(f.cart_pole(), Np=150, Nc=75)), 'r8_2_60_20': (lambda f: dict(f.random_lti(4, nx=8, nu=2, Np=60, xbox=4.0), Nc=20)),
+         'r8_2_60_60': (lambda f: f.random_lti(4, nx=8, nu=2, Np=60, xbox=4.0)), 'quadcopter_nc': (lambda f: dict(f.quadcopter(), Nc=4)),
+         'r3_2_50_20': (lambda f: dict(f.random_lti(5, nx=3, nu=2, Np=50, xbox=4.0), Nc=20)), 'r20_8_60_nc': (lambda f: dict(f.random_lti(4, nx=20, nu=8, Np=60, xbox=4.0), Nc=20)),
+         'r12_4_40': (lambda f: f.random_lti(4, nx=12, nu=4, Np=40, xbox=4.0))}
+
+
+@pytest.mark.parametrize('group', [1, 0])
+@pytest.mark.parametrize('name', sorted(REFAC))
+def test_refactorization_inside_the_solve_reproduces_the_setup_factor(name, group):
+    """What a rho update does -- the factorization run from inside k_mpc_run (mpcqp_refactor = the same phase alone) -- must give the factor
+    k_setup gave for the same rho: the KKT solve before and after agrees to rounding.  Round 4 broke exactly this for bordered 16 x 16 problems
+    (NaN factors from the refactorization phase of the four-per-CU kernels, k_setup's fine) through a callee shared between kernels of different
+    launch bounds, and no test saw it; both grouping settings, held inputs with LDS-resident and global iterates, 32-wide stages."""
+    from pympc_amd import MPCController, fixtures
+    with env(MPCQP_GROUP=group), warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        K = MPCController(**REFAC[name](fixtures)); K.setup(solve=False)
+        bp = K.prob.batch_problem
+        rhs = np.random.default_rng(1).standard_normal((1, bp.n))
+        s0 = bp.kkt_solve(rhs)
+        bp.refactor(); bp.synchronize()
+        s1 = bp.kkt_solve(rhs)
+        assert np.isfinite(s1).all()
+        assert np.abs(s0 - s1).max() <= 1e-12 * np.abs(s0).max()
+        K.solver_settings = {}
+        K2 = MPCController(**REFAC[name](fixtures)); K2.setup()              # ... and a cold solve with its rho updates ends with finite numbers
+        assert np.isfinite(K2.res.x).all() or K2.res.info.status != 'solved', K2.res.info.status
