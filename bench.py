@@ -531,8 +531,15 @@ def latency_leg(kind, nsim=300):
                raw_c_abi_step_us=raw_us, raw_c_abi_update_solve_u0_us=raw3_us, kernel_us=1e3 * ms / max(1, nl), kernel=bp.kernel_name(loop=False))
     from oracle.osqp_oracle import OSQP
     Ko = MPCController(**kw); Ko.prob = OSQP()
-    tso, _ = loop(Ko)
+    tso, itso = loop(Ko)
     out['cpu_oracle_update_us_median'] = float(np.median(tso))
+    # where the tail comes from: update() time follows the ADMM iterations of the step (OSQP checks every 25) -- the first steps after the cold
+    # start need several rounds and a rho update (one refactorization) -- on the CPU in the same proportion
+    out['cpu_oracle_update_us_p95'] = float(np.percentile(tso, 95))
+    out['admm_iters_median'], out['admm_iters_p95'] = float(np.median(its)), float(np.percentile(its, 95))
+    out['us_per_admm_iter_median'] = float(np.median(ts / np.maximum(1, its)))
+    out['tail_note'] = 'p95 / median of update() = %.2f on the GPU, %.2f on the CPU oracle, %.2f in ADMM iterations' % (
+        np.percentile(ts, 95) / np.median(ts), np.percentile(tso, 95) / np.median(tso), np.percentile(its, 95) / max(1.0, np.median(its)))
     if kind == 'notebook':
         out['reference_note'] = 'examples/example_inverted_pendulum_kalman.ipynb cell 17: about 1.05-1.2 ms per MPC step (OSQP, the author\'s laptop)'
     return out
