@@ -76,6 +76,7 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #include "mpcqp_group.h"
 #include "mpcqp_bcr.h"
 #include "mpcqp_wide.h"
+#include "mpcqp_huge.h"
 #include "mpcqp_dense.h"
 #include "mpcqp_border.h"
 #include "mpcqp_phases.h"
@@ -162,7 +163,7 @@ static Lay make_layout(int nx, int nu, int Np, int Nc, int soft) {
     L.n = (L.soft ? 2 : 1) * L.n_x + L.n_u; L.m = 2 * L.n_x + L.n_u + (Nc + 1) * nu;
     L.ou = L.n_x; L.oe = L.n_x + L.n_u;
     L.rs = L.n_x; L.ri = 2 * L.n_x; L.rdu = 2 * L.n_x + L.n_u;
-    L.NB = L.nb <= 16 ? 16 : L.nb <= 32 ? 32 : 64;
+    L.NB = L.nb <= 16 ? 16 : L.nb <= 32 ? 32 : L.nb <= 64 ? 64 : 128;
     L.border = Nc < Np ? 1 : 0;
     L.NcT = L.border ? Nc - 1 : Nc;
     L.rnx = 1.0f / (float)nx; L.rnu = 1.0f / (float)nu;
@@ -178,11 +179,11 @@ static Lay make_layout(int nx, int nu, int Np, int Nc, int soft) {
     L.step_sz = L.odu0 + 2 * nu;
     L.raw = 0;
     L.xref_rows = 1;
-    L.fstage = L.NB == 16 ? FactorFmt<16>::STAGE : L.NB == 32 ? FactorFmt<32>::STAGE : WideFmt::STAGE;
+    L.fstage = L.NB == 16 ? FactorFmt<16>::STAGE : L.NB == 32 ? FactorFmt<32>::STAGE : L.NB == 64 ? WideFmt::STAGE : HugeFmt::STAGE;
     L.fhead = L.NB == 16 ? FactorFmt<16>::HEAD : L.NB == 32 ? FactorFmt<32>::HEAD : 0;
-    L.ffwd = L.NB == 16 ? FactorFmt<16>::FWD : L.NB == 32 ? FactorFmt<32>::FWD : WideFmt::NN;      // (non-zero: the factor starts at the stages)
+    L.ffwd = L.NB == 16 ? FactorFmt<16>::FWD : L.NB == 32 ? FactorFmt<32>::FWD : L.NB == 64 ? WideFmt::NN : HugeFmt::NN;      // (non-zero: the factor starts at the stages)
     L.ftab = L.NB == 16 ? FactorFmt<16>::TAB : L.NB == 32 ? FactorFmt<32>::TAB : 0;
-    L.tsz = L.m + L.N * L.NB * (L.NB == 64 ? 2 : 1);   // [W (m) | Tc (N*NB)] (+ the second stage-major vector of the wide solve); mpcqp_create widens it where the factorization needs more
+    L.tsz = L.m + L.N * L.NB * (L.NB >= 64 ? 2 : 1);   // [W (m) | Tc (N*NB)] (+ the second stage-major vector of the wide solve); mpcqp_create widens it where the factorization needs more
     L.NR = L.N * L.nb; L.dld = L.NR | 1;               // dense mode (decided in mpcqp_create): unknowns, odd LDS row stride
     return L;
 }
@@ -199,7 +200,7 @@ static int dalloc(mpcqp_handle *h, T **p, size_t count) {
 
 extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, int nu, int Np, int Nc, const mpcqp_settings *s) {
     if (!out || batch < 1 || nx < 1 || nu < 1 || Np < 2 || Nc < 1 || Nc > Np) return fail(MPCQP_ERR_ARG, "mpcqp_create: bad dimensions");
-    if (nx + nu > 64) return fail(MPCQP_ERR_UNSUPPORTED, "mpcqp_create: nx+nu > 64 is not implemented");
+    if (nx + nu > 128) return fail(MPCQP_ERR_UNSUPPORTED, "mpcqp_create: nx+nu > 128 is not implemented");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(MPCQP_ERR_NO_DEVICE, "no HIP device available");
     if (device < 0 || device >= ndev) return fail(MPCQP_ERR_ARG, "mpcqp_create: bad device index");
@@ -264,6 +265,7 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     rc |= dalloc(h, &P.dx, B * L.n); rc |= dalloc(h, &P.dy, B * L.m);
     rc |= dalloc(h, &P.qv, B * (size_t)(L.n_x + L.n_u));
     if (bcr) rc |= dalloc(h, &P.bws, B * (size_t)NS * BcrFmt::WSTAGE);
+    if (L.NB == 128) rc |= dalloc(h, &P.bws, B * (size_t)HugeFmt::GWS);      // (the factorization's work matrices of 128-wide stages)
     if (L.border) { rc |= dalloc(h, &P.Bb, B * (size_t)L.nu * L.N * L.NB); rc |= dalloc(h, &P.Zb, B * (size_t)L.nu * L.N * L.NB); rc |= dalloc(h, &P.Sig, B * (size_t)L.nu * L.nu); }
     rc |= dalloc(h, &P.Dt, B * L.n); rc |= dalloc(h, &P.Et, B * L.m);
     rc |= dalloc(h, &P.ctype, B * L.m); rc |= dalloc(h, &P.info, B); rc |= dalloc(h, &P.stats, 8);
@@ -274,7 +276,7 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     if (rc) { std::string msg = g_err; mpcqp_destroy(h); return fail(MPCQP_ERR_HIP, msg); }
     // The factorization's workspace starts at the work area T, the last part of the common block,
     // and may run on into the iterate area (dead while a factorization runs); T is widened only where even that is short.
-    const int fws = dense ? L.NR * L.dld + 2 * DenseFmt::ROWS + L.m + L.n : bcr ? BcrFmt::LDSW + L.m + L.n : (L.NB == 16 ? FactorCfg<16>::WS : L.NB == 32 ? FactorCfg<32>::WS : WideFmt::WS);
+    const int fws = dense ? L.NR * L.dld + 2 * DenseFmt::ROWS + L.m + L.n : bcr ? BcrFmt::LDSW + L.m + L.n : (L.NB == 16 ? FactorCfg<16>::WS : L.NB == 32 ? FactorCfg<32>::WS : L.NB == 64 ? WideFmt::WS : HugeFmt::WS);
     const int avail = L.tsz + (h->lds_state ? (int)state_doubles : 0);
     if (avail < fws) h->L.tsz += fws - avail;
     h->smem_setup = sizeof(double) * ((size_t)smem_common_doubles(h->L) + (h->lds_state ? state_doubles : 0));      // every kernel gets the full block
@@ -351,7 +353,8 @@ static int put(mpcqp_handle *h, double *dst, int stride, int off, const double *
 #define DISPATCH_NB(NBV, EXPR) switch (NBV) { \
     case 16: { constexpr int NB = 16; EXPR; } break; \
     case 32: { constexpr int NB = 32; EXPR; } break; \
-    default: { constexpr int NB = 64; EXPR; } break; }
+    case 64: { constexpr int NB = 64; EXPR; } break; \
+    default: { constexpr int NB = 128; EXPR; } break; }
 
 template <class K>
 static int set_smem(K kernel, size_t bytes) {
@@ -617,7 +620,8 @@ static int launch_run(mpcqp_handle *h, RunArgs R, int plain_iters) {
     else if (L.NB == 32 && !h->lds_state && L.nx == 20 && L.nu == 8 && !L.border) rc = launch_run_t<32, false, 20, 8, MODE_CHAIN>(h, R);
     else if (L.NB == 16) rc = h->lds_state ? launch_run_generic<16, true>(h, R) : launch_run_generic<16, false>(h, R);
     else if (L.NB == 32) rc = h->lds_state ? launch_run_generic<32, true>(h, R) : launch_run_generic<32, false>(h, R);
-    else rc = launch_run_generic<64, false>(h, R);
+    else if (L.NB == 64) rc = launch_run_generic<64, false>(h, R);
+    else rc = launch_run_generic<128, false>(h, R);
     if (rc) return rc;
     HIPCHK(hipGetLastError());
     if (h->profiling) { HIPCHK(hipEventRecord(h->ev1[e], h->stream)); h->ev_count += 1; }
@@ -961,7 +965,7 @@ extern "C" int mpcqp_get_stream_bytes(mpcqp_handle *h, int64_t *per_iter, int64_
     const int64_t sinv = L.fstage - L.ffwd - L.ftab;
     int64_t it = (L.dense || L.bcr) ? 0 /* the factor sits in registers for the round */ : !L.ffwd ? 2 * (int64_t)L.N * sinv + (int64_t)L.N * L.ftab + 2 * (int64_t)L.fhead   // S^-1-only build: S^-1 twice, one of the two tables per sweep, [G | G'] by each sweeping wave
                          : (int64_t)(L.N - 1) * L.ffwd + (int64_t)L.N * sinv + (int64_t)(L.N - 1) * L.ftab + L.fhead;   // forward matrices once, S^-1 once, the tables, G / G' once each
-    if (L.NB == 64) it = (3 * (int64_t)L.N - 2) * WideFmt::NN;      // wide stages: S^-1 of every stage, M and M' of all but the last
+    if (L.NB >= 64) it = (3 * (int64_t)L.N - 2) * (int64_t)L.NB * L.NB;      // wide stages: S^-1 of every stage, M and M' of all but the last
     if (L.grp) it = (3 * (int64_t)group_count(L.N, L.grp) - 1) * GroupFmt::NN;      // grouped small stages: S^-1 of every super-stage, forward matrix and its transpose of all but the ends, the middle's second pair
     if (!h->lds_state && !L.lstage) it += (2 * n + 4 * m) /* x, z, y read + written */ + (m + L.n_x) /* omega */ + (n + L.n_x) /* s */ + nq /* q */;
     if (L.border && !L.dense) it += 2 * (int64_t)L.nu * L.N * NB;      // (the dense inverse holds the held input's couplings itself)
@@ -983,7 +987,7 @@ extern "C" int mpcqp_get_work(mpcqp_handle *h, int64_t *mfma_per_iter) {
     if (!h || !mfma_per_iter) return fail(MPCQP_ERR_ARG, "null argument");
     const Lay &L = h->L;
     int64_t mv = 0;                                  // 16 x 16 mat-vecs (four MFMAs each)
-    if (L.dense || L.NB == 64) mv = 0;               // vector ALU only
+    if (L.dense || L.NB >= 64) mv = 0;               // vector ALU only
     else if (L.bcr) {
         for (int l = 0; l < bcr_levels(L.bcr); ++l)
             for (int kind = 0; kind < 3; ++kind) for (int t = 0; t < lat_count(L.bcr, l, kind); ++t) mv += lat_nfr(L.bcr, l, kind, t);

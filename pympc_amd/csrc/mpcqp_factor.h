@@ -98,7 +98,7 @@ __device__ __forceinline__ int frag_pos(int r, int cidx) {
 //   -Mt_mid in slot 0 of stage 0 (which has none of its own).  Back substitution: x_k += slot0(k+1)' x_{k+1} in the
 //   top half, x_k += slot0(k-1)' x_{k-1} in the bottom half (-Mt_mid' for k = mid+1).
 // W: LDS workspace of 6*NB*NB doubles.  Returns (uniformly) 0, or 1 if a pivot was not positive.
-struct BorderPtrs { double *Bb, *Zb, *Sig, *red; };
+struct BorderPtrs { double *Bb, *Zb, *Sig, *red; double *gws; };      // (gws: the global factorization workspace of 128-wide stages, mpcqp_huge.h)
 
 template <int NB> __device__ __forceinline__ void border_factor(const Ctx &, const double *, const double *, double, const double *, double *, double *, double *, double *, double *, double *);
 
@@ -307,3 +307,4 @@ __device__ __forceinline__ int factor_all(const Ctx &c, const double *om, const 
     return *iflag;
 }
 template <> __device__ __forceinline__ int factor_all<64>(const Ctx &, const double *, const double *, double, double *, double *, int *, BorderPtrs);      // mpcqp_wide.h
+template <> __device__ __forceinline__ int factor_all<128>(const Ctx &, const double *, const double *, double, double *, double *, int *, BorderPtrs);     // mpcqp_huge.h

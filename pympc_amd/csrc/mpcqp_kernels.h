@@ -168,8 +168,8 @@ __global__ __launch_bounds__(NT, run_occupancy(NB, MODE)) void k_mpc_run(RunKArg
     const int nrun = LOOP ? R.nsteps : 1;        // LOOP = false: one solve of the current data (mpcqp_solve)
     for (int k = 0; k < nrun; ++k) {
         if (LOOP) {
-            // scratch in the (idle) work area: un | xn | xt | ym | inn | xu, 64 doubles each (nx + nu <= 64)
-            double *un = S.T, *xn = S.T + 64, *xt = S.T + 128, *ym = S.T + 192, *inn = S.T + 256, *xu = S.T + 320;
+            // scratch in the (idle) work area: un | xn | xt | ym | inn | xu, 128 doubles each (nx + nu <= 128, ny <= 64)
+            double *un = S.T, *xn = S.T + 128, *xt = S.T + 256, *ym = S.T + 384, *inn = S.T + 512, *xu = S.T + 640;
             const size_t kb = (size_t)k * R.batch + b;
             const int ny = R.ny;
             // ---- output(): first input of the current solution, or u_failure

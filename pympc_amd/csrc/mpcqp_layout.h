@@ -9,7 +9,7 @@ constexpr int MAXEV = 64;         // profiling: launches whose HIP events may be
 
 struct Lay {
     int nx, nu, Np, Nc, N, nb, n, m, n_x, n_u, ou, oe, rs, ri, rdu;
-    int NB;                       // padded stage block size (16 or 32)
+    int NB;                       // padded stage block size (16, 32, 64 or 128)
     int soft;                     // 1: slack columns eps_k (soft state box, pyMPC's SOFT_ON); 0: none, the state box is hard
     int NcT;                      // stages 0..NcT-1 carry their input u_k inside the block-tridiagonal part
     int border;                   // 1 if Nc < Np: the held last input u_{Nc-1} couples to every later stage and is
@@ -41,7 +41,7 @@ struct Ptrs {
     double *xo, *yo;              // reported solution
     double *dx, *dy;              // last primal / dual increments (infeasibility certificates)
     double *Bb, *Zb, *Sig;        // border (Nc < Np): K[:,ubar] and T^-1 K[:,ubar] in padded layout [nu][N*NB], Schur inverse [nu*nu]
-    double *bws;                  // block cyclic reduction: global workspace of the factorization, [batch][N * BcrFmt::WSTAGE]
+    double *bws;                  // global workspace of a factorization: block cyclic reduction [batch][N * BcrFmt::WSTAGE]; 128-wide stages [batch][HugeFmt::GWS]
     double *qv;                   // linear cost of the x,u variables [n_x+n_u] (rebuilt by every kernel prologue)
     double *Dt, *Et;              // Ruiz temporaries
     int *ctype;

@@ -20,6 +20,7 @@ __device__ __forceinline__ BorderPtrs border_ptrs(const Lay &L, const Ptrs &P, c
     BorderPtrs bp; bp.red = S.red;
     const size_t npb = (size_t)L.nu * L.N * L.NB;
     const int b = inst_of(P.perm);
+    bp.gws = L.NB == 128 ? P.bws + (size_t)b * HugeFmt::GWS : nullptr;
     bp.Bb = L.border ? P.Bb + b * npb : nullptr;
     bp.Zb = L.border ? P.Zb + b * npb : nullptr;
     bp.Sig = L.border ? P.Sig + (size_t)b * L.nu * L.nu : nullptr;
@@ -257,7 +258,7 @@ __device__ __forceinline__ void check_norms_own(const Ctx &c, const double *X, c
         double px = 0.0;
         for (int l = 0; l < nu; ++l) {
             const int lo = min(jj, l), hi = max(jj, l);
-            px += __dadd_rn(__dmul_rn(iu, Qu[lo * nu + hi]), __dmul_rn(dk, QDu[lo * nu + hi])) * uk[l];
+            px += input_weight(iu, Qu[lo * nu + hi], dk, QDu[lo * nu + hi]) * uk[l];
         }
         if (k + 1 < L.Nc) for (int l = 0; l < nu; ++l) px += -QDu[jj * nu + l] * uk[nu + l];
         if (k > 0) for (int l = 0; l < nu; ++l) px += -QDu[l * nu + jj] * uk[l - nu];
@@ -371,7 +372,7 @@ __device__ __forceinline__ void check_norms_gown(const Ctx &c, const double *gX,
                 double px = 0.0;
                 for (int l = 0; l < nu; ++l) {
                     const int lo = min(jj, l), hi = max(jj, l);
-                    px += __dadd_rn(__dmul_rn(iu, Qu[lo * nu + hi]), __dmul_rn(dk, QDu[lo * nu + hi])) * uk[l];
+                    px += input_weight(iu, Qu[lo * nu + hi], dk, QDu[lo * nu + hi]) * uk[l];
                 }
                 if (k + 1 < L.Nc) for (int l = 0; l < nu; ++l) px += -QDu[jj * nu + l] * uk[nu + l];
                 if (k > 0) for (int l = 0; l < nu; ++l) px += -QDu[l * nu + jj] * uk[l - nu];

@@ -3,6 +3,16 @@
 // entries of the reduced KKT matrix.
 #pragma once
 
+// iu Qu + dk QDu exactly as the reference forms it (mpc.py:510-526: two products, each rounded, then the sum): the entry of P must be BIT-identical
+// to scipy's.  __dmul_rn / __dadd_rn do not stop the compiler from contracting the pair into one fused multiply-add (seen with iu = 5: 0.6000000000000001
+// instead of 0.6; a power-of-two iu hides it), so the products are pinned in registers first.
+__device__ __forceinline__ double input_weight(double iu, double qu, double dk, double qdu) {
+    double a = iu * qu, b = dk * qdu;
+    asm volatile("" : "+v"(a), "+v"(b));
+    return a + b;
+}
+
+
 // ------------------------------------------------------------------------------------------------
 // Row visitors: enumerate (coefficient, index) of one row of A, one column of A, one row of P.
 // They ARE the device-side definition of the reference's matrices (mpc.py:482-598).
@@ -87,7 +97,7 @@ __device__ __forceinline__ void P_row(const Ctx &c, int j, F f) {
         int base = L.ou + k * L.nu;
         for (int l = 0; l < L.nu; ++l) {
             int a = min(jj, l), b = max(jj, l);
-            f(__dadd_rn(__dmul_rn(iu, Qu[a * L.nu + b]), __dmul_rn(dk, QDu[a * L.nu + b])), base + l);
+            f(input_weight(iu, Qu[a * L.nu + b], dk, QDu[a * L.nu + b]), base + l);
         }
         if (k + 1 < L.Nc) for (int l = 0; l < L.nu; ++l) f(-QDu[jj * L.nu + l], base + L.nu + l);
         if (k > 0) for (int l = 0; l < L.nu; ++l) f(-QDu[l * L.nu + jj], base - L.nu + l);

@@ -591,3 +591,4 @@ __device__ __forceinline__ void kkt_core(const CoreArgs &a, double *Tc) {
 #endif
 }
 template <> __device__ __forceinline__ void kkt_core<64, false>(const CoreArgs &, double *);      // mpcqp_wide.h (stages wider than 32)
+template <> __device__ __forceinline__ void kkt_core<128, false>(const CoreArgs &, double *);     // mpcqp_huge.h (stages wider than 64)

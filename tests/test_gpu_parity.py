@@ -451,7 +451,7 @@ def test_boundary_dimensions_match_oracle(dims):
 
 def test_unsupported_dimensions_fail_loudly():
     from pympc_amd import fixtures
-    kw = dict(fixtures.random_lti(1, nx=60, nu=8, Np=3))        # nx + nu > 64 (32 < nx + nu <= 64: tests/test_gpu_wide.py)
+    kw = dict(fixtures.random_lti(1, nx=120, nu=12, Np=3))      # nx + nu > 128 (32 < nx + nu <= 128: tests/test_gpu_wide.py)
     K = _gpu_controller(kw)
     with pytest.raises(NotImplementedError):
         K.setup()

@@ -1,4 +1,4 @@
-"""Stage blocks wider than 32 (32 < nx + nu <= 64; pympc_amd/csrc/mpcqp_wide.h): the reference takes any size (pyMPC/mpc.py:90-96),
+"""Stage blocks wider than 32 (32 < nx + nu <= 64: pympc_amd/csrc/mpcqp_wide.h; up to 128: mpcqp_huge.h): the reference takes any size (pyMPC/mpc.py:90-96),
 the device used to refuse these.  Same checks as the narrower shapes get: the condensed QP against the host build of the
 reference's formulas, the KKT solve against a dense solve, ADMM iterates and a default-tolerance solve against the oracle,
 u* at tight tolerance, the closed loop on the device against the stepwise API."""
@@ -10,7 +10,9 @@ import scipy.sparse as sp
 
 pytestmark = pytest.mark.gpu
 
-WIDE = {'33': (25, 8, 3, 3), '48': (40, 8, 10, 10), '40_nc': (30, 10, 12, 5), '64': (56, 8, 5, 5), '64_u': (48, 16, 4, 4), '36_long': (32, 4, 40, 40)}
+WIDE = {'33': (25, 8, 3, 3), '48': (40, 8, 10, 10), '40_nc': (30, 10, 12, 5), '64': (56, 8, 5, 5), '64_u': (48, 16, 4, 4), '36_long': (32, 4, 40, 40),
+        # 64 < nx + nu <= 128 (pympc_amd/csrc/mpcqp_huge.h: the merely-correct backend of round 4; VERDICT r3 asked for (70,10,5) and (100,20,3))
+        '80': (70, 10, 5, 5), '120': (100, 20, 3, 3), '68_nc': (60, 8, 6, 2), '128': (96, 32, 2, 2)}
 
 
 def _kw(tag):
@@ -44,7 +46,7 @@ def test_wide_qp_and_kkt_solve(tag):
     K, _ = _pair(kw)
     K.setup(solve=False)
     bp = K.prob.batch_problem
-    assert bp.kernel_name(loop=False).startswith('k_mpc_run<64,')
+    assert bp.kernel_name(loop=False).startswith('k_mpc_run<%d,' % (64 if sum(WIDE[tag][:2]) <= 64 else 128))
     P, q, A, l, u = bp.export_qp()
     Pr, qr, Ar, lr, ur = qp_build.build_qp(K)[:5]
     U = sp.triu(Pr).toarray()
@@ -61,7 +63,7 @@ def test_wide_qp_and_kkt_solve(tag):
     assert np.abs(Kmat @ sol - rhs).max() < 1e-8 * max(1.0, np.abs(Kmat).max() * np.abs(sol).max())
 
 
-@pytest.mark.parametrize('tag', ['33', '48', '40_nc', '64'])
+@pytest.mark.parametrize('tag', ['33', '48', '40_nc', '64', '80', '120', '68_nc'])
 def test_wide_iterates_and_default_solve_match_oracle(tag):
     kw = _kw(tag)
     K, Ko = _pair(kw)
@@ -123,8 +125,34 @@ def test_wide_device_loop_equals_stepwise():
         assert [i.status for i in infos] == list(tr['status'][k]) and [i.iter for i in infos] == list(tr['iter'][k]), k
 
 
-def test_beyond_wide_fails_loudly():
+def test_huge_device_loop_equals_stepwise():
+    """Two 80-wide controllers, four closed-loop steps inside one launch against output()/update() per step (stride-128 instantiation of the loop)."""
+    from pympc_amd import BatchMPCController, fixtures
+    kws = [fixtures.random_lti(1400 + i, nx=70, nu=10, Np=4, xbox=3.0) for i in range(2)]
+    keys = ('x0', 'xref', 'uref', 'uminus1', 'Qx', 'QxN', 'Qu', 'QDu', 'xmin', 'xmax', 'umin', 'umax', 'Dumin', 'Dumax')
+    stack = lambda k: np.stack([np.asarray(kw[k], dtype=float) for kw in kws])
+
+    def make():
+        K = BatchMPCController(stack('Ad'), stack('Bd'), Np=4, eps_feas=np.array([[kw.get('eps_feas', 1e6)] for kw in kws]), **{k: stack(k) for k in keys})
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            K.setup()
+        return K
+    Kd, Ks = make(), make()
+    assert Kd.prob.kernel_name(loop=True).startswith('k_mpc_run<128,')
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        tr = Kd.run(4)
+        for k in range(4):
+            assert np.array_equal(Ks.output(), tr['u'][k]), k
+            Ks.update(tr['x'][k + 1])
+            infos = Ks.prob.infos()
+            assert [i.status for i in infos] == list(tr['status'][k]) and [i.iter for i in infos] == list(tr['iter'][k]), k
+
+
+def test_beyond_huge_fails_loudly():
+    """nx + nu > 128: still refused, loudly (the reference itself has no limit, mpc.py:82-105)."""
     from pympc_amd import MPCController, fixtures
-    K = MPCController(**fixtures.random_lti(1, nx=60, nu=8, Np=3))
+    K = MPCController(**fixtures.random_lti(1, nx=120, nu=12, Np=3))
     with pytest.raises(NotImplementedError):
         K.setup()
