@@ -1,7 +1,8 @@
 """bench.py's roofline numerator is a byte MODEL kept in host code (mpcqp_get_stream_bytes): what k_mpc_run is designed to stream per
-ADMM iteration / round / solve.  The committed counter profile of the same kernels (profiles/pmc_hbm_traffic.json: rocprofv3 FETCH_SIZE x 2
-+ WRITE_SIZE per ADMM iteration per QP, scripts/pmc_summary.py) is the measurement it must stay close to: if the factor format or the
-sweeps change, the model changes with them and this test asks for a fresh profile instead of letting the headline fraction drift."""
+ADMM iteration / round / solve.  The committed counter profiles of the same kernels (profiles/pmc_hbm_traffic.json: rocprofv3 FETCH_SIZE x 2
++ WRITE_SIZE per ADMM iteration per QP, scripts/r4_profiles.sh + scripts/pmc_summary.py) are the measurement it must stay close to: if the
+factor format, the sweeps or the check phase change, the model changes with them and this test asks for a fresh profile instead of letting
+the headline fraction drift.  Three profiled command shapes: the headline batch, the HBM-only leg (batch 4096) and cfg-5."""
 import json
 import os
 
@@ -10,20 +11,25 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
+# key in the profile file, shape, batch, ADMM iterations per solve of the profiled launches, measured / model seen when the profile was taken
+CASES = [('cfg3', (12, 4, 30), 1024, 38.0, 1.06), ('cfg3_b4096', (12, 4, 30), 4096, 38.0, 1.07), ('cfg5', (20, 8, 100), 512, 27.5, 0.92)]
 
-@pytest.mark.parametrize('cfg,dims,batch,iters_per_solve', [('cfg3', (12, 4, 30), 1024, 35.5), ('cfg5', (20, 8, 100), 512, 25.1)])
-def test_stream_byte_model_matches_the_committed_counter_profile(cfg, dims, batch, iters_per_solve):
+
+@pytest.mark.parametrize('key,dims,batch,iters_per_solve,seen', CASES, ids=[c[0] for c in CASES])
+def test_stream_byte_model_matches_the_committed_counter_profile(key, dims, batch, iters_per_solve, seen):
     from pympc_amd.solver import BatchProblem
     nx, nu, Np = dims
     bp = BatchProblem(batch, nx, nu, Np)
     per_iter, per_round, per_solve = bp.stream_bytes()
     model = per_iter + per_round / 25.0 + per_solve / iters_per_solve        # one check per 25 iterations (OSQP's default)
-    prof = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_hbm_traffic.json')))[cfg]['device_loop']
+    prof = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_hbm_traffic.json')))[key]['device_loop']
     name = bp.kernel_name(loop=True)
-    assert name in prof, 'profiles/pmc_hbm_traffic.json has no entry for %s: re-profile (scripts/profile_round.sh)' % name
+    assert name in prof, 'profiles/pmc_hbm_traffic.json has no entry for %s: re-profile (scripts/r4_profiles.sh)' % name
     entry = prof[name]
     assert entry['batch'] == batch
-    measured = entry['hbm_bytes_per_iter_per_qp']
-    # measured / designed: 1.12 (cfg-3; per-round and per-solve reads land a little above the model), 0.94 (cfg-5; part of the stream
-    # is served by L2 hits on the shared G fragments)
-    assert 0.85 <= measured / model <= 1.25, (measured, model)
+    ratio = entry['hbm_bytes_per_iter_per_qp'] / model
+    # measured / designed: 1.06 - 1.07 at (12,4,30) (per-round and per-solve reads and the writes land a little above the model; the same at
+    # batch 1024 inside the Infinity Cache and at 4096 beyond it: the counters see every byte either way), 0.92 at cfg-5 (part of the stream --
+    # the shared G fragments, the tables -- is served by L2: hit rate 28 %).  Held to what was seen within 8 %, and to the model within 15 %.
+    assert abs(ratio - seen) <= 0.08, (ratio, seen)
+    assert 0.85 <= ratio <= 1.15, ratio
