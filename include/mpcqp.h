@@ -101,6 +101,11 @@ const char *mpcqp_status_string(int status);
 const char *mpcqp_last_error(void);
 int mpcqp_device_count(void);
 
+/* osqp.OSQP() (mpc.py:241) for `batch` controllers of one shape.  Np >= 2, 1 <= Nc <= Np, nx + nu <= 128 (MPCQP_ERR_UNSUPPORTED beyond:
+ * the reference has no limit).  The KKT backend is chosen here from the shape and the batch: dense register-resident inverse
+ * (N (nx+nu) <= 128), cyclic reduction (nx+nu <= 16, Np <= 30, Nc = Np, at most two instances per compute unit), grouped stages (nx+nu <= 8 on
+ * longer horizons), block-tridiagonal sweeps (everything else up to 32 wide), plain block LDL' (33..128 wide).  Results do not depend on it
+ * beyond rounding. */
 int mpcqp_create(mpcqp_handle **h, int device, int batch, int nx, int nu, int Np, int Nc,
                  const mpcqp_settings *s);
 void mpcqp_destroy(mpcqp_handle *h);
@@ -279,8 +284,8 @@ int mpcqp_refactor(mpcqp_handle *h);
  * the law without inequality constraints need (test_scripts/alternative/unconstrained.py:170-183: k_x0, k_Xref, k_Uref, k_uminus1 --
  * there a dense condensed solve); pympc_amd/unconstrained.py calls it on a batch of unit-vector problems.
  * At most `sweeps` sweeps; an instance stops earlier once a correction is below tol * max(1, |w|_inf) (tol = 0: never).
- * cold != 0: start from zero, else continue from the current iterate.  The result is read with mpcqp_get_solution (status 'solved',
- * iter = sweeps done).  res (host or device, may be NULL): [batch][5] = |P w + q + A_e'y|, max(|P w|, |A_e'y|, |q|), |A_e w - b|,
+ * cold != 0: start from zero, else continue from the current iterate.  The result is read with mpcqp_get_solution (status 'solved', or
+ * 'maximum iterations reached' if a tolerance was given and `sweeps` sweeps did not settle the instance; iter = sweeps done).  res (host or device, may be NULL): [batch][5] = |P w + q + A_e'y|, max(|P w|, |A_e'y|, |q|), |A_e w - b|,
  * max(|A_e w|, |b|) (infinity norms, unscaled) after the last sweep, and the sweeps done.  Synchronous. */
 int mpcqp_eq_solve(mpcqp_handle *h, int sweeps, int cold, double tol, double *res);
 

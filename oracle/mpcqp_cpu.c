@@ -552,7 +552,7 @@ int mpcqp_eq_solve(mpcqp_handle *h, int sweeps, int cold, double tol, double *re
     for (int b = 0; b < h->batch; ++b) {
         if (cold) { memset(xs, 0, sizeof(double) * n); memset(ys, 0, sizeof(double) * m); oracle_warm_start(h->w[b], xs, ys); }
         oracle_get_scaling(h->w[b], D, E, &cc);
-        int done = 0;
+        int done = 0, settled = 0;
         for (int k = 0; k < sweeps; ++k) {
             oracle_get_iterate(h->w[b], xp, zs, ys, &rho);
             oracle_iterate(h->w[b], 1);
@@ -560,13 +560,13 @@ int mpcqp_eq_solve(mpcqp_handle *h, int sweeps, int cold, double tol, double *re
             done = k + 1;
             double dm = 0.0, xm = 0.0;
             for (size_t j = 0; j < n; ++j) { dm = fmax(dm, fabs(D[j] * (xs[j] - xp[j]))); xm = fmax(xm, fabs(D[j] * xs[j])); }
-            if (k >= 2 && dm <= tol * fmax(1.0, xm)) break;      /* (an ADMM iteration sees the right-hand side b only through z: from a cold start the first one moves nothing) */
+            if (k >= 2 && dm <= tol * fmax(1.0, xm)) { settled = 1; break; }      /* (an ADMM iteration sees the right-hand side b only through z: from a cold start the first one moves nothing) */
         }
         oracle_get_iterate(h->w[b], xs, zs, ys, &rho);
         for (size_t j = 0; j < n; ++j) h->xs[(size_t)b * n + j] = D[j] * xs[j];
         for (size_t i = 0; i < m; ++i) h->ys[(size_t)b * m + i] = E[i] * ys[i] / cc;
         mpcqp_info *inf = &h->info[b];
-        inf->status = MPCQP_SOLVED; inf->iter = done; inf->rho_updates = 0; inf->reserved = 0; inf->obj_val = 0.0; inf->pri_res = 0.0; inf->dua_res = 0.0; inf->rho = rho;
+        inf->status = (tol > 0.0 && !settled) ? MPCQP_MAX_ITER_REACHED : MPCQP_SOLVED; inf->iter = done; inf->rho_updates = 0; inf->reserved = 0; inf->obj_val = 0.0; inf->pri_res = 0.0; inf->dua_res = 0.0; inf->rho = rho;
         if (res) { double *r = res + (size_t)b * 5; r[0] = 0.0; r[1] = 1.0; r[2] = 0.0; r[3] = 1.0; r[4] = (double)done; }
     }
     free(D); free(E); free(xs); free(zs); free(ys); free(xp);

@@ -386,7 +386,8 @@ __global__ __launch_bounds__(NT) void k_eq_solve(Lay L, Ptrs P, int sweeps, int 
         z[i] = ax;
     }
     if (tid == 0) {
-        mpcqp_info inf; inf.status = MPCQP_SOLVED; inf.iter = done; inf.rho_updates = 0; inf.reserved = 0;
+        // 'solved': the corrections have vanished (or no tolerance was asked for); 'maximum iterations reached': `sweeps` sweeps did not settle it
+        mpcqp_info inf; inf.status = (tol > 0.0 && !settled) ? MPCQP_MAX_ITER_REACHED : MPCQP_SOLVED; inf.iter = done; inf.rho_updates = 0; inf.reserved = 0;
         inf.obj_val = 0.0; inf.pri_res = nrm[2]; inf.dua_res = nrm[0]; inf.rho = P.rho[b];
         P.info[b] = inf;
     }

@@ -65,7 +65,7 @@ class GainSolver:
         U = x[:, ou:ou + self.Nc * nu].T.copy()                      # column j = U* for the j-th unit argument
         if not np.isfinite(U).all() or not (self.residuals.max() <= RES_SANITY):
             raise RuntimeError('unconstrained_gains: the multiplier sweeps did not converge (KKT residuals %.2e after %d sweeps)' % (self.residuals.max(), self.sweeps))
-        if self.sweeps >= MAX_SWEEPS:
+        if any(i.status != 1 for i in p.infos()):                    # ('maximum iterations reached': a column did not settle within MAX_SWEEPS)
             raise RuntimeError('unconstrained_gains: the multiplier sweeps did not settle within %d sweeps' % self.sweeps)
         return dict(K_x0=U[:, :nx].copy(), K_xref=U[:, nx:2 * nx].copy(), K_uref=U[:, 2 * nx:2 * nx + nu].copy(), K_um1=U[:, 2 * nx + nu:].copy())
 

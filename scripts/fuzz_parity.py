@@ -1,5 +1,5 @@
-"""One-off sweep: seeded random controllers (tests/test_gpu_parity.py::_random_case with larger dimension ranges, including 32- and 64-wide
-stages, Nc < Np, hard and soft state constraints) -- cold solve and one warm step against the CPU oracle at tight tolerance.
+"""One-off sweep: seeded random controllers (tests/test_gpu_parity.py::_random_case with larger dimension ranges: 32-, 64- and 128-wide
+stages, small stages on long horizons, every cyclic-reduction schedule, Nc < Np, hard and soft state constraints) -- cold solve and one warm step against the CPU oracle at tight tolerance.
 python scripts/fuzz_parity.py [first_seed] [count]"""
 import os, sys, warnings
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,10 +13,16 @@ bad = 0
 for seed in range(first, first + count):
     rng = np.random.default_rng(31000 + seed)
     kw = T._random_case(seed)
-    if rng.random() < 0.5:                                  # widen: the generator of the test-suite stops at nx = 13, nu = 5
-        nx = int(rng.integers(10, 50)); nu = int(rng.integers(2, 14)); Np = int(rng.integers(3, 16))
-        if nx + nu > 64:
+    kind = rng.random()
+    if kind < 0.75:                                         # widen: the generator of the test-suite stops at nx = 13, nu = 5
+        if kind < 0.45: nx, nu, Np = int(rng.integers(10, 50)), int(rng.integers(2, 14)), int(rng.integers(3, 16))
+        elif kind < 0.6: nx, nu, Np = int(rng.integers(1, 7)), int(rng.integers(1, 3)), int(rng.integers(32, 130))        # small stages, long horizons (grouped: round 4)
+        elif kind < 0.7: nx, nu, Np = int(rng.integers(3, 13)), int(rng.integers(1, 4)), int(rng.integers(8, 31))        # cyclic-reduction territory, every schedule
+        else: nx, nu, Np = int(rng.integers(55, 110)), int(rng.integers(4, 18)), int(rng.integers(2, 5))                  # 65 .. 128 wide (round 4)
+        if kind < 0.45 and nx + nu > 64:
             nx = 64 - nu
+        if nx + nu > 128:
+            nx = 128 - nu
         kw = dict(fixtures.random_lti(41000 + seed, nx=nx, nu=nu, Np=Np, xbox=4.0)); kw['x0'] = 0.4 * kw['x0']
         if rng.random() < 0.4:
             kw['Nc'] = int(rng.integers(1, Np + 1))
