@@ -21,6 +21,15 @@
 // and zero in the stored inverse, like everywhere else.
 #pragma once
 
+// prefetch ring depths of the two sweeps (stages in flight in registers: 16 VGPRs each forward, 8 backward).  Measured on the notebook shape, one
+// controller: 0.19 us per forward step, 0.11 per backward step; deeper rings (4 / 8, 5 / 8) do NOT help -- update() 461 us against 452 -- so the steps
+// are not waiting for these loads.
+#ifndef MPCQP_GRP_FWD_DEPTH
+#define MPCQP_GRP_FWD_DEPTH 3
+#endif
+#ifndef MPCQP_GRP_BWD_DEPTH
+#define MPCQP_GRP_BWD_DEPTH 4
+#endif
 struct GroupFmt {
     static constexpr int NN = 256;
     static constexpr int OMH = 0, OMHT = NN, OSINV = 2 * NN, REC = 3 * NN;      // (the forward matrix first: chain_sweep reads a stage's record from its start)
@@ -125,7 +134,7 @@ __device__ __forceinline__ int factor_group(const Ctx &c, const double *om, cons
 // sequences in one block, which the scheduler interleaves: w rides in the latency of the chain.  Fragments of the next stages are prefetched
 // into a register ring (branch-free refills with clamped indices, like chain_sweep).
 __device__ __forceinline__ void group_fwd_sweep(const int first, const int dir, const int nsteps, const int ylast, const double *F, double *Tg) {
-    constexpr int NB = 16, DEPTH = 3;
+    constexpr int NB = 16, DEPTH = MPCQP_GRP_FWD_DEPTH;
     const int lane = opaque_lane(threadIdx.x & 63);
     double *tb = Tg + vec_lane_offset(lane);
     const bool writer = MPCQP_STORE_ALL ? true : vec_lane_writer(lane);
@@ -170,7 +179,7 @@ __device__ __forceinline__ void group_fwd_sweep(const int first, const int dir, 
 // One half of the back substitution by ONE wave: for i = 1..nsteps, K = first + dir * i:   Tg[K] (= w_K) <- w_K + MhT(K - dir) Tg[K - dir]
 // (MhT(J): the transposed forward matrix stored with stage J; `extra` replaces J = first, the middle stage, where the bottom half needs -Mt_m').
 __device__ __forceinline__ void group_back_sweep(const int first, const int dir, const int nsteps, const int extra, const double *F, double *Tg) {
-    constexpr int NB = 16, DEPTH = 4;
+    constexpr int NB = 16, DEPTH = MPCQP_GRP_BWD_DEPTH;
     const int lane = opaque_lane(threadIdx.x & 63);
     double *tb = Tg + vec_lane_offset(lane);
     const bool writer = MPCQP_STORE_ALL ? true : vec_lane_writer(lane);

@@ -3,6 +3,8 @@ same loop, and which kernel served it (development / DESIGN.md "one controller o
 import os, sys, time, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+from pympc_amd import _lib
+if os.environ.get('MPCQP_LIB'): _lib.LIB_PATH = os.path.abspath(os.environ['MPCQP_LIB'])
 from pympc_amd import MPCController, fixtures
 
 
