@@ -72,6 +72,14 @@ __device__ __forceinline__ int factor_group(const Ctx &c, const double *om, cons
     const int g = L.grp, NS = group_count(L.N, g), mid = NS / 2, tid = threadIdx.x, A = tid / NB, B = tid % NB;
     double *S = W, *C = W + NN, *Mh = W + 2 * NN, *SnA = W + 3 * NN, *SnB = W + 4 * NN;
     if (tid == 0) *iflag = 0;
+    // omega and s through an LDS copy behind the work matrices where the work area holds them (every entry of a block reads several of them,
+    // one global round trip each: they were a good part of a stage's 9 us)
+    if (5 * NN + L.m + L.n <= L.tsz) {
+        double *oml = W + 5 * NN, *svl = oml + L.m;
+        for (int r = tid; r < L.m; r += NT) oml[r] = om[r];
+        for (int r = tid; r < L.n; r += NT) svl[r] = sv[r];
+        om = oml; sv = svl;
+    }
     __syncthreads();
     // one stage: S_K and its inverse; rec: where -Mh / -Mh' of the neighbour above (up) or below go
     auto stage = [&](int K, const double *SnU, const double *SnD, double *SnOut, double *recU, double *recD) {
