@@ -618,6 +618,8 @@ static int launch_run(mpcqp_handle *h, RunArgs R, int plain_iters) {
     else if (L.bcr == 11) rc = launch_run_t<16, true, 0, 0, MODE_BCR + 11>(h, R);
     else if (L.NB == 16 && h->lds_state && L.nx == 12 && L.nu == 4 && !L.border) rc = launch_run_t<16, true, 12, 4, MODE_CHAIN>(h, R);
     else if (L.NB == 32 && !h->lds_state && L.nx == 20 && L.nu == 8 && !L.border) rc = launch_run_t<32, false, 20, 8, MODE_CHAIN>(h, R);
+    // (the reference's cart pole -- its example system, and the Kalman notebook's long horizon -- with compile-time dimensions in the global-iterate kernel)
+    else if (L.NB == 16 && !h->lds_state && L.nx == 4 && L.nu == 1) rc = L.border ? launch_run_t<16, false, 4, 1, MODE_BORDER>(h, R) : launch_run_t<16, false, 4, 1, MODE_CHAIN>(h, R);
     else if (L.NB == 16) rc = h->lds_state ? launch_run_generic<16, true>(h, R) : launch_run_generic<16, false>(h, R);
     else if (L.NB == 32) rc = h->lds_state ? launch_run_generic<32, true>(h, R) : launch_run_generic<32, false>(h, R);
     else if (L.NB == 64) rc = launch_run_generic<64, false>(h, R);
@@ -1006,8 +1008,9 @@ extern "C" int mpcqp_get_work(mpcqp_handle *h, int64_t *mfma_per_iter) {
 extern "C" int mpcqp_kernel_name(mpcqp_handle *h, int loop, char *buf, int buflen) {
     if (!h || !buf || buflen < 1) return fail(MPCQP_ERR_ARG, "null argument");
     const Lay &L = h->L;
-    const bool spec = !L.border && !L.dense && (L.bcr ? (L.bcr == 31 && L.nx == 12 && L.nu == 4)
-                                                        : ((L.NB == 16 && h->lds_state && L.nx == 12 && L.nu == 4) || (L.NB == 32 && !h->lds_state && L.nx == 20 && L.nu == 8)));
+    const bool spec = L.dense ? false : (L.NB == 16 && !L.bcr && !h->lds_state && L.nx == 4 && L.nu == 1) ? true :
+                      !L.border && (L.bcr ? (L.bcr == 31 && L.nx == 12 && L.nu == 4)
+                                          : ((L.NB == 16 && h->lds_state && L.nx == 12 && L.nu == 4) || (L.NB == 32 && !h->lds_state && L.nx == 20 && L.nu == 8)));
     snprintf(buf, (size_t)buflen, "k_mpc_run<%d,%s,%d,%d,%d,%s>", L.NB, h->lds_state ? "true" : "false", spec ? L.nx : 0, spec ? L.nu : 0,
              L.dense ? MODE_DENSE : L.bcr ? MODE_BCR + L.bcr : L.border ? MODE_BORDER : MODE_CHAIN, loop ? "true" : "false");
     return MPCQP_OK;

@@ -285,7 +285,7 @@ __device__ __forceinline__ void check_norms_own(const Ctx &c, const double *X, c
 // element cu = t + NT j), two items per thread in flight with all their global operands (z, the slack, D, E, q) requested up front.
 // Terms are summed in the order the row visitors enumerate them.  wts: the weight matrices (LDS copy or global).
 __device__ __forceinline__ void check_norms_gown(const Ctx &c, const double *gX, const double *gZ, const double *gY, const double *D, const double *E,
-                                                 const double *Qv, double cc, double *T, double *nrm, double *vsum) {
+                                                 const double *Qv, double cc, double *T, double *hsy, double *nrm, double *vsum) {
     constexpr int GU = 2;
     const Lay &L = c.L;
     const int tid = threadIdx.x, nx = L.nx, nu = L.nu;
@@ -295,6 +295,25 @@ __device__ __forceinline__ void check_norms_gown(const Ctx &c, const double *gX,
     for (int i = tid; i < L.m; i += NT) Y[i] = Yg[i];
     for (int i = tid; i < L.n_x + L.n_u; i += NT) X[i] = Xg[i];
     __syncthreads();
+    // Nc < Np: the held input's part of A'y is a sum over the Np - Nc + 1 stages it acts on.  Its owner used to walk them alone (76 stages of
+    // dependent LDS reads at the reference's Kalman notebook: 4 of a check's 20 us); the last wave forms it beside the state items -- lane l the
+    // stages Nc + l, Nc + l + 64, ..., then a fixed-order butterfly -- and leaves the nu sums in hsy (LDS, nu doubles).
+    const bool held = L.Nc < L.Np;
+    if (held && tid >= NT - 64) {
+        const int lane = tid - (NT - 64);
+        for (int jj = 0; jj < nu; ++jj) {
+            double a = 0.0;
+            for (int s = L.Nc + lane; s <= L.Np; s += 64) {
+                const double *y1 = Y + s * nx;
+                double t = 0.0;
+#pragma unroll 4
+                for (int r = 0; r < nx; ++r) t += Bd[r * nu + jj] * y1[r];
+                a += t;
+            }
+            a = wave_reduce<false>(a);
+            if (lane == 0) hsy[jj] = a;
+        }
+    }
     auto row = [&](double ax, double z, double e) {
         const double d = ax - z;
         nrm[0] = fmax(nrm[0], fabs(d)); nrm[1] = fmax(nrm[1], fabs(ax)); nrm[2] = fmax(nrm[2], fabs(z));
@@ -348,7 +367,8 @@ __device__ __forceinline__ void check_norms_gown(const Ctx &c, const double *gX,
             }
         }
     }
-    for (int c0 = tid; c0 < L.n_u; c0 += GU * NT) {
+    if (held) __syncthreads();                                           // (the held input's sums)
+    for (int c0 = NT - 1 - tid; c0 < L.n_u; c0 += GU * NT) {           // (input items from the last thread downwards, as in gown_rhs)
         double eIn[GU], eDu[GU], eD0[GU], dU[GU], qU[GU], zI[GU], zU[GU], z0[GU];
 #pragma unroll
         for (int u = 0; u < GU; ++u) {
@@ -377,9 +397,9 @@ __device__ __forceinline__ void check_norms_gown(const Ctx &c, const double *gX,
                 if (k + 1 < L.Nc) for (int l = 0; l < nu; ++l) px += -QDu[jj * nu + l] * uk[nu + l];
                 if (k > 0) for (int l = 0; l < nu; ++l) px += -QDu[l * nu + jj] * uk[l - nu];
                 double aty = 0.0;
-                const int s_end = (k == L.Nc - 1) ? L.Np : k + 1;        // the last input is held to the end of the horizon
-                for (int s = k + 1; s <= s_end; ++s) {
-                    const double *y1 = Y + s * nx;
+                if (held && k == L.Nc - 1) aty = hsy[jj];                  // the last input is held to the end of the horizon
+                else {
+                    const double *y1 = Y + (k + 1) * nx;
 #pragma unroll 4
                     for (int r = 0; r < nx; ++r) aty += Bd[r * nu + jj] * y1[r];
                 }
@@ -433,7 +453,7 @@ __device__ __forceinline__ int check_body(const Lay &L, const Ptrs &P, const mpc
     for (int i = 0; i < 11; ++i) nrm[i] = 0.0;
     TICK(10)
     if (Xl) check_norms_own(c, X, Z, Y, D, E, S.Qv, cc, nrm, vsum);      // (LDS-resident iterate: owner-mapped passes)
-    else check_norms_gown(c, X, Z, Y, D, E, S.Qv, cc, S.T, nrm, vsum);   // (iterate in global memory: staged, then the same passes)
+    else check_norms_gown(c, X, Z, Y, D, E, S.Qv, cc, S.T, S.tv, nrm, vsum);   // (iterate in global memory: staged, then the same passes)
     TICK(12)
     block_reduce<11, 1>(nrm, vsum, S.red);
     obj_val = vsum[0]; pri_res = nrm[0]; dua_res = nrm[3];
@@ -593,7 +613,7 @@ __device__ __forceinline__ void own_load(const Lay &L, cgdouble *om, cgdouble *s
         h.sv_x[j] = v ? sv[e] : 0.0; h.cq_x[j] = v ? cc * qv[e] : 0.0; h.sv_e[j] = (v && L.soft) ? sv[L.oe + e] : 0.0;
         h.om_s[j] = v ? om[L.rs + e] : 1.0; h.om_d[j] = v ? om[e] : 1.0;
     }
-    const int cu = tid;
+    const int cu = NT - 1 - tid;                         // (input elements from the last thread downwards: the first threads own two state elements)
     const bool v = cu < L.n_u;
     h.sv_u = v ? sv[L.ou + cu] : 0.0; h.cq_u = v ? cc * qv[L.n_x + cu] : 0.0;
     h.om_i = v ? om[L.ri + cu] : 1.0; h.om_du = v ? om[L.rdu + L.nu + cu] : 1.0; h.om_d0 = cu < L.nu ? om[L.rdu + cu] : 1.0;
@@ -616,10 +636,11 @@ __device__ __forceinline__ void own_rows_w(const Lay &L, const OwnRegs &h, doubl
         const int e = tid + NT * j;
         if (e < L.n_x) { own_scale_row(h.om_d[j], cc, Z, Y, W, e); own_scale_row(h.om_s[j], cc, Z, Y, W, L.rs + e); }
     }
-    if (tid < L.n_u) {
-        const int ri = L.ri + tid, rd = L.rdu + L.nu + tid;
+    const int cu = NT - 1 - tid;
+    if (cu < L.n_u) {
+        const int ri = L.ri + cu, rd = L.rdu + L.nu + cu;
         own_scale_row(h.om_i, cc, Z, Y, W, ri); own_scale_row(h.om_du, cc, Z, Y, W, rd);
-        if (tid < L.nu) own_scale_row(h.om_d0, cc, Z, Y, W, L.rdu + tid);
+        if (cu < L.nu) own_scale_row(h.om_d0, cc, Z, Y, W, L.rdu + cu);
     }
     __syncthreads();
 }
@@ -630,7 +651,7 @@ __device__ __forceinline__ void own_rows_w(const Lay &L, const OwnRegs &h, doubl
 template <int NB>
 __device__ __forceinline__ void held_input_terms(const Lay &L, int nx, int nu, const double *Bd, const double *W, double *Tc) {
     const int npair = (L.Np - L.Nc + 1) * nu;
-    for (int p = threadIdx.x; p < npair; p += NT) {
+    for (int p = NT - 1 - (int)threadIdx.x; p < npair; p += NT) {      // (the last threads: the first ones carry the extra trip of the state items)
         const int so = p / nu, jj = p - so * nu, s = L.Nc + so;
         const double *w1 = W + s * nx;
         double t = 0.0;
@@ -642,7 +663,9 @@ __device__ __forceinline__ void held_input_terms(const Lay &L, int nx, int nu, c
 // shape: 2 us of a 15 us iteration, every other thread waiting at the barrier).  Now wave 0 sums them -- lane l takes stages Nc + l, Nc + l + 64, ...,
 // then a fixed-order butterfly over the lanes -- and leaves the nu sums in `out` (LDS, nu doubles); the parked slots are zeroed on the way.
 // All threads call (one barrier inside); the order of the additions is fixed, so results do not depend on timing.
-template <int NB>
+// ADD: the sums go straight onto the held input's right-hand side slots (stage Nc - 1), which their owners filled before the caller's barrier -- the
+// same last addition as the owner's own `+= out[jj]`, without the second hand-over.
+template <int NB, bool ADD = false>
 __device__ __forceinline__ void held_input_reduce(const Lay &L, int nx, int nu, double *Tc, double *out) {
     if (threadIdx.x < 64) {
         const int lane = threadIdx.x;
@@ -650,7 +673,7 @@ __device__ __forceinline__ void held_input_reduce(const Lay &L, int nx, int nu, 
             double a = 0.0;
             for (int s = L.Nc + lane; s <= L.Np; s += 64) { a += Tc[s * NB + nx + jj]; Tc[s * NB + nx + jj] = 0.0; }
             a = wave_reduce<false>(a);
-            if (lane == 0) out[jj] = a;
+            if (lane == 0) { if (ADD) Tc[(L.Nc - 1) * NB + nx + jj] += a; else out[jj] = a; }
         }
     }
     __syncthreads();
@@ -683,14 +706,12 @@ __device__ __forceinline__ void own_rhs(const Lay &L, const double *hot, const O
             Tc[k * NB + a] = rx + wsoft - h.om_s[j] * te;
         }
     }
-    if (held) { __syncthreads(); held_input_reduce<NB>(L, nx, nu, Tc, hsum); }
-    if (tid < L.n_u) {
-        const int cu = tid, k = divu<NUT>(L, cu), jj = cu - k * nu;
+    if (NT - 1 - tid < L.n_u) {
+        const int cu = NT - 1 - tid, k = divu<NUT>(L, cu), jj = cu - k * nu;
         double ru = h.sv_u * X[L.ou + cu] - h.cq_u + W[L.ri + cu] - W[L.rdu + nu + cu];
         if (k == 0) ru += W[L.rdu + jj];
         if (cu > 0) ru += W[L.rdu + nu + cu - 1];
-        if (held && k == L.Nc - 1) ru += hsum[jj];                                        // the last input acts on every later stage (mpc.py:540-543)
-        else {
+        if (!(held && k == L.Nc - 1)) {                                                   // (the held input's A'W: summed over the later stages below)
             const double *w1 = W + (k + 1) * nx;
 #pragma unroll
             for (int r = 0; r < (NXT ? NXT : 1); ++r) if (NXT) ru += Bd[r * nu + jj] * w1[r];
@@ -698,7 +719,8 @@ __device__ __forceinline__ void own_rhs(const Lay &L, const double *hot, const O
         }
         Tc[k * NB + nx + jj] = ru;
     }
-    __syncthreads();
+    if (held) { __syncthreads(); held_input_reduce<NB, true>(L, nx, nu, Tc, hsum); }      // the last input acts on every later stage (mpc.py:540-543)
+    else __syncthreads();
 }
 // slack back-substitution, zt = A xt, relaxation, projection on [l,u], dual update, x update
 template <int NB, int NXT, int NUT>
@@ -745,8 +767,8 @@ __device__ __forceinline__ void own_update(const Lay &L, const double *hot, cons
             row(L.rs + e, h.om_s[j], xt + et, hot[L.oxmin + a], hot[L.oxmax + a]);      // state-box row (soft: x + eps)
         }
     }
-    if (tid < L.n_u) {
-        const int cu = tid, k = divu<NUT>(L, cu), jj = cu - k * nu;
+    if (NT - 1 - tid < L.n_u) {
+        const int cu = NT - 1 - tid, k = divu<NUT>(L, cu), jj = cu - k * nu;
         const double ut = Tc[k * NB + nx + jj];
         const double uo = X[L.ou + cu], un = alpha * ut + beta * uo;
         X[L.ou + cu] = un;
@@ -769,9 +791,10 @@ __device__ __forceinline__ void own_finish(const Lay &L, const OwnRegs &h, doubl
         const int e = tid + NT * j;
         if (e < L.n_x) { Y[e] *= h.om_d[j] * cinv; Y[L.rs + e] *= h.om_s[j] * cinv; }
     }
-    if (tid < L.n_u) {
-        Y[L.ri + tid] *= h.om_i * cinv; Y[L.rdu + L.nu + tid] *= h.om_du * cinv;
-        if (tid < L.nu) Y[L.rdu + tid] *= h.om_d0 * cinv;
+    const int cu = NT - 1 - tid;
+    if (cu < L.n_u) {
+        Y[L.ri + cu] *= h.om_i * cinv; Y[L.rdu + L.nu + cu] *= h.om_du * cinv;
+        if (cu < L.nu) Y[L.rdu + cu] *= h.om_d0 * cinv;
     }
     __syncthreads();
 }
@@ -848,8 +871,9 @@ __device__ __forceinline__ void gown_rhs(const Lay &L, const double *hot, typena
             }
         }
     }
-    if (held) { __syncthreads(); held_input_reduce<NB>(L, nx, nu, Tc, hsum); }
-    for (int c0 = tid; c0 < L.n_u; c0 += GU * NT) {
+    // (input items from the LAST thread downwards: the threads that ran the short last trip of the state items above are the first ones, so the
+    //  waves' item counts differ by at most one -- with one instance alone on the compute unit the pass lasts as long as its busiest wave)
+    for (int c0 = NT - 1 - tid; c0 < L.n_u; c0 += GU * NT) {
         double svu[GU], qu[GU], uv[GU];
 #pragma unroll
         for (int u = 0; u < GU; ++u) { const int cu = min(c0 + u * NT, L.n_u - 1); svu[u] = sv[L.ou + cu]; qu[u] = qv[L.n_x + cu]; uv[u] = Xg[L.ou + cu]; }
@@ -861,8 +885,7 @@ __device__ __forceinline__ void gown_rhs(const Lay &L, const double *hot, typena
                 double ru = svu[u] * uv[u] - cc * qu[u] + W[L.ri + cu] - W[L.rdu + nu + cu];
                 if (k == 0) ru += W[L.rdu + jj];
                 if (cu > 0) ru += W[L.rdu + nu + cu - 1];
-                if (held && k == L.Nc - 1) ru += hsum[jj];                                // the last input acts on every later stage (mpc.py:540-543)
-                else {
+                if (!(held && k == L.Nc - 1)) {                                           // (the held input's A'W: summed over the later stages below)
                     const double *w1 = W + (k + 1) * nx;
 #pragma unroll
                     for (int r = 0; r < (NXT ? NXT : 1); ++r) if (NXT) ru += Bd[r * nu + jj] * w1[r];
@@ -872,7 +895,8 @@ __device__ __forceinline__ void gown_rhs(const Lay &L, const double *hot, typena
             }
         }
     }
-    __syncthreads();
+    if (held) { __syncthreads(); held_input_reduce<NB, true>(L, nx, nu, Tc, hsum); }      // the last input acts on every later stage (mpc.py:540-543)
+    else __syncthreads();
 }
 template <int NB, int NXT, int NUT, bool INL = false>
 __device__ __forceinline__ void gown_update(const Lay &L, const double *hot, const double *x0s, const double *du0, typename GPtr<INL>::c *om, typename GPtr<INL>::c *sv, double cc, double alpha,
@@ -931,7 +955,7 @@ __device__ __forceinline__ void gown_update(const Lay &L, const double *hot, con
             }
         }
     }
-    for (int c0 = tid; c0 < L.n_u; c0 += GU * NT) {
+    for (int c0 = NT - 1 - tid; c0 < L.n_u; c0 += GU * NT) {      // (from the last thread downwards, as in gown_rhs)
         double uo[GU], omi[GU], omu[GU], om0[GU], zi[GU], yi[GU], zu[GU], yu[GU], z0[GU], y0[GU];
 #pragma unroll
         for (int u = 0; u < GU; ++u) {
@@ -1015,7 +1039,7 @@ __device__ __forceinline__ void admm_round_global(const Lay &L, const HotPtrs &P
 #endif
         TICK(0)
         if (BORDER) border_pre<NB>(L, Bb, Zb, P.Sig + (size_t)b * L.nu * L.nu, Tc, S.tv, S.red);
-        kkt_core<NB, NB == 16 && NXT == 0>(core_args(L, opaque_ptr(F), opaque_ptr((const double *)P.omega + (size_t)b * L.m)), Tc);
+        kkt_core<NB, NB == 16 && (NXT == 0 || NXT == 4)>(core_args(L, opaque_ptr(F), opaque_ptr((const double *)P.omega + (size_t)b * L.m)), Tc);
         if (BORDER) border_post(L, NB, Tc, S.tv);
 #ifndef MPCQP_ABL_NOPAR
         gown_update<NB, NXT, NUT, INL>(L, S.hot, S.x0s, S.du0, gom, gsv, cc, alpha, X, Z, Y, W, Tc, keep_delta, dxg, dyg);
@@ -1037,7 +1061,7 @@ __device__ __forceinline__ void admm_body(const Lay &L, const HotPtrs &P, Smem &
     if constexpr (MODE == MODE_DENSE) { admm_tiny<NB>(L, P, S, X, Z, Y, alpha, iters); return; }      // register-resident iterate and inverse
     if constexpr (MODE >= MODE_BCR) { admm_lat<NXT, NUT, MODE - MODE_BCR>(L, P, S, X, Z, Y, alpha, iters); return; }      // ... and cyclic-reduction factor
     if constexpr (!LDSSTATE) {          // iterate in global memory -- or staged in LDS for the round (generic kernels of small batches)
-        if constexpr (NXT == 0) { if (L.lstage) { admm_round_global<NB, NXT, NUT, MODE, true>(L, P, S, alpha, iters); return; } }
+        if constexpr (NXT == 0 || NXT == 4) { if (L.lstage) { admm_round_global<NB, NXT, NUT, MODE, true>(L, P, S, alpha, iters); return; } }
         admm_round_global<NB, NXT, NUT, MODE, false>(L, P, S, alpha, iters);
         return;
     }
@@ -1072,7 +1096,7 @@ __device__ __forceinline__ void admm_body(const Lay &L, const HotPtrs &P, Smem &
             bp.Bb = (double *)P.Bb + b * npb; bp.Zb = (double *)P.Zb + b * npb; bp.Sig = (double *)P.Sig + (size_t)b * L.nu * L.nu;
         }
         if (BORDER) border_pre<NB>(L, bp.Bb, bp.Zb, bp.Sig, Tc, S.tv, S.red);
-        kkt_core<NB, NB == 16 && NXT == 0>(core_args(L, opaque_ptr(F), opaque_ptr((const double *)P.omega + (size_t)b * L.m)), Tc);
+        kkt_core<NB, NB == 16 && (NXT == 0 || NXT == 4)>(core_args(L, opaque_ptr(F), opaque_ptr((const double *)P.omega + (size_t)b * L.m)), Tc);
         if (BORDER) border_post(L, NB, Tc, S.tv);
 #ifndef MPCQP_ABL_NOPAR
         own_update<NB, NXT, NUT>(L, S.hot, S.x0s, S.du0, hr, cc, alpha, X, Z, Y, W, Tc, keep_delta, dxg, dyg);
