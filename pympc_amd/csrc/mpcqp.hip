@@ -283,7 +283,7 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     // At most one instance per compute unit and an iterate that does not qualify for the LDS-resident owner map: stage it (with the metric
     // vectors, the linear cost and the border matrices) into LDS for the length of a round if one workgroup's LDS holds it (admm_round_global).
     {
-        const size_t stage_doubles = 2 * (size_t)L.n + 3 * (size_t)L.m + (size_t)(L.n_x + L.n_u) + (L.border ? 2 * (size_t)L.nu * L.N * L.NB : 0);
+        const size_t stage_doubles = 2 * (size_t)L.n + 3 * (size_t)L.m + (size_t)(L.n_x + L.n_u) + (L.border ? 2 * (size_t)L.nu * L.N * L.NB + (size_t)L.nu * L.nu : 0);
         const bool specialised = L.NB == 32 && L.nx == 20 && L.nu == 8 && !L.border;      // (the BASELINE cfg-5 instantiation has compile-time dimensions and no staged round)
         bool lstage = !h->lds_state && !dense && !bcr && !specialised && h->ncu > 0 && batch <= h->ncu && h->smem_setup + sizeof(double) * stage_doubles <= 150 * 1024;
         if (const char *e = getenv("MPCQP_LSTAGE")) lstage = lstage && atoi(e) != 0;      // development switch

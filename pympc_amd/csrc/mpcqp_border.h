@@ -76,12 +76,68 @@ __device__ __forceinline__ void border_factor(const Ctx &c, const double *om, co
     __syncthreads();
 }
 
+// NU <= 4 inputs: two barriers instead of 4 nu + 2, Sigma^-1 read before the dot products instead of after them (this step was a seventh of an
+// iteration of the reference's Kalman notebook alone on its compute unit).  Every thread forms ub itself from the four waves' partial sums; the
+// additions are the ones block_reduce makes, in the same order.
+template <int NB, int NU>
+__device__ __forceinline__ void border_pre_few(const Lay &L, const double *Bb, const double *Zb, const double *Sig, double *Tc, double *ubar, double *red) {
+    const int tid = threadIdx.x, NP = L.N * NB;
+    const int slot = (L.Nc - 1) * NB + L.nx;
+    double sg[NU * NU], part[NU], ub[NU];
+#pragma unroll
+    for (int e = 0; e < NU * NU; ++e) sg[e] = Sig[e];
+#pragma unroll
+    for (int j = 0; j < NU; ++j) part[j] = 0.0;
+    for (int idx = tid; idx < NP; idx += NT) {
+        const double tc = Tc[idx];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) part[j] += Zb[j * NP + idx] * tc;                  // Z is zero in the r2 slots
+    }
+#pragma unroll
+    for (int j = 0; j < NU; ++j) part[j] = wave_reduce<false>(part[j]);
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int j = 0; j < NU; ++j) red[(tid >> 6) * NU + j] = part[j];
+    }
+    if (tid < NU) red[4 * NU + tid] = Tc[slot + tid];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+        double v = red[j];
+#pragma unroll
+        for (int w = 1; w < NWAVES; ++w) v += red[w * NU + j];
+        part[j] = red[4 * NU + j] - v;                                                   // r2 - Z' r1
+    }
+#pragma unroll
+    for (int i = 0; i < NU; ++i) {
+        double a = 0.0;
+#pragma unroll
+        for (int j = 0; j < NU; ++j) a += sg[i * NU + j] * part[j];
+        ub[i] = a;
+    }
+#pragma unroll
+    for (int i = 0; i < NU; ++i) if (tid == i) ubar[i] = ub[i];                          // (border_post puts it into the solution)
+    for (int idx = tid; idx < NP; idx += NT) {             // (plain loops: with several elements' operands requested together both loops measured slower)
+        double a = Tc[idx];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) a -= Bb[j * NP + idx] * ub[j];
+        Tc[idx] = (idx >= slot && idx < slot + NU) ? 0.0 : a;
+    }
+    __syncthreads();
+}
 // Before the tridiagonal solve: Tc holds r1 in the padded slots and r2 in the (otherwise padding) u slots of stage
 // Nc-1.  Computes ub, leaves it in ubar[] (LDS, nu doubles) and replaces r1 by r1 - B ub.
 template <int NB>
 __device__ __forceinline__ void border_pre(const Lay &L, const double *Bb, const double *Zb, const double *Sig, double *Tc, double *ubar, double *red) {
     const int tid = threadIdx.x, nu = L.nu, NP = L.N * NB;
     const int slot = (L.Nc - 1) * NB + L.nx;
+    switch (nu) {                                          // few inputs (the usual case): compile-time loops, two barriers
+        case 1: border_pre_few<NB, 1>(L, Bb, Zb, Sig, Tc, ubar, red); return;
+        case 2: border_pre_few<NB, 2>(L, Bb, Zb, Sig, Tc, ubar, red); return;
+        case 3: border_pre_few<NB, 3>(L, Bb, Zb, Sig, Tc, ubar, red); return;
+        case 4: border_pre_few<NB, 4>(L, Bb, Zb, Sig, Tc, ubar, red); return;
+        default: break;
+    }
     for (int j = 0; j < nu; ++j) {
         double vsum[1] = {0.0}, vmax[1] = {0.0};
         for (int idx = tid; idx < NP; idx += NT) vsum[0] += Zb[(size_t)j * NP + idx] * Tc[idx];     // Z is zero in the r2 slots

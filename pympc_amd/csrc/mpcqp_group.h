@@ -232,7 +232,7 @@ __device__ __forceinline__ void kkt_core_group(const CoreArgs &a, double *Tc) {
         Tg[idx] = (A < g * nb && k < N) ? Tc[k * NB + (A - i * nb)] : 0.0;
     }
     __syncthreads();
-    TICK_START
+    TICK(6)
     if (wv == 0) group_fwd_sweep(0, +1, mid - 1, NS, F, Tg);                // w_0 .. w_{mid-1};  yh_{mid-1} -> slot N'
     else if (wv == 1) group_fwd_sweep(NS - 1, -1, NS - 2 - mid, NS + 1, F, Tg);      // w_{N'-1} .. w_{mid+1};  yh_{mid+1} -> slot N'+1
     __syncthreads();

@@ -1007,7 +1007,7 @@ __device__ __forceinline__ void admm_round_global(const Lay &L, const HotPtrs &P
     const size_t npb = (size_t)L.nu * L.N * L.NB;
     const double *Bg = BORDER ? P.Bb + b * npb : nullptr, *Zg = BORDER ? P.Zb + b * npb : nullptr;
     double *X = gx, *Z = gz, *Y = gy;
-    const double *omp = P.omega + (size_t)b * L.m, *svp = P.s + (size_t)b * L.n, *qvp = S.Qv, *Bb = Bg, *Zb = Zg;
+    const double *omp = P.omega + (size_t)b * L.m, *svp = P.s + (size_t)b * L.n, *qvp = S.Qv, *Bb = Bg, *Zb = Zg, *Sg = BORDER ? P.Sig + (size_t)b * L.nu * L.nu : nullptr;
     if constexpr (INL) {
         double *p = S.T + L.tsz;                      // [ x | z | y | omega | s | q | Bb | Zb ] behind the work area
         const int nq = L.n_x + L.n_u;
@@ -1017,9 +1017,10 @@ __device__ __forceinline__ void admm_round_global(const Lay &L, const HotPtrs &P
         for (int j = tid; j < nq; j += NT) qvs[j] = qvp[j];
         X = Xs; Z = Zs; Y = Ys; omp = oms; svp = svs; qvp = qvs;
         if (BORDER) {
-            double *Bs = carve(p, (int)npb), *Zbs = carve(p, (int)npb);
+            double *Bs = carve(p, (int)npb), *Zbs = carve(p, (int)npb), *Sgs = carve(p, L.nu * L.nu);
             for (int i = tid; i < (int)npb; i += NT) { Bs[i] = Bg[i]; Zbs[i] = Zg[i]; }
-            Bb = Bs; Zb = Zbs;
+            for (int i = tid; i < L.nu * L.nu; i += NT) Sgs[i] = P.Sig[(size_t)b * L.nu * L.nu + i];
+            Bb = Bs; Zb = Zbs; Sg = Sgs;
         }
     }
     __syncthreads();
@@ -1038,7 +1039,8 @@ __device__ __forceinline__ void admm_round_global(const Lay &L, const HotPtrs &P
         gown_rhs<NB, NXT, NUT, INL>(L, S.hot, gom, gsv, gqv, cc, X, W, Tc, S.tv);
 #endif
         TICK(0)
-        if (BORDER) border_pre<NB>(L, Bb, Zb, P.Sig + (size_t)b * L.nu * L.nu, Tc, S.tv, S.red);
+        if (BORDER) border_pre<NB>(L, Bb, Zb, Sg, Tc, S.tv, S.red);
+        TICK(4)
         kkt_core<NB, NB == 16 && (NXT == 0 || NXT == 4)>(core_args(L, opaque_ptr(F), opaque_ptr((const double *)P.omega + (size_t)b * L.m)), Tc);
         if (BORDER) border_post(L, NB, Tc, S.tv);
 #ifndef MPCQP_ABL_NOPAR
