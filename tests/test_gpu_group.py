@@ -14,9 +14,11 @@ import scipy.sparse as sp
 pytestmark = pytest.mark.gpu
 
 # (nx, nu, Np, Nc, soft): g = 16 // (nx + nu) stages per block -- 3, 3, 8, 3, 2, 2, 4, 5; horizons that are and are not multiples of g; held
-# inputs (Nc < Np: the bordered correction around the grouped solve) with nu = 1 and nu = 2; a hard state box
+# inputs (Nc < Np: the bordered correction around the grouped solve) with nu = 1 and nu = 2; a hard state box; and held inputs with an iterate
+# too long for the LDS-resident round (more than 512 state elements: the staged round, the check's parallel held-input sum) with nu = 2, 3
+# (the two-barrier correction of mpcqp_border.h) and nu = 5 (the general one)
 SHAPES = [(4, 1, 150, 75, True), (4, 1, 61, 61, True), (1, 1, 90, 90, True), (3, 2, 50, 20, True), (5, 3, 40, 40, True), (7, 1, 45, 45, False),
-          (3, 1, 64, 17, True), (2, 1, 77, 77, False)]
+          (3, 1, 64, 17, True), (2, 1, 77, 77, False), (3, 2, 200, 80, True), (2, 3, 260, 100, True), (2, 5, 300, 120, True)]
 IDS = ['%d_%d_%d_%d%s' % (s[0], s[1], s[2], s[3], '' if s[4] else '_hard') for s in SHAPES]
 
 
