@@ -72,6 +72,13 @@ def self_launch_if_needed(args):
     sys.exit(subprocess.call(cmd, env=env))
 
 
+def comm_on(world):
+    """Does this run talk through the process group?  Always with more than one rank; with ONE rank only when MPCQP_BENCH_FORCE_PG=1 asks for
+    it -- the way to execute the RCCL branch (process group on the device, barrier, max-reduction of the time, all-gather of u*) on a box that
+    has a single GPU (tests/test_gpu_rccl_single_rank.py): same code path, a communicator of one."""
+    return world > 1 or os.environ.get('MPCQP_BENCH_FORCE_PG') == '1'
+
+
 def device_identity(torch, dev):
     """Something that distinguishes physical GPUs: the device UUID if this torch exposes it, else the PCI address."""
     if dev.type != 'cuda':
@@ -104,8 +111,10 @@ def init_distributed(args, torch, dist):
     if args.gpus != world and rank == 0:
         print('bench.py: --gpus %d but WORLD_SIZE=%d; running with %d rank(s)' % (args.gpus, world, world), file=sys.stderr)
     seen = [(rank, device_identity(torch, dev))]
-    if world > 1:
+    if comm_on(world):
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', str(free_port()))      # (a forced single rank outside a launcher)
+        os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')
         if backend == 'nccl':
             dist.init_process_group(backend='nccl', device_id=dev)
         else:
@@ -119,7 +128,7 @@ def init_distributed(args, torch, dist):
         raise SystemExit('bench.py: %d rank(s) on %d distinct device(s) in the process group, expected %d of each: %r'
                          % (ranks_seen, devices_seen, world, seen))
     return rank, world, local_rank, dev, dict(ranks_seen=ranks_seen, devices_seen=devices_seen,
-                                              backend=backend if world > 1 else None, devices=[d for _, d in seen])
+                                              backend=backend if comm_on(world) else None, devices=[d for _, d in seen])
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -275,7 +284,8 @@ class Shard:
         # the batch size, the rank count or the path; rows are consumed in step order across all the measurements of this shard
         from pympc_amd import fixtures
         self.noise_rngs = [fixtures.random_lti_noise_rng(first_instance + rank * B + j) for j in range(B)]
-        self.u_all = torch.empty((world * B, NU), dtype=f64, device=dev) if world > 1 else None
+        self.comm = comm_on(world)
+        self.u_all = torch.empty((world * B, NU), dtype=f64, device=dev) if self.comm else None
 
     def account(self, kind, st=None):
         st = self.prob.stats(reset=True) if st is None else st
@@ -300,16 +310,16 @@ class Shard:
         run_warm()
         self.account(kind)
         prob.profile(enable=True, reset=True)
-        if world > 1:
+        if self.comm:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         run_timed()
-        if world > 1:
+        if self.comm:
             dist.barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-        if world > 1:
+        if self.comm:
             t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -327,7 +337,7 @@ class Shard:
             self.prob.update(self.x, self.u)
             self.prob.solve_async()
             self.prob.u0(out=self.u)
-            if self.world > 1:
+            if self.comm:
                 self.sharding.gather_inputs(self.u, out=self.u_all)
 
         return self.timed('solve', lambda: [step() for _ in range(warmup)], lambda: [step() for _ in range(steps)])
@@ -351,7 +361,7 @@ class Shard:
         w_all = self.noise(warmup + steps)
         outs = (torch.empty((chunk + 1, B, NX), dtype=f64, device=dev), torch.empty((chunk, B, NU), dtype=f64, device=dev),
                 torch.empty((chunk, B), dtype=torch.int32, device=dev), torch.empty((chunk, B), dtype=torch.int32, device=dev))
-        u_hist = torch.empty((world * chunk, B, NU), dtype=f64, device=dev) if world > 1 else None
+        u_hist = torch.empty((world * chunk, B, NU), dtype=f64, device=dev) if self.comm else None
 
         # per launch: an event pair on the launch stream (the handle's stream IS torch's current stream) and the instances' iteration
         # counts, summed on the device (one tiny reduction per launch, inside the timed region: extra work, nothing skipped)
@@ -370,7 +380,7 @@ class Shard:
                 if record:
                     e1.record(); marks.append((e0, e1, k))
                     it_sum.add_(o[3].sum(dim=0))
-                if world > 1 and k == chunk:
+                if self.comm and k == chunk:
                     self.sharding.gather_trajectory(outs[1], out=u_hist)
             return o
 
@@ -556,13 +566,13 @@ def dry_run(args, rank, world, dev, seen, torch, dist):
     loc = sharding.scatter_instances(full, {'x0': (3,)}, B, dev)
     u = 2.0 * loc['x0'][:, :2]
     u_all = sharding.gather_inputs(u)
-    if world > 1:
+    if comm_on(world):
         dist.barrier()
     if rank == 0:
         expect = 2.0 * torch.arange(B * world * 3, dtype=torch.float64).reshape(B * world, 3)[:, :2]
         ok = bool(torch.equal(u_all.cpu(), expect))
         print(json.dumps(dict(dry_run=True, n_gpus=world, gathered_ok=ok, **seen)))
-    if world > 1:
+    if comm_on(world):
         dist.destroy_process_group()
 
 
@@ -600,7 +610,7 @@ def main():
             leg = latency_leg(args.workload)
             print(json.dumps({'metric': 'MPCController.update() latency, one controller (BASELINE configs[1])', 'value': leg['update_us_median'], 'unit': 'us',
                               'n_gpus': 1, 'higher_is_better': False, 'dtype': 'f64', 'data': 'synthetic', 'config': {'workload': leg['workload']}, 'latency': leg}))
-        if world > 1:
+        if comm_on(world):
             dist.barrier(); dist.destroy_process_group()
         return
     dims = WORKLOADS[args.workload][:4]
@@ -771,7 +781,7 @@ def main():
             out['cfg5_leg']['u_err'] = u_err_block(cfg5_samples, refs5)
         out['real_osqp'] = real_osqp_pin() if not args.no_cpu_baseline else {'osqp_available': osqp_available()}
         print(json.dumps(out))
-    if world > 1:
+    if comm_on(world):
         dist.barrier()
         dist.destroy_process_group()
 

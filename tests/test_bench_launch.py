@@ -34,3 +34,11 @@ def test_bench_gpus2_self_launches_two_ranks():
 def test_bench_gpus1_stays_in_process():
     out = _run({}, '--gpus', '1')
     assert out['n_gpus'] == 1 and out['ranks_seen'] == 1 and out['devices_seen'] == 1 and out['gathered_ok'] is True
+
+
+@pytest.mark.timeout(300)
+def test_forced_process_group_of_one_rank_runs_the_collectives():
+    """MPCQP_BENCH_FORCE_PG=1: a single rank still builds the process group and goes through scatter / all-gather / barrier (here gloo;
+    with RCCL on the GPU box: tests/test_gpu_rccl_single_rank.py)."""
+    out = _run({'MPCQP_BENCH_FORCE_PG': '1'}, '--gpus', '1')
+    assert out['n_gpus'] == 1 and out['ranks_seen'] == 1 and out['backend'] == 'gloo' and out['gathered_ok'] is True
