@@ -50,5 +50,9 @@ int main() {
     run("mfma", k_rate<1>, 1, 64); run("mfma", k_rate<2>, 2, 64); run("mfma", k_rate<4>, 4, 64); run("mfma", k_rate<8>, 8, 64); run("mfma", k_rate<16>, 16, 64);
     run("mfma", k_rate<8>, 8, 256);
     run("fma64", k_fma<1>, 1, 64); run("fma64", k_fma<4>, 4, 64); run("fma64", k_fma<8>, 8, 64); run("fma64", k_fma<16>, 16, 64); run("fma64", k_fma<16>, 16, 256);
+    // two and four waves per SIMD (one workgroup of 512 / 1024 threads): does a second wave fill the dependency stalls of the first?
+    run("fma64", k_fma<1>, 1, 256); run("fma64", k_fma<1>, 1, 512); run("fma64", k_fma<1>, 1, 1024);
+    run("fma64", k_fma<4>, 4, 256); run("fma64", k_fma<4>, 4, 512); run("fma64", k_fma<4>, 4, 1024);
+    run("mfma", k_rate<1>, 1, 256); run("mfma", k_rate<1>, 1, 512); run("mfma", k_rate<2>, 2, 512);
     return 0;
 }
