@@ -71,6 +71,10 @@ __device__ __forceinline__ const RunKArgs &run_kargs() {
     return *(const RunKArgs *)(ckargs)((cbytes)__builtin_amdgcn_implicitarg_ptr() - ((sizeof(RunKArgs) + 7) & ~size_t(7)));
 }
 
+// Every phase takes `frame_pin` (see run_admm_phase below: what keeps its calls from being marked `tail`, and with that the phase free of the
+// calling convention's callee-saved set); FRAME_PIN is the caller's side of it.
+#define PHASE_PIN_USE(p) asm volatile("" :: "v"(p) : "memory")
+struct FramePin { int v; __device__ __forceinline__ FramePin() : v(0) { asm volatile("" : "+v"(v)); } __device__ __forceinline__ ~FramePin() { asm volatile("" :: "v"(v)); } };
 struct RunSmem { Smem S; double *X, *Z, *Y; };
 template <bool LDSSTATE>
 __device__ __forceinline__ RunSmem run_smem(const Lay &L, const Ptrs &P) {
@@ -85,7 +89,8 @@ __device__ __forceinline__ RunSmem run_smem(const Lay &L, const Ptrs &P) {
 //  so that the register budget of the one-workgroup-per-CU kernels does not leak into the four-per-CU ones through a shared callee)
 // (the grouped small stages' factorization: a function of its own, see factor_grouped in mpcqp_group.h)
 template <int OCC>
-__device__ __noinline__ void run_group_factor_phase() {
+__device__ __noinline__ void run_group_factor_phase(int *frame_pin) {
+    PHASE_PIN_USE(frame_pin);
     const RunKArgs &A = run_kargs();
     const Lay &L = A.L; const Ptrs &P = A.P;
     RunSmem r = run_smem<false>(L, P);
@@ -95,10 +100,11 @@ __device__ __noinline__ void run_group_factor_phase() {
 }
 
 template <int NB, int OCC>
-__device__ __noinline__ void run_factor_phase() {
+__device__ __noinline__ void run_factor_phase(int *frame_pin) {
+    PHASE_PIN_USE(frame_pin);
     const RunKArgs &A = run_kargs();
     const Lay &L = A.L; const Ptrs &P = A.P;
-    if constexpr (NB == 16) { if (L.grp > 1) { run_group_factor_phase<OCC>(); return; } }
+    if constexpr (NB == 16) { if (L.grp > 1) { FramePin pin; run_group_factor_phase<OCC>(&pin.v); return; } }
     RunSmem r = run_smem<false>(L, P);                       // (the common LDS area comes first in both layouts)
     const int b = inst_of(P.perm);
     Ctx c{L, r.S.hot, P.model + (size_t)b * L.model_sz + L.hot_sz};
@@ -117,24 +123,33 @@ __device__ __forceinline__ void run_admm_phase_body(int iters) {
     hp.Bb = P.Bb; hp.Zb = P.Zb; hp.Sig = P.Sig; hp.x = P.x; hp.z = P.z; hp.y = P.y; hp.dx = P.dx; hp.dy = P.dy; hp.perm = P.perm; hp.fsz = P.fsz;
     admm_body<NB, LDSSTATE, NXT, NUT, MODE>(L, hp, r.S, r.X, r.Z, r.Y, A.S.alpha, __builtin_amdgcn_readfirstlane(iters));
 }
+// (frame_pin: the address of a local of the CALLER, made opaque here.  A call that may reach into its caller's frame cannot be marked `tail`,
+//  and for an internal, non-recursive function none of whose calls is a tail call LLVM's interprocedural register allocation treats NO register
+//  as callee-saved (TargetFrameLowering::isSafeForNoCSROpt): the phase then starts without saving the ~ 340 (latency kernels) / 48 (bandwidth
+//  kernels) registers of the calling convention's callee-saved set -- the kernel keeps the handful of values it has live across the call itself.)
 template <int NB, bool LDSSTATE, int NXT, int NUT, int MODE>
-__device__ __noinline__ void run_admm_phase(int iters) { run_admm_phase_body<NB, LDSSTATE, NXT, NUT, MODE>(iters); }
+__device__ __noinline__ void run_admm_phase(int iters, int *frame_pin) {
+    PHASE_PIN_USE(frame_pin);
+    run_admm_phase_body<NB, LDSSTATE, NXT, NUT, MODE>(iters);
+}
 // (Measured for the latency kernels, whose phase saves and restores ~480 callee-saved registers per call -- 1 MB of scratch traffic per
 //  workgroup and round, 46 KB per iteration and instance in the write counters of a kernel that by design reads nothing: taking
 //  the phase INLINE removes that traffic but makes the allocator spill inside the iteration loop, 914 k -> 885 k solves/s at 256
 //  instances.  The call stays.)
 template <int NB, bool LDSSTATE, int NXT, int NUT, int MODE, int OCC>
-__device__ __forceinline__ void run_admm(int iters) { run_admm_phase<NB, LDSSTATE, NXT, NUT, MODE>(iters); }
+__device__ __forceinline__ void run_admm(int iters) { FramePin pin; run_admm_phase<NB, LDSSTATE, NXT, NUT, MODE>(iters, &pin.v); }
 
 template <int NB, bool LDSSTATE, int OCC>
-__device__ __noinline__ void run_begin_phase(int plain, int warm_x) {
+__device__ __noinline__ void run_begin_phase(int plain, int warm_x, int *frame_pin) {
+    PHASE_PIN_USE(frame_pin);
     const RunKArgs &A = run_kargs();
     RunSmem r = run_smem<LDSSTATE>(A.L, A.P);
     begin_body<NB, OCC>(A.L, A.P, A.S, r.S, __builtin_amdgcn_readfirstlane(plain), __builtin_amdgcn_readfirstlane(warm_x));
 }
 
 template <int NB, bool LDSSTATE, int OCC>
-__device__ __noinline__ int run_check_phase(int iter, int mode) {
+__device__ __noinline__ int run_check_phase(int iter, int mode, int *frame_pin) {
+    PHASE_PIN_USE(frame_pin);
     const RunKArgs &A = run_kargs();
     RunSmem r = run_smem<LDSSTATE>(A.L, A.P);
     return check_body<NB, OCC>(A.L, A.P, A.S, r.S, __builtin_amdgcn_readfirstlane(iter), __builtin_amdgcn_readfirstlane(mode), r.X, r.Z, r.Y);
@@ -161,7 +176,7 @@ __global__ __launch_bounds__(NT, run_occupancy(NB, MODE)) void k_mpc_run(RunKArg
     load_common(L, P.model + (size_t)b * L.model_sz, step, S);
     if (!LOOP && R.part == 3) {                  // mpcqp_refactor: the factorization alone (what one rho update costs)
         __syncthreads();
-        run_factor_phase<NB, OCC>();
+        { FramePin pin; run_factor_phase<NB, OCC>(&pin.v); }
         return;
     }
     const int nx = L.nx, nu = L.nu;
@@ -229,7 +244,7 @@ __global__ __launch_bounds__(NT, run_occupancy(NB, MODE)) void k_mpc_run(RunKArg
 #endif
         int iter = 0, term = 0;
         if (!LOOP && R.part == 2) iter = P.info[b].iter;      // resumed: the first round and its check are done
-        else run_begin_phase<NB, LDSSTATE, OCC>(R.plain, (R.warm_x && k == 0) ? 1 : 0);
+        else { FramePin pin; run_begin_phase<NB, LDSSTATE, OCC>(R.plain, (R.warm_x && k == 0) ? 1 : 0, &pin.v); }
         __syncthreads();
         PHASE_CLOCK(0)
         while (!term) {
@@ -238,7 +253,7 @@ __global__ __launch_bounds__(NT, run_occupancy(NB, MODE)) void k_mpc_run(RunKArg
             iter = nxt;
             __syncthreads();
             PHASE_CLOCK(1)
-            term = run_check_phase<NB, LDSSTATE, OCC>(iter, stop_mode(iter, R.max_iter, R.chk, R.rho_every, R.plain != 0));
+            { FramePin pin; term = run_check_phase<NB, LDSSTATE, OCC>(iter, stop_mode(iter, R.max_iter, R.chk, R.rho_every, R.plain != 0), &pin.v); }
             __syncthreads();
             PHASE_CLOCK(2)
             if (!LOOP && R.part == 1 && !term) {              // hand the instance over to the follow-up launch
