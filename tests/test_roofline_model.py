@@ -1,8 +1,8 @@
 """bench.py's roofline numerator is a byte MODEL kept in host code (mpcqp_get_stream_bytes): what k_mpc_run is designed to stream per
 ADMM iteration / round / solve.  The committed counter profiles of the same kernels (profiles/pmc_hbm_traffic.json: rocprofv3 FETCH_SIZE x 2
-+ WRITE_SIZE per ADMM iteration per QP, scripts/r4_profiles.sh + scripts/pmc_summary.py) are the measurement it must stay close to: if the
++ WRITE_SIZE per ADMM iteration per QP, scripts/r4_profiles.sh / scripts/profile_counters.sh + scripts/pmc_summary.py) are the measurement it must stay close to: if the
 factor format, the sweeps or the check phase change, the model changes with them and this test asks for a fresh profile instead of letting
-the headline fraction drift.  Three profiled command shapes: the headline batch, the HBM-only leg (batch 4096) and cfg-5."""
+the headline fraction drift.  Four profiled command shapes: the headline batch, the HBM-only leg (batch 4096), cfg-5 and the latency backend (batch 256)."""
 import json
 import os
 
@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # key in the profile file, shape, batch, ADMM iterations per solve of the profiled launches, measured / model seen when the profile was taken
-CASES = [('cfg3', (12, 4, 30), 1024, 38.0, 1.06), ('cfg3_b4096', (12, 4, 30), 4096, 38.0, 1.07), ('cfg5', (20, 8, 100), 512, 27.5, 0.92)]
+CASES = [('cfg3', (12, 4, 30), 1024, 38.0, 1.01), ('cfg3_b4096', (12, 4, 30), 4096, 38.0, 1.02), ('cfg5', (20, 8, 100), 512, 27.5, 0.92),
+         ('cfg3_b256', (12, 4, 30), 256, 38.0, 0.91)]
 
 
 @pytest.mark.parametrize('key,dims,batch,iters_per_solve,seen', CASES, ids=[c[0] for c in CASES])
@@ -28,8 +29,10 @@ def test_stream_byte_model_matches_the_committed_counter_profile(key, dims, batc
     entry = prof[name]
     assert entry['batch'] == batch
     ratio = entry['hbm_bytes_per_iter_per_qp'] / model
-    # measured / designed: 1.06 - 1.07 at (12,4,30) (per-round and per-solve reads and the writes land a little above the model; the same at
-    # batch 1024 inside the Infinity Cache and at 4096 beyond it: the counters see every byte either way), 0.92 at cfg-5 (part of the stream --
-    # the shared G fragments, the tables -- is served by L2: hit rate 28 %).  Held to what was seen within 8 %, and to the model within 15 %.
+    # measured / designed: 1.01 - 1.02 at (12,4,30) (1.06 - 1.07 until the phases stopped saving the calling convention's callee-saved registers
+    # on every call: that scratch traffic was a twentieth of the write + read counters; the same at batch 1024 inside the Infinity Cache and at
+    # 4096 beyond it: the counters see every byte either way), 0.92 at cfg-5 (part of the stream -- the shared G fragments, the tables -- is served
+    # by L2: hit rate 28 %), 0.91 for the register-resident latency backend at batch 256 (2.5 x its model while its ADMM phase saved and restored
+    # ~ 340 registers per call).  Held to what was seen within 8 %, and to the model within 15 %.
     assert abs(ratio - seen) <= 0.08, (ratio, seen)
     assert 0.85 <= ratio <= 1.15, ratio
