@@ -132,10 +132,9 @@ __device__ __noinline__ void run_admm_phase(int iters, int *frame_pin) {
     PHASE_PIN_USE(frame_pin);
     run_admm_phase_body<NB, LDSSTATE, NXT, NUT, MODE>(iters);
 }
-// (Measured for the latency kernels, whose phase saves and restores ~480 callee-saved registers per call -- 1 MB of scratch traffic per
-//  workgroup and round, 46 KB per iteration and instance in the write counters of a kernel that by design reads nothing: taking
-//  the phase INLINE removes that traffic but makes the allocator spill inside the iteration loop, 914 k -> 885 k solves/s at 256
-//  instances.  The call stays.)
+// (History: as an ordinary call the latency kernels' phase saved and restored ~ 340 callee-saved registers per call -- 46 KB per iteration and
+//  instance in the write counters of a kernel that by design reads nothing; taking the phase INLINE removed that traffic but made the allocator
+//  spill inside the iteration loop, 914 k -> 885 k solves/s at 256 instances.  With frame_pin the call stays and the saves are gone: 941 k.)
 template <int NB, bool LDSSTATE, int NXT, int NUT, int MODE, int OCC>
 __device__ __forceinline__ void run_admm(int iters) { FramePin pin; run_admm_phase<NB, LDSSTATE, NXT, NUT, MODE>(iters, &pin.v); }
 
