@@ -68,7 +68,26 @@ typedef struct {
     int32_t warm_start;
     int32_t soft_constraints;   /* pyMPC's SOFT_ON switch (mpc.py:237,530-597): 1 (the only public mode) = state box on x_k + eps_k with slack
                                    columns eps; 0 = hard state box, no slack columns (n = (Np+1)nx + Nc nu).  Fixed at mpcqp_create. */
+    int32_t backend;            /* enum mpcqp_backend: which KKT backend the handle runs.  0 = chosen from the shape and the batch (the only
+                                   value a caller needs); the others force one -- MPCQP_ERR_UNSUPPORTED if the shape is not eligible for
+                                   it.  Fixed at mpcqp_create.  No environment variable is read anywhere in the library. */
+    int32_t tuning;             /* bit flags, enum mpcqp_tuning (0 = everything on).  Fixed at mpcqp_create. */
 } mpcqp_settings;
+
+/* Values of mpcqp_settings.backend (results do not depend on the backend beyond rounding; tests/test_gpu_backends.py runs the parity
+ * suite once per backend a fixture is eligible for). */
+enum mpcqp_backend {
+    MPCQP_BACKEND_AUTO = 0,     /* from shape and batch, see mpcqp_create */
+    MPCQP_BACKEND_SWEEPS = 1,   /* block-tridiagonal sweeps (stages of up to 32) / plain block LDL' (33..128), factor streamed every iteration */
+    MPCQP_BACKEND_DENSE = 2,    /* explicit K^-1 in registers: N (nx+nu) <= 128 */
+    MPCQP_BACKEND_BCR = 3,      /* block cyclic reduction, factor resident in registers: nx+nu <= 16, Np <= 30, Nc = Np -- at ANY batch */
+    MPCQP_BACKEND_BCR8 = 4      /* the same with 512-thread workgroups (two waves per SIMD): what AUTO picks at up to one instance per CU */
+};
+enum mpcqp_tuning {
+    MPCQP_TUNE_NO_BALANCE = 1,  /* keep the identity workgroup -> instance map (no load balancing across compute units) */
+    MPCQP_TUNE_NO_LSTAGE = 2,   /* never stage a global-memory iterate into LDS for a round */
+    MPCQP_TUNE_NO_GROUPING = 4  /* one stage per 16 x 16 block even where several small stages would share one */
+};
 
 typedef struct {
     int32_t status;        /* enum mpcqp_status */

@@ -177,6 +177,7 @@ void mpcqp_default_settings(mpcqp_settings *s) {
     s->rho = 0.1; s->sigma = 1e-6; s->alpha = 1.6; s->eps_abs = 1e-3; s->eps_rel = 1e-3; s->eps_prim_inf = 1e-4; s->eps_dual_inf = 1e-4;
     s->adaptive_rho_tolerance = 5.0; s->max_iter = 4000; s->check_termination = 25; s->scaling = 10;
     s->adaptive_rho = 1; s->adaptive_rho_interval = 0; s->warm_start = 1; s->soft_constraints = 1;
+    s->backend = 0; s->tuning = 0;      /* (one backend here: the oracle; the fields are carried for layout compatibility) */
 }
 const char *mpcqp_status_string(int status) {
     switch (status) {

@@ -27,7 +27,12 @@ class Settings(C.Structure):
                 ('adaptive_rho_tolerance', C.c_double),
                 ('max_iter', C.c_int32), ('check_termination', C.c_int32), ('scaling', C.c_int32),
                 ('adaptive_rho', C.c_int32), ('adaptive_rho_interval', C.c_int32), ('warm_start', C.c_int32),
-                ('soft_constraints', C.c_int32)]
+                ('soft_constraints', C.c_int32), ('backend', C.c_int32), ('tuning', C.c_int32)]
+
+
+# enum mpcqp_backend / mpcqp_tuning of include/mpcqp.h
+BACKEND_AUTO, BACKEND_SWEEPS, BACKEND_DENSE, BACKEND_BCR, BACKEND_BCR8 = 0, 1, 2, 3, 4
+TUNE_NO_BALANCE, TUNE_NO_LSTAGE, TUNE_NO_GROUPING = 1, 2, 4
 
 
 class Info(C.Structure):

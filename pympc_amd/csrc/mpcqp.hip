@@ -131,6 +131,7 @@ extern "C" void mpcqp_default_settings(mpcqp_settings *s) {
     s->adaptive_rho_tolerance = 5.0;
     s->max_iter = 4000; s->check_termination = 25; s->scaling = 10;
     s->adaptive_rho = 1; s->adaptive_rho_interval = 0; s->warm_start = 1; s->soft_constraints = 1;
+    s->backend = MPCQP_BACKEND_AUTO; s->tuning = 0;
 }
 
 extern "C" const char *mpcqp_status_string(int status) {
@@ -230,8 +231,14 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     const size_t state_doubles = (size_t)(L.n + 2 * L.m);
     h->lds_state = L.NB <= 32 && sizeof(double) * ((size_t)smem_common_doubles(L) + state_doubles) <= 40 * 1024 && L.m <= 4 * NT && L.N * L.NB <= 2 * NT && L.n_u + L.nu <= NT;      // (the owner map of the parallel phases: two state elements and one input element per thread)
     // The smallest ones (the reference's own examples) solve the KKT system with a register-resident dense inverse (mpcqp_dense.h).
-    bool dense = h->lds_state && L.NB == 16 && L.NR <= DenseFmt::ROWS;      // (Nc < Np included: the dense inverse holds the held input's couplings itself)
-    if (const char *e = getenv("MPCQP_DENSE")) dense = dense && atoi(e) != 0;      // development switch (A/B against the block sweeps)
+    // (mpcqp_settings.backend forces a choice -- what tests/test_gpu_backends.py runs every eligible fixture through; a forced backend the shape
+    //  is not eligible for is refused, never silently replaced)
+    const int want = h->S.backend;
+    auto refuse = [&](const char *what) { mpcqp_destroy(h); return fail(MPCQP_ERR_UNSUPPORTED, std::string("mpcqp_create: backend ") + what + " is not available for this shape"); };
+    if (want < MPCQP_BACKEND_AUTO || want > MPCQP_BACKEND_BCR8) { mpcqp_destroy(h); return fail(MPCQP_ERR_ARG, "mpcqp_create: unknown mpcqp_settings.backend"); }
+    const bool dense_shape = h->lds_state && L.NB == 16 && L.NR <= DenseFmt::ROWS;      // (Nc < Np included: the dense inverse holds the held input's couplings itself)
+    if (want == MPCQP_BACKEND_DENSE && !dense_shape) return refuse("DENSE");
+    const bool dense = dense_shape && (want == MPCQP_BACKEND_AUTO || want == MPCQP_BACKEND_DENSE);
     h->L.dense = dense ? 1 : 0;
     if (dense) h->L.tsz += DenseFmt::SCRATCH;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->ncu = prop.multiProcessorCount; }
@@ -239,13 +246,13 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     // 16 x 16 stages and horizons of up to 30 steps -- the BASELINE shape (12, 4, 30) with compile-time dimensions, anything else with nx + nu <= 16 through
     // the generic instantiations.  Larger batches stream the chain format (the bandwidth backend).
     const bool bcr_shape = !dense && h->lds_state && L.NB == 16 && !L.border && bcr_schedule(L.N) > 0;
-    bool bcr = bcr_shape && h->ncu > 0 && batch <= 2 * h->ncu;      // (measured cross-over with the bandwidth kernel at (12,4,30): between 512 and 768 instances)
-    if (const char *e = getenv("MPCQP_BCR")) bcr = atoi(e) != 0 && bcr_shape;      // development switch: 0 = never, 1 = whenever the shape allows (any batch)
+    if ((want == MPCQP_BACKEND_BCR || want == MPCQP_BACKEND_BCR8) && !bcr_shape) return refuse("BCR");
+    const bool bcr = bcr_shape && (want == MPCQP_BACKEND_AUTO ? (h->ncu > 0 && batch <= 2 * h->ncu)      // (measured cross-over with the bandwidth kernel at (12,4,30): between 512 and 768 instances)
+                                                              : (want == MPCQP_BACKEND_BCR || want == MPCQP_BACKEND_BCR8));
     h->L.bcr = bcr ? bcr_schedule(L.N) : 0;
     // Small stages (nx + nu <= 8) that neither of the register-resident backends takes: several stages per 16 x 16 block (mpcqp_group.h) -- the
     // chain and the factor shrink by the group size.  (Worth it once the chain is long: at least three super-stages.)
-    int grp = (!dense && !bcr && L.NB == 16 && group_size(L.nb) >= 2 && group_count(L.N, group_size(L.nb)) >= 3) ? group_size(L.nb) : 0;
-    if (const char *e = getenv("MPCQP_GROUP")) { if (atoi(e) == 0) grp = 0; }      // development switch (A/B against one stage per block)
+    const int grp = (!dense && !bcr && L.NB == 16 && group_size(L.nb) >= 2 && group_count(L.N, group_size(L.nb)) >= 3 && !(h->S.tuning & MPCQP_TUNE_NO_GROUPING)) ? group_size(L.nb) : 0;
     h->L.grp = grp;
     if (grp) {
         h->L.fstage = GroupFmt::REC; h->L.fhead = 0; h->L.ffwd = GroupFmt::NN; h->L.ftab = 0;
@@ -272,21 +279,24 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
         rc |= dalloc(h, &h->u0_dev, B * L.nu);
     rc |= dalloc(h, &P.work, B); rc |= dalloc(h, &h->perm_dev, B);
     rc |= dalloc(h, &h->pending_dev, B); rc |= dalloc(h, &h->npending_dev, 4);
-    if (const char *e = getenv("MPCQP_BALANCE")) h->auto_balance = atoi(e) != 0;      // development switch
+    if (h->S.tuning & MPCQP_TUNE_NO_BALANCE) h->auto_balance = 0;
     if (rc) { std::string msg = g_err; mpcqp_destroy(h); return fail(MPCQP_ERR_HIP, msg); }
     // The factorization's workspace starts at the work area T, the last part of the common block,
     // and may run on into the iterate area (dead while a factorization runs); T is widened only where even that is short.
     const int fws = dense ? L.NR * L.dld + 2 * DenseFmt::ROWS + L.m + L.n : bcr ? BcrFmt::LDSW + L.m + L.n : (L.NB == 16 ? FactorCfg<16>::WS : L.NB == 32 ? FactorCfg<32>::WS : L.NB == 64 ? WideFmt::WS : HugeFmt::WS);
+    // (a held input, Nc < Np: border_factor also forms Sigma and its inverse, 2 nu^2 doubles, at the start of T -- more than any factorization
+    //  workspace once nu is large: (30, 40, 3, 2) needs 3 200 doubles where the 128-wide factorization asks for 264)
+    const int need = std::max(fws, (L.border && !dense) ? 2 * L.nu * L.nu : 0);
     const int avail = L.tsz + (h->lds_state ? (int)state_doubles : 0);
-    if (avail < fws) h->L.tsz += fws - avail;
+    if (avail < need) h->L.tsz += need - avail;
     h->smem_setup = sizeof(double) * ((size_t)smem_common_doubles(h->L) + (h->lds_state ? state_doubles : 0));      // every kernel gets the full block
     // At most one instance per compute unit and an iterate that does not qualify for the LDS-resident owner map: stage it (with the metric
     // vectors, the linear cost and the border matrices) into LDS for the length of a round if one workgroup's LDS holds it (admm_round_global).
     {
         const size_t stage_doubles = 2 * (size_t)L.n + 3 * (size_t)L.m + (size_t)(L.n_x + L.n_u) + (L.border ? 2 * (size_t)L.nu * L.N * L.NB + (size_t)L.nu * L.nu : 0);
         const bool specialised = L.NB == 32 && L.nx == 20 && L.nu == 8 && !L.border;      // (the BASELINE cfg-5 instantiation has compile-time dimensions and no staged round)
-        bool lstage = !h->lds_state && !dense && !bcr && !specialised && h->ncu > 0 && batch <= h->ncu && h->smem_setup + sizeof(double) * stage_doubles <= 150 * 1024;
-        if (const char *e = getenv("MPCQP_LSTAGE")) lstage = lstage && atoi(e) != 0;      // development switch
+        const bool lstage = !h->lds_state && !dense && !bcr && !specialised && h->ncu > 0 && batch <= h->ncu && h->smem_setup + sizeof(double) * stage_doubles <= 150 * 1024
+                            && !(h->S.tuning & MPCQP_TUNE_NO_LSTAGE);
         h->L.lstage = lstage ? 1 : 0;
         if (lstage) h->smem_setup += sizeof(double) * stage_doubles;
     }
@@ -527,10 +537,11 @@ extern "C" int mpcqp_setup_csc(mpcqp_handle *h, const double *P_val, const doubl
 
 extern "C" int mpcqp_update_settings(mpcqp_handle *h, const mpcqp_settings *s) {
     if (!h || !s) return fail(MPCQP_ERR_ARG, "null argument");
-    double rho = h->S.rho, sigma = h->S.sigma; int scaling = h->S.scaling;
+    double rho = h->S.rho, sigma = h->S.sigma; int scaling = h->S.scaling, backend = h->S.backend, tuning = h->S.tuning;
     h->S = *s;
     h->S.rho = rho; h->S.sigma = sigma; h->S.scaling = scaling;   // fixed at setup (they shape the factorization)
     h->S.soft_constraints = h->L.soft;                            // fixed at creation (it shapes the problem)
+    h->S.backend = backend; h->S.tuning = tuning;                 // ... as are the backend and its tuning flags
     return MPCQP_OK;
 }
 

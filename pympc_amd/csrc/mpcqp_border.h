@@ -138,14 +138,16 @@ __device__ __forceinline__ void border_pre(const Lay &L, const double *Bb, const
         case 4: border_pre_few<NB, 4>(L, Bb, Zb, Sig, Tc, ubar, red); return;
         default: break;
     }
+    // (r2 - Z' r1 is formed IN the r2 slots of Tc -- Z is zero there, so the later dot products do not see the change -- and ubar holds nu
+    //  doubles only: the 128 doubles of Smem::tv are enough for any nu <= 127)
     for (int j = 0; j < nu; ++j) {
         double vsum[1] = {0.0}, vmax[1] = {0.0};
         for (int idx = tid; idx < NP; idx += NT) vsum[0] += Zb[(size_t)j * NP + idx] * Tc[idx];     // Z is zero in the r2 slots
         block_reduce<1, 1>(vmax, vsum, red);
-        if (tid == 0) ubar[nu + j] = Tc[slot + j] - vsum[0];
+        if (tid == 0) Tc[slot + j] -= vsum[0];
         __syncthreads();
     }
-    if (tid < nu) { double a = 0.0; for (int j = 0; j < nu; ++j) a += Sig[tid * nu + j] * ubar[nu + j]; ubar[tid] = a; }
+    if (tid < nu) { double a = 0.0; for (int j = 0; j < nu; ++j) a += Sig[tid * nu + j] * Tc[slot + j]; ubar[tid] = a; }
     __syncthreads();
     for (int idx = tid; idx < NP; idx += NT) {
         double a = Tc[idx];

@@ -353,7 +353,8 @@ __global__ __launch_bounds__(NT) void k_eq_solve(Lay L, Ptrs P, int sweeps, int 
     double nrm[4] = {0.0, 0.0, 0.0, 0.0}, dummy[1] = {0.0};
     int done = 0;
     bool settled = false;
-    for (int sw = 0; sw <= sweeps; ++sw) {
+    bool broken = P.info[b].status == MPCQP_NON_CVX && P.info[b].iter == 0;      // (k_setup's verdict on its factorization: a non-positive pivot)
+    for (int sw = 0; sw <= sweeps && !broken; ++sw) {
         nrm[0] = nrm[1] = nrm[2] = nrm[3] = 0.0;
         for (int i = tid; i < L.n_x; i += NT) {
             double ax = 0.0, lo, hi;
@@ -374,10 +375,13 @@ __global__ __launch_bounds__(NT) void k_eq_solve(Lay L, Ptrs P, int sweeps, int 
         __syncthreads();
         if (sw == sweeps || settled) break;
         kkt_solve<NB>(c, om, sv, cc, P.F + (size_t)b * P.fsz, r, S.T + L.m, d, border_ptrs(L, P, S), S.tv);
-        double mx[2] = {0.0, 0.0};
-        for (int j = tid; j < L.n; j += NT) { const double dj = d[j], xj = x[j] + dj; x[j] = xj; mx[0] = fmax(mx[0], fabs(dj)); mx[1] = fmax(mx[1], fabs(xj)); }
-        block_reduce<2, 1>(mx, dummy, S.red);
+        double mx[2] = {0.0, 0.0}, dsum[1] = {0.0};
+        for (int j = tid; j < L.n; j += NT) { const double dj = d[j], xj = x[j] + dj; x[j] = xj; mx[0] = fmax(mx[0], fabs(dj)); mx[1] = fmax(mx[1], fabs(xj)); dsum[0] += dj; }
+        block_reduce<2, 1>(mx, dsum, S.red);
         done = sw + 1;
+        // (fmax drops NaN operands: a NaN correction -- a bad factor, a non-positive pivot -- would leave mx[0] = 0 and read as 'settled';
+        //  the plain sum of the corrections carries it, as the objective does in check_body)
+        if (dsum[0] != dsum[0]) { broken = true; break; }
         settled = mx[0] <= tol * fmax(1.0, mx[1]);       // (the residuals of the settled iterate are evaluated by one more pass of the loop head)
         for (int i = tid; i < L.n_x; i += NT) {
             double ax = 0.0, lo, hi;
@@ -401,8 +405,9 @@ __global__ __launch_bounds__(NT) void k_eq_solve(Lay L, Ptrs P, int sweeps, int 
     }
     if (tid == 0) {
         // 'solved': the corrections have vanished (or no tolerance was asked for); 'maximum iterations reached': `sweeps` sweeps did not settle it
-        mpcqp_info inf; inf.status = (tol > 0.0 && !settled) ? MPCQP_MAX_ITER_REACHED : MPCQP_SOLVED; inf.iter = done; inf.rho_updates = 0; inf.reserved = 0;
-        inf.obj_val = 0.0; inf.pri_res = nrm[2]; inf.dua_res = nrm[0]; inf.rho = P.rho[b];
+        // 'problem non convex' (OSQP's word for a factorization that failed): a NaN correction, or a factor k_setup already reported bad
+        mpcqp_info inf; inf.status = broken ? MPCQP_NON_CVX : (tol > 0.0 && !settled) ? MPCQP_MAX_ITER_REACHED : MPCQP_SOLVED; inf.iter = done; inf.rho_updates = 0; inf.reserved = 0;
+        inf.obj_val = broken ? NAN : 0.0; inf.pri_res = broken ? NAN : nrm[2]; inf.dua_res = broken ? NAN : nrm[0]; inf.rho = P.rho[b];
         P.info[b] = inf;
     }
 }

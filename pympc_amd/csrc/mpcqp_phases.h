@@ -39,7 +39,7 @@ __device__ __forceinline__ void smem_common(const Lay &L, const PT &P, double *&
     S.um1s = carve(p, L.nu);
     S.du0 = carve(p, 2 * L.nu);
     S.red = carve(p, 64);
-    S.tv = carve(p, 128);          // the bordered solve's [ubar | reduced right-hand side] (2 nu <= 126 doubles); outside it, the held input's A'W sums (nu)
+    S.tv = carve(p, 128);          // the bordered solve's ubar (nu <= 127 doubles); outside it, the held input's A'W sums (nu)
     S.iflag = (int *)carve(p, 2);
     S.T = carve(p, L.tsz);
 }

@@ -49,10 +49,38 @@ def _prep(a, shape, name):
     return np.ascontiguousarray(np.broadcast_to(a, shape))
 
 
+BACKENDS = dict(auto=_lib.BACKEND_AUTO, sweeps=_lib.BACKEND_SWEEPS, dense=_lib.BACKEND_DENSE, bcr=_lib.BACKEND_BCR, bcr8=_lib.BACKEND_BCR8)
+_forced = {}               # settings every handle made inside a ``forced_settings`` block gets (tests: one parity suite per KKT backend)
+
+
+class forced_settings:
+    """``with forced_settings(backend='bcr', tuning=TUNE_NO_BALANCE): ...`` -- every problem created inside the block gets these
+    ``mpcqp_settings`` fields on top of what its caller asked for.  This is how the test-suite forces a KKT backend
+    (``mpcqp_settings.backend``) through code that builds its own controllers; the library itself reads no environment variable."""
+
+    def __init__(self, **kw):
+        if isinstance(kw.get('backend'), str):
+            kw['backend'] = BACKENDS[kw['backend']]
+        self.kw = kw
+
+    def __enter__(self):
+        self.old = dict(_forced)
+        _forced.update(self.kw)
+        return self
+
+    def __exit__(self, *exc):
+        _forced.clear()
+        _forced.update(self.old)
+        return False
+
+
 def make_settings(**kw):
     L = _lib.load()
     s = _lib.Settings()
     L.mpcqp_default_settings(C.byref(s))
+    kw = dict(kw, **_forced)
+    if isinstance(kw.get('backend'), str):
+        kw['backend'] = BACKENDS[kw['backend']]
     for k, v in kw.items():
         if k in _SETTING_NAMES:
             setattr(s, k, v)

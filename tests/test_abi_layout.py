@@ -50,7 +50,7 @@ def test_ctypes_structs_mirror_the_header():
     assert ctypes_struct(_lib.Model) == header_struct('mpcqp_model')
     assert ctypes_struct(_lib.Loop) == header_struct('mpcqp_loop')
     # sizes as the C compiler lays them out (natural alignment; no packing pragmas in the header)
-    assert C.sizeof(_lib.Settings) == 8 * 8 + 7 * 4 + 4          # 7 int32 + tail padding to 8
+    assert C.sizeof(_lib.Settings) == 8 * 8 + 9 * 4 + 4          # 9 int32 + tail padding to 8
     assert C.sizeof(_lib.Info) == 4 * 4 + 4 * 8
 
 

@@ -1,10 +1,8 @@
 """The KKT system of an ADMM iteration has more than one solver on the device -- the block-tridiagonal sweeps (every size),
 the dense register-resident inverse (N (nx+nu) <= 128: the reference's own examples), block cyclic reduction with a register-resident
 factor (16 x 16 stages, up to 31 of them) -- and mpcqp_create picks one by problem size and batch.  Everything must hold for EVERY backend a problem is eligible for: the same tests as tests/test_gpu_parity.py, with
-the development switches MPCQP_DENSE / MPCQP_BCR forcing the choice, plus bit-level agreement of the paths that must not depend on it."""
-import os
+mpcqp_settings.backend forcing the choice (pympc_amd.solver.forced_settings), plus bit-level agreement of the paths that must not depend on it."""
 import warnings
-from contextlib import contextmanager
 
 import numpy as np
 import pytest
@@ -15,18 +13,10 @@ from util import golden_names, load_golden, golden_kwargs, golden_csc, apply_att
 pytestmark = pytest.mark.gpu
 
 
-@contextmanager
-def backend(**env):
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update({k: str(v) for k, v in env.items()})
-    try:
-        yield
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+def backend(**forced):
+    """Every controller built inside the block gets these mpcqp_settings fields (the KKT backend, include/mpcqp.h: enum mpcqp_backend)."""
+    from pympc_amd.solver import forced_settings
+    return forced_settings(**forced)
 
 
 def _dense_eligible(name):
@@ -49,7 +39,7 @@ def _bcr_schedule(name):
 
 
 SMALL = [n for n in golden_names() if _dense_eligible(n)]
-SWEEPS, DENSE, BCR = dict(MPCQP_DENSE=0, MPCQP_BCR=0), dict(MPCQP_DENSE=1), dict(MPCQP_DENSE=0, MPCQP_BCR=1)
+SWEEPS, DENSE, BCR, BCR8 = dict(backend='sweeps'), dict(backend='dense'), dict(backend='bcr'), dict(backend='bcr8')
 BACKENDS = [SWEEPS, DENSE]
 IDS = ['sweeps', 'dense']
 # block cyclic reduction (register-resident factor): any fixture with 16 x 16 stages, Nc = Np and at most 31 stages -- the BASELINE shape (12, 4, 30) with

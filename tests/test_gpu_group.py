@@ -2,10 +2,8 @@
 the KKT factor (the reference's published timing example, examples/example_inverted_pendulum_kalman.ipynb, is such a problem: nx = 4, nu = 1,
 Np = 150, Nc = 75).  The backend is chosen by mpcqp_create; everything the other backends are held to must hold here too: the reduced-KKT solve
 against dense numpy, ADMM iterates, status / iteration counts at the default tolerance and u* at the north-star tolerance against the oracle,
-the device loop against the stepwise API bit for bit, and agreement with the one-stage-per-block sweeps (development switch MPCQP_GROUP=0)."""
-import os
+the device loop against the stepwise API bit for bit, and agreement with the one-stage-per-block sweeps (mpcqp_settings.tuning = MPCQP_TUNE_NO_GROUPING)."""
 import warnings
-from contextlib import contextmanager
 
 import numpy as np
 import pytest
@@ -22,18 +20,11 @@ SHAPES = [(4, 1, 150, 75, True), (4, 1, 61, 61, True), (1, 1, 90, 90, True), (3,
 IDS = ['%d_%d_%d_%d%s' % (s[0], s[1], s[2], s[3], '' if s[4] else '_hard') for s in SHAPES]
 
 
-@contextmanager
-def env(**kv):
-    old = {k: os.environ.get(k) for k in kv}
-    os.environ.update({k: str(v) for k, v in kv.items()})
-    try:
-        yield
-    finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+def grouping(on):
+    """Controllers built inside the block run with (1) or without (0) several small stages per 16 x 16 block (mpcqp_settings.tuning)."""
+    from pympc_amd import _lib
+    from pympc_amd.solver import forced_settings
+    return forced_settings(tuning=0 if on else _lib.TUNE_NO_GROUPING)
 
 
 def _kw(shape, seed=0, **more):
@@ -109,7 +100,7 @@ def test_admm_iterates_match_oracle(shape, iters):
 @pytest.mark.parametrize('shape', SHAPES, ids=IDS)
 def test_solves_like_the_oracle_and_like_one_stage_per_block(shape):
     """Default tolerance (mpc.py:80): status, iteration count and rho updates of the oracle; parity tolerance: the whole input sequence within
-    1e-6 of the oracle's at 1e-10 (north-star criterion) and of the ungrouped sweeps' (MPCQP_GROUP=0); one warm step further."""
+    1e-6 of the oracle's at 1e-10 (north-star criterion) and of the ungrouped sweeps' (MPCQP_TUNE_NO_GROUPING); one warm step further."""
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         K, Ko = _ctrl(shape), _ctrl(shape, oracle=True)
@@ -122,7 +113,7 @@ def test_solves_like_the_oracle_and_like_one_stage_per_block(shape):
         (u, info), (uo, infoo) = K.output(return_u_seq=True), Ko.output(return_u_seq=True)
         scale = max(1e-3, np.abs(infoo['u_seq']).max())
         assert np.abs(info['u_seq'] - infoo['u_seq']).max() <= 1e-6 * scale
-        with env(MPCQP_GROUP=0):
+        with grouping(0):
             Kp = _ctrl(shape, settings=dict(max_iter=400000), **tight); Kp.setup()
             assert not _grouped(Kp.prob.batch_problem, shape)
         # (the one-stage-per-block sweeps do not get every one of these to 1e-10 -- 151 blocks that are nine tenths padding around an unstable
@@ -183,7 +174,7 @@ def test_refactorization_inside_the_solve_reproduces_the_setup_factor(name, grou
     (NaN factors from the refactorization phase of the four-per-CU kernels, k_setup's fine) through a callee shared between kernels of different
     launch bounds, and no test saw it; both grouping settings, held inputs with LDS-resident and global iterates, 32-wide stages."""
     from pympc_amd import MPCController, fixtures
-    with env(MPCQP_GROUP=group), warnings.catch_warnings():
+    with grouping(group), warnings.catch_warnings():
         warnings.simplefilter('ignore')
         K = MPCController(**REFAC[name](fixtures)); K.setup(solve=False)
         bp = K.prob.batch_problem

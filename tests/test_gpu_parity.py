@@ -532,8 +532,10 @@ def test_load_balancing_map_never_changes_results(monkeypatch):
     w = 0.02 * rng.standard_normal((30, B, 12))
     out = {}
     for flag in ('1', '0'):
-        monkeypatch.setenv('MPCQP_BALANCE', flag)
-        K = _stacked_batch(kws); K.setup()
+        from pympc_amd import _lib
+        from pympc_amd.solver import forced_settings
+        with forced_settings(tuning=0 if flag == '1' else _lib.TUNE_NO_BALANCE):
+            K = _stacked_batch(kws); K.setup()
         parts = [K.run(10, w=w[10 * i:10 * (i + 1)]) for i in range(3)]       # the map is rebuilt after every launch
         x = parts[-1]['x'][-1]
         us = []
