@@ -80,8 +80,10 @@ enum mpcqp_backend {
     MPCQP_BACKEND_AUTO = 0,     /* from shape and batch, see mpcqp_create */
     MPCQP_BACKEND_SWEEPS = 1,   /* block-tridiagonal sweeps (stages of up to 32) / plain block LDL' (33..128), factor streamed every iteration */
     MPCQP_BACKEND_DENSE = 2,    /* explicit K^-1 in registers: N (nx+nu) <= 128 */
-    MPCQP_BACKEND_BCR = 3,      /* block cyclic reduction, factor resident in registers: nx+nu <= 16, Np <= 30, Nc = Np -- at ANY batch */
-    MPCQP_BACKEND_BCR8 = 4      /* the same with 512-thread workgroups (two waves per SIMD): what AUTO picks at up to one instance per CU */
+    MPCQP_BACKEND_BCR = 3,      /* block cyclic reduction, factor resident in registers, 256-thread workgroups: nx+nu <= 16, Np <= 30, Nc = Np -- at ANY batch */
+    MPCQP_BACKEND_BCR8 = 4,     /* the same with 512-thread workgroups (two waves per SIMD) and the explicit inverse of what two levels of
+                                   reduction leave ("dense top"): what AUTO picks for such shapes at up to three instances per compute unit */
+    MPCQP_BACKEND_BCRT = 5      /* the dense-top factor on 256-thread workgroups (the comparison BCR8 was measured against) */
 };
 enum mpcqp_tuning {
     MPCQP_TUNE_NO_BALANCE = 1,  /* keep the identity workgroup -> instance map (no load balancing across compute units) */
@@ -122,7 +124,7 @@ int mpcqp_device_count(void);
 
 /* osqp.OSQP() (mpc.py:241) for `batch` controllers of one shape.  Np >= 2, 1 <= Nc <= Np, nx + nu <= 128 (MPCQP_ERR_UNSUPPORTED beyond:
  * the reference has no limit).  The KKT backend is chosen here from the shape and the batch: dense register-resident inverse
- * (N (nx+nu) <= 128), cyclic reduction (nx+nu <= 16, Np <= 30, Nc = Np, at most two instances per compute unit), grouped stages (nx+nu <= 8 on
+ * (N (nx+nu) <= 128), cyclic reduction (nx+nu <= 16, Np <= 30, Nc = Np, at most three instances per compute unit), grouped stages (nx+nu <= 8 on
  * longer horizons), block-tridiagonal sweeps (everything else up to 32 wide), plain block LDL' (33..128 wide).  Results do not depend on it
  * beyond rounding. */
 int mpcqp_create(mpcqp_handle **h, int device, int batch, int nx, int nu, int Np, int Nc,

@@ -41,17 +41,7 @@
 
 #include "../../include/mpcqp.h"
 
-#ifndef NT
-#define NT 256                 // threads per workgroup (one workgroup = one MPC instance)
-#endif
-#define NWAVES (NT / 64)
-#define QP_INFTY 1e30
-#define MIN_SCALING 1e-4
-#define MAX_SCALING 1e4
-#define RHO_MIN 1e-6
-#define RHO_MAX 1e6
-#define RHO_EQ_OVER_RHO_INEQ 1e3
-#define RHO_TOL 1e-4
+#include "mpcqp_defs.h"
 
 // one polite spin of a host-side busy wait
 static inline void cpu_relax() {
@@ -82,6 +72,7 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #include "mpcqp_phases.h"
 #include "mpcqp_tiny.h"
 #include "mpcqp_lat.h"
+#include "mpcqp_latw.h"
 #include "mpcqp_kernels.h"
 #include "mpcqp_csc.h"
 
@@ -92,6 +83,15 @@ constexpr int BCR_STAGES = 31;      // the largest stage count the register-resi
 // The static schedule of mpcqp_lat.h exists for 11, 21 and 31 stages; a problem runs the smallest one that holds its N = Np + 1 stages (the rest
 // are identity padding: factor_bcr).  0: too long a horizon for this backend.
 static int bcr_schedule(int N) { return N <= 11 ? 11 : N <= 21 ? 21 : N <= BCR_STAGES ? BCR_STAGES : 0; }
+// AUTO at up to one instance per compute unit: the eight-wave kernels of mpcqp_w8.hip (measured against the four-wave ones: DESIGN.md section 5b)
+#ifndef MPCQP_AUTO_BCR8
+#define MPCQP_AUTO_BCR8 1
+#endif
+// mpcqp_w8.hip: the second translation unit (NT = 512).  kargs: this unit's RunKArgs, byte for byte the other's.
+int mpcqp_w8_launch(const void *kargs, size_t kargs_bytes, int spec12_4, int sched, int loop, int grid, size_t smem, hipStream_t stream);
+#ifdef MPCQP_RUN_TIMING
+void mpcqp_w8_ticks(unsigned long long *out16);
+#endif
 constexpr int BALANCE_EVERY = 16;  // solves between two rebuilds of the workgroup -> instance map
 constexpr int BALANCE_FIRST = 4;   // ... before the first one (an instance shows its character within a few solves; a short run should not end unbalanced)
 
@@ -186,6 +186,7 @@ static Lay make_layout(int nx, int nu, int Np, int Nc, int soft) {
     L.ftab = L.NB == 16 ? FactorFmt<16>::TAB : L.NB == 32 ? FactorFmt<32>::TAB : 0;
     L.tsz = L.m + L.N * L.NB * (L.NB >= 64 ? 2 : 1);   // [W (m) | Tc (N*NB)] (+ the second stage-major vector of the wide solve); mpcqp_create widens it where the factorization needs more
     L.NR = L.N * L.nb; L.dld = L.NR | 1;               // dense mode (decided in mpcqp_create): unknowns, odd LDS row stride
+    L.nw = NWAVES; L.bcrtop = 0;                        // (mpcqp_create: eight waves and a dense top for the kernels of mpcqp_w8.hip)
     return L;
 }
 
@@ -235,7 +236,7 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     //  is not eligible for is refused, never silently replaced)
     const int want = h->S.backend;
     auto refuse = [&](const char *what) { mpcqp_destroy(h); return fail(MPCQP_ERR_UNSUPPORTED, std::string("mpcqp_create: backend ") + what + " is not available for this shape"); };
-    if (want < MPCQP_BACKEND_AUTO || want > MPCQP_BACKEND_BCR8) { mpcqp_destroy(h); return fail(MPCQP_ERR_ARG, "mpcqp_create: unknown mpcqp_settings.backend"); }
+    if (want < MPCQP_BACKEND_AUTO || want > MPCQP_BACKEND_BCRT) { mpcqp_destroy(h); return fail(MPCQP_ERR_ARG, "mpcqp_create: unknown mpcqp_settings.backend"); }
     const bool dense_shape = h->lds_state && L.NB == 16 && L.NR <= DenseFmt::ROWS;      // (Nc < Np included: the dense inverse holds the held input's couplings itself)
     if (want == MPCQP_BACKEND_DENSE && !dense_shape) return refuse("DENSE");
     const bool dense = dense_shape && (want == MPCQP_BACKEND_AUTO || want == MPCQP_BACKEND_DENSE);
@@ -246,10 +247,18 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     // 16 x 16 stages and horizons of up to 30 steps -- the BASELINE shape (12, 4, 30) with compile-time dimensions, anything else with nx + nu <= 16 through
     // the generic instantiations.  Larger batches stream the chain format (the bandwidth backend).
     const bool bcr_shape = !dense && h->lds_state && L.NB == 16 && !L.border && bcr_schedule(L.N) > 0;
-    if ((want == MPCQP_BACKEND_BCR || want == MPCQP_BACKEND_BCR8) && !bcr_shape) return refuse("BCR");
-    const bool bcr = bcr_shape && (want == MPCQP_BACKEND_AUTO ? (h->ncu > 0 && batch <= 2 * h->ncu)      // (measured cross-over with the bandwidth kernel at (12,4,30): between 512 and 768 instances)
-                                                              : (want == MPCQP_BACKEND_BCR || want == MPCQP_BACKEND_BCR8));
+    const bool want_bcr = want == MPCQP_BACKEND_BCR || want == MPCQP_BACKEND_BCR8 || want == MPCQP_BACKEND_BCRT;
+    if (want_bcr && !bcr_shape) return refuse("BCR");
+    const bool bcr = bcr_shape && (want == MPCQP_BACKEND_AUTO ? (h->ncu > 0 && batch <= 3 * h->ncu)      // (measured cross-over with the bandwidth kernel at (12,4,30): 768 instances -- 1.14 M solves/s either way; 640: 1.13 M against 0.99 M)
+                                                              : want_bcr);
     h->L.bcr = bcr ? bcr_schedule(L.N) : 0;
+    // What AUTO runs it on: 512-thread workgroups (two waves per SIMD) with a dense top (mpcqp_latw.h, mpcqp_w8.hip) -- 128 / 256 / 512 instances
+    // 608 k / 1.03 M / 1.13 M solves/s against 506 k / 841 k / 935 k on four waves with the plain reduction (MPCQP_BACKEND_BCR, mpcqp_lat.h).
+    // MPCQP_BACKEND_BCRT: the dense-top format on four waves (533 k / 890 k: what the eight waves add on top of the format).
+    const bool bcr8 = bcr && (want == MPCQP_BACKEND_BCR8 || (want == MPCQP_BACKEND_AUTO && MPCQP_AUTO_BCR8));
+    const bool bcrt = bcr8 || (bcr && want == MPCQP_BACKEND_BCRT);
+    h->L.bcrtop = bcrt ? BcrFmt::top_count(h->L.bcr) : 0;
+    h->L.nw = bcr8 ? 8 : NWAVES;
     // Small stages (nx + nu <= 8) that neither of the register-resident backends takes: several stages per 16 x 16 block (mpcqp_group.h) -- the
     // chain and the factor shrink by the group size.  (Worth it once the chain is long: at least three super-stages.)
     const int grp = (!dense && !bcr && L.NB == 16 && group_size(L.nb) >= 2 && group_count(L.N, group_size(L.nb)) >= 3 && !(h->S.tuning & MPCQP_TUNE_NO_GROUPING)) ? group_size(L.nb) : 0;
@@ -260,7 +269,7 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     }
     const int NS = h->L.bcr;                                        // stages of the schedule (>= L.N)
     if (bcr) h->L.tsz = std::max(h->L.tsz + NS * L.NB, LAT_LDS_DOUBLES(NS));      // the stage-major vectors of the latency round (mpcqp_lat.h); c_e of the streaming solve
-    P.fsz = dense ? (long long)DenseFmt::DOUBLES : bcr ? (long long)NS * BcrFmt::REC : grp ? (long long)(group_count(L.N, grp) + 1) * GroupFmt::REC
+    P.fsz = dense ? (long long)DenseFmt::DOUBLES : bcr ? BcrFmt::doubles(NS, bcrt) : grp ? (long long)(group_count(L.N, grp) + 1) * GroupFmt::REC
                   : (long long)L.fhead + (long long)L.N * L.fstage;
     int rc = 0;
     rc |= dalloc(h, &P.model, B * L.model_sz); rc |= dalloc(h, &P.step, B * L.step_sz);
@@ -283,13 +292,14 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     if (rc) { std::string msg = g_err; mpcqp_destroy(h); return fail(MPCQP_ERR_HIP, msg); }
     // The factorization's workspace starts at the work area T, the last part of the common block,
     // and may run on into the iterate area (dead while a factorization runs); T is widened only where even that is short.
-    const int fws = dense ? L.NR * L.dld + 2 * DenseFmt::ROWS + L.m + L.n : bcr ? BcrFmt::LDSW + L.m + L.n : (L.NB == 16 ? FactorCfg<16>::WS : L.NB == 32 ? FactorCfg<32>::WS : L.NB == 64 ? WideFmt::WS : HugeFmt::WS);
+    const int toplds = bcrt ? LATW_TOP_LDS(NS) + 2 : 0;      // the round's LDS copy of the top inverse, behind the iterate (+ alignment slack)
+    const int fws = dense ? L.NR * L.dld + 2 * DenseFmt::ROWS + L.m + L.n : bcr ? std::max(BcrFmt::LDSW + L.m + L.n, bcrt ? BcrFmt::top_lds(NS) : 0) : (L.NB == 16 ? FactorCfg<16>::WS : L.NB == 32 ? FactorCfg<32>::WS : L.NB == 64 ? WideFmt::WS : HugeFmt::WS);
     // (a held input, Nc < Np: border_factor also forms Sigma and its inverse, 2 nu^2 doubles, at the start of T -- more than any factorization
     //  workspace once nu is large: (30, 40, 3, 2) needs 3 200 doubles where the 128-wide factorization asks for 264)
     const int need = std::max(fws, (L.border && !dense) ? 2 * L.nu * L.nu : 0);
-    const int avail = L.tsz + (h->lds_state ? (int)state_doubles : 0);
+    const int avail = L.tsz + (h->lds_state ? (int)state_doubles : 0) + toplds;
     if (avail < need) h->L.tsz += need - avail;
-    h->smem_setup = sizeof(double) * ((size_t)smem_common_doubles(h->L) + (h->lds_state ? state_doubles : 0));      // every kernel gets the full block
+    h->smem_setup = sizeof(double) * ((size_t)smem_common_doubles(h->L) + (h->lds_state ? state_doubles : 0) + (size_t)toplds);      // every kernel gets the full block
     // At most one instance per compute unit and an iterate that does not qualify for the LDS-resident owner map: stage it (with the metric
     // vectors, the linear cost and the border matrices) into LDS for the length of a round if one workgroup's LDS holds it (admm_round_global).
     {
@@ -623,6 +633,15 @@ static int launch_run(mpcqp_handle *h, RunArgs R, int plain_iters) {
     }
     int rc;
     if (L.dense) rc = launch_run_t<16, true, 0, 0, MODE_DENSE>(h, R);
+    else if (L.bcr && L.nw == 8) {                  // 512-thread workgroups: the other translation unit
+        RunKArgs A; A.L = h->L; A.P = h->P; A.S = h->S; A.R = R;
+        rc = mpcqp_w8_launch(&A, sizeof(A), L.bcr == 31 && L.nx == 12 && L.nu == 4, L.bcr, R.nsteps > 0, h->batch, h->smem_solve, h->stream);
+        if (rc) return fail(MPCQP_ERR_HIP, "mpcqp_w8_launch failed");
+    }
+    else if (L.bcrtop && L.bcr == 31 && L.nx == 12 && L.nu == 4) rc = launch_run_t<16, true, 12, 4, MODE_BCRT + 31>(h, R);
+    else if (L.bcrtop && L.bcr == 31) rc = launch_run_t<16, true, 0, 0, MODE_BCRT + 31>(h, R);
+    else if (L.bcrtop && L.bcr == 21) rc = launch_run_t<16, true, 0, 0, MODE_BCRT + 21>(h, R);
+    else if (L.bcrtop && L.bcr == 11) rc = launch_run_t<16, true, 0, 0, MODE_BCRT + 11>(h, R);
     else if (L.bcr == 31 && L.nx == 12 && L.nu == 4) rc = launch_run_t<16, true, 12, 4, MODE_BCR + 31>(h, R);
     else if (L.bcr == 31) rc = launch_run_t<16, true, 0, 0, MODE_BCR + 31>(h, R);
     else if (L.bcr == 21) rc = launch_run_t<16, true, 0, 0, MODE_BCR + 21>(h, R);
@@ -915,6 +934,7 @@ extern "C" int mpcqp_get_stats(mpcqp_handle *h, uint64_t *out4, int reset) {
 #ifdef MPCQP_RUN_TIMING
     { uint64_t t[4]; hipMemcpy(t, h->P.stats + 4, sizeof(t), hipMemcpyDeviceToHost); fprintf(stderr, "phase wall-clock ticks: begin %llu admm %llu check %llu\n", (unsigned long long)t[0], (unsigned long long)t[1], (unsigned long long)t[2]);
       unsigned long long g[16]; hipMemcpyFromSymbol(g, HIP_SYMBOL(g_ticks), sizeof(g)); unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(g_ticks), z, sizeof(z));
+      if (h->L.nw == 8) mpcqp_w8_ticks(g);      // (the 512-thread kernels count in their own translation unit)
       { double tot = 0; for (int i = 0; i < 7; ++i) tot += (double)g[i]; if (tot <= 0) tot = 1;
         fprintf(stderr, "iteration cycles (thread 0, summed over workgroups): rhs %.1f%% fwd %.1f%% middle %.1f%% bwd %.1f%% t4 %.1f%% t5 %.1f%% t6 %.1f%% total %.3g;  outside the iterations (same unit): t7 %.3g t8 %.3g t9 %.3g;  check: setup+tail %.3g rows %.3g vars %.3g reduce %.3g decide %.3g\n",
                 100 * g[0] / tot, 100 * g[1] / tot, 100 * g[2] / tot, 100 * g[3] / tot, 100 * g[4] / tot, 100 * g[5] / tot, 100 * g[6] / tot, tot, (double)g[7], (double)g[8], (double)g[9], (double)g[10], (double)g[11], (double)g[12], (double)g[13], (double)g[14]); } }
@@ -984,7 +1004,12 @@ extern "C" int mpcqp_get_stream_bytes(mpcqp_handle *h, int64_t *per_iter, int64_
     if (L.border && !L.dense) it += 2 * (int64_t)L.nu * L.N * NB;      // (the dense inverse holds the held input's couplings itself)
     int64_t rd = (L.model_sz - L.hot_sz) + 2 * n + 2 * m /* D, s, E, omega */ + n + m /* dx, dy */;
     if (L.dense) rd += DenseFmt::DOUBLES;               // the round's load of K^-1 into registers
-    if (L.bcr) rd += (int64_t)L.bcr * BcrFmt::REC - 4 * BcrFmt::NN;      // ... of the cyclic-reduction fragments (the two end stages have one neighbour)
+    if (L.bcr && !L.bcrtop) rd += (int64_t)L.bcr * BcrFmt::REC - 4 * BcrFmt::NN;      // ... of the cyclic-reduction fragments (the two end stages have one neighbour)
+    if (L.bcrtop) {                                     // ... of levels 0 and 1 and of the top inverse
+        int64_t fr = (int64_t)L.bcrtop * L.bcrtop;
+        for (int l = 0; l < 2; ++l) for (int kind = 0; kind < 3; ++kind) for (int t = 0; t < lat_count(L.bcr, l, kind); ++t) fr += lat_nfr(L.bcr, l, kind, t);
+        rd += fr * BcrFmt::NN;
+    }
     rd += (h->lds_state || L.lstage) ? 2 * (n + 2 * m) /* iterate in and out of LDS */ + (m + L.n_x) + (n + L.n_x) + nq : (n + 2 * m);
     if (L.lstage && L.border) rd += 2 * (int64_t)L.nu * L.N * NB;      // the border matrices staged with it
     int64_t sv = L.hot_sz + L.step_sz + 3 * m /* E, types, omega */ + nq + 2 * (n + m) /* solution out, iterate read */;
@@ -1002,8 +1027,9 @@ extern "C" int mpcqp_get_work(mpcqp_handle *h, int64_t *mfma_per_iter) {
     int64_t mv = 0;                                  // 16 x 16 mat-vecs (four MFMAs each)
     if (L.dense || L.NB >= 64) mv = 0;               // vector ALU only
     else if (L.bcr) {
-        for (int l = 0; l < bcr_levels(L.bcr); ++l)
+        for (int l = 0; l < (L.bcrtop ? 2 : bcr_levels(L.bcr)); ++l)
             for (int kind = 0; kind < 3; ++kind) for (int t = 0; t < lat_count(L.bcr, l, kind); ++t) mv += lat_nfr(L.bcr, l, kind, t);
+        mv += (int64_t)L.bcrtop * L.bcrtop;            // dense top: one mat-vec per block of the inverse
         mv += 2 * ((L.bcr + 3) / 4);                 // G v and G'W: one group per four stages each
     } else if (L.grp) mv = 3 * (int64_t)group_count(L.N, L.grp) - 1;      // forward 1, backward 2 mat-vecs per super-stage, the middle stage
     else {
@@ -1022,8 +1048,8 @@ extern "C" int mpcqp_kernel_name(mpcqp_handle *h, int loop, char *buf, int bufle
     const bool spec = L.dense ? false : (L.NB == 16 && !L.bcr && !h->lds_state && L.nx == 4 && L.nu == 1) ? true :
                       !L.border && (L.bcr ? (L.bcr == 31 && L.nx == 12 && L.nu == 4)
                                           : ((L.NB == 16 && h->lds_state && L.nx == 12 && L.nu == 4) || (L.NB == 32 && !h->lds_state && L.nx == 20 && L.nu == 8)));
-    snprintf(buf, (size_t)buflen, "k_mpc_run<%d,%s,%d,%d,%d,%s>", L.NB, h->lds_state ? "true" : "false", spec ? L.nx : 0, spec ? L.nu : 0,
-             L.dense ? MODE_DENSE : L.bcr ? MODE_BCR + L.bcr : L.border ? MODE_BORDER : MODE_CHAIN, loop ? "true" : "false");
+    snprintf(buf, (size_t)buflen, "%sk_mpc_run<%d,%s,%d,%d,%d,%s>", L.nw == 8 ? "w8::" : "", L.NB, h->lds_state ? "true" : "false", spec ? L.nx : 0, spec ? L.nu : 0,
+             L.dense ? MODE_DENSE : L.bcr ? (L.bcrtop ? MODE_BCRT : MODE_BCR) + L.bcr : L.border ? MODE_BORDER : MODE_CHAIN, loop ? "true" : "false");
     return MPCQP_OK;
 }
 

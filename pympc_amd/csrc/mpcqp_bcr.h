@@ -28,6 +28,14 @@ struct BcrFmt {
     static constexpr int ODINV = 0, OLBL = NN, OLBR = 2 * NN, OLBLT = 3 * NN, OLBRT = 4 * NN;
     static constexpr int WSTAGE = 4 * NN;                     // global workspace per stage of the factorization: K_ii | K_{i,next} | dK_L | dK_R
     static constexpr int LDSW = 4 * 5 * NN;                   // LDS of the factorization: four groups x [ D | B_L | B_R | Lb_L | Lb_R ]
+    // Dense top (Lay::bcrtop = nt > 0): the reduction stops after levels 0 and 1; the nt = N / 4 stages i = 4 (r + 1) - 1 that are left form a block
+    // tridiagonal Schur complement of order 16 nt (112 at N = 31) whose EXPLICIT inverse is stored as nt x nt fragments behind the stage records:
+    // block (r, c) at TOPOFF(N) + (r nt + c) NN.  Levels 2 .. 4 of the plain reduction are a chain of five dependent level steps that one wave
+    // walks alone (2 700 of an iteration's 11 000 cycles); the inverse is nt independent block rows of nt mat-vecs each.
+    static constexpr int top_count(int N) { return N / 4; }
+    static constexpr long long top_off(int N) { return (long long)N * REC; }
+    static constexpr long long doubles(int N, bool top) { return (long long)N * REC + (top ? (long long)top_count(N) * top_count(N) * NN : 0); }
+    static constexpr int top_lds(int N) { return 16 * top_count(N) * (16 * top_count(N) + 1) + 2 * 16 * top_count(N); }      // LDS of the inversion: matrix (odd row stride), pivot row, pivot column
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -56,6 +64,7 @@ __device__ __forceinline__ int factor_bcr(const Ctx &c, const double *om, const 
     __syncthreads();
     double *D = W + g * 5 * NN, *BL = D + NN, *BR = D + 2 * NN, *LL = D + 3 * NN, *LR = D + 4 * NN;
     for (int h = 1; h - 1 < N; h <<= 1) {
+        if (L.bcrtop && h == 4) break;                        // (dense top: what is left after levels 0 and 1 is inverted explicitly below)
         const int ne = (N + h) / (2 * h);                     // stages e = h (2t+1) - 1 < N
         for (int t0 = 0; t0 < ne; t0 += G) {
             const int t = t0 + g;
@@ -149,6 +158,51 @@ __device__ __forceinline__ int factor_bcr(const Ctx &c, const double *om, const 
         }
         __syncthreads();
     }
+    if (L.bcrtop) {
+        // ---- the top: stages i_r = 4 (r + 1) - 1, r < nt, with the Schur complements the two levels left in Kd (diagonal blocks) and Up (Up[i] =
+        // K_{i,i+4} for a kept i).  Assembled dense in LDS (odd row stride), inverted in place by Gauss-Jordan sweeps -- SPD: no pivoting, a
+        // non-positive pivot is reported as everywhere else -- with thread t owning column t mod 128 of every (NT / 128)-th row, then written as
+        // fragments with zero rows and columns where a stage has no variable (as D^-1 above).
+        const int nt = L.bcrtop, NRt = nt * NB, ld = NRt + 1;
+        double *M = W, *prow = M + NRt * ld, *pcol = prow + NRt;
+        for (int idx = tid; idx < NRt * NRt; idx += NT) {
+            const int r = idx / NRt, cx = idx - r * NRt, br = r / NB, a = r % NB, bc = cx / NB, b = cx % NB;
+            const int i = 4 * (br + 1) - 1, j = 4 * (bc + 1) - 1;
+            double v = 0.0;
+            if (br == bc) v = Kd[(size_t)i * NN + a * NB + b];
+            else if (bc == br + 1) v = Up[(size_t)i * NN + a * NB + b];          // K_{i,j}, j = i + 4
+            else if (bc + 1 == br) v = Up[(size_t)j * NN + b * NB + a];          // K_{i,j} = K_{j,i}'
+            M[r * ld + cx] = v;
+        }
+        __syncthreads();
+        const int jc = tid & 127, i0 = tid >> 7;
+        constexpr int RG = NT / 128;                          // row groups
+        for (int pv = 0; pv < NRt; ++pv) {
+            for (int t = tid; t < NRt; t += NT) { prow[t] = M[pv * ld + t]; pcol[t] = M[t * ld + pv]; }
+            __syncthreads();
+            double d = prow[pv];
+            if (!(d > 0.0)) { if (tid == 0) *iflag = 1; d = 1e-300; }
+            const double inv = 1.0 / d;
+            if (jc < NRt) {
+                const double rpj = prow[jc];
+                for (int i = i0; i < NRt; i += RG) {
+                    const double rip = pcol[i], cur = M[i * ld + jc];
+                    M[i * ld + jc] = (i == pv) ? (jc == pv ? inv : rpj * inv) : (jc == pv ? -rip * inv : cur - rip * rpj * inv);
+                }
+            }
+            __syncthreads();
+        }
+        double *Ft = F + BcrFmt::top_off(N);
+        for (int idx = tid; idx < nt * nt * NN; idx += NT) {
+            const int blk = idx / NN, e = idx - blk * NN, a = e / NB, b = e % NB, br = blk / nt, bc = blk - br * nt;
+            const int i = 4 * (br + 1) - 1, j = 4 * (bc + 1) - 1;
+            const int nbi = i >= NR ? 0 : (i < L.NcT) ? L.nb : L.nx, nbj = j >= NR ? 0 : (j < L.NcT) ? L.nb : L.nx;
+            const double v = (a >= nbi || b >= nbj) ? 0.0 : 0.5 * (M[(br * NB + a) * ld + bc * NB + b] + M[(bc * NB + b) * ld + br * NB + a]);
+            Ft[(size_t)blk * NN + frag_pos<NB>(a, b)] = v;
+        }
+        if (tid == 0) iflag[2] = 0;                          // (the rounds' LDS copy of the top is stale -- and this workspace has just run over it: admm_latw)
+        __syncthreads();
+    }
     return *iflag;
 }
 
@@ -168,11 +222,13 @@ __device__ __forceinline__ d4 bcr_frag(const double *F, int stage, int off, int 
 // Solve, streaming version (run time N; fragments read from memory as they are needed): the verification kernel and any caller
 // outside an ADMM round.  Tc <- K^-1 Tc, Cc: LDS, N * 16 doubles.  All threads call; barriers inside.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void bcr_core_stream(const double *F, int N, double *Tc, double *Cc) {
+// ntop > 0: the factor has a dense top (BcrFmt): two levels of reduction, the explicit inverse for the ntop stages that are left, two levels back.
+__device__ __forceinline__ void bcr_core_stream(const double *F, int N, double *Tc, double *Cc, int ntop = 0) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     double *tb = Tc + vec_lane_offset(lane), *cb = Cc + vec_lane_offset(lane);
     int top = 1;
     for (int h = 1; h - 1 < N; h <<= 1) {
+        if (ntop && h == 4) break;
         top = h;
         const int ne = (N + h) / (2 * h), nk = N / (2 * h);
         for (int t = wv; t < nk; t += NWAVES) {
@@ -188,6 +244,17 @@ __device__ __forceinline__ void bcr_core_stream(const double *F, int N, double *
             bcr_mv(bcr_frag(F, e, BcrFmt::ODINV, lane), tb[e * 16], p, q);
             cb[e * 16] = p + q;
         }
+        __syncthreads();
+    }
+    if (ntop) {                                               // x_top = (Schur complement)^-1 b_top, one block row per wave at a time
+        const double *Ft = F + BcrFmt::top_off(N);
+        for (int r = wv; r < ntop; r += NWAVES) {
+            double p = 0.0, q = 0.0;
+            for (int c = 0; c < ntop; ++c) bcr_mv(*(cgd4 *)(Ft + (size_t)(r * ntop + c) * BcrFmt::NN + lane * 4), tb[(4 * (c + 1) - 1) * 16], p, q);
+            cb[(4 * (r + 1) - 1) * 16] = p + q;
+        }
+        __syncthreads();
+        for (int r = wv; r < ntop; r += NWAVES) tb[(4 * (r + 1) - 1) * 16] = cb[(4 * (r + 1) - 1) * 16];
         __syncthreads();
     }
     for (int h = top; h >= 1; h >>= 1) {

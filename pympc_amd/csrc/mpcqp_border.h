@@ -188,7 +188,7 @@ __device__ __forceinline__ void kkt_solve(const Ctx &c, const double *om, const 
     else if (NB == 16 && L.bcr) {
         for (int idx = L.N * NB + threadIdx.x; idx < L.bcr * NB; idx += NT) Tc[idx] = 0.0;      // (the schedule's padding stages)
         __syncthreads();
-        bcr_core_stream(F, L.bcr, Tc, Tc + L.bcr * NB);
+        bcr_core_stream(F, L.bcr, Tc, Tc + L.bcr * NB, L.bcrtop);
     }
     else kkt_core<NB>(core_args(L, F, om), Tc);
     if (bordered) border_post(L, NB, Tc, ubar);

@@ -30,7 +30,7 @@ __device__ __forceinline__ double lane_swap1(double x) {
     const int lo = __builtin_amdgcn_mov_dpp((int)xi, 0xB1, 0xF, 0xF, false), hi = __builtin_amdgcn_mov_dpp((int)(xi >> 32), 0xB1, 0xF, 0xF, false);
     return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
 }
-static_assert(NT == 256, "the dense path maps 128 rows x 2 column halves onto 256 threads");
+static_assert(kLatOnly || NT == 256, "the dense path maps 128 rows x 2 column halves onto 256 threads");
 
 __device__ __forceinline__ bool dense_dead(const Lay &L, int v) {       // variable slot v = (k, a) without a variable
     const int k = v / L.nb, a = v - k * L.nb;

@@ -34,6 +34,7 @@ __device__ __forceinline__ int opaque_lane(int v) { asm volatile("" : "+v"(v)); 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) double gdouble;     // explicit global address space: plain global_load/store,
 typedef __attribute__((address_space(1))) const double cgdouble;  // not flat_* (which also counts on lgkmcnt)
+typedef gdouble gdouble_g;                                     // (for signatures of templates that re-typedef gdouble locally)
 typedef __attribute__((address_space(1))) const d4 cgd4;
 
 // The factor of one instance.  Per stage  [ forward matrix -Mh_k | packed S_k^-1 | table ]  and, behind the last stage, the
@@ -201,7 +202,7 @@ __device__ __forceinline__ int factor_all(const Ctx &c, const double *om, const 
         TICK(3)
         // in-place Gauss-Jordan inversion of the SPD block: step p uses the OLD pivot row and column (read, barrier, write)
         constexpr int EPT = NN / (NT / G);                   // entries per thread (2 with two groups of 128, 4 for 32 x 32), kept in registers through the NB steps
-        static_assert(NN % (NT / G) == 0, "whole entries per thread");
+        static_assert(kLatOnly || NN % (NT / G) == 0, "whole entries per thread");
         double cur[EPT];
         if (on) {
 #pragma unroll

@@ -67,7 +67,7 @@ __device__ __forceinline__ bool grp_dead(const Lay &L, int g, int K, int A) {
 // Factorization: one super-stage at a time by the whole workgroup (one entry per thread), twisted order.  W: LDS, 5 * 256 doubles.
 __device__ __forceinline__ int factor_group(const Ctx &c, const double *om, const double *sv, double cc, double *F, double *W, int *iflag) {
     constexpr int NN = GroupFmt::NN, NB = 16;
-    static_assert(NT == NN, "one entry of a 16 x 16 block per thread");
+    static_assert(kLatOnly || NT == NN, "one entry of a 16 x 16 block per thread");
     const Lay &L = c.L;
     const int g = L.grp, NS = group_count(L.N, g), mid = NS / 2, tid = threadIdx.x, A = tid / NB, B = tid % NB;
     double *S = W, *C = W + NN, *Mh = W + 2 * NN, *SnA = W + 3 * NN, *SnB = W + 4 * NN;

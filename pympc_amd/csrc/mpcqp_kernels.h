@@ -104,10 +104,14 @@ __device__ __noinline__ void run_factor_phase(int *frame_pin) {
     PHASE_PIN_USE(frame_pin);
     const RunKArgs &A = run_kargs();
     const Lay &L = A.L; const Ptrs &P = A.P;
-    if constexpr (NB == 16) { if (L.grp > 1) { FramePin pin; run_group_factor_phase<OCC>(&pin.v); return; } }
+    if constexpr (NB == 16 && !kLatOnly) { if (L.grp > 1) { FramePin pin; run_group_factor_phase<OCC>(&pin.v); return; } }
     RunSmem r = run_smem<false>(L, P);                       // (the common LDS area comes first in both layouts)
     const int b = inst_of(P.perm);
     Ctx c{L, r.S.hot, P.model + (size_t)b * L.model_sz + L.hot_sz};
+    if constexpr (kLatOnly) {                                // (mpcqp_w8.hip: cyclic-reduction handles only)
+        factor_bcr(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], P.F + (size_t)b * P.fsz, P.bws + (size_t)b * L.bcr * BcrFmt::WSTAGE, r.S.T, r.S.iflag);
+        return;
+    }
     if (NB == 16 && L.dense) factor_dense(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], P.F + (size_t)b * P.fsz, r.S.T, r.S.iflag);      // (the register-resident backends: 16 x 16 stages only)
     else if (NB == 16 && L.bcr) factor_bcr(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], P.F + (size_t)b * P.fsz, P.bws + (size_t)b * L.bcr * BcrFmt::WSTAGE, r.S.T, r.S.iflag);
     else factor_all<NB>(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], P.F + (size_t)b * P.fsz, r.S.T, r.S.iflag,
@@ -165,6 +169,7 @@ __global__ __launch_bounds__(NT, run_occupancy(NB, MODE)) void k_mpc_run(RunKArg
     Smem &S = rs.S;
     const int b = inst_of(P.perm), tid = threadIdx.x;
     double *step = P.step + (size_t)b * L.step_sz;
+    if (MODE >= MODE_BCRT && tid == 0) S.iflag[2] = 0;      // (the rounds' LDS-resident part of the factor is not loaded yet: admm_latw; a barrier follows in load_common)
     if (!LOOP && R.pin_in) {                     // update(x0, u_{-1}, xref) straight from the caller's (mapped) memory: one PCIe round trip
         const double *src = R.pin_in + (size_t)b * R.pin_stride;
         if (R.pin_mask & 1) for (int i = tid; i < L.nx; i += NT) step[i] = src[i];

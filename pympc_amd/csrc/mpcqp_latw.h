@@ -1,0 +1,372 @@
+// mpcqp_latw.h -- part of libmpcqp_hip (included by mpcqp.hip and by mpcqp_w8.hip, one translation unit each).
+// The latency round of mpcqp_lat.h (block cyclic reduction, factor and iterate resident on the compute unit) for ANY number of waves per
+// workgroup -- built for EIGHT (mpcqp_w8.hip: NT = 512, two waves per SIMD), also instantiated for four -- with a DENSE TOP (MODE_BCRT + N).
+//
+// What the four-wave kernel of mpcqp_lat.h spends an iteration of one (12,4,30) instance on (cycles, alone on its compute unit): owner
+// passes 1 370 + 820, level 0 forward 2 290 / back 1 570, level 1 forward 1 240 / back 1 060, levels 2 .. 4 on ONE wave 2 700.  None of it
+// is issue-bound: a wave's 11 mat-vecs of level 0 are 46 MFMAs = 780 cycles of matrix-pipe issue and take 2 100 -- in-order waves, one per
+// SIMD, waiting on dependent MFMAs (44 cycles), on LDS round trips and on double-precision vector instructions (32 cycles dependent).  Two
+// changes, both about that:
+//   * eight waves: every level step and both owner passes have work for all of them (half a group of four stages' owner items and half the
+//     mat-vecs per wave), and the second wave of a SIMD issues into the first one's stalls.  A wave then has 256 registers instead of 512, so
+//     it holds its <= 15 level fragments (120 registers) and no more:
+//   * the levels above 1 are replaced by the explicit inverse of what two levels leave (BcrFmt, factor_bcr): nt = N / 4 stages (7 of 31), nt
+//     block rows of nt mat-vecs, one row per wave, ONE barrier instead of a five-deep chain on one wave.  Its nt^2 fragments (49: 98 KB) are
+//     what the registers no longer hold: they sit in LDS for the round -- the latency kernels use 44 of the compute unit's 160 KB -- as
+//     [block][half][lane][2 doubles], so a lane's 32 bytes are two conflict-free 16-byte reads.
+// Seven barriers per iteration as before:  G'W + right-hand side | level 0 | level 1 | top | level 1 back | level 0 back | G v + row updates.
+#pragma once
+
+// ---- static schedule of levels 0 and 1 over NWAVES waves (task kinds as in mpcqp_lat.h: 0 kept stage forward, 1 eliminated stage forward, 2 back substitution)
+// kept stages (two mat-vecs each) are dealt from wave 0 up, eliminated ones (one mat-vec) from the last wave down
+constexpr int latw_owner(int /*N*/, int /*L*/, int kind, int t) { return kind == 1 ? NWAVES - 1 - t % NWAVES : t % NWAVES; }
+// slot of a task's first fragment in its wave's register array: level 0 forward, level 1 forward, level 1 back, level 0 back
+constexpr int latw_slot(int N, int W, int Lq, int kq, int tq) {
+    int s = 0;
+    for (int pass = 0; pass < 2; ++pass)
+        for (int li = 0; li < 2; ++li) {
+            const int L = pass == 0 ? li : 1 - li;
+            for (int kind = (pass == 0 ? 0 : 2); kind < (pass == 0 ? 2 : 3); ++kind)
+                for (int t = 0; t < lat_count(N, L, kind); ++t) {
+                    if (L == Lq && kind == kq && t == tq) return s;
+                    if (latw_owner(N, L, kind, t) == W) s += lat_nfr(N, L, kind, t);
+                }
+        }
+    return s;
+}
+constexpr int latw_slots(int N, int W) { return latw_slot(N, W, -1, -1, -1); }
+constexpr int latw_max_slots(int N) { int m = 0; for (int w = 0; w < NWAVES; ++w) m = latw_slots(N, w) > m ? latw_slots(N, w) : m; return m; }
+constexpr int latw_top_stage(int r) { return 4 * (r + 1) - 1; }
+
+#define LATW_TOP_LDS(N) ((BcrFmt::top_count(N) * BcrFmt::top_count(N) + 2) * BcrFmt::NN)      /* LDS doubles of the top inverse and, behind it, of the fragments G and G' */
+#if NT == 512
+#define LATW_DISPATCH(wv, CALL) switch (wv) { \
+    case 0: { constexpr int W = 0; CALL; } break; case 1: { constexpr int W = 1; CALL; } break; \
+    case 2: { constexpr int W = 2; CALL; } break; case 3: { constexpr int W = 3; CALL; } break; \
+    case 4: { constexpr int W = 4; CALL; } break; case 5: { constexpr int W = 5; CALL; } break; \
+    case 6: { constexpr int W = 6; CALL; } break; default: { constexpr int W = 7; CALL; } break; }
+#else
+#define LATW_DISPATCH(wv, CALL) LAT_DISPATCH(wv, CALL)
+#endif
+
+template <int N, int W>
+__device__ __forceinline__ void latw_load(const double *F, d4 *fr) {
+    const int lane = threadIdx.x & 63;
+    static_for<0, 2>([&](auto lc) {
+        constexpr int L = decltype(lc)::value, h = 1 << L;
+        static_for<0, lat_count(N, L, 0)>([&](auto tc) {
+            constexpr int t = decltype(tc)::value, i = lat_stage(L, 0, t);
+            if constexpr (latw_owner(N, L, 0, t) == W) {
+                constexpr int s = latw_slot(N, W, L, 0, t);
+                fr[s] = bcr_frag(F, i - h, BcrFmt::OLBRT, lane);
+                if constexpr (i + h < N) fr[s + 1] = bcr_frag(F, i + h, BcrFmt::OLBLT, lane);
+            }
+        });
+        static_for<0, lat_count(N, L, 1)>([&](auto tc) {
+            constexpr int t = decltype(tc)::value, e = lat_stage(L, 1, t);
+            if constexpr (latw_owner(N, L, 1, t) == W) { constexpr int s1 = latw_slot(N, W, L, 1, t); fr[s1] = bcr_frag(F, e, BcrFmt::ODINV, lane); }
+            if constexpr (latw_owner(N, L, 2, t) == W) {
+                constexpr int s = latw_slot(N, W, L, 2, t);
+                if constexpr (e - h >= 0) fr[s] = bcr_frag(F, e, BcrFmt::OLBL, lane);
+                constexpr int s2 = s + (e - h >= 0 ? 1 : 0);
+                if constexpr (e + h < N) fr[s2] = bcr_frag(F, e, BcrFmt::OLBR, lane);
+            }
+        });
+    });
+}
+
+// LDS vectors of the round (stage-major, stride 16; mpcqp_lat.h): tb right-hand side / solution, cb c_e of the reduction -- and, at the top stages'
+// slots, the top's solution until level 1 back has copied it into tb; each seen through the lane bases of the four block rotations.
+struct LatwVecs { double *tb, *cb; const double *t1, *t2, *t3, *c1, *c2, *c3; };
+template <bool FROMC>
+__device__ __forceinline__ void latw_mv_lds(const d4 a, const LatwVecs &v, int off, double &p, double &q) {
+    const double i0 = FROMC ? v.cb[off] : v.tb[off], i1 = FROMC ? v.c1[off] : v.t1[off], i2 = FROMC ? v.c2[off] : v.t2[off], i3 = FROMC ? v.c3[off] : v.t3[off];
+    p = __builtin_amdgcn_mfma_f64_4x4x4f64(a[0], i0, p, 0, 0, 0);
+    q = __builtin_amdgcn_mfma_f64_4x4x4f64(a[2], i2, q, 0, 0, 0);
+    p = __builtin_amdgcn_mfma_f64_4x4x4f64(a[1], i1, p, 0, 0, 0);
+    q = __builtin_amdgcn_mfma_f64_4x4x4f64(a[3], i3, q, 0, 0, 0);
+}
+
+template <int N, int W, int L>
+__device__ __forceinline__ void latw_fwd(const d4 *fr, const LatwVecs &v) {
+    constexpr int h = 1 << L;
+    static_for<0, lat_count(N, L, 0)>([&](auto tc) {
+        constexpr int t = decltype(tc)::value, i = lat_stage(L, 0, t);
+        if constexpr (latw_owner(N, L, 0, t) == W) {
+            constexpr int s = latw_slot(N, W, L, 0, t);
+            double p = v.tb[i * 16], q = 0.0;                 // (the stage's own right-hand side starts the chain)
+            latw_mv_lds<false>(fr[s], v, (i - h) * 16, p, q);
+            if constexpr (i + h < N) latw_mv_lds<false>(fr[s + 1], v, (i + h) * 16, p, q);
+            v.tb[i * 16] = p + q;
+        }
+    });
+    static_for<0, lat_count(N, L, 1)>([&](auto tc) {
+        constexpr int t = decltype(tc)::value, e = lat_stage(L, 1, t);
+        if constexpr (latw_owner(N, L, 1, t) == W) {
+            constexpr int s1 = latw_slot(N, W, L, 1, t);
+            double p = 0.0, q = 0.0;
+            latw_mv_lds<false>(fr[s1], v, e * 16, p, q);
+            v.cb[e * 16] = p + q;
+        }
+    });
+}
+// back substitution of level L; TOPIN: the neighbours are top stages whose solution still sits in cb (level 1)
+template <int N, int W, int L, bool TOPIN>
+__device__ __forceinline__ void latw_bwd(const d4 *fr, const LatwVecs &v) {
+    constexpr int h = 1 << L;
+    static_for<0, lat_count(N, L, 2)>([&](auto tc) {
+        constexpr int t = decltype(tc)::value, e = lat_stage(L, 2, t);
+        if constexpr (latw_owner(N, L, 2, t) == W) {
+            constexpr int s = latw_slot(N, W, L, 2, t), s2 = s + (e - h >= 0 ? 1 : 0);
+            double p = v.cb[e * 16], q = 0.0;
+            if constexpr (e - h >= 0) latw_mv_lds<TOPIN>(fr[s], v, (e - h) * 16, p, q);
+            if constexpr (e + h < N) latw_mv_lds<TOPIN>(fr[s2], v, (e + h) * 16, p, q);
+            v.tb[e * 16] = p + q;
+        }
+    });
+}
+
+template <int N, int W>
+__device__ __forceinline__ void latw_bwd1(const d4 *fr, const LatwVecs &v) {
+    static_for<0, BcrFmt::top_count(N)>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        if constexpr (r % NWAVES == W) v.tb[latw_top_stage(r) * 16] = v.cb[latw_top_stage(r) * 16];
+    });
+    latw_bwd<N, W, 1, true>(fr, v);
+}
+
+// one fragment of the top inverse from its LDS copy: [block][half][lane][2]
+typedef double d2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ d4 latw_top_frag(const double *TopL, int blk, int lane) {
+    const d2 lo = *(const d2 *)(TopL + ((blk * 2 + 0) * 64 + lane) * 2), hi = *(const d2 *)(TopL + ((blk * 2 + 1) * 64 + lane) * 2);
+    return d4{lo[0], lo[1], hi[0], hi[1]};
+}
+// the top: block row r of the inverse times the reduced right-hand sides of the nt top stages (tb), into cb at stage i_r.
+// Measured on the way (cycles of this phase for one (12,4,30) instance alone, 8 waves; scripts/lat_phase.py with a -DMPCQP_RUN_TIMING build):
+//   * left to itself the compiler requests a row's fragments one or two at a time, each right in front of the MFMAs that need it (it has ~ 30
+//     free registers), and the wave sits through an LDS round trip per block: 2 115 - 2 340;
+//   * all fragments of the row up front, inputs read once and rotated by DPP moves: 2 320 -- the 42 moves alone cost 600 (without them 1 810),
+//     the MFMAs alone 1 120 (28 per wave, two waves per SIMD: 20 cycles each, the matrix pipe's rate), the fragment reads alone 980;
+//   * independent accumulators per column instead of two pairs of chains: 2 380; the chains of two columns interleaved MFMA by MFMA: 2 200;
+//   * inputs as four 8-byte LDS reads through the rotated lane bases, the row in groups of LATW_TOP_HALF columns whose fragments and inputs
+//     are requested together and whose chains are interleaved: 2 columns 1 975 (kept), 4: 2 206, all 7: 2 270 and spills in other phases.
+// The phase is at twice its matrix-pipe time; what is left is LDS delivery (98 KB of fragments per iteration) not overlapping with it.
+#ifndef LATW_TOP_HALF
+#define LATW_TOP_HALF 2
+#endif
+template <int N, int W>
+__device__ __forceinline__ void latw_top(const double *TopL, const LatwVecs &v, int lane) {
+    constexpr int NTOP = BcrFmt::top_count(N), H = LATW_TOP_HALF;
+    static_for<0, NTOP>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        if constexpr (r % NWAVES == W) {
+            double p0 = 0.0, q0 = 0.0, p1 = 0.0, q1 = 0.0;
+            static_for<0, (NTOP + H - 1) / H>([&](auto hc) {
+                constexpr int c0 = decltype(hc)::value * H, c1 = c0 + H < NTOP ? c0 + H : NTOP, n = c1 - c0;
+                d4 a[H]; double x[H][4];
+                static_for<0, n>([&](auto cc_) {
+                    constexpr int j = decltype(cc_)::value, off = latw_top_stage(c0 + j) * 16;
+                    a[j] = latw_top_frag(TopL, r * NTOP + c0 + j, lane);
+                    x[j][0] = v.tb[off]; x[j][1] = v.t1[off]; x[j][2] = v.t2[off]; x[j][3] = v.t3[off];
+                });
+                __builtin_amdgcn_sched_barrier(0);
+                static_for<0, (n + 1) / 2>([&](auto pc) {
+                    constexpr int j = 2 * decltype(pc)::value;
+                    if constexpr (j + 1 < n) {
+                        p0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a[j][0], x[j][0], p0, 0, 0, 0); p1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a[j + 1][0], x[j + 1][0], p1, 0, 0, 0);
+                        q0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a[j][2], x[j][2], q0, 0, 0, 0); q1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a[j + 1][2], x[j + 1][2], q1, 0, 0, 0);
+                        p0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a[j][1], x[j][1], p0, 0, 0, 0); p1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a[j + 1][1], x[j + 1][1], p1, 0, 0, 0);
+                        q0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a[j][3], x[j][3], q0, 0, 0, 0); q1 = __builtin_amdgcn_mfma_f64_4x4x4f64(a[j + 1][3], x[j + 1][3], q1, 0, 0, 0);
+                    } else {
+                        p0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a[j][0], x[j][0], p0, 0, 0, 0); q0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a[j][2], x[j][2], q0, 0, 0, 0);
+                        p0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a[j][1], x[j][1], p0, 0, 0, 0); q0 = __builtin_amdgcn_mfma_f64_4x4x4f64(a[j][3], x[j][3], q0, 0, 0, 0);
+                    }
+                });
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            v.cb[latw_top_stage(r) * 16] = (p0 + q0) + (p1 + q1);
+        }
+    });
+}
+
+// Tc <- K^-1 Tc.  All threads call; four barriers inside, none after the last phase (the caller's follows).
+template <int N>
+__device__ __forceinline__ void latw_solve(const d4 *fr, const double *TopL, const LatwVecs &v, int wv, int lane) {
+    constexpr int NTOP = BcrFmt::top_count(N);
+    static_assert(bcr_levels(N) >= 3 && NTOP >= 1, "two levels of reduction, then the dense top");
+    LATW_DISPATCH(wv, (latw_fwd<N, W, 0>(fr, v)))
+    __syncthreads();
+    TICK(1)
+    LATW_DISPATCH(wv, (latw_fwd<N, W, 1>(fr, v)))
+    __syncthreads();
+    TICK(2)
+    LATW_DISPATCH(wv, (latw_top<N, W>(TopL, v, lane)))
+    __syncthreads();
+    TICK(3)
+    // level 1 back reads the top's solution from cb; on the way every top row's owner moves its stage into tb, where level 0 back (and the
+    // owner passes) look for it -- nobody reads tb at a top stage during this phase
+    LATW_DISPATCH(wv, (latw_bwd1<N, W>(fr, v)))
+    __syncthreads();
+    TICK(4)
+    LATW_DISPATCH(wv, (latw_bwd<N, W, 0, false>(fr, v)))
+}
+
+// ---- the round (as admm_lat, with ceil(NG / NWAVES) groups of four stages per wave) -----------------------------------------------------
+template <int NXT, int NUT, int NST>
+__device__ __forceinline__ void admm_latw(const Lay &L, const HotPtrs &P, Smem &S, double *Xl, double *Zl, double *Yl, double alpha, int iters) {
+    constexpr int NB = 16, N = NST, NG = (N + 3) / 4, QN = (NG + NWAVES - 1) / NWAVES;
+    static_assert(NXT + NUT <= NB, "16 x 16 stages");
+    const int nx = NXT ? NXT : L.nx, nu = NUT ? NUT : L.nu, NR = L.N;
+    const int b = inst_of(P.perm), tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    gdouble *gx = (gdouble *)(P.x + (size_t)b * L.n), *gz = (gdouble *)(P.z + (size_t)b * L.m), *gy = (gdouble *)(P.y + (size_t)b * L.m);
+    cgdouble *om = (cgdouble *)(P.omega + (size_t)b * L.m), *sv = (cgdouble *)(P.s + (size_t)b * L.n), *qv = (cgdouble *)S.Qv;
+    gdouble *dxg = (gdouble *)(P.dx + (size_t)b * L.n), *dyg = (gdouble *)(P.dy + (size_t)b * L.m);
+    const double cc = P.c[b], cinv = 1.0 / cc, beta = 1.0 - alpha;
+    const double *hot = S.hot;
+    constexpr int VS = LAT_VS(N);
+    double *Tc = S.T + NB, *Cc = Tc + VS, *WA = Cc + VS, *WB = WA + VS;      // right-hand side / solution, c_e, W of the first / second row of a slot
+    // the top inverse: behind the LDS copy of the iterate, on a 16-byte boundary
+    double *TopL = Yl + L.m + ((smem_common_doubles(L) + L.n + 2 * L.m) & 1);      // (the dynamic LDS block itself starts on one)
+    TICK_RESET
+    TICK_START
+    for (int i = tid; i < LAT_LDS_DOUBLES(N); i += NT) S.T[i] = 0.0;
+    const double *Fb = P.F + (size_t)b * P.fsz;
+    // The LDS-resident part of the factor -- the top inverse and the constant fragments G = [Ad Bd] (rows: dynamics rows, columns: (x, u)) and
+    // G' -- outlives the round: nothing between two rounds touches that part of LDS except a refactorization, which says so (Smem::iflag[2],
+    // cleared by factor_bcr and at kernel start).  98 KB per ROUND from L2 otherwise: 4 of a round's 7 microseconds of prologue.
+    constexpr int NTOP = BcrFmt::top_count(N);
+    if (S.iflag[2] == 0) {
+        typedef __attribute__((address_space(1))) const d2 cgd2;
+        cgd2 *Ft = (cgd2 *)(Fb + BcrFmt::top_off(N));
+        for (int idx = tid; idx < NTOP * NTOP * 128; idx += NT) {           // (16 bytes per thread and trip: fragment element pairs (lane, j = 0,1 | 2,3))
+            const int blk = idx >> 7, r = idx & 127, ln = r >> 1, hf = r & 1;
+            *(d2 *)(TopL + ((blk * 2 + hf) * 64 + ln) * 2) = Ft[idx];
+        }
+        const double *Ad = hot + L.oAd, *Bd = hot + L.oBd;
+        auto gent = [&](int r, int c) { return r < nx ? (c < nx ? Ad[r * nx + c] : (c < nx + nu ? Bd[r * nu + (c - nx)] : 0.0)) : 0.0; };
+        if (wv == 0) {
+            const d4 g = lat_make_frag(lane, gent);
+            *(d2 *)(TopL + (((NTOP * NTOP) * 2 + 0) * 64 + lane) * 2) = d2{g[0], g[1]}; *(d2 *)(TopL + (((NTOP * NTOP) * 2 + 1) * 64 + lane) * 2) = d2{g[2], g[3]};
+        } else if (wv == 1) {
+            const d4 g = lat_make_frag(lane, [&](int r, int c) { return gent(c, r); });
+            *(d2 *)(TopL + (((NTOP * NTOP + 1) * 2 + 0) * 64 + lane) * 2) = d2{g[0], g[1]}; *(d2 *)(TopL + (((NTOP * NTOP + 1) * 2 + 1) * 64 + lane) * 2) = d2{g[2], g[3]};
+        }
+        __syncthreads();
+        if (tid == 0) S.iflag[2] = 1;
+    }
+    d4 fr[latw_max_slots(N)];
+    LATW_DISPATCH(wv, (latw_load<N, W>(Fb, fr)))
+    TICK(7)
+    const int lo16 = vec_lane_offset(lane);
+    const int lI = lane >> 4, lB = (lane >> 2) & 3;
+    const int o1 = 4 * ((lB + 1) & 3) + lI, o2 = 4 * ((lB + 2) & 3) + lI, o3 = 4 * ((lB + 3) & 3) + lI;
+    const LatwVecs vec{Tc + lo16, Cc + lo16, Tc + o1, Tc + o2, Tc + o3, Cc + o1, Cc + o2, Cc + o3};
+    // ---- owner map: lane (I, B, J), group g = wv + NWAVES q  ->  slot a = 4B + I of stage s = 4g + J
+    const int a = 4 * ((lane >> 2) & 3) + (lane >> 4), J = lane & 3;
+    const bool is_x = a < nx;
+    const int jj = a - nx;
+    const double cef = cc * hot[L.oeps];
+    double pv[QN], pv2[QN], svp[QN], ncq[QN], sve[QN], kap[QN], okap[QN], te[QN], loA[QN], hiA[QN], loB[QN], hiB[QN];
+    LatRow rA[QN], rB[QN], r0{0.0, 0.0, 0.0, 1.0};
+    int sl[QN], pidx[QN], aidx[QN], bidx[QN];
+    bool ok[QN];
+#pragma unroll
+    for (int q = 0; q < QN; ++q) {
+        // (a group beyond the schedule's last owns nothing: it is parked on the zero slot behind the last stage)
+        const int g = wv + NWAVES * q, s = g < NG ? 4 * g + J : 4 * NG;
+        sl[q] = s * NB + a;
+        ok[q] = is_x ? s < NR : (a < nx + nu && s < NR - 1);
+        const int e = s * nx + a, cu = s * nu + jj;
+        pidx[q] = is_x ? e : L.ou + cu; aidx[q] = is_x ? e : L.ri + cu; bidx[q] = is_x ? L.rs + e : L.rdu + nu + cu;
+        pv[q] = pv2[q] = svp[q] = ncq[q] = sve[q] = kap[q] = okap[q] = te[q] = 0.0;
+        loA[q] = hiA[q] = loB[q] = hiB[q] = 0.0;
+        rA[q] = LatRow{0.0, 0.0, 0.0, 1.0}; rB[q] = LatRow{0.0, 0.0, 0.0, 1.0};
+        if (ok[q]) {
+            pv[q] = gx[pidx[q]]; svp[q] = sv[pidx[q]]; ncq[q] = -cc * qv[is_x ? e : L.n_x + cu];
+            lat_row_load(rA[q], gz, gy, om, cc, aidx[q]);
+            lat_row_load(rB[q], gz, gy, om, cc, bidx[q]);
+            if (is_x) {
+                if (L.soft) { pv2[q] = gx[L.oe + e]; sve[q] = sv[L.oe + e]; kap[q] = 1.0 / (cef + sve[q] + rB[q].om); okap[q] = rB[q].om * kap[q]; }
+                loA[q] = hiA[q] = s == 0 ? -S.x0s[a] : 0.0;
+                loB[q] = hot[L.oxmin + a]; hiB[q] = hot[L.oxmax + a];
+            } else {
+                loA[q] = hot[L.oumin + jj]; hiA[q] = hot[L.oumax + jj]; loB[q] = hot[L.oDumin + jj]; hiB[q] = hot[L.oDumax + jj];
+            }
+        }
+    }
+    const bool u0v = wv == 0 && J == 0 && !is_x && a < nx + nu;      // the first-step rows u_0 - u_{-1} (mpc.py:574): stage 0's inputs
+    if (u0v) lat_row_load(r0, gz, gy, om, cc, L.rdu + jj);
+    // neighbours in the flattened input sequence (mpc.py:570): slot a + 1 / a - 1, across the stage boundary at the ends
+    const int onext = (jj + 1 < nu) ? 1 : NB - nu + 1, oprev = (jj > 0) ? -1 : -(NB - nu + 1);
+    const double selx = is_x ? 1.0 : 0.0, sgnA = is_x ? -1.0 : 1.0;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < QN; ++q) { WA[sl[q]] = rA[q].w; WB[sl[q]] = rB[q].w; }
+    __syncthreads();
+    TICK(8)
+    for (int it = 1; it <= iters; ++it) {
+        const bool keep_delta = it == iters;
+        TICK_START
+        // ---- right-hand side  s x - c q + A'W  with the slack eliminated; A'W = own rows' W + G' W_dyn of the next stage (MFMA, four stages a group)
+        {
+            double g[QN], h2[QN];
+#pragma unroll
+            for (int q = 0; q < QN; ++q) { g[q] = 0.0; h2[q] = 0.0; lat_mv(latw_top_frag(TopL, NTOP * NTOP + 1, lane), WA[sl[q] + NB], g[q], h2[q]); }
+#pragma unroll
+            for (int q = 0; q < QN; ++q) {
+                const double wprev = WB[sl[q] + oprev];
+                te[q] = fma(sve[q], pv2[q], rB[q].w) * kap[q];                     // (inputs and a hard state box: kap = 0, no slack)
+                const double viaB = is_x ? fma(-rB[q].om, te[q], rB[q].w) : wprev - rB[q].w;
+                double rhs = fma(svp[q], pv[q], ncq[q]) + (g[q] + h2[q]);
+                rhs = fma(sgnA, rA[q].w, rhs) + viaB;
+                if (q == 0) rhs += r0.w;
+                Tc[sl[q]] = ok[q] ? rhs : 0.0;
+            }
+        }
+        __syncthreads();
+        TICK(0)
+        latw_solve<N>(fr, TopL, vec, wv, lane);
+        __syncthreads();
+        TICK(5)
+        // ---- G v of the previous stage (MFMA), relaxation, projection, dual step of the owned rows
+        {
+            double g[QN], h2[QN];
+#pragma unroll
+            for (int q = 0; q < QN; ++q) { g[q] = 0.0; h2[q] = 0.0; lat_mv(latw_top_frag(TopL, NTOP * NTOP, lane), Tc[sl[q] - NB], g[q], h2[q]); }
+#pragma unroll
+            for (int q = 0; q < QN; ++q) {
+                const double xt = Tc[sl[q]], un = Tc[sl[q] + onext];
+                const double et = fma(-okap[q], xt, te[q]);
+                const double vn = fma(alpha, xt, beta * pv[q]), en = fma(alpha, et, beta * pv2[q]);
+                const double ztA = fma(selx, (g[q] + h2[q]) - xt - xt, xt);       // x: G v - xt;  u: ut
+                const double ztB = is_x ? xt + et : un - xt;
+                const double dA = lat_row_step(rA[q], ztA, loA[q], hiA[q], alpha, beta);
+                const double dB = lat_row_step(rB[q], ztB, loB[q], hiB[q], alpha, beta);
+                if (keep_delta && ok[q]) {
+                    dxg[pidx[q]] = vn - pv[q];
+                    if (is_x && L.soft) dxg[pidx[q] + L.oe] = en - pv2[q];
+                    dyg[aidx[q]] = (rA[q].om * cinv) * dA; dyg[bidx[q]] = (rB[q].om * cinv) * dB;
+                }
+                pv[q] = vn; pv2[q] = en;
+                if (q == 0 && u0v) { const double d0 = lat_row_step(r0, xt, S.du0[jj], S.du0[nu + jj], alpha, beta); if (keep_delta) dyg[L.rdu + jj] = (r0.om * cinv) * d0; }
+                WA[sl[q]] = ok[q] ? rA[q].w : 0.0; WB[sl[q]] = ok[q] ? rB[q].w : 0.0;      // (a slot without a variable contributes nothing)
+            }
+        }
+        __syncthreads();
+        TICK(6)
+    }
+    TICK_START
+    // ---- end of the round: the iterate back to memory (global: next round / warm start; LDS copy: the residual evaluation)
+    auto put_row = [&](const LatRow &r, int idx) { const double y = r.ys * (r.om * cinv); gz[idx] = r.z; gy[idx] = y; Zl[idx] = r.z; Yl[idx] = y; };
+#pragma unroll
+    for (int q = 0; q < QN; ++q) {
+        if (ok[q]) {
+            gx[pidx[q]] = pv[q]; Xl[pidx[q]] = pv[q];
+            if (is_x && L.soft) { gx[pidx[q] + L.oe] = pv2[q]; Xl[pidx[q] + L.oe] = pv2[q]; }
+            put_row(rA[q], aidx[q]); put_row(rB[q], bidx[q]);
+        }
+    }
+    if (u0v) put_row(r0, L.rdu + jj);
+    TICK(9)
+    TICK_FLUSH
+}

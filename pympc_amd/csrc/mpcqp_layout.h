@@ -28,6 +28,9 @@ struct Lay {
     int dense;                    // 1: small problem -- the KKT solve is a dense mat-vec with K^-1 held in registers (mpcqp_dense.h)
     int bcr;                      // > 0: block cyclic reduction instead of the twisted sweeps (mpcqp_bcr.h; small batches of 16 x 16 stages); the value is the
                                   // stage count of the schedule the handle runs (11, 21 or 31 >= N: stages N .. bcr-1 are identity padding)
+    int bcrtop;                   // > 0 (with bcr): the cyclic reduction stops after two levels and the stages that are left -- this many, every fourth -- are
+                                  // solved with the explicit inverse of their Schur complement (BcrFmt: the fragments behind the stage records; mpcqp_latw.h)
+    int nw;                       // waves per workgroup of the handle's solve kernels: 4 (NT = 256), or 8 for the kernels of mpcqp_w8.hip (sizes the reduction scratch)
     int lstage;                   // 1: the iterate lives in global memory between rounds but is STAGED into LDS for a round (admm_round_global: small batches of problems too large for the owner-mapped LDS round)
     int grp;                      // > 1: this many consecutive small stages share a 16 x 16 block of the KKT factor (mpcqp_group.h; long horizons of small stages)
     int NR, dld;                  // dense: unknowns N*(nx+nu) of the reduced KKT system; LDS row stride of the inversion workspace (odd)

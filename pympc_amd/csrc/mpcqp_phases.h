@@ -38,12 +38,12 @@ __device__ __forceinline__ void smem_common(const Lay &L, const PT &P, double *&
     S.x0s = carve(p, L.nx);
     S.um1s = carve(p, L.nu);
     S.du0 = carve(p, 2 * L.nu);
-    S.red = carve(p, 64);
+    S.red = carve(p, 16 * L.nw);   // block_reduce: up to 12 values per wave
     S.tv = carve(p, 128);          // the bordered solve's ubar (nu <= 127 doubles); outside it, the held input's A'W sums (nu)
     S.iflag = (int *)carve(p, 2);
     S.T = carve(p, L.tsz);
 }
-__host__ __device__ inline int smem_common_doubles(const Lay &L) { return L.tsz + L.hot_sz + L.nx + 3 * L.nu + 64 + 128 + 2; }
+__host__ __device__ inline int smem_common_doubles(const Lay &L) { return L.tsz + L.hot_sz + L.nx + 3 * L.nu + 16 * L.nw + 128 + 2; }
 
 __device__ __forceinline__ void load_common(const Lay &L, const double *model, const double *step, Smem &S) {
     for (int i = threadIdx.x; i < L.hot_sz; i += NT) S.hot[i] = model[i];
@@ -900,7 +900,7 @@ __device__ __forceinline__ void gown_rhs(const Lay &L, const double *hot, typena
 }
 template <int NB, int NXT, int NUT, bool INL = false>
 __device__ __forceinline__ void gown_update(const Lay &L, const double *hot, const double *x0s, const double *du0, typename GPtr<INL>::c *om, typename GPtr<INL>::c *sv, double cc, double alpha,
-                                            double *X, double *Z, double *Y, double *W, const double *Tc, bool keep_delta, ::gdouble *dxg, ::gdouble *dyg) {
+                                            double *X, double *Z, double *Y, double *W, const double *Tc, bool keep_delta, gdouble_g *dxg, gdouble_g *dyg) {
     typedef typename GPtr<INL>::m gdouble;
     constexpr int GU = GownCfg<NB>::U;
     const int tid = opaque_lane(threadIdx.x);
@@ -988,9 +988,11 @@ __device__ __forceinline__ void gown_update(const Lay &L, const double *hot, con
 // MODE: how the KKT system is solved -- block-tridiagonal sweeps (MODE_CHAIN), the same with the bordered correction of a
 // control horizon Nc < Np (MODE_BORDER), or the dense register-resident inverse of small problems (MODE_DENSE, mpcqp_dense.h).
 // MODE_BCR + N: block cyclic reduction with the factor of an N-stage problem resident in registers (mpcqp_bcr.h).
-enum { MODE_CHAIN = 0, MODE_BORDER = 1, MODE_DENSE = 2, MODE_BCR = 100 };
+// MODE_BCRT + N: the same with a dense top instead of the levels above 1, for any number of waves per workgroup (mpcqp_latw.h).
+enum { MODE_CHAIN = 0, MODE_BORDER = 1, MODE_DENSE = 2, MODE_BCR = 100, MODE_BCRT = 200 };
 template <int NB> __device__ __forceinline__ void admm_tiny(const Lay &, const HotPtrs &, Smem &, double *, double *, double *, double, int);      // mpcqp_tiny.h
 template <int NXT, int NUT, int NST> __device__ __forceinline__ void admm_lat(const Lay &, const HotPtrs &, Smem &, double *, double *, double *, double, int);      // mpcqp_lat.h
+template <int NXT, int NUT, int NST> __device__ __forceinline__ void admm_latw(const Lay &, const HotPtrs &, Smem &, double *, double *, double *, double, int);     // mpcqp_latw.h
 // The ADMM round of a problem whose iterate does not live in LDS for the owner-mapped phases above (n_x > 2 NT, or too large for four workgroups
 // per CU).  INL = false: x, z, y, omega, s, q in global memory (L2 / HBM), every pass pays its round trips -- right for batches, where other
 // workgroups fill them.  INL = true (the handle holds at most one instance per compute unit, Lay::lstage): everything the passes read is STAGED
@@ -1061,7 +1063,8 @@ __device__ __forceinline__ void admm_round_global(const Lay &L, const HotPtrs &P
 template <int NB, bool LDSSTATE, int NXT, int NUT, int MODE>
 __device__ __forceinline__ void admm_body(const Lay &L, const HotPtrs &P, Smem &S, double *X, double *Z, double *Y, double alpha, int iters) {
     if constexpr (MODE == MODE_DENSE) { admm_tiny<NB>(L, P, S, X, Z, Y, alpha, iters); return; }      // register-resident iterate and inverse
-    if constexpr (MODE >= MODE_BCR) { admm_lat<NXT, NUT, MODE - MODE_BCR>(L, P, S, X, Z, Y, alpha, iters); return; }      // ... and cyclic-reduction factor
+    if constexpr (MODE >= MODE_BCRT) { admm_latw<NXT, NUT, MODE - MODE_BCRT>(L, P, S, X, Z, Y, alpha, iters); return; }   // ... and cyclic-reduction factor with a dense top
+    else if constexpr (MODE >= MODE_BCR) { admm_lat<NXT, NUT, MODE - MODE_BCR>(L, P, S, X, Z, Y, alpha, iters); return; } // ... and cyclic-reduction factor
     if constexpr (!LDSSTATE) {          // iterate in global memory -- or staged in LDS for the round (generic kernels of small batches)
         if constexpr (NXT == 0 || NXT == 4) { if (L.lstage) { admm_round_global<NB, NXT, NUT, MODE, true>(L, P, S, alpha, iters); return; } }
         admm_round_global<NB, NXT, NUT, MODE, false>(L, P, S, alpha, iters);

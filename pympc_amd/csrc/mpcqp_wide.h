@@ -20,7 +20,7 @@ struct WideFmt {
     static constexpr int LD = NB + 1;                         // LDS row stride of the factorization's two work matrices
     static constexpr int WS = 2 * NB * LD + NB;               // LDS doubles of the factorization: two work matrices, one stage's dynamics-row weights
 };
-static_assert(NT == 4 * WideFmt::NB, "wide stages: four threads per row");
+static_assert(kLatOnly || NT == 4 * WideFmt::NB, "wide stages: four threads per row");
 __device__ __forceinline__ int wide_pos(int r, int j) { return (r * 4 + (j & 3)) * 16 + (j >> 2); }
 
 // sum over the four lanes of a quad (DPP quad_perm [1,0,3,2], then [2,3,0,1])

@@ -49,7 +49,7 @@ def _prep(a, shape, name):
     return np.ascontiguousarray(np.broadcast_to(a, shape))
 
 
-BACKENDS = dict(auto=_lib.BACKEND_AUTO, sweeps=_lib.BACKEND_SWEEPS, dense=_lib.BACKEND_DENSE, bcr=_lib.BACKEND_BCR, bcr8=_lib.BACKEND_BCR8)
+BACKENDS = dict(auto=_lib.BACKEND_AUTO, sweeps=_lib.BACKEND_SWEEPS, dense=_lib.BACKEND_DENSE, bcr=_lib.BACKEND_BCR, bcr8=_lib.BACKEND_BCR8, bcrt=_lib.BACKEND_BCRT)
 _forced = {}               # settings every handle made inside a ``forced_settings`` block gets (tests: one parity suite per KKT backend)
 
 

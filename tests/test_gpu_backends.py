@@ -45,7 +45,10 @@ IDS = ['sweeps', 'dense']
 # block cyclic reduction (register-resident factor): any fixture with 16 x 16 stages, Nc = Np and at most 31 stages -- the BASELINE shape (12, 4, 30) with
 # compile-time dimensions, everything else (the reference's examples, the quadcopter, soft and hard state boxes) through the generic instantiations
 BCR_NAMES = [n for n in golden_names() if _bcr_schedule(n)]
-CASES = [(n, e, i) for n in SMALL for e, i in zip(BACKENDS, IDS)] + [(n, SWEEPS, 'sweeps') for n in BCR_NAMES if n not in SMALL] + [(n, BCR, 'bcr') for n in BCR_NAMES]
+# ... and, for the same fixtures, the dense-top factor (mpcqp_latw.h) on 512-thread workgroups ('bcr8': what mpcqp_create picks for at most one
+# instance per compute unit) and on 256-thread ones ('bcrt')
+CASES = ([(n, e, i) for n in SMALL for e, i in zip(BACKENDS, IDS)] + [(n, SWEEPS, 'sweeps') for n in BCR_NAMES if n not in SMALL] + [(n, BCR, 'bcr') for n in BCR_NAMES]
+         + [(n, BCR8, 'bcr8') for n in BCR_NAMES] + [(n, dict(backend='bcrt'), 'bcrt') for n in BCR_NAMES])
 CASE_IDS = ['%s-%s' % (n, i) for n, e, i in CASES]
 
 
@@ -73,7 +76,9 @@ def test_backend_is_the_one_asked_for(name, env, tag):
     with backend(**env):
         K = _ctrl(golden_kwargs(load_golden(name))); K.setup(solve=False)
         kn = K.prob.batch_problem.kernel_name(loop=False)
-    assert kn.split(',')[4] == {'sweeps': '0', 'dense': '2', 'bcr': str(100 + _bcr_schedule(name))}[tag], kn
+    assert kn.split(',')[4] == {'sweeps': '0', 'dense': '2', 'bcr': str(100 + _bcr_schedule(name)), 'bcr8': str(200 + _bcr_schedule(name)),
+                                'bcrt': str(200 + _bcr_schedule(name))}[tag], kn
+    assert kn.startswith('w8::') == (tag == 'bcr8'), kn                     # the 512-thread kernels live in the second translation unit
 
 
 @pytest.mark.parametrize('name,env,tag', CASES, ids=CASE_IDS)
@@ -183,3 +188,40 @@ def test_held_multi_input_on_the_dense_backend_is_reproducible():
             assert np.array_equal(Kb.output(), tr['u'][k]), k
             Kb.update(tr['x'][k + 1])
             assert [i.iter for i in Kb.prob.infos()] == list(tr['iter'][k])
+
+
+def test_a_backend_the_shape_is_not_eligible_for_is_refused():
+    """mpcqp_settings.backend forces; it never silently falls back: the dense inverse for 864 unknowns, cyclic reduction for a 41-stage
+    horizon or a held input -> MPCQP_ERR_UNSUPPORTED (NotImplementedError through the Python layer)."""
+    from pympc_amd import MPCController, fixtures
+    for forced, kw in (('dense', fixtures.random_lti(3)), ('bcr', fixtures.random_lti(3, Np=40)), ('bcr8', dict(fixtures.random_lti(3, nx=5, nu=3, Np=8), Nc=4))):
+        with backend(backend=forced):
+            with pytest.raises(NotImplementedError):
+                MPCController(**kw).setup(solve=False)
+
+
+@pytest.mark.parametrize('tag', ['bcr', 'bcr8', 'bcrt'])
+def test_cyclic_reduction_device_loop_is_the_stepwise_api(tag):
+    """A batch of the BASELINE shape on each cyclic-reduction kernel: 12 closed-loop steps inside the device loop equal the same steps through
+    output() / update() bit for bit (inputs, statuses, iteration counts), and the inputs agree with the auto-selected backend's to 1e-9 at a
+    tight tolerance (different elimination orders of the same KKT solve)."""
+    from pympc_amd import fixtures
+    from test_gpu_parity import _stacked_batch
+    B = 24
+    kws = [fixtures.random_lti(1000 + i) for i in range(B)]
+    w = 0.01 * np.stack([fixtures.random_lti_noise_rng(1000 + i).standard_normal((12, 12)) for i in range(B)], axis=1)      # [step][instance][nx]
+    tight = dict(eps_abs=1e-9, eps_rel=1e-9, max_iter=20000)
+    out = {}
+    for t in (tag, 'sweeps'):
+        with backend(backend=t), warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            K = _stacked_batch(kws, **tight); K.setup()
+            tr = K.run(12, w=w)
+            K2 = _stacked_batch(kws, **tight); K2.setup()
+            for k in range(12):
+                assert np.array_equal(K2.output(), tr['u'][k]), (t, k)
+                K2.update(tr['x'][k + 1])
+                assert [i.iter for i in K2.prob.infos()] == list(tr['iter'][k]), (t, k)
+            out[t] = tr
+    assert (out[tag]['status'] == 1).all()
+    assert np.abs(out[tag]['u'] - out['sweeps']['u']).max() <= 1e-7 * max(1.0, np.abs(out['sweeps']['u']).max())

@@ -159,7 +159,7 @@ def test_seam_b_closed_loop_follows_the_reference_class(name):
 @pytest.mark.parametrize('B', [128, 512])
 def test_auto_selected_latency_backend_at_per_gpu_batches_matches_oracle(B):
     """BASELINE configs[3] read literally leaves 128 instances per GPU (1024 / 8); up to two instances per compute unit the library
-    chooses the cyclic-reduction backend on its own (mpcqp_create).  That regime against the oracle: cold solve at the parity tolerance
+    chooses a cyclic-reduction backend on its own (mpcqp_create).  That regime against the oracle: cold solve at the parity tolerance
     (u* of 32 sampled instances to 1e-6 relative), then 10 warm closed-loop steps inside the device loop at the default tolerance
     with the oracle stepping alongside (status and iteration count of every step, inputs to 1e-7)."""
     from pympc_amd import MPCController
@@ -170,7 +170,9 @@ def test_auto_selected_latency_backend_at_per_gpu_batches_matches_oracle(B):
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')
         K.setup()
-    assert ',131,' in K.prob.kernel_name(loop=True), K.prob.kernel_name(loop=True)      # MODE_BCR + 31 stages: chosen by the library, not forced
+    # chosen by the library, not forced: 31 stages of cyclic reduction on 512-thread workgroups with a dense top (MODE_BCRT, mpcqp_w8.hip) -- up to
+    # three instances per compute unit
+    assert K.prob.kernel_name(loop=True) == 'w8::k_mpc_run<16,true,12,4,231,true>', K.prob.kernel_name(loop=True)
     U, st = K.output(return_status=True)
     idx = np.unique(np.linspace(0, B - 1, 32).astype(int))
     worst = 0.0

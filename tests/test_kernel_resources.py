@@ -48,3 +48,15 @@ def test_occupancy_of_the_solve_kernels():
         else:
             assert occ >= 1
     assert (16, 1, 12, 4, 0, 1) in rk and (32, 0, 20, 8, 0, 1) in rk          # the BASELINE specialisations exist
+
+
+def test_the_512_thread_latency_kernels_fit_two_waves_per_simd():
+    """mpcqp_w8.hip: eight waves per workgroup share a compute unit's four SIMDs two by two, so a wave has 256 registers -- the kernels must
+    be allocated for exactly that (occupancy 2), and the scratch the whole call tree asks for stays small (the hot loop itself is
+    spill-free: the factorization phase is what uses it)."""
+    ks = _kernels()
+    w8 = {n: v for n, v in ks.items() if n.startswith('_ZN2w89k_mpc_runILi16ELb1E')}
+    assert len(w8) == 8, sorted(w8)                          # (12,4) and generic at 31 stages, generic at 21 and 11; solve and closed loop
+    for n, v in w8.items():
+        assert int(v['Occupancy']) == 2 and int(v['VGPRs']) + int(v['AGPRs']) <= 256, (n, v)
+        assert int(v['ScratchSize']) <= 512, (n, v)
