@@ -366,7 +366,9 @@ class Shard:
         # per launch: an event pair on the launch stream (the handle's stream IS torch's current stream) and the instances' iteration
         # counts, summed on the device (one tiny reduction per launch, inside the timed region: extra work, nothing skipped)
         marks, it_sum = [], torch.zeros((B,), dtype=torch.int64, device=dev)
+        it_last = torch.zeros((B,), dtype=torch.int64, device=dev)
         it_sum.add_(outs[3].sum(dim=0)); it_sum.zero_()            # (torch loads a kernel the first time it is used, ~100 ms: not inside the timed region)
+        it_last.copy_(outs[3].sum(dim=0)); it_last.zero_()
 
         def run(first, count, record):
             o = None
@@ -379,7 +381,8 @@ class Shard:
                 self.prob.mpc_run(k, w=w_all[c:c + k], out=o)
                 if record:
                     e1.record(); marks.append((e0, e1, k))
-                    it_sum.add_(o[3].sum(dim=0))
+                    it_last.copy_(o[3].sum(dim=0))
+                    it_sum.add_(it_last)
                 if self.comm and k == chunk:
                     self.sharding.gather_trajectory(outs[1], out=u_hist)
             return o
@@ -390,6 +393,9 @@ class Shard:
         self.u.copy_(last['o'][1][-1])
         r['chunk'] = chunk
         ms = [e0.elapsed_time(e1) for e0, e1, _ in marks]
+        # the LAST timed launch, instance by instance: when its workgroup entered and left (the kernel stamps the chip's 100 MHz clock) and how many
+        # iterations it ran -- what roofline() turns into the streaming rate BEFORE the launch's tail (frac_excluding_tail)
+        r['last_launch'] = {'t': self.prob.launch_times(), 'its': it_last.cpu().numpy().astype(float), 'steps': marks[-1][2], 'ms': ms[-1]}
         its = it_sum.cpu().numpy().astype(float)
         med = float(np.median(its))
         # a launch ends with its slowest instance (no instance can run ahead of its own closed loop): how uneven the work was
@@ -434,6 +440,28 @@ class Shard:
         per = 8 * (p.factor_doubles + 3 * p.n + 5 * p.m + 2 * (p.n + p.m)) + 8 * 1024
         return int(per * self.B)
 
+    @staticmethod
+    def tail_split(res, per_iter, per_round, per_solve, check_every=25):
+        """A launch ends with its slowest instance: the compute units are full only for part of it.  From the last timed launch's per-instance
+        entry / exit stamps and iteration counts: design bytes of instance i = its_i per_iter + (its_i / 25) per_round + steps per_solve, assumed to
+        be moved evenly between ITS entry and exit; t10 = the moment 10 % of the instances have left (90 % of the slots still busy);
+        bytes_before = sum_i bytes_i * clip((t10 - entry_i) / (exit_i - entry_i), 0, 1).  Returns bytes_before / t10 in B/s and the times."""
+        ll = res.get('last_launch')
+        if not ll or not ll['t'].any():
+            return None
+        t = ll['t'].astype(np.float64) * 1e-8              # 100 MHz ticks -> seconds
+        t0 = t[:, 0].min()
+        s, e = t[:, 0] - t0, t[:, 1] - t0
+        by = ll['its'] * per_iter + ll['its'] / check_every * per_round + ll['steps'] * per_solve
+        q = lambda f: float(np.quantile(e, f))
+        t10 = q(0.10)
+        done = np.clip((t10 - s) / np.maximum(e - s, 1e-12), 0.0, 1.0)
+        return {'rate_before_tail': float((by * done).sum() / t10), 'bytes_before_tail': float((by * done).sum()), 'bytes_launch': float(by.sum()),
+                'ms_10pct_left': 1e3 * t10, 'ms_50pct_left': 1e3 * q(0.5), 'ms_90pct_left': 1e3 * q(0.9), 'ms_all_left': 1e3 * float(e.max()),
+                'ms_launch_hip_events': ll['ms'], 'steps': ll['steps'],
+                'definition': 'last timed launch, per-instance entry/exit stamps of the chip\'s 100 MHz clock (mpcqp_get_launch_times) and iteration counts: design bytes of an '
+                              'instance spread evenly over its own residence; rate_before_tail = bytes moved until 10 % of the instances have left / that time'}
+
     def roofline(self, res, path, workload_key):
         """HBM roofline of the one kernel of the path, k_mpc_run (QP refresh, ADMM iterations, residual checks).  HIP events
         bracket every launch on its stream (mpcqp_profile); `achieved` divides the bytes this implementation streams BY
@@ -460,17 +488,20 @@ class Shard:
             # memory -- the kernel is bound by the matrix cores' issue rate and the dependent level steps, not by HBM
             mfma = prob.mfma_per_iter()
             flops = 512.0 * mfma * iters
-            return {'bound': 'mfma', 'achieved': flops / (admm_ms * 1e-3) / 1e12, 'peak': MFMA_F64_PEAK / 1e12, 'unit': 'TFLOP/s',
+            tail = self.tail_split(res, 512.0 * mfma, 0.0, 0.0) if path == 'device_loop' else None
+            return {'bound': 'mfma', 'frac_excluding_tail': (tail['rate_before_tail'] / MFMA_F64_PEAK) if tail else None, 'tail': tail, 'achieved': flops / (admm_ms * 1e-3) / 1e12, 'peak': MFMA_F64_PEAK / 1e12, 'unit': 'TFLOP/s',
                     'frac': flops / (admm_ms * 1e-3) / MFMA_F64_PEAK, 'traffic': None,
                     'frac_is': 'executed v_mfma_f64_4x4x4_4b_f64 flops (512 per instruction, mpcqp_get_work x the device-side iteration count) / HIP-event kernel '
                                'time / the FP64 matrix peak; a mat-vec uses one of the four B-operand columns, so a quarter of these flops is useful',
                     'useful_frac': 0.25 * flops / (admm_ms * 1e-3) / MFMA_F64_PEAK, 'mfma_per_iter_per_qp': mfma,
-                    'occupancy_note': '%d instances on %d CUs: %s' % (self.B, 256, 'one workgroup per CU, one wave per SIMD: no latency hiding by design' if self.B <= 256 else 'two rounds of workgroups'),
+                    'occupancy_note': '%d instances on %d CUs: one workgroup per CU at a time (%s)' % (self.B, 256, 'w8:: kernels: 512 threads, two waves per SIMD' if kname.startswith('w8::') else '256 threads, one wave per SIMD'),
                     'hbm_design_bytes_per_launch': design_bytes / launches, 'hbm_frac': achieved / HBM_PEAK,
                     'working_set_bytes': ws, 'fits_infinity_cache': bool(ws <= INFINITY_CACHE),
                     'kernel': kname, 'kernel_ms': admm_ms / launches, 'launches': res['launches'], 'steps_per_launch': res.get('chunk', 1)}
+        tail = self.tail_split(res, per_iter, per_round, per_solve) if path == 'device_loop' else None
         return {'bound': 'hbm', 'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                 'frac': achieved / HBM_PEAK, 'frac_is': 'model-based: design bytes (below) / HIP-event kernel time / 8 TB/s',
+                'frac_excluding_tail': (tail['rate_before_tail'] / HBM_PEAK) if tail else None, 'tail': tail,
                 'frac_of_achievable': achieved / HBM_ACHIEVABLE, 'achievable_GBps': HBM_ACHIEVABLE / 1e9,      # (MI355X_MICROARCH.md: 6.29 TB/s measured with a float4 copy)
                 'traffic': traffic,
                 'traffic_source': ('from_profile: profiles/pmc_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE per ADMM iteration per QP, profiled at batch %s) x this run\'s iterations per launch'
@@ -502,12 +533,15 @@ def latency_leg(kind, nsim=300):
     """One controller through the drop-in class, `MPCController.update()` per step (pyMPC/mpc.py:338-364), median microseconds;
     beside it the CPU oracle on the same loop.  kind = 'cfg2': examples/example_inverted_pendulum.py:10-69 (4,1,20);
     'notebook': examples/example_inverted_pendulum_kalman.ipynb cells 3/12/13/15 (4,1,Np=150,Nc=75; the notebook's own
-    timing cell reports about 1.05-1.2 ms per step for its OSQP-backed controller)."""
+    timing cell reports about 1.05-1.2 ms per step for its OSQP-backed controller); 'kalman_np200': the script version of that example,
+    examples/example_inverted_pendulum_kalman.py:19,71-110 (Ts = 5 ms, Np = Nc = 200, eps_feas = 1e3)."""
     import warnings
     from pympc_amd import MPCController, fixtures
     kw = fixtures.cart_pole()
     if kind == 'notebook':
         kw.update(Np=150, Nc=75)
+    if kind == 'kalman_np200':                       # examples/example_inverted_pendulum_kalman.py:19,71-110: Ts = 5 ms, Np = Nc = 200, eps_feas = 1e3
+        kw = fixtures.cart_pole_kalman()
 
     def loop(K):
         x = np.array(kw['x0'], dtype=float)
@@ -591,7 +625,7 @@ def main():
     ap.add_argument('--path', default='device_loop', choices=['stepwise', 'device_loop'],
                     help='stepwise: update()/solve()/output() per step from the host (the reference call pattern); '
                          'device_loop: the same K steps inside mpcqp_mpc_loop (SURVEY 8f-1)')
-    ap.add_argument('--workload', default='cfg3', choices=['cfg3', 'cfg5', 'cfg2', 'notebook'],
+    ap.add_argument('--workload', default='cfg3', choices=['cfg3', 'cfg5', 'cfg2', 'notebook', 'kalman_np200'],
                     help='cfg3: 1024 x (12,4,30) (headline); cfg5: 512 x (20,8,100), tight state box (SURVEY 8d); '
                          'cfg2 / notebook: single-controller latency legs only')
     ap.add_argument('--hbm-leg-batch', type=int, default=4096, help='cfg3, 1 GPU: second leg with a working set beyond the Infinity Cache (0 = skip)')
@@ -605,7 +639,7 @@ def main():
     rank, world, local_rank, dev, seen = init_distributed(args, torch, dist)
     if args.dry_run:
         return dry_run(args, rank, world, dev, seen, torch, dist)
-    if args.workload in ('cfg2', 'notebook'):
+    if args.workload in ('cfg2', 'notebook', 'kalman_np200'):
         if rank == 0:
             leg = latency_leg(args.workload)
             print(json.dumps({'metric': 'MPCController.update() latency, one controller (BASELINE configs[1])', 'value': leg['update_us_median'], 'unit': 'us',
@@ -676,7 +710,7 @@ def main():
             extra['hbm_leg'] = {'batch': args.hbm_leg_batch, 'value': args.hbm_leg_batch * min(args.steps, 25) / r3['elapsed'], 'unit': 'QP-solves/s',
                                 'ms_per_step': 1e3 * r3['elapsed'] / min(args.steps, 25), 'mean_admm_iters': r3['iters'] / max(1, r3['solves']),
                                 'launch_spread': r3.get('launch_spread'),
-                                'roofline': {k: ro3[k] for k in ('achieved', 'peak', 'unit', 'frac', 'frac_of_achievable', 'achievable_GBps', 'traffic', 'traffic_source', 'traffic_GBps',
+                                'roofline': {k: ro3[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'frac_excluding_tail', 'tail', 'frac_of_achievable', 'achievable_GBps', 'traffic', 'traffic_source', 'traffic_GBps',
                                                                  'measured_bytes_per_iter_per_qp', 'design_bytes_per_iter_per_qp', 'working_set_bytes',
                                                                  'fits_infinity_cache', 'kernel', 'kernel_ms', 'design_bytes_per_launch')},
                                 'note': 'frac_of_achievable compares with the guide\'s float4-COPY rate (6.29 TB/s: half reads, half writes, every byte from HBM); this '
@@ -703,7 +737,7 @@ def main():
                                  'value': B5 * 50 / r5['elapsed'], 'unit': 'QP-solves/s', 'ms_per_step': 1e3 * r5['elapsed'] / 50,
                                  'mean_admm_iters': r5['iters'] / max(1, r5['solves']), 'solved_fraction_last_step': sum(1 for i in inf5 if i.status == 1) / B5,
                                  'launch_spread': r5.get('launch_spread'), 'cold': s5.cold,
-                                 'roofline': {k: ro5[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'frac_is', 'frac_of_achievable', 'traffic', 'traffic_source', 'traffic_GBps',
+                                 'roofline': {k: ro5[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'frac_is', 'frac_excluding_tail', 'tail', 'frac_of_achievable', 'traffic', 'traffic_source', 'traffic_GBps',
                                                                   'measured_bytes_per_iter_per_qp', 'design_bytes_per_iter_per_qp', 'design_bytes_per_round_per_qp',
                                                                   'design_bytes_per_solve_per_qp', 'working_set_bytes', 'fits_infinity_cache', 'kernel', 'kernel_ms',
                                                                   'launches', 'steps_per_launch', 'design_bytes_per_launch')},
@@ -717,20 +751,55 @@ def main():
             s8 = Shard(args, dims, B // 8, rank, world, dev, 0, torch, dist)
             r8 = s8.measure(args.path, args.steps, args.warmup)
             v8 = (B // 8) * args.steps / r8['elapsed']
+            ro8 = s8.roofline(r8, args.path, None)
+            extra['small_batch_legs'] = {'b%d' % (B // 8): {'batch': B // 8, 'value': v8, 'ms_per_step': 1e3 * r8['elapsed'] / args.steps, 'launch_spread': r8.get('launch_spread'), 'roofline': ro8}}
+            if B % 4 == 0:
+                s4 = Shard(args, dims, B // 4, rank, world, dev, 0, torch, dist)
+                r4 = s4.measure(args.path, args.steps, args.warmup)
+                extra['small_batch_legs']['b%d' % (B // 4)] = {'batch': B // 4, 'value': (B // 4) * args.steps / r4['elapsed'], 'ms_per_step': 1e3 * r4['elapsed'] / args.steps,
+                                                               'launch_spread': r4.get('launch_spread'), 'roofline': s4.roofline(r4, args.path, None)}
+                del s4
+                torch.cuda.empty_cache()
             extra['strong_scaling_projection'] = {'total_batch': B, 'batch_per_gpu_at_8': B // 8, 'measured_1gpu_value_at_that_batch': v8, 'kernel': s8.prob.kernel_name(loop=True),
                                                   'projected_8gpu_value': 8 * v8, 'projected_vs_1gpu_full_batch': 8 * v8 / (B * world * args.steps / elapsed),
                                                   'weak_scaling_projection_8gpu_value': 8 * B * world * args.steps / elapsed,
-                                                  'note': 'strong scaling (total batch fixed) leaves %d instances on 256 CUs per GPU: one workgroup (latency backend) per instance, half the '
-                                                          'CUs idle at 128; the >= 6x target at 8 GPUs is reachable as weak scaling (%d instances per GPU), which is what --gpus N measures; '
-                                                          '--total-batch measures the strong reading on real GPUs' % (B // 8, B)}
+                                                  'note': 'strong scaling (total batch fixed) leaves %d instances on 256 CUs per GPU: one 512-thread workgroup (latency backend, mpcqp_w8.hip) per instance, '
+                                                          'half the CUs idle at 128, and a launch as long as its slowest instance; weak scaling (%d instances per GPU) is what --gpus N measures, '
+                                                          '--total-batch the strong reading on real GPUs' % (B // 8, B)}
             del s8
             torch.cuda.empty_cache()
         if rank == 0 and args.workload == 'cfg3':
             try:
-                extra['latency'] = {'cfg2': latency_leg('cfg2', nsim=200), 'notebook': latency_leg('notebook', nsim=100)}
+                extra['latency'] = {'cfg2': latency_leg('cfg2', nsim=200), 'notebook': latency_leg('notebook', nsim=100), 'kalman_np200': latency_leg('kalman_np200', nsim=60)}
             except Exception as e:
                 extra['latency'] = {'error': repr(e)}
 
+    if rank == 0 and roof is not None:
+        # every BASELINE config's number inside the roofline object (compact: value, fraction of ITS roofline, kernel time, counter traffic, tail)
+        def compact(leg, ro=None):
+            ro = ro if ro is not None else leg.get('roofline') or {}
+            sp = leg.get('launch_spread') or {}
+            return {'value': leg.get('value'), 'unit': 'QP-solves/s', 'batch': leg.get('batch'), 'bound': ro.get('bound', 'hbm'), 'frac': ro.get('frac'),
+                    'frac_excluding_tail': ro.get('frac_excluding_tail'), 'kernel': ro.get('kernel'), 'kernel_ms': ro.get('kernel_ms'),
+                    'measured_bytes_per_iter_per_qp': ro.get('measured_bytes_per_iter_per_qp'), 'design_bytes_per_iter_per_qp': ro.get('design_bytes_per_iter_per_qp'),
+                    'critical_path_ratio': sp.get('critical_path_ratio'), 'ms_per_step': leg.get('ms_per_step')}
+        legs = {}
+        if 'hbm_leg' in extra:
+            legs['hbm_b%d' % extra['hbm_leg']['batch']] = compact(extra['hbm_leg'])
+        if 'cfg5_leg' in extra:
+            legs['cfg5_b%d' % extra['cfg5_leg']['batch']] = dict(compact(extra['cfg5_leg']), parity_setting_value=extra['cfg5_leg']['parity_setting']['value'])
+        for k, v in (extra.get('small_batch_legs') or {}).items():
+            legs[k] = compact(v)
+        if parity:
+            legs['parity_eps_1e-9'] = {'value': parity['value'], 'unit': 'QP-solves/s', 'batch': B, 'mean_admm_iters': parity['mean_admm_iters']}
+        if other:
+            legs[other['path']] = {'value': other['value'], 'unit': 'QP-solves/s', 'batch': B}
+        lat = extra.get('latency') or {}
+        for k in ('cfg2', 'notebook', 'kalman_np200'):
+            if k in lat:
+                legs['latency_' + k] = {'update_us_median': lat[k]['update_us_median'], 'update_us_p95': lat[k]['update_us_p95'], 'kernel_us': lat[k]['kernel_us'],
+                                        'cpu_oracle_update_us_median': lat[k]['cpu_oracle_update_us_median'], 'kernel': lat[k]['kernel']}
+        roof['legs'] = legs
     if rank == 0:
         out = {
             'metric': 'QP-solves/sec (MPC steps/sec) at nx=%d nu=%d Np=%d; max |u*-u*_ref|' % (NX, NU, NP),

@@ -287,6 +287,7 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     rc |= dalloc(h, &P.ctype, B * L.m); rc |= dalloc(h, &P.info, B); rc |= dalloc(h, &P.stats, 8);
         rc |= dalloc(h, &h->u0_dev, B * L.nu);
     rc |= dalloc(h, &P.work, B); rc |= dalloc(h, &h->perm_dev, B);
+    rc |= dalloc(h, &P.tstamp, 2 * B);
     rc |= dalloc(h, &h->pending_dev, B); rc |= dalloc(h, &h->npending_dev, 4);
     if (h->S.tuning & MPCQP_TUNE_NO_BALANCE) h->auto_balance = 0;
     if (rc) { std::string msg = g_err; mpcqp_destroy(h); return fail(MPCQP_ERR_HIP, msg); }
@@ -940,6 +941,14 @@ extern "C" int mpcqp_get_stats(mpcqp_handle *h, uint64_t *out4, int reset) {
                 100 * g[0] / tot, 100 * g[1] / tot, 100 * g[2] / tot, 100 * g[3] / tot, 100 * g[4] / tot, 100 * g[5] / tot, 100 * g[6] / tot, tot, (double)g[7], (double)g[8], (double)g[9], (double)g[10], (double)g[11], (double)g[12], (double)g[13], (double)g[14]); } }
 #endif
     if (reset) HIPCHK(hipMemsetAsync(h->P.stats, 0, 8 * sizeof(uint64_t), h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return MPCQP_OK;
+}
+
+extern "C" int mpcqp_get_launch_times(mpcqp_handle *h, uint64_t *out) {
+    if (!h || !out) return fail(MPCQP_ERR_ARG, "null argument");
+    HIPCHK(hipSetDevice(h->device));
+    HIPCHK(hipMemcpyAsync(out, h->P.tstamp, 2 * sizeof(uint64_t) * (size_t)h->batch, hipMemcpyDefault, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return MPCQP_OK;
 }

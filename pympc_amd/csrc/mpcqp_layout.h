@@ -52,6 +52,7 @@ struct Ptrs {
     mpcqp_info *info;
     const int *perm;              // workgroup -> instance map (load balancing, see rebalance() in mpcqp.hip), or null = identity
     unsigned *work;               // per instance: ADMM iterations since the map was last rebuilt
+    unsigned long long *tstamp;   // per instance: { entry, exit } of the last closed-loop launch, 100 MHz ticks (mpcqp_get_launch_times)
     long long fsz;                // factor doubles per instance
 };
 

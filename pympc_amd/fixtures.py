@@ -51,6 +51,20 @@ def cart_pole(Np=20):
     )
 
 
+def cart_pole_kalman(Np=200):
+    """examples/example_inverted_pendulum_kalman.py:11-110: the same cart pole sampled at Ts = 5 ms, position box [-1, 1], Np = Nc = 200,
+    eps_feas = 1e3 -- the reference's long-horizon output-feedback example (estimator: Q_kal = 10 I, R_kal = I, :100-103)."""
+    kw = cart_pole(Np)
+    M, m, b, ftheta, l, g, Ts = 0.5, 0.2, 0.1, 0.1, 0.3, 9.81, 5e-3
+    Ac = np.array([[0, 1, 0, 0],
+                   [0, -b / M, -(g * m) / M, (ftheta * m) / M],
+                   [0, 0, 0, 1],
+                   [0, b / (M * l), (M * g + g * m) / (M * l), -(M * ftheta + ftheta * m) / (M * l)]])
+    Bc = np.array([[0.0], [1.0 / M], [0.0], [-1 / (M * l)]])
+    kw.update(Ad=np.eye(4) + Ac * Ts, Bd=Bc * Ts, xmax=np.array([1.0, 100.0, 100.0, 100.0]))
+    return kw
+
+
 def accel_brake(Np=20):
     """examples/example_accelerate_brake.py:10-72 (nu=2, infinite Delta-u bounds)."""
     Ts, M, b = 0.2, 2.0, 0.3
@@ -165,6 +179,7 @@ def point_mass_nc(Np=25, Nc=10):
 NAMED = {
     'point_mass': point_mass,
     'cart_pole': cart_pole,
+    'cart_pole_kalman': cart_pole_kalman,         # the reference's long-horizon output-feedback example: (4, 1, Np = Nc = 200)
     'accel_brake': accel_brake,
     'quadcopter': quadcopter,
     'quadcopter_nodu': lambda: quadcopter(finite_du=False),

@@ -22,6 +22,9 @@ Loops (inputs are the constants of pympc_amd/fixtures.py, cited there):
         module and restores the alias (= numpy.size, what it was) for the duration of the run.  The filter gain L is
         INPUT data (designed by pympc_amd.kalman.kalman_design_simple) and is stored with the trajectory.
 
+  kalman_cart_pole_np200              : the same loop with the example's own controller and estimator settings (Ts = 5 ms, Np = Nc = 200,
+        eps_feas = 1e3, Q_kal = 10 I, R_kal = I: example_inverted_pendulum_kalman.py:19,100-110), fixture cart_pole_kalman.
+
     python tests/golden/make_traj.py [name ...]   # needs /root/reference; writes tests/golden/traj_<name>.npz
 """
 import os
@@ -93,17 +96,19 @@ def run(Ctrl, kw, steps, pattern, plant):
     return np.array(xs), np.array(us)
 
 
-def run_kalman(Ctrl, Estimator, kw, steps):
+def run_kalman(Ctrl, Estimator, kw, steps, Q_kal=None, R_kal=None, vstd=0.01, wstd=0.001):
     """Output-feedback closed loop with the reference's own estimator class; returns everything the replay needs."""
     from pympc_amd.kalman import kalman_design_simple
     Ad, Bd = kw['Ad'], kw['Bd']
     nx, nu = Bd.shape
     Cd = np.array([[1.0, 0, 0, 0], [0, 0, 1.0, 0]])            # position and angle are measured (example :62-66)
     Dd = np.zeros((2, nu))
-    L, _, _ = kalman_design_simple(Ad, Bd, Cd, Dd, np.diag([0.1, 10, 0.1, 10]), 0.01 * np.eye(2), type='filter')
+    Q_kal = np.diag([0.1, 10, 0.1, 10]) if Q_kal is None else Q_kal
+    R_kal = 0.01 * np.eye(2) if R_kal is None else R_kal
+    L, _, _ = kalman_design_simple(Ad, Bd, Cd, Dd, Q_kal, R_kal, type='filter')
     rng = np.random.default_rng(77)
-    v = 0.01 * rng.standard_normal((steps, 2))
-    w = 0.001 * rng.standard_normal((steps, nx))
+    v = vstd * rng.standard_normal((steps, 2))
+    w = wstd * rng.standard_normal((steps, nx))
     x = np.array(kw['x0'], dtype=float) * 1.05                 # the controller starts from a wrong estimate
     x_true0 = x.copy()
     KF = Estimator(np.array(kw['x0'], dtype=float), Ad, Bd, Cd, Dd, L)
@@ -163,6 +168,18 @@ def main():
             out = run_kalman(RefController, RefEstimator, kw, 40)
             np.savez_compressed(os.path.join(HERE, 'traj_kalman_cart_pole.npz'), pattern='output_feedback', fixture='cart_pole', eps=EPS, **out)
             print('%-14s %3d steps  |x|max %.3f  |u|max %.3f  u[0] %s' % ('kalman_cart_pole', 40, np.abs(out['x']).max(), np.abs(out['u']).max(), out['u'][0]))
+        if not sys.argv[1:] or 'kalman_cart_pole_np200' in sys.argv[1:]:
+            # the example's OWN configuration (example_inverted_pendulum_kalman.py:19,71-110): Ts = 5 ms, Np = Nc = 200, eps_feas = 1e3, estimator
+            # Q_kal = 10 I, R_kal = I; measurement noise at the level the example has commented out (0.005), linear plant, 30 steps
+            import scipy
+            if not hasattr(scipy, 'size'):
+                scipy.size = np.size
+            from pyMPC.kalman import LinearStateEstimator as RefEstimator
+            kw = dict(fixtures.NAMED['cart_pole_kalman']())
+            kw.update(eps_abs=EPS, eps_rel=EPS)
+            out = run_kalman(RefController, RefEstimator, kw, 30, Q_kal=10 * np.eye(4), R_kal=np.eye(2), vstd=0.005, wstd=0.0)
+            np.savez_compressed(os.path.join(HERE, 'traj_kalman_cart_pole_np200.npz'), pattern='output_feedback', fixture='cart_pole_kalman', eps=EPS, **out)
+            print('%-14s %3d steps  |x|max %.3f  |u|max %.3f  u[0] %s' % ('kalman_cart_pole_np200', 30, np.abs(out['x']).max(), np.abs(out['u']).max(), out['u'][0]))
         for name, (fix, steps, pattern) in CASES.items():
             if sys.argv[1:] and name not in sys.argv[1:]:
                 continue

@@ -121,7 +121,7 @@ def test_device_loop_default_tolerance_iterates_like_oracle():
 
 
 # ---- (c) output feedback: reference LinearStateEstimator + MPCController ----------------------------------------------
-@pytest.mark.parametrize('name', ['kalman_cart_pole'])
+@pytest.mark.parametrize('name', ['kalman_cart_pole', 'kalman_cart_pole_np200'])      # (the second: the example's own Ts = 5 ms, Np = Nc = 200, eps_feas = 1e3)
 def test_device_loop_output_feedback_follows_reference_classes(name):
     """The loop of examples/example_inverted_pendulum_kalman.py:135-174 run by the REFERENCE's MPCController and
     LinearStateEstimator (make_traj.py, linear plant, recorded noise) against the same loop inside mpcqp_mpc_loop."""
