@@ -237,9 +237,16 @@ def cpu_legs(dims, eps, samples, want_baseline, seconds_budget=12.0, inst=400, s
 class Shard:
     """One rank's share of the batch: B instances set up on this GPU, and the two measured ways through the library."""
 
-    def __init__(self, args, dims, B, rank, world, dev, first_instance, torch, dist):
+    def __init__(self, args, dims, B, rank, world, dev, first_instance, torch, dist, total=None):
         from pympc_amd.solver import BatchProblem
         from pympc_amd import sharding
+        # total: instances over all ranks (default world * B); with a total that does not divide, the last rank(s) are short (sharding.shard_range)
+        total = B * world if total is None else total                # (B may be None when total is given)
+        lo, hi = sharding.shard_range(total, rank, world)
+        B = hi - lo
+        if B < 1:
+            raise SystemExit('bench.py: rank %d of %d has no instance of the %d to work on (more GPUs than blocks of %d)' % (rank, world, total, sharding.shard_rows(total, world)))
+        self.total, self.first_local = total, lo
         self.args, self.dims, self.B, self.rank, self.world, self.dev = args, dims, B, rank, world, dev
         self.torch, self.dist, self.sharding = torch, dist, sharding
         NX, NU, NP, XBOX = dims
@@ -247,8 +254,16 @@ class Shard:
         # ---- problem data: generated on rank 0, scattered over RCCL (north_star: scatter problem data)
         full = None
         if rank == 0:
-            full = {k: torch.from_numpy(v).to(dev) for k, v in make_instances(dims, first_instance, B * world).items()}
-        loc = sharding.scatter_instances(full, {'Ad': (NX, NX), 'Bd': (NX, NU), 'x0': (NX,)}, B, dev)
+            full = {k: torch.from_numpy(v).to(dev) for k, v in make_instances(dims, first_instance, total).items()}
+        self.comm = comm_on(world)
+        if self.comm:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loc = sharding.scatter_instances(full, {'Ad': (NX, NX), 'Bd': (NX, NU), 'x0': (NX,)}, None, dev, total=total)      # one packed collective
+        torch.cuda.synchronize()
+        self.scatter_ms = 1e3 * (time.perf_counter() - t0)
+        self.gather_ms, self.gathers = 0.0, 0
         self.Ad, self.Bd, self.x = loc['Ad'], loc['Bd'], loc['x0'].clone()
         stream = torch.cuda.current_stream(dev)
         self.prob = prob = BatchProblem(B, NX, NU, NP, device=dev.index, stream=stream.cuda_stream,
@@ -283,9 +298,9 @@ class Shard:
         # "w from the same rng" recipe) -- the same realisation the CPU baseline's closed loop uses (oracle/cpu_bench.py), whatever
         # the batch size, the rank count or the path; rows are consumed in step order across all the measurements of this shard
         from pympc_amd import fixtures
-        self.noise_rngs = [fixtures.random_lti_noise_rng(first_instance + rank * B + j) for j in range(B)]
-        self.comm = comm_on(world)
-        self.u_all = torch.empty((world * B, NU), dtype=f64, device=dev) if self.comm else None
+        self.noise_rngs = [fixtures.random_lti_noise_rng(first_instance + lo + j) for j in range(B)]
+        self.per = sharding.shard_rows(total, world)
+        self.u_all = torch.empty((world * self.per, NU), dtype=f64, device=dev) if self.comm else None
 
     def account(self, kind, st=None):
         st = self.prob.stats(reset=True) if st is None else st
@@ -322,10 +337,22 @@ class Shard:
         if self.comm:
             t = torch.tensor([elapsed], dtype=torch.float64, device=self.dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+            elapsed_local, elapsed = elapsed, float(t.item())
+        else:
+            elapsed_local = elapsed
         iters, checks, refacts, solves = self.account(kind)
         run_ms, launches = prob.profile(enable=False)
-        return dict(elapsed=elapsed, iters=iters, checks=checks, refacts=refacts, solves=solves, run_ms=run_ms, launches=launches)
+        return dict(elapsed=elapsed, elapsed_local=elapsed_local, iters=iters, checks=checks, refacts=refacts, solves=solves, run_ms=run_ms, launches=launches)
+
+    def timed_gather(self, fn):
+        """An all-gather of u* with its wall time on this rank (host clock around a synchronised call: the exchange is 32 B per instance and
+        step, its cost is latency) -- reported per rank beside the scatter."""
+        torch = self.torch
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        self.gather_ms += 1e3 * (time.perf_counter() - t0); self.gathers += 1
 
     def measure_stepwise(self, steps, warmup):
         """The reference's call pattern: per step the host calls update(), solve(), output() (one kernel launch per
@@ -338,7 +365,7 @@ class Shard:
             self.prob.solve_async()
             self.prob.u0(out=self.u)
             if self.comm:
-                self.sharding.gather_inputs(self.u, out=self.u_all)
+                self.timed_gather(lambda: self.sharding.gather_inputs(self.u, out=self.u_all, total=self.total))
 
         return self.timed('solve', lambda: [step() for _ in range(warmup)], lambda: [step() for _ in range(steps)])
 
@@ -361,7 +388,7 @@ class Shard:
         w_all = self.noise(warmup + steps)
         outs = (torch.empty((chunk + 1, B, NX), dtype=f64, device=dev), torch.empty((chunk, B, NU), dtype=f64, device=dev),
                 torch.empty((chunk, B), dtype=torch.int32, device=dev), torch.empty((chunk, B), dtype=torch.int32, device=dev))
-        u_hist = torch.empty((world * chunk, B, NU), dtype=f64, device=dev) if self.comm else None
+        u_hist = torch.empty((world * chunk, self.per, NU), dtype=f64, device=dev) if self.comm else None
 
         # per launch: an event pair on the launch stream (the handle's stream IS torch's current stream) and the instances' iteration
         # counts, summed on the device (one tiny reduction per launch, inside the timed region: extra work, nothing skipped)
@@ -384,7 +411,7 @@ class Shard:
                     it_last.copy_(o[3].sum(dim=0))
                     it_sum.add_(it_last)
                 if self.comm and k == chunk:
-                    self.sharding.gather_trajectory(outs[1], out=u_hist)
+                    self.timed_gather(lambda: self.sharding.gather_trajectory(outs[1], out=u_hist, total=self.total))
             return o
 
         last = {}
@@ -395,7 +422,8 @@ class Shard:
         ms = [e0.elapsed_time(e1) for e0, e1, _ in marks]
         # the LAST timed launch, instance by instance: when its workgroup entered and left (the kernel stamps the chip's 100 MHz clock) and how many
         # iterations it ran -- what roofline() turns into the streaming rate BEFORE the launch's tail (frac_excluding_tail)
-        r['last_launch'] = {'t': self.prob.launch_times(), 'its': it_last.cpu().numpy().astype(float), 'steps': marks[-1][2], 'ms': ms[-1]}
+        kl = marks[-1][2]
+        r['last_launch'] = {'t': self.prob.launch_times(min(kl, 64)), 'its_step': last['o'][3][:kl].cpu().numpy().astype(float), 'steps': kl, 'ms': ms[-1]}
         its = it_sum.cpu().numpy().astype(float)
         med = float(np.median(its))
         # a launch ends with its slowest instance (no instance can run ahead of its own closed loop): how uneven the work was
@@ -442,25 +470,32 @@ class Shard:
 
     @staticmethod
     def tail_split(res, per_iter, per_round, per_solve, check_every=25):
-        """A launch ends with its slowest instance: the compute units are full only for part of it.  From the last timed launch's per-instance
-        entry / exit stamps and iteration counts: design bytes of instance i = its_i per_iter + (its_i / 25) per_round + steps per_solve, assumed to
-        be moved evenly between ITS entry and exit; t10 = the moment 10 % of the instances have left (90 % of the slots still busy);
-        bytes_before = sum_i bytes_i * clip((t10 - entry_i) / (exit_i - entry_i), 0, 1).  Returns bytes_before / t10 in B/s and the times."""
+        """A launch ends with its slowest instance: the compute units are full only for part of it.  From the last timed launch: every instance
+        stamps the chip's 100 MHz clock when its workgroup enters, after each closed-loop step, and when it leaves (mpcqp_get_launch_times); the
+        design bytes of a step of instance i are its_ij per_iter + (its_ij / 25) per_round + per_solve, moved between the end of its previous step
+        and the end of this one.  t10 = the moment 10 % of the instances have left (90 % of the slots still busy); bytes_before = the bytes of all
+        steps completed by then plus the running steps' share in proportion of time.  Returns bytes_before / t10 in B/s and the landmark times."""
         ll = res.get('last_launch')
         if not ll or not ll['t'].any():
             return None
-        t = ll['t'].astype(np.float64) * 1e-8              # 100 MHz ticks -> seconds
+        t = ll['t'].astype(np.float64) * 1e-8              # 100 MHz ticks -> seconds; [B, 2 + k]
         t0 = t[:, 0].min()
-        s, e = t[:, 0] - t0, t[:, 1] - t0
-        by = ll['its'] * per_iter + ll['its'] / check_every * per_round + ll['steps'] * per_solve
-        q = lambda f: float(np.quantile(e, f))
+        entry, leave = t[:, 0] - t0, t[:, 1] - t0
+        k = t.shape[1] - 2
+        ends = t[:, 2:] - t0                                # [B, k]
+        begins = np.concatenate([entry[:, None], ends[:, :-1]], axis=1)
+        its = ll['its_step'].T[:, :k]                       # [B, k]
+        by = its * per_iter + its / check_every * per_round + per_solve
+        q = lambda f: float(np.quantile(leave, f))
         t10 = q(0.10)
-        done = np.clip((t10 - s) / np.maximum(e - s, 1e-12), 0.0, 1.0)
-        return {'rate_before_tail': float((by * done).sum() / t10), 'bytes_before_tail': float((by * done).sum()), 'bytes_launch': float(by.sum()),
-                'ms_10pct_left': 1e3 * t10, 'ms_50pct_left': 1e3 * q(0.5), 'ms_90pct_left': 1e3 * q(0.9), 'ms_all_left': 1e3 * float(e.max()),
+        share = np.clip((t10 - begins) / np.maximum(ends - begins, 1e-12), 0.0, 1.0)
+        before = float((by * share).sum())
+        return {'rate_before_tail': before / t10, 'bytes_before_tail': before, 'bytes_launch': float(by.sum()),
+                'ms_10pct_left': 1e3 * t10, 'ms_50pct_left': 1e3 * q(0.5), 'ms_90pct_left': 1e3 * q(0.9), 'ms_all_left': 1e3 * float(leave.max()),
                 'ms_launch_hip_events': ll['ms'], 'steps': ll['steps'],
-                'definition': 'last timed launch, per-instance entry/exit stamps of the chip\'s 100 MHz clock (mpcqp_get_launch_times) and iteration counts: design bytes of an '
-                              'instance spread evenly over its own residence; rate_before_tail = bytes moved until 10 % of the instances have left / that time'}
+                'definition': 'last timed launch: per-instance stamps of the chip\'s 100 MHz clock at workgroup entry, after every closed-loop step and at exit '
+                              '(mpcqp_get_launch_times) with the per-step iteration counts give the design bytes moved by any moment to within one step of one instance; '
+                              'rate_before_tail = bytes moved until 10 % of the instances have left / that time'}
 
     def roofline(self, res, path, workload_key):
         """HBM roofline of the one kernel of the path, k_mpc_run (QP refresh, ADMM iterations, residual checks).  HIP events
@@ -590,22 +625,33 @@ def latency_leg(kind, nsim=300):
 
 
 def dry_run(args, rank, world, dev, seen, torch, dist):
-    """The distributed plumbing of the bench without the solver: scatter from rank 0, a stand-in per-shard result, all-gather,
-    one JSON line.  Used by the CPU test of `bench.py --gpus N` (gloo) -- nothing here is a measurement."""
+    """The distributed plumbing of the bench without the solver: the packed scatter from rank 0 (two arrays, one collective), a stand-in
+    per-shard result, the all-gather of "u*" per step and per launch, a per-rank report, one JSON line.  `--total-batch T` as in the real
+    run: T need not divide by the ranks (the last one is short).  Used by the CPU tests of `bench.py --gpus N` (gloo) -- nothing here is a
+    measurement."""
     from pympc_amd import sharding
-    B = 4
+    total = args.total_batch if args.total_batch is not None else 4 * world
+    lo, hi = sharding.shard_range(total, rank, world)
     full = None
     if rank == 0:
-        full = {'x0': torch.arange(B * world * 3, dtype=torch.float64, device=dev).reshape(B * world, 3)}
-    loc = sharding.scatter_instances(full, {'x0': (3,)}, B, dev)
-    u = 2.0 * loc['x0'][:, :2]
-    u_all = sharding.gather_inputs(u)
+        full = {'x0': torch.arange(total * 3, dtype=torch.float64, device=dev).reshape(total, 3), 'Ad': torch.arange(total * 4, dtype=torch.float64, device=dev).reshape(total, 2, 2)}
+    loc = sharding.scatter_instances(full, {'Ad': (2, 2), 'x0': (3,)}, None, dev, total=total)
+    assert loc['x0'].shape == (hi - lo, 3) and loc['Ad'].shape == (hi - lo, 2, 2)
+    u = 2.0 * loc['x0'][:, :2] + loc['Ad'][:, 1, 1:2]
+    u_all = sharding.gather_inputs(u, total=total)
+    traj = torch.stack([u + 10.0 * k for k in range(3)])              # [steps, count, nu]: a device-loop launch's inputs
+    tr_all = sharding.gather_trajectory(traj, total=total)
+    mine = {'rank': rank, 'instances': hi - lo, 'first_instance': lo}
+    per_rank = [mine]
     if comm_on(world):
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
         dist.barrier()
     if rank == 0:
-        expect = 2.0 * torch.arange(B * world * 3, dtype=torch.float64).reshape(B * world, 3)[:, :2]
-        ok = bool(torch.equal(u_all.cpu(), expect))
-        print(json.dumps(dict(dry_run=True, n_gpus=world, gathered_ok=ok, **seen)))
+        x0 = torch.arange(total * 3, dtype=torch.float64).reshape(total, 3)
+        expect = 2.0 * x0[:, :2] + torch.arange(total * 4, dtype=torch.float64).reshape(total, 2, 2)[:, 1, 1:2]
+        ok = bool(torch.equal(u_all.cpu(), expect)) and tuple(tr_all.shape) == (3, total, 2) and bool(torch.equal(tr_all[2].cpu(), expect + 20.0))
+        print(json.dumps(dict(dry_run=True, n_gpus=world, total_batch=total, gathered_ok=ok, per_rank=per_rank, **seen)))
     if comm_on(world):
         dist.destroy_process_group()
 
@@ -650,13 +696,12 @@ def main():
     dims = WORKLOADS[args.workload][:4]
     NX, NU, NP, XBOX = dims
     if args.total_batch is not None:
-        if args.total_batch % world:
-            raise SystemExit('--total-batch must be divisible by the number of GPUs')
-        B, scaling = args.total_batch // world, 'strong'
+        TOTAL, scaling = args.total_batch, 'strong'                 # (need not divide: the last rank is short, pympc_amd/sharding.py)
     else:
-        B, scaling = (args.batch if args.batch is not None else WORKLOADS[args.workload][4]), 'weak'
+        TOTAL, scaling = (args.batch if args.batch is not None else WORKLOADS[args.workload][4]) * world, 'weak'
 
-    sh = Shard(args, dims, B, rank, world, dev, 0, torch, dist)
+    sh = Shard(args, dims, None, rank, world, dev, 0, torch, dist, total=TOTAL)
+    B = sh.B                                                          # this rank's instances
     prob = sh.prob
     res = sh.measure(args.path, args.steps, args.warmup)
     elapsed, iters, refacts, solves = res['elapsed'], res['iters'], res['refacts'], res['solves']
@@ -667,7 +712,7 @@ def main():
     if not args.no_other_path:
         oname = 'stepwise' if args.path == 'device_loop' else 'device_loop'
         o = sh.measure(oname, args.steps, args.warmup)
-        other = {'path': oname, 'value': B * world * args.steps / o['elapsed'], 'ms_per_step': 1e3 * o['elapsed'] / args.steps,
+        other = {'path': oname, 'value': TOTAL * args.steps / o['elapsed'], 'ms_per_step': 1e3 * o['elapsed'] / args.steps,
                  'mean_admm_iters': o['iters'] / max(1, o['solves'])}
     parity = None
     if not args.no_other_path and args.eps > 1e-8:
@@ -675,7 +720,7 @@ def main():
         prob.update_settings(eps_abs=1e-9, eps_rel=1e-9)
         pr = sh.measure(args.path, args.steps, args.warmup)
         pinf = prob.infos()
-        parity = {'eps_abs': 1e-9, 'eps_rel': 1e-9, 'path': args.path, 'value': B * world * args.steps / pr['elapsed'],
+        parity = {'eps_abs': 1e-9, 'eps_rel': 1e-9, 'path': args.path, 'value': TOTAL * args.steps / pr['elapsed'],
                   'ms_per_step': 1e3 * pr['elapsed'] / args.steps, 'mean_admm_iters': pr['iters'] / max(1, pr['solves']),
                   'solved_fraction_last_step': sum(1 for i in pinf if i.status == 1) / B}
         samples.append(dict(sh.sample_point(), eps=1e-9))
@@ -683,7 +728,17 @@ def main():
     # what one rho update costs: the block factorization of every instance, timed alone (mpcqp_refactor rewrites the factor
     # that is already in place); the steady-state loop above needs none, the cold solve a few per instance
     refactor_ms = None if args.no_refactor_timing else sh.refactor_ms()
-    roof = sh.roofline(res, args.path, args.workload) if rank == 0 else None
+    roof_local = sh.roofline(res, args.path, args.workload)
+    roof = roof_local if rank == 0 else None
+    # what every rank did, beside the job's line: its share, its own rate (its clock, before the max over ranks), its kernel's roofline fraction,
+    # and what the two exchanges cost it -- the scatter of the problem data (one packed collective at setup) and the all-gathers of u*
+    mine = {'rank': rank, 'instances': B, 'first_instance': sh.first_local, 'value': B * args.steps / res['elapsed_local'], 'ms_per_step': 1e3 * res['elapsed_local'] / args.steps,
+            'roofline_bound': roof_local['bound'], 'roofline_frac': roof_local['frac'], 'kernel': roof_local['kernel'], 'kernel_ms': roof_local['kernel_ms'],
+            'scatter_ms': sh.scatter_ms, 'gather_calls': sh.gathers, 'gather_ms_per_call': (sh.gather_ms / sh.gathers) if sh.gathers else None}
+    per_rank = [mine]
+    if comm_on(world):
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
     totals, cold, n, m = sh.totals, sh.cold, prob.n, prob.m
     knames = {k: prob.kernel_name(loop=(k == 'loop')) for k in totals}
 
@@ -692,9 +747,9 @@ def main():
     if not args.no_other_path:
         del sh, prob
         torch.cuda.empty_cache()
-        if world > 1 and scaling == 'weak' and args.workload == 'cfg3' and 1024 % world == 0:
+        if world > 1 and scaling == 'weak' and args.workload == 'cfg3':
             # BASELINE configs[3] read literally: the SAME 1024 instances split over the N GPUs
-            s2 = Shard(args, dims, 1024 // world, rank, world, dev, 0, torch, dist)
+            s2 = Shard(args, dims, None, rank, world, dev, 0, torch, dist, total=1024)
             r2 = s2.measure(args.path, args.steps, args.warmup)
             extra['strong_scaling'] = {'scaling': 'strong', 'total_batch': 1024, 'batch_per_gpu': 1024 // world, 'path': args.path,
                                        'value': 1024 * args.steps / r2['elapsed'], 'ms_per_step': 1e3 * r2['elapsed'] / args.steps,
@@ -761,8 +816,8 @@ def main():
                 del s4
                 torch.cuda.empty_cache()
             extra['strong_scaling_projection'] = {'total_batch': B, 'batch_per_gpu_at_8': B // 8, 'measured_1gpu_value_at_that_batch': v8, 'kernel': s8.prob.kernel_name(loop=True),
-                                                  'projected_8gpu_value': 8 * v8, 'projected_vs_1gpu_full_batch': 8 * v8 / (B * world * args.steps / elapsed),
-                                                  'weak_scaling_projection_8gpu_value': 8 * B * world * args.steps / elapsed,
+                                                  'projected_8gpu_value': 8 * v8, 'projected_vs_1gpu_full_batch': 8 * v8 / (TOTAL * args.steps / elapsed),
+                                                  'weak_scaling_projection_8gpu_value': 8 * TOTAL * args.steps / elapsed,
                                                   'note': 'strong scaling (total batch fixed) leaves %d instances on 256 CUs per GPU: one 512-thread workgroup (latency backend, mpcqp_w8.hip) per instance, '
                                                           'half the CUs idle at 128, and a launch as long as its slowest instance; weak scaling (%d instances per GPU) is what --gpus N measures, '
                                                           '--total-batch the strong reading on real GPUs' % (B // 8, B)}
@@ -803,7 +858,7 @@ def main():
     if rank == 0:
         out = {
             'metric': 'QP-solves/sec (MPC steps/sec) at nx=%d nu=%d Np=%d; max |u*-u*_ref|' % (NX, NU, NP),
-            'value': B * world * args.steps / elapsed,
+            'value': TOTAL * args.steps / elapsed,
             'unit': 'QP-solves/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * elapsed / args.steps,
@@ -812,7 +867,7 @@ def main():
             'ranks_seen': seen['ranks_seen'], 'devices_seen': seen['devices_seen'], 'collective_backend': seen['backend'],
             'config': {'workload': '%s: %d random stable LTI MPC instances per GPU (nx=%d, nu=%d, Np=Nc=%d, n=%d, m=%d), '
                                    'warm-started receding horizon x+=Ad x+Bd u*+w' % ('cfg-3' if args.workload == 'cfg3' else 'cfg-5', B, NX, NU, NP, n, m),
-                       'batch_per_gpu': B, 'total_batch': B * world, 'eps_abs': args.eps, 'eps_rel': args.eps, 'path': args.path,
+                       'batch_per_gpu': B, 'total_batch': TOTAL, 'eps_abs': args.eps, 'eps_rel': args.eps, 'path': args.path,
                        'parallelism': 'instances sharded over %d GPU(s); RCCL scatter of data, all-gather of u*' % world},
             'mean_admm_iters': iters / max(1, solves),
             'solved_fraction_last_step': n_solved / B,
@@ -822,6 +877,7 @@ def main():
                                         'receding-horizon loop, a few per instance during the cold solve' % B},
             'cold': cold,
             'roofline': roof,
+            'per_rank': per_rank,
             'launch_spread': res.get('launch_spread'),
             'accounting': {'timed': {'iters': iters, 'rounds': res['checks'], 'solves': solves, 'launches': res['launches'], 'kernel_ms_total': res['run_ms']},
                            'process_totals': {knames[k]: dict(iters=v[0], rounds=v[1], solves=v[2]) for k, v in totals.items()}},

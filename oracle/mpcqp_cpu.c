@@ -474,8 +474,8 @@ int mpcqp_get_stats(mpcqp_handle *h, uint64_t *out4, int reset) {
     memcpy(out4, h->stats, sizeof(h->stats)); if (reset) memset(h->stats, 0, sizeof(h->stats));
     return MPCQP_OK;
 }
-int mpcqp_get_launch_times(mpcqp_handle *h, uint64_t *out) {      /* no launches here: zeros */
-    if (!h || !out) return fail(MPCQP_ERR_ARG, "null argument"); memset(out, 0, 2 * sizeof(uint64_t) * (size_t)h->batch); return MPCQP_OK;
+int mpcqp_get_launch_times(mpcqp_handle *h, uint64_t *out, int nsteps) {      /* no launches here: zeros */
+    if (!h || !out || nsteps < 0 || nsteps > 64) return fail(MPCQP_ERR_ARG, "mpcqp_get_launch_times: bad argument"); memset(out, 0, (size_t)(2 + nsteps) * sizeof(uint64_t) * (size_t)h->batch); return MPCQP_OK;
 }
 int mpcqp_profile(mpcqp_handle *h, int enable, double *run_ms, int64_t *run_launches, int reset) {      /* no kernels to time */
     (void)enable; (void)reset; if (!h) return fail(MPCQP_ERR_ARG, "null handle"); if (run_ms) *run_ms = 0.0; if (run_launches) *run_launches = 0; return MPCQP_OK;

@@ -111,7 +111,7 @@ def load():
     L.mpcqp_get_work.argtypes = [H, C.POINTER(C.c_int64)]
     L.mpcqp_kernel_name.argtypes = [H, C.c_int, C.c_char_p, C.c_int]
     L.mpcqp_get_stats.argtypes = [H, C.POINTER(C.c_uint64), C.c_int]
-    L.mpcqp_get_launch_times.argtypes = [H, C.c_void_p]
+    L.mpcqp_get_launch_times.argtypes = [H, C.c_void_p, C.c_int]
     L.mpcqp_profile.argtypes = [H, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int]
     L.mpcqp_export_qp.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.mpcqp_get_scaling.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

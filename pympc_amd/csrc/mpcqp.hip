@@ -287,7 +287,7 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     rc |= dalloc(h, &P.ctype, B * L.m); rc |= dalloc(h, &P.info, B); rc |= dalloc(h, &P.stats, 8);
         rc |= dalloc(h, &h->u0_dev, B * L.nu);
     rc |= dalloc(h, &P.work, B); rc |= dalloc(h, &h->perm_dev, B);
-    rc |= dalloc(h, &P.tstamp, 2 * B);
+    rc |= dalloc(h, &P.tstamp, (size_t)TS_STRIDE * B);
     rc |= dalloc(h, &h->pending_dev, B); rc |= dalloc(h, &h->npending_dev, 4);
     if (h->S.tuning & MPCQP_TUNE_NO_BALANCE) h->auto_balance = 0;
     if (rc) { std::string msg = g_err; mpcqp_destroy(h); return fail(MPCQP_ERR_HIP, msg); }
@@ -945,10 +945,11 @@ extern "C" int mpcqp_get_stats(mpcqp_handle *h, uint64_t *out4, int reset) {
     return MPCQP_OK;
 }
 
-extern "C" int mpcqp_get_launch_times(mpcqp_handle *h, uint64_t *out) {
-    if (!h || !out) return fail(MPCQP_ERR_ARG, "null argument");
+extern "C" int mpcqp_get_launch_times(mpcqp_handle *h, uint64_t *out, int nsteps) {
+    if (!h || !out || nsteps < 0 || nsteps > TS_STEPS) return fail(MPCQP_ERR_ARG, "mpcqp_get_launch_times: bad argument (0 <= nsteps <= 64)");
     HIPCHK(hipSetDevice(h->device));
-    HIPCHK(hipMemcpyAsync(out, h->P.tstamp, 2 * sizeof(uint64_t) * (size_t)h->batch, hipMemcpyDefault, h->stream));
+    HIPCHK(hipMemcpy2DAsync(out, sizeof(uint64_t) * (size_t)(2 + nsteps), h->P.tstamp, sizeof(uint64_t) * (size_t)TS_STRIDE, sizeof(uint64_t) * (size_t)(2 + nsteps),
+                            (size_t)h->batch, hipMemcpyDefault, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return MPCQP_OK;
 }

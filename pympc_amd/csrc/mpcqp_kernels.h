@@ -169,7 +169,7 @@ __global__ __launch_bounds__(NT, run_occupancy(NB, MODE)) void k_mpc_run(RunKArg
     Smem &S = rs.S;
     const int b = inst_of(P.perm), tid = threadIdx.x;
     double *step = P.step + (size_t)b * L.step_sz;
-    if (LOOP && tid == 0) P.tstamp[2 * b] = wall_clock64();
+    if (LOOP && tid == 0) P.tstamp[(size_t)TS_STRIDE * b] = wall_clock64();
     if (MODE >= MODE_BCRT && tid == 0) S.iflag[2] = 0;      // (the rounds' LDS-resident part of the factor is not loaded yet: admm_latw; a barrier follows in load_common)
     if (!LOOP && R.pin_in) {                     // update(x0, u_{-1}, xref) straight from the caller's (mapped) memory: one PCIe round trip
         const double *src = R.pin_in + (size_t)b * R.pin_stride;
@@ -269,6 +269,7 @@ __global__ __launch_bounds__(NT, run_occupancy(NB, MODE)) void k_mpc_run(RunKArg
         if (LOOP && tid == 0) {
             R.status_traj[(size_t)k * R.batch + b] = P.info[b].status;
             R.iter_traj[(size_t)k * R.batch + b] = iter;
+            if (k < TS_STEPS) P.tstamp[(size_t)TS_STRIDE * b + 2 + k] = wall_clock64();
         }
         __syncthreads();
     }
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(NT, run_occupancy(NB, MODE)) void k_mpc_run(RunKArg
             }
         }
     }
-    if (LOOP && tid == 0) P.tstamp[2 * b + 1] = wall_clock64();
+    if (LOOP && tid == 0) P.tstamp[(size_t)TS_STRIDE * b + 1] = wall_clock64();
     if (LOOP && tid < nx) {
         const size_t e = ((size_t)R.nsteps * R.batch + b) * nx + tid;
         R.x_traj[e] = R.ny ? R.x_true[(size_t)b * nx + tid] : S.x0s[tid];

@@ -6,6 +6,7 @@
 // Layout of one instance
 // ------------------------------------------------------------------------------------------------
 constexpr int MAXEV = 64;         // profiling: launches whose HIP events may be pending
+constexpr int TS_STEPS = 64, TS_STRIDE = 2 + TS_STEPS;      // per-instance time stamps of a closed-loop launch (Ptrs::tstamp)
 
 struct Lay {
     int nx, nu, Np, Nc, N, nb, n, m, n_x, n_u, ou, oe, rs, ri, rdu;
@@ -52,7 +53,7 @@ struct Ptrs {
     mpcqp_info *info;
     const int *perm;              // workgroup -> instance map (load balancing, see rebalance() in mpcqp.hip), or null = identity
     unsigned *work;               // per instance: ADMM iterations since the map was last rebuilt
-    unsigned long long *tstamp;   // per instance: { entry, exit } of the last closed-loop launch, 100 MHz ticks (mpcqp_get_launch_times)
+    unsigned long long *tstamp;   // per instance [TS_STRIDE]: { entry, exit, end of step 0 .. TS_STEPS-1 } of the last closed-loop launch, 100 MHz ticks (mpcqp_get_launch_times)
     long long fsz;                // factor doubles per instance
 };
 

@@ -414,10 +414,11 @@ class BatchProblem:
         _lib.check(self._L.mpcqp_kernel_name(self._h, int(bool(loop)), buf, 128), 'mpcqp_kernel_name')
         return buf.value.decode()
 
-    def launch_times(self):
-        """[batch, 2] uint64: entry and exit of every instance's workgroup in the last closed-loop launch, ticks of the GPU's 100 MHz clock."""
-        out = np.zeros((self.batch, 2), dtype=np.uint64)
-        _lib.check(self._L.mpcqp_get_launch_times(self._h, _ptr(out)), 'mpcqp_get_launch_times')
+    def launch_times(self, nsteps=0):
+        """[batch, 2 + nsteps] uint64: entry and exit of every instance's workgroup in the last closed-loop launch and the end of each of its
+        first ``nsteps`` (<= 64) steps, ticks of the GPU's 100 MHz clock."""
+        out = np.zeros((self.batch, 2 + int(nsteps)), dtype=np.uint64)
+        _lib.check(self._L.mpcqp_get_launch_times(self._h, _ptr(out), int(nsteps)), 'mpcqp_get_launch_times')
         return out
 
     def profile(self, enable=None, reset=False):

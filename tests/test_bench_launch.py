@@ -42,3 +42,18 @@ def test_forced_process_group_of_one_rank_runs_the_collectives():
     with RCCL on the GPU box: tests/test_gpu_rccl_single_rank.py)."""
     out = _run({'MPCQP_BENCH_FORCE_PG': '1'}, '--gpus', '1')
     assert out['n_gpus'] == 1 and out['ranks_seen'] == 1 and out['backend'] == 'gloo' and out['gathered_ok'] is True
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus4_total_batch_1024_is_the_strong_scaling_command():
+    """`bench.py --gpus 4 --total-batch 1024` (BASELINE configs[3] read literally, on four ranks): 256 instances each, one packed scatter, the
+    all-gathers, a per-rank report in the line."""
+    out = _run({}, '--gpus', '4', '--total-batch', '1024')
+    assert out['n_gpus'] == 4 and out['ranks_seen'] == 4 and out['devices_seen'] == 4 and out['total_batch'] == 1024 and out['gathered_ok'] is True
+    assert [(r['rank'], r['instances'], r['first_instance']) for r in out['per_rank']] == [(i, 256, 256 * i) for i in range(4)]
+
+
+@pytest.mark.timeout(300)
+def test_bench_total_batch_need_not_divide():
+    out = _run({}, '--gpus', '4', '--total-batch', '10')
+    assert out['gathered_ok'] is True and [r['instances'] for r in out['per_rank']] == [3, 3, 3, 1]

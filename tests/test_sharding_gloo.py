@@ -79,9 +79,52 @@ def test_scatter_solve_gather_world2():
     assert np.allclose(got, ref, rtol=1e-9, atol=1e-12)
 
 
-def test_shard_range_rejects_uneven():
+def test_shard_range_handles_totals_that_do_not_divide():
+    """Contiguous blocks of ceil(total / world) instances; the last rank(s) short or empty."""
     sys.path.insert(0, ROOT)
     from pympc_amd import sharding
-    with pytest.raises(ValueError):
-        sharding.shard_range(10, 0, 4)
+    assert [sharding.shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
+    assert [sharding.shard_range(1024, r, 8) for r in range(8)] == [(128 * r, 128 * (r + 1)) for r in range(8)]
+    assert [sharding.shard_range(5, r, 4) for r in range(4)] == [(0, 2), (2, 4), (4, 5), (5, 5)]
     assert sharding.world() == (0, 1)
+
+
+def _worker_uneven(rank, world_size, port, total, q):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world_size)
+    sys.path.insert(0, ROOT)
+    from pympc_amd import sharding
+    full = _make(total) if rank == 0 else None
+    loc = sharding.scatter_instances(full, {'Ad': (5, 5), 'Bd': (5, 3), 'x0': (5,)}, None, torch.device('cpu'), total=total)
+    lo, hi = sharding.shard_range(total, rank, world_size)
+    assert loc['Ad'].shape == (hi - lo, 5, 5) and loc['x0'].shape == (hi - lo, 5)
+    u = loc['x0'][:, :3] + loc['Ad'][:, 0, :3] * 2.0 + loc['Bd'][:, 4, :]        # something every array enters
+    u_all = sharding.gather_inputs(u, total=total)
+    traj = torch.stack([u + 10.0 * k for k in range(4)])
+    tr_all = sharding.gather_trajectory(traj, total=total)
+    assert tuple(u_all.shape) == (total, 3) and tuple(tr_all.shape) == (4, total, 3)
+    assert torch.equal(tr_all[0], u_all) and torch.equal(tr_all[3], u_all + 30.0) and torch.equal(u_all[lo:hi], u)
+    if rank == 0:
+        q.put(u_all.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_packed_scatter_and_padded_gathers_with_a_short_last_rank_world3():
+    """7 instances over 3 ranks (3, 3, 1): one packed scatter of three arrays, all-gathers padded to 3 rows and trimmed to 7."""
+    total, ws = 7, 3
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_uneven, args=(r, ws, port, total, q)) for r in range(ws)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    full = _make(total)
+    ref = (full['x0'][:, :3] + full['Ad'][:, 0, :3] * 2.0 + full['Bd'][:, 4, :]).numpy()
+    assert np.array_equal(got, ref)
