@@ -28,5 +28,5 @@ for f in range(4):
     run(4, 2, 10, 3, 1, first=f)
 for it in (25, 26, 50, 51, 75):
     run(4, 2, 10, 3, 4, iters=it)
-os.environ['MPCQP_DENSE'] = '0'
+from pympc_amd.solver import forced_settings; forced_settings(backend='sweeps').__enter__()      # (the block sweeps instead of the dense inverse)
 run(4, 2, 10, 3, 4)

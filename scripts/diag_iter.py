@@ -1,9 +1,12 @@
-"""Where do the GPU iterates leave the oracle's?  python scripts/diag_iter.py <golden fixture> [iters...]  (env MPCQP_BCR / MPCQP_DENSE select the backend)"""
+"""Where do the GPU iterates leave the oracle's?  python scripts/diag_iter.py <golden fixture> [iters...]  (BACKEND=sweeps|dense|bcr|bcr8|bcrt in the environment of THIS script forces the backend through mpcqp_settings.backend)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
 import numpy as np
 from util import load_golden, golden_kwargs, apply_attrs
 from pympc_amd import MPCController
+from pympc_amd.solver import forced_settings
+if os.environ.get('BACKEND'):
+    forced_settings(backend=os.environ['BACKEND']).__enter__()
 from oracle.osqp_oracle import OSQP
 name = sys.argv[1]; its = [int(v) for v in sys.argv[2:]] or [1, 2, 3]
 kw = golden_kwargs(load_golden(name))

@@ -1,5 +1,5 @@
 """Phase split of ONE small controller's warm closed loop (cart-pole by default) with a -DMPCQP_RUN_TIMING build:
-MPCQP_LIB=<timing lib> [MPCQP_DENSE=0|1] [NP= NC=] [NX= NU= NP= SEED= : fixtures.random_lti] python scripts/diag_small.py [fixture] [steps]"""
+MPCQP_LIB=<timing lib> [BACKEND=sweeps|dense|bcr|bcr8|bcrt] [NP= NC=] [NX= NU= NP= SEED= : fixtures.random_lti] python scripts/diag_small.py [fixture] [steps]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -7,7 +7,9 @@ from pympc_amd import _lib
 if os.environ.get('MPCQP_LIB'):
     _lib.LIB_PATH = os.path.abspath(os.environ['MPCQP_LIB'])
 from pympc_amd import fixtures
-from pympc_amd.solver import BatchProblem
+from pympc_amd.solver import BatchProblem, forced_settings
+if os.environ.get('BACKEND'):
+    forced_settings(backend=os.environ['BACKEND']).__enter__()
 name = sys.argv[1] if len(sys.argv) > 1 else 'cart_pole'
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 kw = fixtures.random_lti(int(os.environ.get('SEED', '3')), nx=int(os.environ['NX']), nu=int(os.environ['NU']), Np=int(os.environ['NP']), xbox=float(os.environ.get('XBOX', '10'))) if os.environ.get('NX') else getattr(fixtures, name)()

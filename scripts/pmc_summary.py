@@ -21,7 +21,7 @@ for path in sys.argv[2:]:
     with open(path) as f:
         for row in csv.DictReader(f):
             name = row['Kernel_Name'].split('(')[0].replace('void ', '').replace(' ', '').strip()     # full template signature
-            if not name.startswith('k_'):
+            if not name.startswith(('k_', 'w8::k_')):          # (w8::: the 512-thread kernels of mpcqp_w8.hip)
                 continue
             d = res.setdefault(name, collections.defaultdict(lambda: [0, 0.0, 0]))
             a = d[row['Counter_Name']]
