@@ -278,24 +278,33 @@ __device__ __forceinline__ void admm_latw(const Lay &L, const HotPtrs &P, Smem &
         ok[q] = is_x ? s < NR : (a < nx + nu && s < NR - 1);
         const int e = s * nx + a, cu = s * nu + jj;
         pidx[q] = is_x ? e : L.ou + cu; aidx[q] = is_x ? e : L.ri + cu; bidx[q] = is_x ? L.rs + e : L.rdu + nu + cu;
-        pv[q] = pv2[q] = svp[q] = ncq[q] = sve[q] = kap[q] = okap[q] = te[q] = 0.0;
-        loA[q] = hiA[q] = loB[q] = hiB[q] = 0.0;
+        te[q] = 0.0;
+        // (every lane requests everything it may need, at clamped addresses, in one go -- the branches this replaces made a wave walk the state and
+        //  the input lanes' loads one after the other, three memory round trips instead of one -- and keeps what applies to it)
+        const bool live = ok[q], sx = live && is_x && L.soft;
+        const int ip = live ? pidx[q] : 0, ia = live ? aidx[q] : 0, ib = live ? bidx[q] : 0, iq = live ? (is_x ? e : L.n_x + cu) : 0, ie = sx ? L.oe + e : 0;
+        const double g_pv = gx[ip], g_sv = sv[ip], g_q = qv[iq], g_oA = om[ia], g_zA = gz[ia], g_yA = gy[ia], g_oB = om[ib], g_zB = gz[ib], g_yB = gy[ib];
+        const double g_pe = gx[ie], g_se = sv[ie];
+        const int jc = (jj >= 0 && jj < nu) ? jj : 0, ac = a < nx ? a : 0;
+        const double b_x0 = S.x0s[ac], b_xlo = hot[L.oxmin + ac], b_xhi = hot[L.oxmax + ac];
+        const double b_ulo = hot[L.oumin + jc], b_uhi = hot[L.oumax + jc], b_dlo = hot[L.oDumin + jc], b_dhi = hot[L.oDumax + jc];
+        pv[q] = live ? g_pv : 0.0; svp[q] = live ? g_sv : 0.0; ncq[q] = live ? -cc * g_q : 0.0;
         rA[q] = LatRow{0.0, 0.0, 0.0, 1.0}; rB[q] = LatRow{0.0, 0.0, 0.0, 1.0};
-        if (ok[q]) {
-            pv[q] = gx[pidx[q]]; svp[q] = sv[pidx[q]]; ncq[q] = -cc * qv[is_x ? e : L.n_x + cu];
-            lat_row_load(rA[q], gz, gy, om, cc, aidx[q]);
-            lat_row_load(rB[q], gz, gy, om, cc, bidx[q]);
-            if (is_x) {
-                if (L.soft) { pv2[q] = gx[L.oe + e]; sve[q] = sv[L.oe + e]; kap[q] = 1.0 / (cef + sve[q] + rB[q].om); okap[q] = rB[q].om * kap[q]; }
-                loA[q] = hiA[q] = s == 0 ? -S.x0s[a] : 0.0;
-                loB[q] = hot[L.oxmin + a]; hiB[q] = hot[L.oxmax + a];
-            } else {
-                loA[q] = hot[L.oumin + jj]; hiA[q] = hot[L.oumax + jj]; loB[q] = hot[L.oDumin + jj]; hiB[q] = hot[L.oDumax + jj];
-            }
+        if (live) {
+            rA[q].om = g_oA; rA[q].z = g_zA; rA[q].ys = cc * g_yA / g_oA; rA[q].w = g_oA * (g_zA - rA[q].ys);
+            rB[q].om = g_oB; rB[q].z = g_zB; rB[q].ys = cc * g_yB / g_oB; rB[q].w = g_oB * (g_zB - rB[q].ys);
         }
+        pv2[q] = sx ? g_pe : 0.0; sve[q] = sx ? g_se : 0.0;
+        kap[q] = sx ? 1.0 / (cef + g_se + g_oB) : 0.0; okap[q] = sx ? g_oB * kap[q] : 0.0;
+        loA[q] = live ? (is_x ? (s == 0 ? -b_x0 : 0.0) : b_ulo) : 0.0; hiA[q] = live ? (is_x ? (s == 0 ? -b_x0 : 0.0) : b_uhi) : 0.0;
+        loB[q] = live ? (is_x ? b_xlo : b_dlo) : 0.0; hiB[q] = live ? (is_x ? b_xhi : b_dhi) : 0.0;
     }
     const bool u0v = wv == 0 && J == 0 && !is_x && a < nx + nu;      // the first-step rows u_0 - u_{-1} (mpc.py:574): stage 0's inputs
-    if (u0v) lat_row_load(r0, gz, gy, om, cc, L.rdu + jj);
+    {   // (requested by every lane, as above: no second round trip for wave 0 behind the branch)
+        const int i0 = L.rdu + ((jj >= 0 && jj < nu) ? jj : 0);
+        const double o0 = om[i0], z0 = gz[i0], y0 = gy[i0];
+        if (u0v) { r0.om = o0; r0.z = z0; r0.ys = cc * y0 / o0; r0.w = o0 * (z0 - r0.ys); }
+    }
     // neighbours in the flattened input sequence (mpc.py:570): slot a + 1 / a - 1, across the stage boundary at the ends
     const int onext = (jj + 1 < nu) ? 1 : NB - nu + 1, oprev = (jj > 0) ? -1 : -(NB - nu + 1);
     const double selx = is_x ? 1.0 : 0.0, sgnA = is_x ? -1.0 : 1.0;

@@ -186,10 +186,14 @@ __device__ __forceinline__ void begin_body(const Lay &L, const Ptrs &P, const mp
 // no tree over four row types and three variable kinds per visitor call -- and the thread's D, E, q values are fetched together up front
 // instead of one global round trip per item.  Terms are summed in the order the row visitors (mpcqp_qp.h) enumerate them.
 // nrm / vsum as in check_body.  Needs n_x <= 2 NT and n_u <= NT (what the LDS-resident mode is chosen by).
+// NXT / NUT > 0: compile-time nx / nu (the one-workgroup-per-CU latency kernels, which have the registers for the unrolled sums: the same
+// copy inside the four-per-CU kernels' 128 registers measured slower in round 3); 0: from the layout.
+template <int NXT = 0, int NUT = 0>
 __device__ __forceinline__ void check_norms_own(const Ctx &c, const double *X, const double *Z, const double *Y, const double *D, const double *E,
                                                 const double *Qv, double cc, double *nrm, double *vsum) {
     const Lay &L = c.L;
-    const int tid = threadIdx.x, nx = L.nx, nu = L.nu;
+    constexpr int UNR = NXT ? 16 : 4;                  // (compile-time dimensions: the nx-long sums fully unrolled)
+    const int tid = threadIdx.x, nx = NXT ? NXT : L.nx, nu = NUT ? NUT : L.nu;
     const double *Ad = c.Ad(), *Bd = c.Bd();
     auto row = [&](double ax, double z, double e) {
         const double d = ax - z;
@@ -218,14 +222,14 @@ __device__ __forceinline__ void check_norms_own(const Ctx &c, const double *X, c
     for (int j = 0; j < 2; ++j) {
         const int e = tid + NT * j;
         if (e < L.n_x) {
-            const int k = idiv(e, L.rnx), a = e - k * nx;
+            const int k = NXT ? e / (NXT ? NXT : 1) : idiv(e, L.rnx), a = e - k * nx;
             const double xe = X[e], ee = L.soft ? X[L.oe + e] : 0.0;
             double ax = -xe;                                           // dynamics row e  (mpc.py:537-552)
             if (k > 0) {
                 const double *xp = X + (k - 1) * nx, *up = X + L.ou + min(k - 1, L.Nc - 1) * nu;
-#pragma unroll 4
+#pragma unroll UNR
                 for (int i = 0; i < nx; ++i) ax += Ad[a * nx + i] * xp[i];
-#pragma unroll 4
+#pragma unroll UNR
                 for (int i = 0; i < nu; ++i) ax += Bd[a * nu + i] * up[i];
             }
             row(ax, Z[e], eDyn[j]);
@@ -233,11 +237,11 @@ __device__ __forceinline__ void check_norms_own(const Ctx &c, const double *X, c
             const double *Q = (k < L.Np) ? c.Qx() : c.QxN();
             const double *xk = X + k * nx;
             double px = 0.0, aty = -Y[e];
-#pragma unroll 4
+#pragma unroll UNR
             for (int l = 0; l < nx; ++l) px += Q[min(a, l) * nx + max(a, l)] * xk[l];
             if (k < L.Np) {
                 const double *y1 = Y + (k + 1) * nx;
-#pragma unroll 4
+#pragma unroll UNR
                 for (int r = 0; r < nx; ++r) aty += Ad[r * nx + a] * y1[r];
             }
             aty += Y[L.rs + e];
@@ -246,7 +250,7 @@ __device__ __forceinline__ void check_norms_own(const Ctx &c, const double *X, c
         }
     }
     if (vu) {
-        const int k = idiv(cu, L.rnu), jj = cu - k * nu;
+        const int k = NUT ? cu / (NUT ? NUT : 1) : idiv(cu, L.rnu), jj = cu - k * nu;
         const double ut = X[L.ou + cu];
         row(ut, Z[L.ri + cu], eIn);                                    // input box
         double ax = -ut;                                               // Delta-u row nu + cu (mpc.py:570)
@@ -266,7 +270,7 @@ __device__ __forceinline__ void check_norms_own(const Ctx &c, const double *X, c
         const int s_end = (k == L.Nc - 1) ? L.Np : k + 1;            // the last input is held to the end of the horizon
         for (int s = k + 1; s <= s_end; ++s) {
             const double *y1 = Y + s * nx;
-#pragma unroll 4
+#pragma unroll UNR
             for (int r = 0; r < nx; ++r) aty += Bd[r * nu + jj] * y1[r];
         }
         aty += Y[L.ri + cu];
@@ -452,7 +456,11 @@ __device__ __forceinline__ int check_body(const Lay &L, const Ptrs &P, const mpc
 #pragma unroll
     for (int i = 0; i < 11; ++i) nrm[i] = 0.0;
     TICK(10)
-    if (Xl) check_norms_own(c, X, Z, Y, D, E, S.Qv, cc, nrm, vsum);      // (LDS-resident iterate: owner-mapped passes)
+    if (Xl) {                                                             // (LDS-resident iterate: owner-mapped passes)
+        bool done = false;
+        if constexpr (kLatOnly) { if (L.nx == 12 && L.nu == 4) { check_norms_own<12, 4>(c, X, Z, Y, D, E, S.Qv, cc, nrm, vsum); done = true; } }      // (mpcqp_w8.hip: the BASELINE shape unrolled)
+        if (!done) check_norms_own(c, X, Z, Y, D, E, S.Qv, cc, nrm, vsum);
+    }
     else check_norms_gown(c, X, Z, Y, D, E, S.Qv, cc, S.T, S.tv, nrm, vsum);   // (iterate in global memory: staged, then the same passes)
     TICK(12)
     block_reduce<11, 1>(nrm, vsum, S.red);

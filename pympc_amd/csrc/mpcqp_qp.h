@@ -179,10 +179,14 @@ __device__ __forceinline__ double wave_reduce(double v) {
     v = op(v, dpp_move_f64<0x128>(v));           // row_ror:8
     return op(op(readlane_f64(v, 0), readlane_f64(v, 16)), op(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
+// The waves' partial results meet in LDS: thread i < K combines value i over the waves (in wave order: the sums are formed exactly as when
+// every thread did this for all K values itself -- NWAVES x K dependent LDS reads per thread, a fifth of the termination check's reduction at
+// four waves and more at eight) and publishes it; everybody reads K broadcast values.  red: >= (NWAVES + 1) K doubles.
 template <int KMAX, int KSUM>
 __device__ __forceinline__ void block_reduce(double *vmax, double *vsum, double *red) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     constexpr int K = KMAX + KSUM;
+    static_assert((NWAVES + 1) * K <= 16 * NWAVES, "Smem::red holds 16 doubles per wave");
 #pragma unroll
     for (int i = 0; i < KMAX; ++i) vmax[i] = wave_reduce<true>(vmax[i]);
 #pragma unroll
@@ -195,10 +199,18 @@ __device__ __forceinline__ void block_reduce(double *vmax, double *vsum, double 
         for (int i = 0; i < KSUM; ++i) red[wv * K + KMAX + i] = vsum[i];
     }
     __syncthreads();
+    if (threadIdx.x < K) {
+        const int i = threadIdx.x;
+        double v = red[i];
+        if (i < KMAX) { for (int w = 1; w < NWAVES; ++w) v = fmax(v, red[w * K + i]); }
+        else { for (int w = 1; w < NWAVES; ++w) v += red[w * K + i]; }
+        red[NWAVES * K + i] = v;
+    }
+    __syncthreads();
 #pragma unroll
-    for (int i = 0; i < KMAX; ++i) { double v = red[i]; for (int w = 1; w < NWAVES; ++w) v = fmax(v, red[w * K + i]); vmax[i] = v; }
+    for (int i = 0; i < KMAX; ++i) vmax[i] = red[NWAVES * K + i];
 #pragma unroll
-    for (int i = 0; i < KSUM; ++i) { double v = red[KMAX + i]; for (int w = 1; w < NWAVES; ++w) v += red[w * K + KMAX + i]; vsum[i] = v; }
+    for (int i = 0; i < KSUM; ++i) vsum[i] = red[NWAVES * K + KMAX + i];
     __syncthreads();
 }
 
