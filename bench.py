@@ -40,6 +40,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md chip-level parameters (achievable: ~6.3e12)
 HBM_ACHIEVABLE = 6.29e12   # B/s, the same guide's measured streaming rate (float4 copy, 79 % of the spec figure)
+# Whole-chip READ-ONLY streams shaped like the factor stream (1024 workgroups x 4 waves, 32 bytes per lane; scripts/diag/hbm_stream.hip,
+# profiles/r5_hbm_stream.txt): 5.9-6.0 TB/s from HBM (1 and 4 GB buffers), 6.9 TB/s from the Infinity Cache (128 MB); a copy of the same shape 5.0 / 6.2
+HBM_READ_STREAM = 5.95e12
+MALL_READ_STREAM = 6.90e12
 MFMA_F64_PEAK = 78.6e12    # flop/s, FP64 matrix peak of MI355X (AMD datasheet; scripts/diag/mfma_rate.hip: 17 cycles per v_mfma_f64_4x4x4_4b = 74e12 measured)
 INFINITY_CACHE = 256 << 20  # bytes, MI355X_MICROARCH.md (memory-side cache in front of HBM)
 U_ERR_SAMPLE = 32          # instances whose u* is compared with the tight-tolerance CPU reference
@@ -462,11 +466,13 @@ class Shard:
         ev1.record(); torch.cuda.synchronize()
         return ev0.elapsed_time(ev1) / 3
 
-    def working_set_bytes(self):
-        """Bytes the timed loop touches per GPU: every instance's KKT factor, iterate, metric, model and step data."""
+    def working_set_bytes(self, active_instances=None):
+        """Bytes the timed loop touches per GPU: every instance's KKT factor, iterate, metric, model and step data.
+        active_instances: only that many instances are in flight at a time (the device loop: one per resident workgroup slot -- an instance runs
+        its whole K-step closed loop before the slot takes the next one, so the ACTIVE set is what the caches see)."""
         p = self.prob
         per = 8 * (p.factor_doubles + 3 * p.n + 5 * p.m + 2 * (p.n + p.m)) + 8 * 1024
-        return int(per * self.B)
+        return int(per * (self.B if active_instances is None else min(self.B, active_instances)))
 
     @staticmethod
     def tail_split(res, per_iter, per_round, per_solve, check_every=25):
@@ -518,6 +524,12 @@ class Shard:
         ws = self.working_set_bytes()
         NX, NU = self.dims[0], self.dims[1]
         mode = int(kname.split('<')[1].split(',')[4])
+        # resident workgroup slots of the kernel: 4 per CU (16 x 16 sweeps), 2 (32 x 32), 1 (latency kernels, wide stages) x 256 CUs
+        slots = 256 * (1 if (mode >= 100 or mode == 2 or NX + NU > 32) else 4 if NX + NU <= 16 else 2)
+        # what the memory-side cache sees: the instances IN FLIGHT.  An instance re-reads its factor every iteration while it is resident -- for a whole
+        # closed loop on the device-loop path, for a round of 25 iterations per launch on the stepwise one -- so the reuse distance of the stream is one
+        # iteration of the resident instances, not the batch
+        ws_active = self.working_set_bytes(slots)
         if mode >= 100:
             # the latency backend (at most two instances per CU): factor and iterate live in registers, an iteration reads nothing from
             # memory -- the kernel is bound by the matrix cores' issue rate and the dependent level steps, not by HBM
@@ -531,7 +543,7 @@ class Shard:
                     'useful_frac': 0.25 * flops / (admm_ms * 1e-3) / MFMA_F64_PEAK, 'mfma_per_iter_per_qp': mfma,
                     'occupancy_note': '%d instances on %d CUs: one workgroup per CU at a time (%s)' % (self.B, 256, 'w8:: kernels: 512 threads, two waves per SIMD' if kname.startswith('w8::') else '256 threads, one wave per SIMD'),
                     'hbm_design_bytes_per_launch': design_bytes / launches, 'hbm_frac': achieved / HBM_PEAK,
-                    'working_set_bytes': ws, 'fits_infinity_cache': bool(ws <= INFINITY_CACHE),
+                    'working_set_bytes': ws, 'active_working_set_bytes': ws_active, 'fits_infinity_cache': bool(ws_active <= INFINITY_CACHE),
                     'kernel': kname, 'kernel_ms': admm_ms / launches, 'launches': res['launches'], 'steps_per_launch': res.get('chunk', 1)}
         tail = self.tail_split(res, per_iter, per_round, per_solve) if path == 'device_loop' else None
         return {'bound': 'hbm', 'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
@@ -542,7 +554,11 @@ class Shard:
                 'traffic_source': ('from_profile: profiles/pmc_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE per ADMM iteration per QP, profiled at batch %s) x this run\'s iterations per launch'
                                    % (pmc_batch if pmc_batch is not None else 'of the same command')) if pmc_b else None,
                 'traffic_GBps': (traffic / (admm_ms / launches * 1e-3) / 1e9) if traffic else None,
-                'working_set_bytes': ws, 'fits_infinity_cache': bool(ws <= INFINITY_CACHE),
+                'working_set_bytes': ws, 'active_working_set_bytes': ws_active, 'fits_infinity_cache': bool(ws_active <= INFINITY_CACHE),
+                'working_set_note': 'one instance per resident workgroup slot is in flight (%d slots) and re-reads its factor every iteration while it is: the ACTIVE set is what the '
+                                    '256 MiB Infinity Cache sees, whatever the batch (HBM delivers an instance\'s first touch per launch); cfg-5\'s active set (768 MB) is the one beyond it' % slots,
+                'frac_of_read_stream': achieved / (MALL_READ_STREAM if ws_active <= INFINITY_CACHE else HBM_READ_STREAM),
+                'read_stream_GBps': (MALL_READ_STREAM if ws_active <= INFINITY_CACHE else HBM_READ_STREAM) / 1e9,
                 'bytes_model': 'design: what k_mpc_run streams per instance (mpcqp_get_stream_bytes) -- per ADMM iteration the KKT factor '
                                '(%s%s), per round the residual-evaluation inputs and the '
                                'iterate in/out of LDS, per solve the QP refresh and the write-out'
@@ -762,15 +778,26 @@ def main():
             s3 = Shard(args, dims, args.hbm_leg_batch, rank, world, dev, 0, torch, dist)
             r3 = s3.measure(args.path, min(args.steps, 25), min(args.warmup, 25) or 5)
             ro3 = s3.roofline(r3, args.path, 'cfg3_b%d' % args.hbm_leg_batch)
+            # the stepwise API at this batch: every solve walks all the instances (878 MB) -- but 25 iterations at a time, and an instance re-reads its
+            # factor 25 times while it is resident: HBM delivers the first touch, the Infinity Cache the other 24 (active set: 1024 resident instances, 219 MB)
+            r3s = s3.measure('stepwise', min(args.steps, 25), min(args.warmup, 25) or 5)
+            ro3s = s3.roofline(r3s, 'stepwise', None)
             extra['hbm_leg'] = {'batch': args.hbm_leg_batch, 'value': args.hbm_leg_batch * min(args.steps, 25) / r3['elapsed'], 'unit': 'QP-solves/s',
                                 'ms_per_step': 1e3 * r3['elapsed'] / min(args.steps, 25), 'mean_admm_iters': r3['iters'] / max(1, r3['solves']),
                                 'launch_spread': r3.get('launch_spread'),
-                                'roofline': {k: ro3[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'frac_excluding_tail', 'tail', 'frac_of_achievable', 'achievable_GBps', 'traffic', 'traffic_source', 'traffic_GBps',
+                                'stepwise': {'value': args.hbm_leg_batch * min(args.steps, 25) / r3s['elapsed'], 'unit': 'QP-solves/s', 'ms_per_step': 1e3 * r3s['elapsed'] / min(args.steps, 25),
+                                             'mean_admm_iters': r3s['iters'] / max(1, r3s['solves']),
+                                             'roofline': {k: ro3s[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'frac_of_read_stream', 'read_stream_GBps', 'working_set_bytes',
+                                                                               'active_working_set_bytes', 'fits_infinity_cache', 'kernel', 'kernel_ms', 'launches', 'design_bytes_per_launch')}},
+                                'roofline': {k: ro3[k] for k in ('active_working_set_bytes', 'working_set_note', 'frac_of_read_stream', 'read_stream_GBps', 'bound', 'achieved', 'peak', 'unit', 'frac', 'frac_excluding_tail', 'tail', 'frac_of_achievable', 'achievable_GBps', 'traffic', 'traffic_source', 'traffic_GBps',
                                                                  'measured_bytes_per_iter_per_qp', 'design_bytes_per_iter_per_qp', 'working_set_bytes',
                                                                  'fits_infinity_cache', 'kernel', 'kernel_ms', 'design_bytes_per_launch')},
-                                'note': 'frac_of_achievable compares with the guide\'s float4-COPY rate (6.29 TB/s: half reads, half writes, every byte from HBM); this '
-                                        'kernel is a read-only stream (writes < 5 %) of which the counters see every byte (FETCH_SIZE includes Infinity-Cache hits): a value '
-                                        'slightly above 1 says read-only streaming beats a copy, not that the HBM peak was exceeded -- frac (against 8 TB/s) is the claim'}
+                                'note': '4096 instances pass through 1024 resident workgroup slots; an instance re-reads its factor every ADMM iteration while it is resident, so the stream '
+                                        're-reads an ACTIVE set of 219 MB whatever the batch -- inside the 256 MiB Infinity Cache, like the headline (rounds 2-4 called this leg "HBM-only": it is '
+                                        'not; what the larger batch removes is the idle tail, finished slots refill).  `stepwise` walks all 878 MB per solve, 25 iterations per launch: HBM serves '
+                                        'the first of them.  frac_of_read_stream compares with a whole-chip READ-ONLY stream of the same shape from the same place (profiles/r5_hbm_stream.txt: '
+                                        '6.9 TB/s from the Infinity Cache, 5.95 TB/s from HBM); frac is against the 8 TB/s HBM peak either way.  The leg whose active set (768 MB) IS beyond the '
+                                        'Infinity Cache is cfg5_leg'}
             del s3
             torch.cuda.empty_cache()
         if world == 1 and args.workload == 'cfg3' and args.cfg5_leg_batch:
@@ -840,7 +867,11 @@ def main():
                     'critical_path_ratio': sp.get('critical_path_ratio'), 'ms_per_step': leg.get('ms_per_step')}
         legs = {}
         if 'hbm_leg' in extra:
-            legs['hbm_b%d' % extra['hbm_leg']['batch']] = compact(extra['hbm_leg'])
+            sw = extra['hbm_leg']['stepwise']
+            legs['hbm_b%d' % extra['hbm_leg']['batch']] = dict(compact(extra['hbm_leg']), fits_infinity_cache=extra['hbm_leg']['roofline']['fits_infinity_cache'],
+                                                             frac_of_read_stream=extra['hbm_leg']['roofline']['frac_of_read_stream'],
+                                                             stepwise_value=sw['value'], stepwise_frac=sw['roofline']['frac'], stepwise_frac_of_read_stream=sw['roofline']['frac_of_read_stream'],
+                                                             stepwise_fits_infinity_cache=sw['roofline']['fits_infinity_cache'], stepwise_kernel_ms=sw['roofline']['kernel_ms'])
         if 'cfg5_leg' in extra:
             legs['cfg5_b%d' % extra['cfg5_leg']['batch']] = dict(compact(extra['cfg5_leg']), parity_setting_value=extra['cfg5_leg']['parity_setting']['value'])
         for k, v in (extra.get('small_batch_legs') or {}).items():

@@ -1015,8 +1015,8 @@ extern "C" int mpcqp_get_stream_bytes(mpcqp_handle *h, int64_t *per_iter, int64_
     int64_t rd = (L.model_sz - L.hot_sz) + 2 * n + 2 * m /* D, s, E, omega */ + n + m /* dx, dy */;
     if (L.dense) rd += DenseFmt::DOUBLES;               // the round's load of K^-1 into registers
     if (L.bcr && !L.bcrtop) rd += (int64_t)L.bcr * BcrFmt::REC - 4 * BcrFmt::NN;      // ... of the cyclic-reduction fragments (the two end stages have one neighbour)
-    if (L.bcrtop) {                                     // ... of levels 0 and 1 and of the top inverse
-        int64_t fr = (int64_t)L.bcrtop * L.bcrtop;
+    if (L.bcrtop) {                                     // ... of levels 0 and 1 (the top inverse and G, G' enter LDS once per LAUNCH: admm_latw)
+        int64_t fr = 0;
         for (int l = 0; l < 2; ++l) for (int kind = 0; kind < 3; ++kind) for (int t = 0; t < lat_count(L.bcr, l, kind); ++t) fr += lat_nfr(L.bcr, l, kind, t);
         rd += fr * BcrFmt::NN;
     }
