@@ -547,7 +547,7 @@ int mpcqp_iterate(mpcqp_handle *h, int iters) {
 }
 /* the equality-constrained part by multiplier sweeps: with the settings the caller gives such a handle (alpha = 1, fixed rho, all
  * inequality bounds infinite) one ADMM iteration of the oracle IS one sweep; an instance stops once a sweep moves x by less than
- * tol * max(1, |x|); the residuals are not evaluated here (zeros) */
+ * tol * max(1, |x|); the four residual norms are evaluated on the instance's own P and A as the device does (k_eq_solve) */
 int mpcqp_eq_solve(mpcqp_handle *h, int sweeps, int cold, double tol, double *res) {
     if (!h || sweeps < 0) return fail(MPCQP_ERR_ARG, "mpcqp_eq_solve: bad argument");
     if (!h->is_setup) return fail(MPCQP_ERR_STATE, "mpcqp_eq_solve before mpcqp_setup");
@@ -571,7 +571,33 @@ int mpcqp_eq_solve(mpcqp_handle *h, int sweeps, int cold, double tol, double *re
         for (size_t i = 0; i < m; ++i) h->ys[(size_t)b * m + i] = E[i] * ys[i] / cc;
         mpcqp_info *inf = &h->info[b];
         inf->status = (tol > 0.0 && !settled) ? MPCQP_MAX_ITER_REACHED : MPCQP_SOLVED; inf->iter = done; inf->rho_updates = 0; inf->reserved = 0; inf->obj_val = 0.0; inf->pri_res = 0.0; inf->dua_res = 0.0; inf->rho = rho;
-        if (res) { double *r = res + (size_t)b * 5; r[0] = 0.0; r[1] = 1.0; r[2] = 0.0; r[3] = 1.0; r[4] = (double)done; }
+        if (res) {
+            /* the four KKT norms of the EQUALITY-constrained problem as the device reports them (k_eq_solve): |P x + q + A_e' y|, max(|P x|, |A_e' y|, |q|),
+             * |A_e x - b|, max(|A_e x|, |b|) over the dynamics rows (the first n_x), on the unscaled solution, from the instance's own P and A */
+            double *r = res + (size_t)b * 5; r[0] = 0.0; r[1] = 1.0; r[2] = 0.0; r[3] = 1.0; r[4] = (double)done;
+            if (!h->generic && h->Pp) {
+                const int64_t ne = h->d.rs;                               /* dynamics rows: 0 .. n_x - 1 */
+                double *Pv = (double *)malloc(sizeof(double) * (size_t)(h->nnzP ? h->nnzP : 1)), *Av = (double *)malloc(sizeof(double) * (size_t)(h->nnzA ? h->nnzA : 1));
+                double *px = dcalloc(n), *aty = dcalloc(n), *ax = dcalloc(m);
+                const double *x = h->xs + (size_t)b * n, *y = h->ys + (size_t)b * m, *q = h->q + (size_t)b * n, *lo = h->l + (size_t)b * m;
+                build_values(h, b, Pv, Av);
+                for (size_t c = 0; c < n; ++c) {
+                    for (int64_t k = h->Pp[c]; k < h->Pp[c + 1]; ++k) {      /* upper triangle: both halves */
+                        const int64_t i = h->Pi[k];
+                        px[i] += Pv[k] * x[c]; if (i != (int64_t)c) px[c] += Pv[k] * x[i];
+                    }
+                    for (int64_t k = h->Ap[c]; k < h->Ap[c + 1]; ++k) {
+                        const int64_t i = h->Ai[k];
+                        if (i < ne) { ax[i] += Av[k] * x[c]; aty[c] += Av[k] * y[i]; }
+                    }
+                }
+                double n0 = 0.0, n1 = 0.0, n2 = 0.0, n3 = 0.0;
+                for (size_t j = 0; j < n; ++j) { n0 = fmax(n0, fabs(px[j] + q[j] + aty[j])); n1 = fmax(n1, fmax(fabs(px[j]), fmax(fabs(aty[j]), fabs(q[j])))); }
+                for (int64_t i = 0; i < ne; ++i) { n2 = fmax(n2, fabs(ax[i] - lo[i])); n3 = fmax(n3, fmax(fabs(ax[i]), fabs(lo[i]))); }
+                r[0] = n0; r[1] = n1; r[2] = n2; r[3] = n3;
+                free(Pv); free(Av); free(px); free(aty); free(ax);
+            }
+        }
     }
     free(D); free(E); free(xs); free(zs); free(ys); free(xp);
     return MPCQP_OK;

@@ -198,3 +198,38 @@ def test_auto_selected_latency_backend_at_per_gpu_batches_matches_oracle(B):
                 assert np.abs(tr['u'][k, i] - uo).max() <= 1e-7 * max(1e-3, np.abs(uo).max()), (B, i, k)
                 Ko.update(tr['x'][k + 1, i], tr['u'][k, i])
                 assert (Ko.res.info.iter, Ko.res.info.status_val) == (tr['iter'][k, i], tr['status'][k, i]), (B, i, k)
+
+
+@pytest.mark.parametrize('rho', [0.1, 3.8e4])
+@pytest.mark.parametrize('name', ['random_20_8_100', 'random_12_4_30', 'cart_pole_kalman'])
+def test_kkt_solve_backward_error_also_at_the_rho_a_tight_state_box_drives_it_to(name, rho):
+    """cfg-5's tight state box drives OSQP's rho to ~ 4e4 (rho_eq / sigma = 4e13): there a double-precision KKT solve is only as accurate in the
+    FORWARD sense as the tolerance itself, which is why the closed-loop comparison above allows those instances' iteration counts to differ by
+    a round.  What must hold at ANY rho is the backward error of the device's solve -- the residual of K sol = rhs on the reference-built
+    matrices, relative to |K| |sol| + |rhs| -- so a factorization or refactorization defect at high rho cannot hide behind that allowance."""
+    import scipy.sparse as sp
+    from pympc_amd import MPCController
+    from util import load_golden, golden_kwargs, golden_csc, apply_attrs
+    g = load_golden(name)
+    K = apply_attrs(MPCController(**golden_kwargs(g)), golden_kwargs(g))
+    K.solver_settings = dict(rho=rho, adaptive_rho=0)
+    K.setup(solve=False)
+    bp = K.prob.batch_problem
+    D, E, c, rho_dev = bp.scaling()
+    assert abs(rho_dev[0] - rho) <= 1e-12 * rho
+    U = sp.triu(golden_csc(g, 'P')).tocsc(); P = U + sp.triu(U, 1).T
+    A = golden_csc(g, 'A').tocsc()
+    l, u = np.clip(g['l'], -1e30, 1e30), np.clip(g['u'], -1e30, 1e30)
+    ls, us = E[0] * l, E[0] * u
+    rho_vec = np.where((ls < -1e26) & (us > 1e26), 1e-6, np.where(us - ls < 1e-4, 1e3 * rho, rho))
+    Kmat = (c[0] * P + sp.diags(1e-6 / D[0] ** 2) + A.T @ sp.diags(rho_vec * E[0] ** 2) @ A).tocsr()
+    rng = np.random.default_rng(9)
+    for _ in range(3):
+        rhs = rng.standard_normal(P.shape[0])
+        sol = bp.kkt_solve(rhs[None])[0]
+        assert np.isfinite(sol).all()
+        back = np.abs(Kmat @ sol - rhs).max() / (abs(Kmat).dot(np.abs(sol)).max() + np.abs(rhs).max())
+        assert back <= 1e-12, (name, rho, back)
+    bp.refactor(); bp.synchronize()                                       # the factorization run from inside k_mpc_run must do as well
+    sol = bp.kkt_solve(rhs[None])[0]
+    assert np.abs(Kmat @ sol - rhs).max() / (abs(Kmat).dot(np.abs(sol)).max() + np.abs(rhs).max()) <= 1e-12
