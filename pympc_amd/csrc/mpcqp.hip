@@ -310,6 +310,12 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
                             && !(h->S.tuning & MPCQP_TUNE_NO_LSTAGE);
         h->L.lstage = lstage ? 1 : 0;
         if (lstage) h->smem_setup += sizeof(double) * stage_doubles;
+        // ... and of those, the reference's cart pole on grouped stages (its notebook (4,1,150,75) and Kalman (4,1,200,200) examples) runs the
+        // 512-thread instantiation of the same kernel (mpcqp_w8.hip): eight waves for the owner passes that are half of its iteration
+        if (lstage && h->L.grp > 1 && L.nx == 4 && L.nu == 1 && !(h->S.tuning & MPCQP_TUNE_NO_W8)) {
+            h->smem_setup += sizeof(double) * 16 * (8 - h->L.nw);      // (the reduction scratch grows with the waves: smem_common)
+            h->L.nw = 8;
+        }
     }
     h->smem_solve = h->smem_setup;
     if (h->smem_solve > 160 * 1024) { mpcqp_destroy(h); return fail(MPCQP_ERR_UNSUPPORTED, "problem too large for one workgroup's LDS"); }
@@ -634,6 +640,11 @@ static int launch_run(mpcqp_handle *h, RunArgs R, int plain_iters) {
     }
     int rc;
     if (L.dense) rc = launch_run_t<16, true, 0, 0, MODE_DENSE>(h, R);
+    else if (!L.bcr && L.nw == 8) {                 // 512-thread workgroups (the reference's cart pole on a long horizon): the other translation unit
+        RunKArgs A; A.L = h->L; A.P = h->P; A.S = h->S; A.R = R;
+        rc = mpcqp_w8_launch(&A, sizeof(A), L.border, 0, R.nsteps > 0, h->batch, h->smem_solve, h->stream);
+        if (rc) return fail(MPCQP_ERR_HIP, "mpcqp_w8_launch failed");
+    }
     else if (L.bcr && L.nw == 8) {                  // 512-thread workgroups: the other translation unit
         RunKArgs A; A.L = h->L; A.P = h->P; A.S = h->S; A.R = R;
         rc = mpcqp_w8_launch(&A, sizeof(A), L.bcr == 31 && L.nx == 12 && L.nu == 4, L.bcr, R.nsteps > 0, h->batch, h->smem_solve, h->stream);

@@ -99,14 +99,14 @@ __device__ __forceinline__ void border_pre_few(const Lay &L, const double *Bb, c
 #pragma unroll
         for (int j = 0; j < NU; ++j) red[(tid >> 6) * NU + j] = part[j];
     }
-    if (tid < NU) red[4 * NU + tid] = Tc[slot + tid];
+    if (tid < NU) red[NWAVES * NU + tid] = Tc[slot + tid];
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < NU; ++j) {
         double v = red[j];
 #pragma unroll
         for (int w = 1; w < NWAVES; ++w) v += red[w * NU + j];
-        part[j] = red[4 * NU + j] - v;                                                   // r2 - Z' r1
+        part[j] = red[NWAVES * NU + j] - v;                                              // r2 - Z' r1
     }
 #pragma unroll
     for (int i = 0; i < NU; ++i) {

@@ -67,9 +67,11 @@ __device__ __forceinline__ bool grp_dead(const Lay &L, int g, int K, int A) {
 // Factorization: one super-stage at a time by the whole workgroup (one entry per thread), twisted order.  W: LDS, 5 * 256 doubles.
 __device__ __forceinline__ int factor_group(const Ctx &c, const double *om, const double *sv, double cc, double *F, double *W, int *iflag) {
     constexpr int NN = GroupFmt::NN, NB = 16;
-    static_assert(kLatOnly || NT == NN, "one entry of a 16 x 16 block per thread");
+    static_assert(NT >= NN, "one entry of a 16 x 16 block per thread (threads beyond 256 -- the 512-thread kernels of mpcqp_w8.hip -- only keep the barriers company)");
     const Lay &L = c.L;
-    const int g = L.grp, NS = group_count(L.N, g), mid = NS / 2, tid = threadIdx.x, A = tid / NB, B = tid % NB;
+    const int g = L.grp, NS = group_count(L.N, g), mid = NS / 2, tid = threadIdx.x;
+    const bool on = tid < NN;                                   // this thread owns an entry
+    const int et = on ? tid : 0, A = et / NB, B = et % NB;
     double *S = W, *C = W + NN, *Mh = W + 2 * NN, *SnA = W + 3 * NN, *SnB = W + 4 * NN;
     if (tid == 0) *iflag = 0;
     // omega and s through an LDS copy behind the work matrices where the work area holds them (every entry of a block reads several of them,
@@ -83,29 +85,31 @@ __device__ __forceinline__ int factor_group(const Ctx &c, const double *om, cons
     __syncthreads();
     // one stage: S_K and its inverse; rec: where -Mh / -Mh' of the neighbour above (up) or below go
     auto stage = [&](int K, const double *SnU, const double *SnD, double *SnOut, double *recU, double *recD) {
-        S[tid] = grp_diag_entry(c, om, sv, cc, g, K, A, B);
+        if (on) S[tid] = grp_diag_entry(c, om, sv, cc, g, K, A, B);
         for (int side = 0; side < 2; ++side) {
             const double *Sn = side == 0 ? SnU : SnD;
             double *rec = side == 0 ? recU : recD;
             if (!Sn) continue;                                      // (uniform)
             __syncthreads();
-            C[tid] = side == 0 ? grp_sub_entry(c, om, cc, g, K, A, B) : grp_sub_entry(c, om, cc, g, K + 1, B, A);      // K_{K,K-1} / K_{K,K+1} = K_{K+1,K}'
+            if (on) C[tid] = side == 0 ? grp_sub_entry(c, om, cc, g, K, A, B) : grp_sub_entry(c, om, cc, g, K + 1, B, A);      // K_{K,K-1} / K_{K,K+1} = K_{K+1,K}'
             __syncthreads();
             double acc = 0.0;
 #pragma unroll
             for (int l = 0; l < NB; ++l) acc = fma(C[A * NB + l], Sn[l * NB + B], acc);
-            Mh[tid] = acc;
-            rec[GroupFmt::OMH + frag_pos<NB>(A, B)] = -acc;
-            rec[GroupFmt::OMHT + frag_pos<NB>(B, A)] = -acc;
+            if (on) {
+                Mh[tid] = acc;
+                rec[GroupFmt::OMH + frag_pos<NB>(A, B)] = -acc;
+                rec[GroupFmt::OMHT + frag_pos<NB>(B, A)] = -acc;
+            }
             __syncthreads();
             double sub = 0.0;
 #pragma unroll
             for (int l = 0; l < NB; ++l) sub = fma(Mh[A * NB + l], C[B * NB + l], sub);
-            S[tid] -= sub;
+            if (on) S[tid] -= sub;
         }
         __syncthreads();
         // in-place Gauss-Jordan inversion (SPD block; step p reads the matrix step p-1 wrote and writes the other buffer: one barrier per step)
-        double cur = S[tid];
+        double cur = S[et];
         for (int pv = 0; pv < NB; ++pv) {
             const double *Sr = (pv & 1) ? C : S;
             double *Sw = (pv & 1) ? S : C;
@@ -116,13 +120,15 @@ __device__ __forceinline__ int factor_group(const Ctx &c, const double *om, cons
             const bool rowp = A == pv, colp = B == pv;
             const double off = rowp ? rpj * inv : fma(-t, rpj, cur), onp = rowp ? inv : -t;
             cur = colp ? onp : off;
-            Sw[tid] = cur;
+            if (on) Sw[tid] = cur;
             __syncthreads();
         }
         const double sym = 0.5 * (S[A * NB + B] + S[B * NB + A]);
         __syncthreads();
-        SnOut[tid] = sym;
-        F[(size_t)K * GroupFmt::REC + GroupFmt::OSINV + frag_pos<NB>(A, B)] = (grp_dead(L, g, K, A) || grp_dead(L, g, K, B)) ? 0.0 : sym;
+        if (on) {
+            SnOut[tid] = sym;
+            F[(size_t)K * GroupFmt::REC + GroupFmt::OSINV + frag_pos<NB>(A, B)] = (grp_dead(L, g, K, A) || grp_dead(L, g, K, B)) ? 0.0 : sym;
+        }
         __syncthreads();
     };
     auto rec = [&](int K) { return F + (size_t)K * GroupFmt::REC; };

@@ -108,8 +108,9 @@ __device__ __noinline__ void run_factor_phase(int *frame_pin) {
     RunSmem r = run_smem<false>(L, P);                       // (the common LDS area comes first in both layouts)
     const int b = inst_of(P.perm);
     Ctx c{L, r.S.hot, P.model + (size_t)b * L.model_sz + L.hot_sz};
-    if constexpr (kLatOnly) {                                // (mpcqp_w8.hip: cyclic-reduction handles only)
-        factor_bcr(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], P.F + (size_t)b * P.fsz, P.bws + (size_t)b * L.bcr * BcrFmt::WSTAGE, r.S.T, r.S.iflag);
+    if constexpr (kLatOnly) {                                // (mpcqp_w8.hip: cyclic-reduction handles, or grouped small stages)
+        if (L.bcr) factor_bcr(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], P.F + (size_t)b * P.fsz, P.bws + (size_t)b * L.bcr * BcrFmt::WSTAGE, r.S.T, r.S.iflag);
+        else factor_grouped(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], P.F + (size_t)b * P.fsz, r.S.T, r.S.iflag, border_ptrs(L, P, r.S));
         return;
     }
     if (NB == 16 && L.dense) factor_dense(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], P.F + (size_t)b * P.fsz, r.S.T, r.S.iflag);      // (the register-resident backends: 16 x 16 stages only)
@@ -158,7 +159,7 @@ __device__ __noinline__ int run_check_phase(int iter, int mode, int *frame_pin) 
     return check_body<NB, OCC>(A.L, A.P, A.S, r.S, __builtin_amdgcn_readfirstlane(iter), __builtin_amdgcn_readfirstlane(mode), r.X, r.Z, r.Y);
 }
 
-constexpr int run_occupancy(int NB, int MODE) { return (MODE == MODE_DENSE || MODE >= MODE_BCR || NB > 32) ? 1 : NB <= 16 ? 4 : 2; }      // workgroups per CU
+constexpr int run_occupancy(int NB, int MODE) { return (NT > 256 || MODE == MODE_DENSE || MODE >= MODE_BCR || NB > 32) ? 1 : NB <= 16 ? 4 : 2; }      // workgroups per CU (512-thread kernels: one, two waves per SIMD)
 template <int NB, bool LDSSTATE, int NXT, int NUT, int MODE, bool LOOP>
 __global__ __launch_bounds__(NT, run_occupancy(NB, MODE)) void k_mpc_run(RunKArgs A_) {
     constexpr int OCC = run_occupancy(NB, MODE);
