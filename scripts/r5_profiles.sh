@@ -12,4 +12,4 @@ bash scripts/profile_counters.sh r5b128 cfg3 --batch 128 > $O/r5_profile_b128.lo
 bash scripts/profile_counters.sh r5 cfg5 --steps 50 --warmup 25 > $O/r5_profile_cfg5.log 2>&1
 bash scripts/pmc_sq.sh r5b128 128 > $O/r5_sq_b128.log 2>&1
 bash scripts/pmc_sq.sh r5b256 256 > $O/r5_sq_b256.log 2>&1
-tail -3 $O/r5_profile_cfg3.log $O/r5_profile_b4096.log $O/r5_profile_b256.log $O/r5_profile_b128.log $O/r5_profile_cfg5.log; tail -12 $O/r5_sq_b128.log; cat $O/r5_hbm_stream.txt
+for f in cfg3 b4096 b256 b128 cfg5; do tail -n 3 $O/r5_profile_$f.log; done; tail -n 12 $O/r5_sq_b128.log; cat $O/r5_hbm_stream.txt
