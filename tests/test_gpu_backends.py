@@ -225,3 +225,24 @@ def test_cyclic_reduction_device_loop_is_the_stepwise_api(tag):
             out[t] = tr
     assert (out[tag]['status'] == 1).all()
     assert np.abs(out[tag]['u'] - out['sweeps']['u']).max() <= 1e-7 * max(1.0, np.abs(out['sweeps']['u']).max())
+
+
+@pytest.mark.parametrize('tag', ['bcr', 'bcr8', 'bcrt'])
+@pytest.mark.parametrize('name', ['random_12_4_30', 'quadcopter', 'cart_pole', 'random_12_4_30_hard'])
+def test_refactorization_inside_the_cyclic_reduction_kernels_reproduces_the_setup_factor(name, tag):
+    """The factorization run from inside k_mpc_run (mpcqp_refactor: what a rho update does) -- at 512 threads in mpcqp_w8.hip, with the dense top
+    inverted in the LDS of the solve kernel -- must give the factor k_setup gave at 256 threads: the KKT solve before and after agrees to rounding
+    (every schedule: 31, 11 and 21 stages; soft and hard state box)."""
+    g = load_golden(name)
+    with backend(backend=tag), warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        K = _ctrl(golden_kwargs(g)); K.setup(solve=False)
+        bp = K.prob.batch_problem
+        rhs = np.random.default_rng(2).standard_normal((1, bp.n))
+        s0 = bp.kkt_solve(rhs)
+        bp.refactor(); bp.synchronize()
+        s1 = bp.kkt_solve(rhs)
+        assert np.isfinite(s1).all()
+        assert np.abs(s0 - s1).max() <= 1e-12 * np.abs(s0).max()
+        K2 = _ctrl(golden_kwargs(g)); K2.setup()              # ... and a cold solve with its rho updates ends 'solved' with finite numbers
+        assert K2.res.info.status == 'solved' and np.isfinite(K2.res.x).all()
