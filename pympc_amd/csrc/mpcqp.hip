@@ -16,13 +16,15 @@
 //     cores (v_mfma_f64_4x4x4_4b_f64, stage output registers = next stage's B operand), all waves run the
 //     stage-parallel parts.
 //
-//   - that is the bandwidth backend (any size, large batches).  Three more KKT backends, chosen per handle at mpcqp_create (DESIGN.md
-//     section 3): an explicit K^-1 held in registers for the reference's own small examples (mpcqp_dense.h, mpcqp_tiny.h), block
-//     cyclic reduction with the whole factor resident in the register files for the BASELINE shape at small batches (mpcqp_bcr.h,
-//     mpcqp_lat.h), and a plain vector-ALU block LDL' for stages wider than 32 (mpcqp_wide.h).
+//   - that is the bandwidth backend (any size, large batches).  Further KKT backends, chosen per handle at mpcqp_create (DESIGN.md
+//     section 3): block cyclic reduction with the factor resident on the compute unit for 16 x 16 stages at small batches -- on 512-thread
+//     workgroups with a dense top (mpcqp_latw.h, compiled in mpcqp_w8.hip; mpcqp_bcr.h, mpcqp_lat.h: the 256-thread original) --, an explicit K^-1
+//     held in registers for the reference's own small examples (mpcqp_dense.h, mpcqp_tiny.h), grouped small stages for long horizons
+//     (mpcqp_group.h), and plain vector-ALU block LDL' for stages wider than 32 (mpcqp_wide.h, mpcqp_huge.h).
 //
 // This file: host side and C ABI (include/mpcqp.h).  Device code: mpcqp_layout.h, mpcqp_qp.h, mpcqp_factor.h, mpcqp_sweeps.h,
-// mpcqp_bcr.h, mpcqp_wide.h, mpcqp_dense.h, mpcqp_border.h, mpcqp_phases.h, mpcqp_tiny.h, mpcqp_lat.h, mpcqp_kernels.h; host only:
+// mpcqp_group.h, mpcqp_bcr.h, mpcqp_wide.h, mpcqp_huge.h, mpcqp_dense.h, mpcqp_border.h, mpcqp_phases.h, mpcqp_tiny.h, mpcqp_lat.h, mpcqp_latw.h,
+// mpcqp_kernels.h (the last block also compiled at 512 threads per workgroup by mpcqp_w8.hip); host only:
 // mpcqp_csc.h (one translation unit).
 //
 // FP64 throughout.  No CPU fallback exists in this library.
@@ -243,7 +245,7 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     h->L.dense = dense ? 1 : 0;
     if (dense) h->L.tsz += DenseFmt::SCRATCH;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->ncu = prop.multiProcessorCount; }
-    // Up to two instances per compute unit (one resident, one queued): the latency backend (block cyclic reduction, factor resident in registers) for
+    // Up to three instances per compute unit (one resident, the others queued): the latency backend (block cyclic reduction, factor resident on the compute unit) for
     // 16 x 16 stages and horizons of up to 30 steps -- the BASELINE shape (12, 4, 30) with compile-time dimensions, anything else with nx + nu <= 16 through
     // the generic instantiations.  Larger batches stream the chain format (the bandwidth backend).
     const bool bcr_shape = !dense && h->lds_state && L.NB == 16 && !L.border && bcr_schedule(L.N) > 0;

@@ -1,5 +1,5 @@
 // mpcqp_lat.h -- part of libmpcqp_hip (included by mpcqp.hip, one translation unit).
-// The LATENCY round of 16 x 16 stages (MODE_BCR + N: at most two instances per compute unit; any nx + nu <= 16 and up to 31 stages, the BASELINE
+// The LATENCY round of 16 x 16 stages on 256-thread workgroups (MODE_BCR + N: forced only since round 5 -- AUTO runs mpcqp_latw.h; any nx + nu <= 16 and up to 31 stages, the BASELINE
 // shape (12, 4, 30) with compile-time dimensions):
 // block cyclic reduction with the factor resident in registers (mpcqp_bcr.h), the iterate resident in registers, the
 // products with [Ad Bd] on the matrix cores.
