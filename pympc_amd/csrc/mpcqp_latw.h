@@ -78,8 +78,15 @@ __device__ __forceinline__ void latw_load(const double *F, d4 *fr) {
 // LDS vectors of the round (stage-major, stride 16; mpcqp_lat.h): tb right-hand side / solution, cb c_e of the reduction -- and, at the top stages'
 // slots, the top's solution until level 1 back has copied it into tb; each seen through the lane bases of the four block rotations.
 struct LatwVecs { double *tb, *cb; const double *t1, *t2, *t3, *c1, *c2, *c3; };
+#ifndef LATW_IN_DPP
+#define LATW_IN_DPP 0              // 1: one LDS read per input vector and three DPP block rotations instead of four reads (measured: see LAB_NOTES.md)
+#endif
 template <bool FROMC>
 __device__ __forceinline__ void latw_mv_lds(const d4 a, const LatwVecs &v, int off, double &p, double &q) {
+#if LATW_IN_DPP
+    lat_mv(a, FROMC ? v.cb[off] : v.tb[off], p, q);
+    return;
+#endif
     const double i0 = FROMC ? v.cb[off] : v.tb[off], i1 = FROMC ? v.c1[off] : v.t1[off], i2 = FROMC ? v.c2[off] : v.t2[off], i3 = FROMC ? v.c3[off] : v.t3[off];
     p = __builtin_amdgcn_mfma_f64_4x4x4f64(a[0], i0, p, 0, 0, 0);
     q = __builtin_amdgcn_mfma_f64_4x4x4f64(a[2], i2, q, 0, 0, 0);

@@ -246,3 +246,25 @@ def test_refactorization_inside_the_cyclic_reduction_kernels_reproduces_the_setu
         assert np.abs(s0 - s1).max() <= 1e-12 * np.abs(s0).max()
         K2 = _ctrl(golden_kwargs(g)); K2.setup()              # ... and a cold solve with its rho updates ends 'solved' with finite numbers
         assert K2.res.info.status == 'solved' and np.isfinite(K2.res.x).all()
+
+
+def test_launch_times_bracket_every_step_of_the_device_loop():
+    """mpcqp_get_launch_times: per instance, entry <= end of step 0 <= ... <= end of step K-1 <= exit on one clock (100 MHz), exits within the
+    HIP-event duration of the launch -- what bench.py's tail split (roofline.frac_excluding_tail) is computed from."""
+    from pympc_amd import fixtures
+    from test_gpu_parity import _stacked_batch
+    B, K_STEPS = 40, 8
+    K = _stacked_batch([fixtures.random_lti(2000 + i) for i in range(B)]); K.setup()
+    bp = K.prob
+    bp.profile(enable=True, reset=True)
+    tr = K.run(K_STEPS)
+    ms, launches = bp.profile(enable=False)
+    t = bp.launch_times(K_STEPS).astype(np.int64)
+    assert t.shape == (B, 2 + K_STEPS) and launches == 1
+    seq = np.concatenate([t[:, :1], t[:, 2:], t[:, 1:2]], axis=1)          # entry, step ends, exit
+    assert (np.diff(seq, axis=1) >= 0).all() and (t[:, 0] > 0).all()
+    span_ms = (t[:, 1].max() - t[:, 0].min()) * 1e-5                       # 10 ns ticks
+    assert 0.0 < span_ms <= ms * 1.05 + 0.05, (span_ms, ms)
+    assert (tr['status'] == 1).all()
+    with pytest.raises(RuntimeError):
+        bp.launch_times(65)                                                 # at most 64 step stamps are kept
