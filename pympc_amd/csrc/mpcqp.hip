@@ -608,10 +608,13 @@ static int rebalance(mpcqp_handle *h) {
     std::vector<int> order(B), perm(B);
     for (int i = 0; i < B; ++i) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return h->work_ema[a] > h->work_ema[b]; });
+    // One workgroup per compute unit at a time (the latency kernels, wide stages): workgroups start in index order as compute units come
+    // free, so the map is the longest-expected-work-first list -- the classic greedy schedule, makespan within one instance of the mean.
+    const bool one_at_a_time = h->L.bcr || h->L.dense || h->L.NB > 32 || h->L.nw == 8;
     const int full_rows = B / ncu;
     for (int j = 0; j < B; ++j) {
         const int row = j / ncu, pos = j % ncu;
-        const bool reversed = (row & 1) && row < full_rows;            // a partial last row keeps forward order
+        const bool reversed = !one_at_a_time && (row & 1) && row < full_rows;      // a partial last row keeps forward order
         perm[row * ncu + (reversed ? ncu - 1 - pos : pos)] = order[j];
     }
     HIPCHK(hipMemcpyAsync(h->perm_dev, perm.data(), sizeof(int) * (size_t)B, hipMemcpyHostToDevice, h->stream));
