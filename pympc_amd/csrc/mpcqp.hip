@@ -312,9 +312,10 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
                             && !(h->S.tuning & MPCQP_TUNE_NO_LSTAGE);
         h->L.lstage = lstage ? 1 : 0;
         if (lstage) h->smem_setup += sizeof(double) * stage_doubles;
-        // ... and of those, the reference's cart pole on grouped stages (its notebook (4,1,150,75) and Kalman (4,1,200,200) examples) runs the
-        // 512-thread instantiation of the same kernel (mpcqp_w8.hip): eight waves for the owner passes that are half of its iteration
-        if (lstage && h->L.grp > 1 && L.nx == 4 && L.nu == 1 && !(h->S.tuning & MPCQP_TUNE_NO_W8)) {
+        // ... and of those, the ones on grouped stages (nx + nu <= 8 on a long horizon: the reference's notebook (4,1,150,75) and Kalman (4,1,200,200)
+        // examples with compile-time dimensions, anything else generically) run the 512-thread instantiation of the same kernel (mpcqp_w8.hip):
+        // eight waves for the owner passes that are half of their iteration
+        if (lstage && h->L.grp > 1 && !(h->S.tuning & MPCQP_TUNE_NO_W8)) {
             h->smem_setup += sizeof(double) * 16 * (8 - h->L.nw);      // (the reduction scratch grows with the waves: smem_common)
             h->L.nw = 8;
         }
@@ -645,7 +646,7 @@ static int launch_run(mpcqp_handle *h, RunArgs R, int plain_iters) {
     }
     int rc;
     if (L.dense) rc = launch_run_t<16, true, 0, 0, MODE_DENSE>(h, R);
-    else if (!L.bcr && L.nw == 8) {                 // 512-thread workgroups (the reference's cart pole on a long horizon): the other translation unit
+    else if (!L.bcr && L.nw == 8) {                 // 512-thread workgroups (one long-horizon controller on grouped stages): the other translation unit
         RunKArgs A; A.L = h->L; A.P = h->P; A.S = h->S; A.R = R;
         rc = mpcqp_w8_launch(&A, sizeof(A), L.border, 0, R.nsteps > 0, h->batch, h->smem_solve, h->stream);
         if (rc) return fail(MPCQP_ERR_HIP, "mpcqp_w8_launch failed");

@@ -51,13 +51,15 @@ static int launch_lp(const RunKArgs &A, int loop, int grid, size_t smem, hipStre
 }
 }  // namespace w8
 
-// sched: 11 / 21 / 31 = the cyclic-reduction schedule (spec12_4: the BASELINE shape with compile-time dimensions); 0 = the reference's cart pole
-// (nx = 4, nu = 1) on grouped stages with the round staged in LDS (long horizons: its notebook and Kalman examples), spec12_4 then says "held input"
+// sched: 11 / 21 / 31 = the cyclic-reduction schedule (spec12_4: the BASELINE shape with compile-time dimensions); 0 = ONE long-horizon controller
+// on grouped stages with the round staged in LDS (the reference's cart pole -- its notebook and Kalman examples -- with compile-time dimensions,
+// any other nx + nu <= 8 through the generic instantiation), spec12_4 then says "held input"
 int mpcqp_w8_launch(const void *kargs, size_t kargs_bytes, int spec12_4, int sched, int loop, int grid, size_t smem, hipStream_t stream) {
     using namespace w8;
     if (kargs_bytes != sizeof(RunKArgs)) return 2;
     RunKArgs A; memcpy(&A, kargs, sizeof(A));
-    if (sched == 0) return spec12_4 ? launch_lp<4, 1, MODE_BORDER, false>(A, loop, grid, smem, stream) : launch_lp<4, 1, MODE_CHAIN, false>(A, loop, grid, smem, stream);
+    if (sched == 0 && A.L.nx == 4 && A.L.nu == 1) return spec12_4 ? launch_lp<4, 1, MODE_BORDER, false>(A, loop, grid, smem, stream) : launch_lp<4, 1, MODE_CHAIN, false>(A, loop, grid, smem, stream);
+    if (sched == 0) return spec12_4 ? launch_lp<0, 0, MODE_BORDER, false>(A, loop, grid, smem, stream) : launch_lp<0, 0, MODE_CHAIN, false>(A, loop, grid, smem, stream);
     if (sched == 31 && spec12_4) return launch_lp<12, 4, MODE_BCRT + 31>(A, loop, grid, smem, stream);
     if (sched == 31) return launch_lp<0, 0, MODE_BCRT + 31>(A, loop, grid, smem, stream);
     if (sched == 21) return launch_lp<0, 0, MODE_BCRT + 21>(A, loop, grid, smem, stream);

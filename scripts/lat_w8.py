@@ -8,7 +8,9 @@ from pympc_amd import MPCController, fixtures, _lib
 from pympc_amd.solver import forced_settings
 from oracle.osqp_oracle import OSQP
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-for name, kw in (('notebook (4,1,150,75)', dict(fixtures.cart_pole(), Np=150, Nc=75)), ('kalman (4,1,200,200)', fixtures.cart_pole_kalman()), ('(4,1,100,100)', dict(fixtures.cart_pole(), Np=100))):
+for name, kw in (('notebook (4,1,150,75)', dict(fixtures.cart_pole(), Np=150, Nc=75)), ('kalman (4,1,200,200)', fixtures.cart_pole_kalman()), ('(4,1,100,100)', dict(fixtures.cart_pole(), Np=100)),
+                 ('random (3,2,200,80)', dict(fixtures.random_lti(5, nx=3, nu=2, Np=200, xbox=4.0), Nc=80)), ('random (5,3,60,60)', fixtures.random_lti(6, nx=5, nu=3, Np=60, xbox=4.0)),
+                 ('random (2,1,120,120)', fixtures.random_lti(7, nx=2, nu=1, Np=120, xbox=4.0))):
     res = {}
     for tag, tun in (('w8', 0), ('w4', _lib.TUNE_NO_W8), ('cpu', None)):
         with forced_settings(**({} if tun is None else dict(tuning=tun))), warnings.catch_warnings():
