@@ -12,8 +12,9 @@
 //     it holds its <= 15 level fragments (120 registers) and no more:
 //   * the levels above 1 are replaced by the explicit inverse of what two levels leave (BcrFmt, factor_bcr): nt = N / 4 stages (7 of 31), nt
 //     block rows of nt mat-vecs, one row per wave, ONE barrier instead of a five-deep chain on one wave.  Its nt^2 fragments (49: 98 KB) are
-//     what the registers no longer hold: they sit in LDS for the round -- the latency kernels use 44 of the compute unit's 160 KB -- as
-//     [block][half][lane][2 doubles], so a lane's 32 bytes are two conflict-free 16-byte reads.
+//     what the registers no longer hold: they sit in LDS for the whole launch (with the constant fragments G, G'; a refactorization says when
+//     they are stale) -- the latency kernels use 44 of the compute unit's 160 KB otherwise -- as [block][half][lane][2 doubles], so a lane's
+//     32 bytes are two conflict-free 16-byte reads.
 // Seven barriers per iteration as before:  G'W + right-hand side | level 0 | level 1 | top | level 1 back | level 0 back | G v + row updates.
 #pragma once
 
