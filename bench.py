@@ -539,7 +539,8 @@ class Shard:
             return {'bound': 'mfma', 'frac_excluding_tail': (tail['rate_before_tail'] / MFMA_F64_PEAK) if tail else None, 'tail': tail, 'achieved': flops / (admm_ms * 1e-3) / 1e12, 'peak': MFMA_F64_PEAK / 1e12, 'unit': 'TFLOP/s',
                     'frac': flops / (admm_ms * 1e-3) / MFMA_F64_PEAK, 'traffic': None,
                     'frac_is': 'executed v_mfma_f64_4x4x4_4b_f64 flops (512 per instruction, mpcqp_get_work x the device-side iteration count) / HIP-event kernel '
-                               'time / the FP64 matrix peak; a mat-vec uses one of the four B-operand columns, so a quarter of these flops is useful',
+                               'time / the FP64 matrix peak; a mat-vec uses one of the four B-operand columns, so a quarter of these flops is useful; the dense top of the cyclic-reduction '
+                               'backends (16 nt x 16 nt mat-vec per iteration) runs on the vector ALU and is not in this count',
                     'useful_frac': 0.25 * flops / (admm_ms * 1e-3) / MFMA_F64_PEAK, 'mfma_per_iter_per_qp': mfma,
                     'occupancy_note': '%d instances on %d CUs: one workgroup per CU at a time (%s)' % (self.B, 256, 'w8:: kernels: 512 threads, two waves per SIMD' if kname.startswith('w8::') else '256 threads, one wave per SIMD'),
                     'hbm_design_bytes_per_launch': design_bytes / launches, 'hbm_frac': achieved / HBM_PEAK,
@@ -849,6 +850,20 @@ def main():
                                                           'half the CUs idle at 128, and a launch as long as its slowest instance; weak scaling (%d instances per GPU) is what --gpus N measures, '
                                                           '--total-batch the strong reading on real GPUs' % (B // 8, B)}
             del s8
+            torch.cuda.empty_cache()
+            # the register-resident kernel FORCED at the headline batch (AUTO runs it up to three instances per compute unit): since its top block row
+            # moved to the vector ALU it measures above the bandwidth kernel on this shape -- a full 31-stage schedule of 16-wide stages -- and below it on
+            # shorter horizons and narrower stages (LAB_NOTES.md), so AUTO's batch rule stands and the number is reported beside the headline
+            from pympc_amd.solver import forced_settings
+            try:
+                with forced_settings(backend='bcr8'):
+                    sL = Shard(args, dims, B, rank, world, dev, 0, torch, dist)
+                rL = sL.measure(args.path, args.steps, args.warmup)
+                extra['small_batch_legs']['latency_backend_b%d' % B] = {'batch': B, 'value': B * args.steps / rL['elapsed'], 'ms_per_step': 1e3 * rL['elapsed'] / args.steps,
+                                                                        'launch_spread': rL.get('launch_spread'), 'roofline': sL.roofline(rL, args.path, None)}
+                del sL
+            except Exception as e:                       # (a shape the backend is not eligible for: --workload cfg3 with other dimensions)
+                extra['small_batch_legs']['latency_backend_b%d' % B] = {'error': repr(e)}
             torch.cuda.empty_cache()
         if rank == 0 and args.workload == 'cfg3':
             try:

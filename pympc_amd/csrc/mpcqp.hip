@@ -178,6 +178,7 @@ static Lay make_layout(int nx, int nu, int Np, int Nc, int soft) {
     L.hot_sz = o;
     L.oQx = o; o += nx * nx; L.oQxN = o; o += nx * nx; L.oQu = o; o += nu * nu; L.oQDu = o; o += nu * nu;
     L.model_sz = o;
+    L.hot_lds = L.hot_sz;                              // (mpcqp_create: model_sz where the weight matrices fit in LDS beside everything else)
     L.odu0 = nx + nu + L.N * nx;
     L.step_sz = L.odu0 + 2 * nu;
     L.raw = 0;
@@ -319,6 +320,13 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
             h->smem_setup += sizeof(double) * 16 * (8 - h->L.nw);      // (the reduction scratch grows with the waves: smem_common)
             h->L.nw = 8;
         }
+    }
+    {   // The weight matrices [Qx | QxN | Qu | QDu] ride with the hot prefix into LDS (Lay::hot_lds) where that costs no residency: the kernels that
+        // run one workgroup per compute unit (latency backends, 512 threads, wide stages) or two (32 x 32 stages), not the four-per-CU bandwidth
+        // kernel of 16 x 16 stages, whose 40 KB are spoken for.
+        const size_t extra = sizeof(double) * (size_t)(h->L.model_sz - h->L.hot_sz);
+        const int occ = (h->L.nw == 8 || h->L.dense || h->L.bcr || h->L.NB > 32) ? 1 : h->L.NB <= 16 ? 4 : 2;
+        if ((h->smem_setup + extra + 1024) * (size_t)occ <= 160 * 1024) { h->L.hot_lds = h->L.model_sz; h->smem_setup += extra; }
     }
     h->smem_solve = h->smem_setup;
     if (h->smem_solve > 160 * 1024) { mpcqp_destroy(h); return fail(MPCQP_ERR_UNSUPPORTED, "problem too large for one workgroup's LDS"); }
@@ -1029,7 +1037,7 @@ extern "C" int mpcqp_get_stream_bytes(mpcqp_handle *h, int64_t *per_iter, int64_
     if (L.grp) it = (3 * (int64_t)group_count(L.N, L.grp) - 1) * GroupFmt::NN;      // grouped small stages: S^-1 of every super-stage, forward matrix and its transpose of all but the ends, the middle's second pair
     if (!h->lds_state && !L.lstage) it += (2 * n + 4 * m) /* x, z, y read + written */ + (m + L.n_x) /* omega */ + (n + L.n_x) /* s */ + nq /* q */;
     if (L.border && !L.dense) it += 2 * (int64_t)L.nu * L.N * NB;      // (the dense inverse holds the held input's couplings itself)
-    int64_t rd = (L.model_sz - L.hot_sz) + 2 * n + 2 * m /* D, s, E, omega */ + n + m /* dx, dy */;
+    int64_t rd = (L.model_sz - L.hot_lds) /* the weight matrices, unless they are staged with the hot prefix */ + 2 * n + 2 * m /* D, s, E, omega */ + n + m /* dx, dy */;
     if (L.dense) rd += DenseFmt::DOUBLES;               // the round's load of K^-1 into registers
     if (L.bcr && !L.bcrtop) rd += (int64_t)L.bcr * BcrFmt::REC - 4 * BcrFmt::NN;      // ... of the cyclic-reduction fragments (the two end stages have one neighbour)
     if (L.bcrtop) {                                     // ... of levels 0 and 1 (the top inverse and G, G' enter LDS once per LAUNCH: admm_latw)
@@ -1039,7 +1047,7 @@ extern "C" int mpcqp_get_stream_bytes(mpcqp_handle *h, int64_t *per_iter, int64_
     }
     rd += (h->lds_state || L.lstage) ? 2 * (n + 2 * m) /* iterate in and out of LDS */ + (m + L.n_x) + (n + L.n_x) + nq : (n + 2 * m);
     if (L.lstage && L.border) rd += 2 * (int64_t)L.nu * L.N * NB;      // the border matrices staged with it
-    int64_t sv = L.hot_sz + L.step_sz + 3 * m /* E, types, omega */ + nq + 2 * (n + m) /* solution out, iterate read */;
+    int64_t sv = L.hot_lds + L.step_sz + 3 * m /* E, types, omega */ + nq + 2 * (n + m) /* solution out, iterate read */;
     if (per_iter) *per_iter = 8 * it;
     if (per_round) *per_round = 8 * rd;
     if (per_solve) *per_solve = 8 * sv;
@@ -1056,7 +1064,7 @@ extern "C" int mpcqp_get_work(mpcqp_handle *h, int64_t *mfma_per_iter) {
     else if (L.bcr) {
         for (int l = 0; l < (L.bcrtop ? 2 : bcr_levels(L.bcr)); ++l)
             for (int kind = 0; kind < 3; ++kind) for (int t = 0; t < lat_count(L.bcr, l, kind); ++t) mv += lat_nfr(L.bcr, l, kind, t);
-        mv += (int64_t)L.bcrtop * L.bcrtop;            // dense top: one mat-vec per block of the inverse
+        if (!LATW_TOP_VALU) mv += (int64_t)L.bcrtop * L.bcrtop;      // dense top on the matrix cores: one mat-vec per block of the inverse (LATW_TOP_VALU: 512 nt^2 flop per iteration on the vector ALU instead, not counted here)
         mv += 2 * ((L.bcr + 3) / 4);                 // G v and G'W: one group per four stages each
     } else if (L.grp) mv = 3 * (int64_t)group_count(L.N, L.grp) - 1;      // forward 1, backward 2 mat-vecs per super-stage, the middle stage
     else {

@@ -13,8 +13,9 @@
 //   * the levels above 1 are replaced by the explicit inverse of what two levels leave (BcrFmt, factor_bcr): nt = N / 4 stages (7 of 31), nt
 //     block rows of nt mat-vecs, one row per wave, ONE barrier instead of a five-deep chain on one wave.  Its nt^2 fragments (49: 98 KB) are
 //     what the registers no longer hold: they sit in LDS for the whole launch (with the constant fragments G, G'; a refactorization says when
-//     they are stale) -- the latency kernels use 44 of the compute unit's 160 KB otherwise -- as [block][half][lane][2 doubles], so a lane's
-//     32 bytes are two conflict-free 16-byte reads.
+//     they are stale) -- the latency kernels use 44 of the compute unit's 160 KB otherwise.  Since the second half of round 5 the top is a
+//     VECTOR-ALU mat-vec over that LDS copy (LATW_TOP_VALU below: 2 043 -> 1 214 cycles of an iteration's 8 138); the matrix-core form
+//     (fragments as [block][half][lane][2 doubles], a lane's 32 bytes two conflict-free 16-byte reads) remains as a build switch.
 // Seven barriers per iteration as before:  G'W + right-hand side | level 0 | level 1 | top | level 1 back | level 0 back | G v + row updates.
 #pragma once
 
@@ -39,7 +40,20 @@ constexpr int latw_slots(int N, int W) { return latw_slot(N, W, -1, -1, -1); }
 constexpr int latw_max_slots(int N) { int m = 0; for (int w = 0; w < NWAVES; ++w) m = latw_slots(N, w) > m ? latw_slots(N, w) : m; return m; }
 constexpr int latw_top_stage(int r) { return 4 * (r + 1) - 1; }
 
-#define LATW_TOP_LDS(N) ((BcrFmt::top_count(N) * BcrFmt::top_count(N) + 2) * BcrFmt::NN)      /* LDS doubles of the top inverse and, behind it, of the fragments G and G' */
+// The top on the VECTOR ALU (LATW_TOP_VALU; 0 = on the matrix cores, latw_top, as until the middle of round 5): a mat-vec uses one of the four
+// B columns of v_mfma_f64_4x4x4, so the 28 MFMAs a wave issues for its block row carry 64 useful products each at 17-20 cycles of the matrix
+// pipe; the same 64 products are ONE v_fma_f64 at 6.5 cycles when enough of them are independent (scripts/diag/mfma_rate.hip).  The inverse then
+// sits in LDS in row-part order instead of fragment order, the reduced right-hand sides of the top stages in a compact vector Xt behind it:
+//   1: lane (i = lane & 15, p = lane >> 4) of the wave that owns block row r: row 16 r + i times columns [4 nt p, 4 nt (p + 1)) -- 2 nt 16-byte reads
+//      of the matrix, 2 nt 16-byte broadcast reads of Xt, 4 nt FMAs on 7 independent accumulators, two cross-lane steps (p);
+//   2: lane (q = lane >> 3, p = lane & 7): rows 16 r + 2 q, 2 q + 1 times columns [2 nt p, 2 nt (p + 1)) -- half the reads of Xt, three DPP steps.
+// Measured (one (12,4,30) instance alone, cycles of the top phase / of the iteration; 128 / 256 instances, driver's flags):
+//   matrix cores 2 043 / 8 138, 628 k / 1.04 M solves/s;  mode 1 (groups of 2, pipelined) 1 464 / 7 545, 654 k / 1.08 M;  mode 2 (the same) 1 214 / 7 310,
+//   682 k / 1.13 M;  larger groups (3 or 4 column pairs in flight twice) spill in the owner passes and lose more there than they gain here.
+#ifndef LATW_TOP_VALU
+#define LATW_TOP_VALU 2
+#endif
+#define LATW_TOP_LDS(N) ((BcrFmt::top_count(N) * BcrFmt::top_count(N) + 2) * BcrFmt::NN + 16 * BcrFmt::top_count(N))      /* LDS doubles of the top inverse and, behind it, of the fragments G and G' and of Xt */
 #if NT == 512
 #define LATW_DISPATCH(wv, CALL) switch (wv) { \
     case 0: { constexpr int W = 0; CALL; } break; case 1: { constexpr int W = 1; CALL; } break; \
@@ -78,7 +92,7 @@ __device__ __forceinline__ void latw_load(const double *F, d4 *fr) {
 
 // LDS vectors of the round (stage-major, stride 16; mpcqp_lat.h): tb right-hand side / solution, cb c_e of the reduction -- and, at the top stages'
 // slots, the top's solution until level 1 back has copied it into tb; each seen through the lane bases of the four block rotations.
-struct LatwVecs { double *tb, *cb; const double *t1, *t2, *t3, *c1, *c2, *c3; };
+struct LatwVecs { double *tb, *cb; const double *t1, *t2, *t3, *c1, *c2, *c3; double *xt; };      // (xt: LATW_TOP_VALU, the top's compact input, per-lane base as tb)
 #ifndef LATW_IN_DPP
 #define LATW_IN_DPP 0              // 1: one LDS read per input vector and three DPP block rotations instead of four reads (measured: see LAB_NOTES.md)
 #endif
@@ -105,7 +119,10 @@ __device__ __forceinline__ void latw_fwd(const d4 *fr, const LatwVecs &v) {
             double p = v.tb[i * 16], q = 0.0;                 // (the stage's own right-hand side starts the chain)
             latw_mv_lds<false>(fr[s], v, (i - h) * 16, p, q);
             if constexpr (i + h < N) latw_mv_lds<false>(fr[s + 1], v, (i + h) * 16, p, q);
-            v.tb[i * 16] = p + q;
+            // (level 1 keeps exactly the top stages 4 (r + 1) - 1: with the vector-ALU top their reduced right-hand side goes to the compact Xt --
+            //  nobody reads tb there before level 1 back has put the top's solution in its place)
+            if constexpr (LATW_TOP_VALU && L == 1) v.xt[((i + 1) / 4 - 1) * 16] = p + q;
+            else v.tb[i * 16] = p + q;
         }
     });
     static_for<0, lat_count(N, L, 1)>([&](auto tc) {
@@ -197,9 +214,117 @@ __device__ __forceinline__ void latw_top(const double *TopL, const LatwVecs &v, 
     });
 }
 
+// ---- the top on the vector ALU (LATW_TOP_VALU) ------------------------------------------------------------------------------------------
+// LDS order of the inverse, in 16-byte pairs: pair index ((r * 2 nt + k) * 64 + lane) holds
+//   mode 1: T[16 r + (lane & 15)][4 nt (lane >> 4) + 2 k .. + 1],                       k < 2 nt
+//   mode 2: T[16 r + 2 (lane >> 3) + k / nt][2 nt (lane & 7) + 2 (k % nt) .. + 1],      k < 2 nt
+// -- a wave's read k is 64 consecutive pairs (conflict-free).  latw_topv_rc: (row, first column) of a pair.
+__device__ __forceinline__ void latw_topv_rc(int nt, int pair, int &row, int &col) {
+    const int ln = pair & 63, rk = pair >> 6, r = rk / (2 * nt), k = rk - r * 2 * nt;
+#if LATW_TOP_VALU == 2
+    const int rr = k / nt, kc = k - rr * nt;
+    row = 16 * r + 2 * (ln >> 3) + rr; col = 2 * nt * (ln & 7) + 2 * kc;
+#else
+    row = 16 * r + (ln & 15); col = 4 * nt * (ln >> 4) + 2 * k;
+#endif
+}
+template <int CTRL>
+__device__ __forceinline__ double latw_dpp(double x) {
+    const long long xi = __builtin_bit_cast(long long, x);
+    const int lo = DPP_MOVE((int)xi, CTRL), hi = DPP_MOVE((int)(xi >> 32), CTRL);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+// Left to itself the compiler requests one or two 16-byte reads at a time and waits for each (an LDS round trip per pair of FMAs: it has ~ 30
+// free registers here), so the reads are issued in groups of LATW_TOPV_GRP column pairs behind scheduling fences; LATW_TOPV_PIPE: the next
+// group's reads are issued before the current group's FMAs (two groups of registers in flight).  (Requesting a wave's first group of matrix
+// pairs on the other side of the barrier, at the start of level 1 forward -- they depend on nothing the iteration computes -- took 80 cycles off
+// this phase and, through 16 more live registers, added 300 to the owner passes: 7 572 against 7 352 cycles per iteration; not kept.)
+#ifndef LATW_TOPV_GRP
+#define LATW_TOPV_GRP 2
+#endif
+#ifndef LATW_TOPV_PIPE
+#define LATW_TOPV_PIPE 1
+#endif
+template <int N, int W>
+__device__ __forceinline__ void latw_top_valu(const double *TopL, const double *Xt, double *Cc, int lane) {
+    constexpr int NTOP = BcrFmt::top_count(N), H = LATW_TOPV_GRP;
+    static_for<0, NTOP>([&](auto rc) {
+        constexpr int r = decltype(rc)::value;
+        if constexpr (r % NWAVES == W) {
+            const d2 *tm = (const d2 *)TopL + (size_t)(r * 2 * NTOP) * 64 + lane;
+#if LATW_TOP_VALU == 2
+            constexpr int KQ = NTOP, NA = NTOP < 4 ? NTOP : 4, NG = (KQ + H - 1) / H;
+            const d2 *xv = (const d2 *)(Xt + 2 * NTOP * (lane & 7));
+            double a0[NA], a1[NA];
+            d2 bx[2][H], b0[2][H], b1[2][H];
+            auto load = [&](auto gc) {
+                constexpr int g = decltype(gc)::value, k0 = g * H, n = (k0 + H < KQ ? k0 + H : KQ) - k0;
+                static_for<0, n>([&](auto jc) { constexpr int j = decltype(jc)::value, k = k0 + j; bx[g & 1][j] = xv[k]; b0[g & 1][j] = tm[k * 64]; b1[g & 1][j] = tm[(NTOP + k) * 64]; });
+            };
+            auto compute = [&](auto gc) {
+                constexpr int g = decltype(gc)::value, k0 = g * H, n = (k0 + H < KQ ? k0 + H : KQ) - k0;
+                static_for<0, n>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value, k = k0 + j, q = k % NA;
+                    const d2 x = bx[g & 1][j], t0 = b0[g & 1][j], t1 = b1[g & 1][j];
+                    if constexpr (k < NA) { a0[q] = t0[0] * x[0]; a1[q] = t1[0] * x[0]; }
+                    else { a0[q] = fma(t0[0], x[0], a0[q]); a1[q] = fma(t1[0], x[0], a1[q]); }
+                    a0[q] = fma(t0[1], x[1], a0[q]); a1[q] = fma(t1[1], x[1], a1[q]);
+                });
+            };
+#else
+            constexpr int KQ = 2 * NTOP, NA = KQ < 7 ? KQ : 7, NG = (KQ + H - 1) / H;
+            const d2 *xv = (const d2 *)(Xt + 4 * NTOP * (lane >> 4));
+            double a[NA];
+            d2 bx[2][H], b0[2][H];
+            auto load = [&](auto gc) {
+                constexpr int g = decltype(gc)::value, k0 = g * H, n = (k0 + H < KQ ? k0 + H : KQ) - k0;
+                static_for<0, n>([&](auto jc) { constexpr int j = decltype(jc)::value, k = k0 + j; bx[g & 1][j] = xv[k]; b0[g & 1][j] = tm[k * 64]; });
+            };
+            auto compute = [&](auto gc) {
+                constexpr int g = decltype(gc)::value, k0 = g * H, n = (k0 + H < KQ ? k0 + H : KQ) - k0;
+                static_for<0, n>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value, k = k0 + j, q = k % NA;
+                    const d2 x = bx[g & 1][j], t = b0[g & 1][j];
+                    if constexpr (k < NA) a[q] = t[0] * x[0]; else a[q] = fma(t[0], x[0], a[q]);
+                    a[q] = fma(t[1], x[1], a[q]);
+                });
+            };
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (LATW_TOPV_PIPE) { load(std::integral_constant<int, 0>{}); __builtin_amdgcn_sched_barrier(0); }
+            static_for<0, NG>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                if constexpr (LATW_TOPV_PIPE) { if constexpr (g + 1 < NG) load(std::integral_constant<int, g + 1>{}); }
+                else load(gc);
+                __builtin_amdgcn_sched_barrier(0);
+                compute(gc);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+#if LATW_TOP_VALU == 2
+            double s0 = a0[0], s1 = a1[0];
+            if constexpr (NA == 4) { s0 = (a0[0] + a0[1]) + (a0[2] + a0[3]); s1 = (a1[0] + a1[1]) + (a1[2] + a1[3]); }
+            else { static_for<1, NA>([&](auto jc) { constexpr int j = decltype(jc)::value; s0 += a0[j]; s1 += a1[j]; }); }
+            // the eight column parts sit in eight neighbouring lanes: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror -- every lane of a
+            // group ends with the same bits (each step adds the same two numbers on both sides)
+            s0 += latw_dpp<0xB1>(s0); s1 += latw_dpp<0xB1>(s1);
+            s0 += latw_dpp<0x4E>(s0); s1 += latw_dpp<0x4E>(s1);
+            s0 += latw_dpp<0x141>(s0); s1 += latw_dpp<0x141>(s1);
+            if ((lane & 7) == 0) *(d2 *)(Cc + latw_top_stage(r) * 16 + 2 * (lane >> 3)) = d2{s0, s1};
+#else
+            double s = a[0];
+            if constexpr (NA == 7) s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + a[6]);
+            else { static_for<1, NA>([&](auto jc) { s += a[decltype(jc)::value]; }); }
+            s += lane_permute(s, 4 * (lane ^ 16));
+            s += lane_permute(s, 4 * (lane ^ 32));
+            if (lane < 16) Cc[latw_top_stage(r) * 16 + lane] = s;
+#endif
+        }
+    });
+}
+
 // Tc <- K^-1 Tc.  All threads call; four barriers inside, none after the last phase (the caller's follows).
 template <int N>
-__device__ __forceinline__ void latw_solve(const d4 *fr, const double *TopL, const LatwVecs &v, int wv, int lane) {
+__device__ __forceinline__ void latw_solve(const d4 *fr, const double *TopL, const LatwVecs &v, double *Cc, int wv, int lane) {
     constexpr int NTOP = BcrFmt::top_count(N);
     static_assert(bcr_levels(N) >= 3 && NTOP >= 1, "two levels of reduction, then the dense top");
     LATW_DISPATCH(wv, (latw_fwd<N, W, 0>(fr, v)))
@@ -208,7 +333,11 @@ __device__ __forceinline__ void latw_solve(const d4 *fr, const double *TopL, con
     LATW_DISPATCH(wv, (latw_fwd<N, W, 1>(fr, v)))
     __syncthreads();
     TICK(2)
+#if LATW_TOP_VALU
+    LATW_DISPATCH(wv, (latw_top_valu<N, W>(TopL, TopL + LATW_TOP_LDS(N) - 16 * NTOP, Cc, lane)))
+#else
     LATW_DISPATCH(wv, (latw_top<N, W>(TopL, v, lane)))
+#endif
     __syncthreads();
     TICK(3)
     // level 1 back reads the top's solution from cb; on the way every top row's owner moves its stage into tb, where level 0 back (and the
@@ -246,10 +375,20 @@ __device__ __forceinline__ void admm_latw(const Lay &L, const HotPtrs &P, Smem &
     if (S.iflag[2] == 0) {
         typedef __attribute__((address_space(1))) const d2 cgd2;
         cgd2 *Ft = (cgd2 *)(Fb + BcrFmt::top_off(N));
+#if LATW_TOP_VALU
+        cgdouble *Fs = (cgdouble *)(Fb + BcrFmt::top_off(N));
+        for (int idx = tid; idx < NTOP * NTOP * 128; idx += NT) {           // (the row-part order of latw_top_valu, gathered from the fragments)
+            int row, col; latw_topv_rc(NTOP, idx, row, col);
+            cgdouble *blk = Fs + (size_t)((row >> 4) * NTOP + (col >> 4)) * BcrFmt::NN;
+            *(d2 *)(TopL + 2 * idx) = d2{blk[frag_pos<16>(row & 15, col & 15)], blk[frag_pos<16>(row & 15, (col & 15) + 1)]};
+        }
+        (void)Ft;
+#else
         for (int idx = tid; idx < NTOP * NTOP * 128; idx += NT) {           // (16 bytes per thread and trip: fragment element pairs (lane, j = 0,1 | 2,3))
             const int blk = idx >> 7, r = idx & 127, ln = r >> 1, hf = r & 1;
             *(d2 *)(TopL + ((blk * 2 + hf) * 64 + ln) * 2) = Ft[idx];
         }
+#endif
         const double *Ad = hot + L.oAd, *Bd = hot + L.oBd;
         auto gent = [&](int r, int c) { return r < nx ? (c < nx ? Ad[r * nx + c] : (c < nx + nu ? Bd[r * nu + (c - nx)] : 0.0)) : 0.0; };
         if (wv == 0) {
@@ -268,7 +407,7 @@ __device__ __forceinline__ void admm_latw(const Lay &L, const HotPtrs &P, Smem &
     const int lo16 = vec_lane_offset(lane);
     const int lI = lane >> 4, lB = (lane >> 2) & 3;
     const int o1 = 4 * ((lB + 1) & 3) + lI, o2 = 4 * ((lB + 2) & 3) + lI, o3 = 4 * ((lB + 3) & 3) + lI;
-    const LatwVecs vec{Tc + lo16, Cc + lo16, Tc + o1, Tc + o2, Tc + o3, Cc + o1, Cc + o2, Cc + o3};
+    const LatwVecs vec{Tc + lo16, Cc + lo16, Tc + o1, Tc + o2, Tc + o3, Cc + o1, Cc + o2, Cc + o3, TopL + LATW_TOP_LDS(N) - 16 * BcrFmt::top_count(N) + lo16};
     // ---- owner map: lane (I, B, J), group g = wv + NWAVES q  ->  slot a = 4B + I of stage s = 4g + J
     const int a = 4 * ((lane >> 2) & 3) + (lane >> 4), J = lane & 3;
     const bool is_x = a < nx;
@@ -342,7 +481,7 @@ __device__ __forceinline__ void admm_latw(const Lay &L, const HotPtrs &P, Smem &
         }
         __syncthreads();
         TICK(0)
-        latw_solve<N>(fr, TopL, vec, wv, lane);
+        latw_solve<N>(fr, TopL, vec, Cc, wv, lane);
         __syncthreads();
         TICK(5)
         // ---- G v of the previous stage (MFMA), relaxation, projection, dual step of the owned rows

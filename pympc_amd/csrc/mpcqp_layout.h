@@ -19,6 +19,9 @@ struct Lay {
     // model blob: hot prefix [Ad|Bd|xmin|xmax|umin|umax|Dumin|Dumax|uref|eps_feas] then [Qx|QxN|Qu|QDu]
     int oAd, oBd, oxmin, oxmax, oumin, oumax, oDumin, oDumax, ouref, oeps, hot_sz;
     int oQx, oQxN, oQu, oQDu, model_sz;
+    int hot_lds;                  // doubles of the model blob every kernel stages into LDS at its start: hot_sz, or model_sz where the workgroup's LDS has room
+                                  // for the weight matrices too (mpcqp_create: kernels that run one or two workgroups per compute unit) -- a termination check
+                                  // then reads them where they are instead of copying them in (a global round trip and a barrier per check)
     int step_sz;                  // [x0 | um1 | xref(N*nx) | du0lo(nu) | du0hi(nu)]  (the last two: raw-vector mode only)
     int odu0;                     // offset of du0lo in the step blob
     int raw;                      // 1: q and the bounds are what mpcqp_update_vectors uploaded (not rebuilt from x0, u_{-1}, xref)

@@ -34,7 +34,7 @@ __device__ __forceinline__ double *carve(double *&p, int n) { double *r = p; p +
 template <class PT>
 __device__ __forceinline__ void smem_common(const Lay &L, const PT &P, double *&p, Smem &S) {
     S.Qv = (double *)P.qv + (size_t)inst_of(P.perm) * (L.n_x + L.n_u);
-    S.hot = carve(p, L.hot_sz);
+    S.hot = carve(p, L.hot_lds);
     S.x0s = carve(p, L.nx);
     S.um1s = carve(p, L.nu);
     S.du0 = carve(p, 2 * L.nu);
@@ -43,10 +43,10 @@ __device__ __forceinline__ void smem_common(const Lay &L, const PT &P, double *&
     S.iflag = (int *)carve(p, 2);
     S.T = carve(p, L.tsz);
 }
-__host__ __device__ inline int smem_common_doubles(const Lay &L) { return L.tsz + L.hot_sz + L.nx + 3 * L.nu + 16 * L.nw + 128 + 2; }
+__host__ __device__ inline int smem_common_doubles(const Lay &L) { return L.tsz + L.hot_lds + L.nx + 3 * L.nu + 16 * L.nw + 128 + 2; }
 
 __device__ __forceinline__ void load_common(const Lay &L, const double *model, const double *step, Smem &S) {
-    for (int i = threadIdx.x; i < L.hot_sz; i += NT) S.hot[i] = model[i];
+    for (int i = threadIdx.x; i < L.hot_lds; i += NT) S.hot[i] = model[i];
     for (int i = threadIdx.x; i < L.nx; i += NT) S.x0s[i] = step[i];
     for (int i = threadIdx.x; i < L.nu; i += NT) {
         const double um1 = step[L.nx + i];
@@ -150,7 +150,7 @@ template <int NB, int OCC>
 __device__ __forceinline__ void begin_body(const Lay &L, const Ptrs &P, const mpcqp_settings &S_, Smem &S, int plain, int warm_x) {
     const int b = inst_of(P.perm), tid = threadIdx.x;
     const double *model = P.model + (size_t)b * L.model_sz, *step = P.step + (size_t)b * L.step_sz;
-    Ctx c{L, S.hot, model + L.hot_sz};
+    Ctx c{L, S.hot, L.hot_lds > L.hot_sz ? S.hot + L.hot_sz : model + L.hot_sz};      // (the weight matrices: the LDS copy where there is one)
     if (!L.raw) build_q(c, step, S.Qv);
     double *gx = P.x + (size_t)b * L.n, *gz = P.z + (size_t)b * L.m, *gy = P.y + (size_t)b * L.m;
     if (!(S_.warm_start || plain)) {
@@ -188,9 +188,10 @@ __device__ __forceinline__ void begin_body(const Lay &L, const Ptrs &P, const mp
 // nrm / vsum as in check_body.  Needs n_x <= 2 NT and n_u <= NT (what the LDS-resident mode is chosen by).
 // NXT / NUT > 0: compile-time nx / nu (the one-workgroup-per-CU latency kernels, which have the registers for the unrolled sums: the same
 // copy inside the four-per-CU kernels' 128 registers measured slower in round 3); 0: from the layout.
+// scaled: also the scaled norms 7 .. 10, which only the rho estimate reads (every adaptive_rho_interval-th iteration: one check in four).
 template <int NXT = 0, int NUT = 0>
 __device__ __forceinline__ void check_norms_own(const Ctx &c, const double *X, const double *Z, const double *Y, const double *D, const double *E,
-                                                const double *Qv, double cc, double *nrm, double *vsum) {
+                                                const double *Qv, double cc, double *nrm, double *vsum, const bool scaled) {
     const Lay &L = c.L;
     constexpr int UNR = NXT ? 16 : 4;                  // (compile-time dimensions: the nx-long sums fully unrolled)
     const int tid = threadIdx.x, nx = NXT ? NXT : L.nx, nu = NUT ? NUT : L.nu;
@@ -198,13 +199,15 @@ __device__ __forceinline__ void check_norms_own(const Ctx &c, const double *X, c
     auto row = [&](double ax, double z, double e) {
         const double d = ax - z;
         nrm[0] = fmax(nrm[0], fabs(d)); nrm[1] = fmax(nrm[1], fabs(ax)); nrm[2] = fmax(nrm[2], fabs(z));
-        nrm[7] = fmax(nrm[7], fabs(e * d)); nrm[8] = fmax(nrm[8], fmax(fabs(e * ax), fabs(e * z)));
+        if (scaled) { nrm[7] = fmax(nrm[7], fabs(e * d)); nrm[8] = fmax(nrm[8], fmax(fabs(e * ax), fabs(e * z))); }
     };
     auto var = [&](double px, double aty, double qj, double xj, double cd) {
         const double d = px + qj + aty;
         nrm[3] = fmax(nrm[3], fabs(d)); nrm[4] = fmax(nrm[4], fabs(px)); nrm[5] = fmax(nrm[5], fabs(aty)); nrm[6] = fmax(nrm[6], fabs(qj));
-        nrm[9] = fmax(nrm[9], fabs(cd * d));
-        nrm[10] = fmax(nrm[10], fmax(fabs(cd * qj), fmax(fabs(cd * aty), fabs(cd * px))));
+        if (scaled) {
+            nrm[9] = fmax(nrm[9], fabs(cd * d));
+            nrm[10] = fmax(nrm[10], fmax(fabs(cd * qj), fmax(fabs(cd * aty), fabs(cd * px))));
+        }
         vsum[0] += xj * (0.5 * px + qj);
     };
     double eDyn[2], eBox[2], dXe[2], dEe[2], qXe[2];
@@ -289,7 +292,7 @@ __device__ __forceinline__ void check_norms_own(const Ctx &c, const double *X, c
 // element cu = t + NT j), two items per thread in flight with all their global operands (z, the slack, D, E, q) requested up front.
 // Terms are summed in the order the row visitors enumerate them.  wts: the weight matrices (LDS copy or global).
 __device__ __forceinline__ void check_norms_gown(const Ctx &c, const double *gX, const double *gZ, const double *gY, const double *D, const double *E,
-                                                 const double *Qv, double cc, double *T, double *hsy, double *nrm, double *vsum) {
+                                                 const double *Qv, double cc, double *T, double *hsy, double *nrm, double *vsum, const bool scaled) {
     constexpr int GU = 2;
     const Lay &L = c.L;
     const int tid = threadIdx.x, nx = L.nx, nu = L.nu;
@@ -321,13 +324,15 @@ __device__ __forceinline__ void check_norms_gown(const Ctx &c, const double *gX,
     auto row = [&](double ax, double z, double e) {
         const double d = ax - z;
         nrm[0] = fmax(nrm[0], fabs(d)); nrm[1] = fmax(nrm[1], fabs(ax)); nrm[2] = fmax(nrm[2], fabs(z));
-        nrm[7] = fmax(nrm[7], fabs(e * d)); nrm[8] = fmax(nrm[8], fmax(fabs(e * ax), fabs(e * z)));
+        if (scaled) { nrm[7] = fmax(nrm[7], fabs(e * d)); nrm[8] = fmax(nrm[8], fmax(fabs(e * ax), fabs(e * z))); }
     };
     auto var = [&](double px, double aty, double qj, double xj, double cd) {
         const double d = px + qj + aty;
         nrm[3] = fmax(nrm[3], fabs(d)); nrm[4] = fmax(nrm[4], fabs(px)); nrm[5] = fmax(nrm[5], fabs(aty)); nrm[6] = fmax(nrm[6], fabs(qj));
-        nrm[9] = fmax(nrm[9], fabs(cd * d));
-        nrm[10] = fmax(nrm[10], fmax(fabs(cd * qj), fmax(fabs(cd * aty), fabs(cd * px))));
+        if (scaled) {
+            nrm[9] = fmax(nrm[9], fabs(cd * d));
+            nrm[10] = fmax(nrm[10], fmax(fabs(cd * qj), fmax(fabs(cd * aty), fabs(cd * px))));
+        }
         vsum[0] += xj * (0.5 * px + qj);
     };
     for (int e0 = tid; e0 < L.n_x; e0 += GU * NT) {
@@ -430,7 +435,8 @@ __device__ __forceinline__ int check_body(const Lay &L, const Ptrs &P, const mpc
     const int nweights = L.model_sz - L.hot_sz;
     const double *wts = model + L.hot_sz;
     const int wq_off = L.m + (Xl ? 0 : L.n_x + L.n_u);
-    if (nweights <= L.tsz - wq_off) {
+    if (L.hot_lds > L.hot_sz) wts = S.hot + L.hot_sz;                     // (staged with the hot prefix when the kernel started: Lay::hot_lds)
+    else if (nweights <= L.tsz - wq_off) {
         double *wq = S.T + wq_off;
         for (int i = tid; i < nweights; i += NT) wq[i] = model[L.hot_sz + i];
         __syncthreads();
@@ -453,17 +459,19 @@ __device__ __forceinline__ int check_body(const Lay &L, const Ptrs &P, const mpc
     // ---- OSQP update_info: objective, unscaled residuals, and the scaled norms the rho estimate needs
     // vmax: 0 pri, 1 |Ax|, 2 |z|, 3 dua, 4 |Px|, 5 |A'y|, 6 |q|; scaled: 7 pri, 8 max(|EAx|,|Ez|), 9 dua, 10 max(|cD(..)|)
     double nrm[11], vsum[1] = {0.0};
+    const bool scaled = (mode & COLD_RHO) != 0;                           // (the scaled norms 7 .. 10 feed the rho estimate alone)
 #pragma unroll
     for (int i = 0; i < 11; ++i) nrm[i] = 0.0;
     TICK(10)
     if (Xl) {                                                             // (LDS-resident iterate: owner-mapped passes)
         bool done = false;
-        if constexpr (kLatOnly) { if (L.nx == 12 && L.nu == 4) { check_norms_own<12, 4>(c, X, Z, Y, D, E, S.Qv, cc, nrm, vsum); done = true; } }      // (mpcqp_w8.hip: the BASELINE shape unrolled)
-        if (!done) check_norms_own(c, X, Z, Y, D, E, S.Qv, cc, nrm, vsum);
+        if constexpr (kLatOnly) { if (L.nx == 12 && L.nu == 4) { check_norms_own<12, 4>(c, X, Z, Y, D, E, S.Qv, cc, nrm, vsum, scaled); done = true; } }      // (mpcqp_w8.hip: the BASELINE shape unrolled)
+        if (!done) check_norms_own(c, X, Z, Y, D, E, S.Qv, cc, nrm, vsum, scaled);
     }
-    else check_norms_gown(c, X, Z, Y, D, E, S.Qv, cc, S.T, S.tv, nrm, vsum);   // (iterate in global memory: staged, then the same passes)
+    else check_norms_gown(c, X, Z, Y, D, E, S.Qv, cc, S.T, S.tv, nrm, vsum, scaled);   // (iterate in global memory: staged, then the same passes)
     TICK(12)
-    block_reduce<11, 1>(nrm, vsum, S.red);
+    if (scaled) block_reduce<11, 1>(nrm, vsum, S.red);
+    else block_reduce<7, 1>(nrm, vsum, S.red);
     obj_val = vsum[0]; pri_res = nrm[0]; dua_res = nrm[3];
     TICK(13)
 

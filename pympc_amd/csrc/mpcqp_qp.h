@@ -179,6 +179,27 @@ __device__ __forceinline__ double wave_reduce(double v) {
     v = op(v, dpp_move_f64<0x128>(v));           // row_ror:8
     return op(op(readlane_f64(v, 0), readlane_f64(v, 16)), op(readlane_f64(v, 32), readlane_f64(v, 48)));
 }
+// The same with the result in the LAST lane only: the four rows meet through the wave-level DPP broadcasts (lane 15 of a row into the next
+// row: rows 1 and 3, then lane 31 into rows 2 and 3) instead of eight v_readlane and three more operations per value.  Lanes a broadcast does
+// not write see 0 -- the identity here: sums, and maxima of non-negative numbers.  Pairs are combined as in wave_reduce ((r0, r1), (r2, r3),
+// then the two): the same bits.
+template <int CTRL, int ROWS>
+__device__ __forceinline__ double dpp_bcast_f64(double x) {
+    const long long xi = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)xi, CTRL, ROWS, 0xF, false), hi = __builtin_amdgcn_update_dpp(0, (int)(xi >> 32), CTRL, ROWS, 0xF, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+template <bool MAX>
+__device__ __forceinline__ double wave_reduce_last(double v) {
+    auto op = [](double a, double b) { return MAX ? fmax(a, b) : a + b; };
+    v = op(v, dpp_move_f64<0xB1>(v));            // quad_perm [1,0,3,2]
+    v = op(v, dpp_move_f64<0x4E>(v));            // quad_perm [2,3,0,1]
+    v = op(v, dpp_move_f64<0x124>(v));           // row_ror:4
+    v = op(v, dpp_move_f64<0x128>(v));           // row_ror:8
+    v = op(v, dpp_bcast_f64<0x142, 0xA>(v));     // row_bcast:15 -> rows 1, 3
+    v = op(v, dpp_bcast_f64<0x143, 0xC>(v));     // row_bcast:31 -> rows 2, 3
+    return v;
+}
 // The waves' partial results meet in LDS: thread i < K combines value i over the waves (in wave order: the sums are formed exactly as when
 // every thread did this for all K values itself -- NWAVES x K dependent LDS reads per thread, a fifth of the termination check's reduction at
 // four waves and more at eight) and publishes it; everybody reads K broadcast values.  red: >= (NWAVES + 1) K doubles.
@@ -188,11 +209,11 @@ __device__ __forceinline__ void block_reduce(double *vmax, double *vsum, double 
     constexpr int K = KMAX + KSUM;
     static_assert((NWAVES + 1) * K <= 16 * NWAVES, "Smem::red holds 16 doubles per wave");
 #pragma unroll
-    for (int i = 0; i < KMAX; ++i) vmax[i] = wave_reduce<true>(vmax[i]);
+    for (int i = 0; i < KMAX; ++i) vmax[i] = wave_reduce_last<true>(vmax[i]);
 #pragma unroll
-    for (int i = 0; i < KSUM; ++i) vsum[i] = wave_reduce<false>(vsum[i]);
+    for (int i = 0; i < KSUM; ++i) vsum[i] = wave_reduce_last<false>(vsum[i]);
     __syncthreads();
-    if (lane == 0) {
+    if (lane == 63) {
 #pragma unroll
         for (int i = 0; i < KMAX; ++i) red[wv * K + i] = vmax[i];
 #pragma unroll
