@@ -233,7 +233,12 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     // Small problems keep the iterate x, z, y in LDS behind the common block (four workgroups per CU: 40 KB each); larger
     // ones keep it in L2/HBM.
     const size_t state_doubles = (size_t)(L.n + 2 * L.m);
+    // (an LDS-resident iterate's termination check reads the weight matrices from LDS too -- check_norms_own: behind W in the work area unless
+    //  they are staged with the hot prefix -- so the work area of such a handle holds at least W and them: short horizons of wide stages only)
+    const int tsz_plain = L.tsz;
+    if (L.NB <= 32) h->L.tsz = std::max(L.tsz, L.m + (L.model_sz - L.hot_sz));
     h->lds_state = L.NB <= 32 && sizeof(double) * ((size_t)smem_common_doubles(L) + state_doubles) <= 40 * 1024 && L.m <= 4 * NT && L.N * L.NB <= 2 * NT && L.n_u + L.nu <= NT;      // (the owner map of the parallel phases: two state elements and one input element per thread)
+    if (!h->lds_state) h->L.tsz = tsz_plain;
     // The smallest ones (the reference's own examples) solve the KKT system with a register-resident dense inverse (mpcqp_dense.h).
     // (mpcqp_settings.backend forces a choice -- what tests/test_gpu_backends.py runs every eligible fixture through; a forced backend the shape
     //  is not eligible for is refused, never silently replaced)
@@ -252,8 +257,11 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     const bool bcr_shape = !dense && h->lds_state && L.NB == 16 && !L.border && bcr_schedule(L.N) > 0;
     const bool want_bcr = want == MPCQP_BACKEND_BCR || want == MPCQP_BACKEND_BCR8 || want == MPCQP_BACKEND_BCRT;
     if (want_bcr && !bcr_shape) return refuse("BCR");
-    const bool bcr = bcr_shape && (want == MPCQP_BACKEND_AUTO ? (h->ncu > 0 && batch <= 3 * h->ncu)      // (measured cross-over with the bandwidth kernel at (12,4,30): 768 instances -- 1.14 M solves/s either way; 640: 1.13 M against 0.99 M)
-                                                              : want_bcr);
+    // (measured cross-over with the bandwidth kernel, device loop: three instances per compute unit for stages of 5 .. 16 variables -- at 768 instances (12,4,30) 1.31 against
+    //  1.14 M solves/s, (12,4,10) 2.32 / 2.21, (6,2,20) 1.71 / 1.61, (8,8,30) 1.66 / 1.21, and behind it at 1024 on every shape but full 31-stage schedules of wide stages (LAB_NOTES.md);
+    //  two per compute unit for stages of at most 4 variables, four of which share a 16 x 16 block of the bandwidth kernel's factor: (3,1,30) 1.28 / 1.25 at 512, 1.41 / 1.77 at 768)
+    const int bcr_per_cu = L.nb <= 4 ? 2 : 3;
+    const bool bcr = bcr_shape && (want == MPCQP_BACKEND_AUTO ? (h->ncu > 0 && batch <= bcr_per_cu * h->ncu) : want_bcr);
     h->L.bcr = bcr ? bcr_schedule(L.N) : 0;
     // What AUTO runs it on: 512-thread workgroups (two waves per SIMD) with a dense top (mpcqp_latw.h, mpcqp_w8.hip) -- 128 / 256 / 512 instances
     // 608 k / 1.03 M / 1.13 M solves/s against 506 k / 841 k / 935 k on four waves with the plain reduction (MPCQP_BACKEND_BCR, mpcqp_lat.h).

@@ -164,9 +164,7 @@ __device__ __forceinline__ double dense_row(const double *Kreg, const double *F,
     const int tid = threadIdx.x;
     const double *cv = cvec + (tid & 1) * (DenseFmt::JW + DenseFmt::HPAD);
     cgdouble *Fg = (cgdouble *)F;
-    // (eight accumulator chains: a dependent v_fma_f64 costs a lone wave 32 cycles, an independent one 6.5 -- four chains leave the wave waiting
-    //  on its own results, 64 FMAs in ~ 512 cycles instead of ~ 420)
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0, a6 = 0.0, a7 = 0.0;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     // The reads are issued in groups and fenced: left alone, a scheduler that is short of registers (the inverse takes 128 of
     // them) waits for every single read before the two FMAs that use it -- 32 LDS round trips per mat-vec instead of 4.
     // 8-byte reads on purpose: every lane of a half reads the SAME address, which the LDS serves as a broadcast for 4- and 8-byte
@@ -178,15 +176,15 @@ __device__ __forceinline__ double dense_row(const double *Kreg, const double *F,
         for (int q = 0; q < BATCH; ++q) c[q] = cv[jb + q];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int q = 0; q < BATCH; q += 8) {
+        for (int q = 0; q < BATCH; q += 4) {
             const int j = jb + q;
-            auto kv = [&](int jj) { return REGS ? Kreg[jj] : Fg[(size_t)jj * NT + tid]; };
-            a0 = fma(kv(j), c[q], a0); a1 = fma(kv(j + 1), c[q + 1], a1); a2 = fma(kv(j + 2), c[q + 2], a2); a3 = fma(kv(j + 3), c[q + 3], a3);
-            a4 = fma(kv(j + 4), c[q + 4], a4); a5 = fma(kv(j + 5), c[q + 5], a5); a6 = fma(kv(j + 6), c[q + 6], a6); a7 = fma(kv(j + 7), c[q + 7], a7);
+            const double k0 = REGS ? Kreg[j] : Fg[(size_t)j * NT + tid], k1 = REGS ? Kreg[j + 1] : Fg[(size_t)(j + 1) * NT + tid];
+            const double k2 = REGS ? Kreg[j + 2] : Fg[(size_t)(j + 2) * NT + tid], k3 = REGS ? Kreg[j + 3] : Fg[(size_t)(j + 3) * NT + tid];
+            a0 = fma(k0, c[q], a0); a1 = fma(k1, c[q + 1], a1); a2 = fma(k2, c[q + 2], a2); a3 = fma(k3, c[q + 3], a3);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    const double part = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
+    const double part = (a0 + a1) + (a2 + a3);
     return part + lane_swap1(part);
 }
 

@@ -194,8 +194,9 @@ __global__ __launch_bounds__(NT, run_occupancy(NB, MODE)) void k_mpc_run(RunKArg
             const size_t kb = (size_t)k * R.batch + b;
             const int ny = R.ny;
             // ---- output(): first input of the current solution, or u_failure
-            const int status = P.info[b].status;
-            if (tid < nu) un[tid] = status == MPCQP_SOLVED ? P.xo[(size_t)b * L.n + L.ou + tid] : S.hot[L.ouref + tid];
+            // (from the second step on, status and first input of the solve that just ended are where its last check left them in LDS)
+            const int status = k ? S.iflag[4] : P.info[b].status;
+            if (tid < nu) un[tid] = status == MPCQP_SOLVED ? (k ? S.uo[tid] : P.xo[(size_t)b * L.n + L.ou + tid]) : S.hot[L.ouref + tid];
             if (tid < nx) xt[tid] = ny ? R.x_true[(size_t)b * nx + tid] : S.x0s[tid];      // the plant state
             __syncthreads();
             if (ny && tid < ny) {                            // measurement y = C x + v and innovation y - C xhat
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(NT, run_occupancy(NB, MODE)) void k_mpc_run(RunKArg
             // ---- update(x): new initial state, previous input (mpc.py:338-364) and, if given, reference
             if (tid < nx) { S.x0s[tid] = xn[tid]; step[tid] = xn[tid]; }
             if (tid < nu) { S.um1s[tid] = un[tid]; step[nx + tid] = un[tid]; S.du0[tid] = S.hot[L.oDumin + tid] + un[tid]; S.du0[nu + tid] = S.hot[L.oDumax + tid] + un[tid]; }
-            if (R.xref_traj) for (int i = tid; i < R.xref_blk; i += NT) step[nx + nu + i] = R.xref_traj[kb * R.xref_blk + i];
+            if (R.xref_traj) for (int i = tid; i < R.xref_blk; i += NT) { const double xr = R.xref_traj[kb * R.xref_blk + i]; step[nx + nu + i] = xr; if (i < nx) S.xrs[i] = xr; }
             __syncthreads();
         }
 #ifdef MPCQP_RUN_TIMING
@@ -249,7 +250,11 @@ __global__ __launch_bounds__(NT, run_occupancy(NB, MODE)) void k_mpc_run(RunKArg
 #define PHASE_CLOCK(i)
 #endif
         int iter = 0, term = 0;
-        if (!LOOP && R.part == 2) iter = P.info[b].iter;      // resumed: the first round and its check are done
+        if (!LOOP && R.part == 2) {                           // resumed: the first round and its check are done
+            const mpcqp_info pi = P.info[b];
+            iter = pi.iter;
+            if (tid == 0) { S.iflag[1] = pi.rho_updates; S.iflag[3] = pi.reserved; }
+        }
         else { FramePin pin; run_begin_phase<NB, LDSSTATE, OCC>(R.plain, (R.warm_x && k == 0) ? 1 : 0, &pin.v); }
         __syncthreads();
         PHASE_CLOCK(0)
@@ -268,7 +273,7 @@ __global__ __launch_bounds__(NT, run_occupancy(NB, MODE)) void k_mpc_run(RunKArg
             }
         }
         if (LOOP && tid == 0) {
-            R.status_traj[(size_t)k * R.batch + b] = P.info[b].status;
+            R.status_traj[(size_t)k * R.batch + b] = S.iflag[4];
             R.iter_traj[(size_t)k * R.batch + b] = iter;
             if (k < TS_STEPS) P.tstamp[(size_t)TS_STRIDE * b + 2 + k] = wall_clock64();
         }

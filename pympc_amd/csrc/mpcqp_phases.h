@@ -13,9 +13,13 @@ __device__ __forceinline__ double row_rho(int type, double rho) { return type < 
 
 // Shared prologue: stage the hot model prefix and the step data in LDS.
 struct Smem {
-    double *T, *Qv, *hot, *x0s, *um1s, *du0, *red, *tv;
+    double *T, *Qv, *hot, *x0s, *um1s, *du0, *red, *tv, *xrs, *uo;
     int *iflag;
 };
+// Smem::iflag (ints): [0] a factorization's non-positive-pivot flag, [1] rho updates and [3] termination checks of the solve in progress (what
+// mpcqp_info reports: kept here so that a check writes the record without reading it back first), [2] the latency round's LDS copy of the top
+// inverse is valid (mpcqp_latw.h), [4] status of the solve that just ended.  Smem::uo: its first input (what output() returns), Smem::xrs: the
+// constant reference (xref_rows == 1) -- both for the next step of the closed loop on the device, which would otherwise fetch them from memory.
 __device__ __forceinline__ BorderPtrs border_ptrs(const Lay &L, const Ptrs &P, const Smem &S) {
     BorderPtrs bp; bp.red = S.red;
     const size_t npb = (size_t)L.nu * L.N * L.NB;
@@ -40,14 +44,16 @@ __device__ __forceinline__ void smem_common(const Lay &L, const PT &P, double *&
     S.du0 = carve(p, 2 * L.nu);
     S.red = carve(p, 16 * L.nw);   // block_reduce: up to 12 values per wave
     S.tv = carve(p, 128);          // the bordered solve's ubar (nu <= 127 doubles); outside it, the held input's A'W sums (nu)
-    S.iflag = (int *)carve(p, 2);
+    S.xrs = carve(p, L.nx);
+    S.uo = carve(p, L.nu);
+    S.iflag = (int *)carve(p, 4);
     S.T = carve(p, L.tsz);
 }
-__host__ __device__ inline int smem_common_doubles(const Lay &L) { return L.tsz + L.hot_lds + L.nx + 3 * L.nu + 16 * L.nw + 128 + 2; }
+__host__ __device__ inline int smem_common_doubles(const Lay &L) { return L.tsz + L.hot_lds + 2 * L.nx + 4 * L.nu + 16 * L.nw + 128 + 4; }
 
 __device__ __forceinline__ void load_common(const Lay &L, const double *model, const double *step, Smem &S) {
     for (int i = threadIdx.x; i < L.hot_lds; i += NT) S.hot[i] = model[i];
-    for (int i = threadIdx.x; i < L.nx; i += NT) S.x0s[i] = step[i];
+    for (int i = threadIdx.x; i < L.nx; i += NT) { S.x0s[i] = step[i]; S.xrs[i] = step[L.nx + L.nu + i]; }      // (xrs: row 0 of the reference; used where it is the only row)
     for (int i = threadIdx.x; i < L.nu; i += NT) {
         const double um1 = step[L.nx + i];
         S.um1s[i] = um1;
@@ -69,7 +75,7 @@ __global__ __launch_bounds__(NT) void k_setup(Lay L, Ptrs P, mpcqp_settings S_) 
     const double *model = P.model + (size_t)b * L.model_sz, *step = P.step + (size_t)b * L.step_sz;
     load_common(L, model, step, S);
     Ctx c{L, S.hot, model + L.hot_sz};
-    if (!L.raw) build_q(c, step, S.Qv);              // (raw vectors: q was uploaded by mpcqp_update_vectors)
+    if (!L.raw) build_q(c, step, S.Qv, S.um1s, L.xref_rows == 1 ? S.xrs : nullptr);      // (raw vectors: q was uploaded by mpcqp_update_vectors)
     double *D = P.D + (size_t)b * L.n, *E = P.E + (size_t)b * L.m, *Dt = P.Dt + (size_t)b * L.n, *Et = P.Et + (size_t)b * L.m;
     for (int j = tid; j < L.n; j += NT) D[j] = 1.0;
     for (int r = tid; r < L.m; r += NT) E[r] = 1.0;
@@ -151,7 +157,7 @@ __device__ __forceinline__ void begin_body(const Lay &L, const Ptrs &P, const mp
     const int b = inst_of(P.perm), tid = threadIdx.x;
     const double *model = P.model + (size_t)b * L.model_sz, *step = P.step + (size_t)b * L.step_sz;
     Ctx c{L, S.hot, L.hot_lds > L.hot_sz ? S.hot + L.hot_sz : model + L.hot_sz};      // (the weight matrices: the LDS copy where there is one)
-    if (!L.raw) build_q(c, step, S.Qv);
+    if (!L.raw) build_q(c, step, S.Qv, S.um1s, L.xref_rows == 1 ? S.xrs : nullptr);
     double *gx = P.x + (size_t)b * L.n, *gz = P.z + (size_t)b * L.m, *gy = P.y + (size_t)b * L.m;
     if (!(S_.warm_start || plain)) {
         for (int j = tid; j < L.n; j += NT) gx[j] = 0.0;
@@ -176,8 +182,12 @@ __device__ __forceinline__ void begin_body(const Lay &L, const Ptrs &P, const mp
         mpcqp_info inf; inf.status = MPCQP_UNSOLVED; inf.iter = 0; inf.rho_updates = 0; inf.reserved = 0;
         inf.obj_val = 0.0; inf.pri_res = 0.0; inf.dua_res = 0.0; inf.rho = rho;
         P.info[b] = inf;
+        S.iflag[1] = 0; S.iflag[3] = 0;
     }
 }
+
+typedef __attribute__((address_space(3))) const double ldsd;      // an LDS view of a generic pointer that is known to point into LDS (its low 32 bits)
+__device__ __forceinline__ ldsd *as_lds(const double *p) { return (ldsd *)(size_t)(unsigned)(unsigned long long)p; }
 
 // Returns 1 (to every thread) if the instance has terminated.
 // Residual norms and objective of the termination check for an LDS-resident iterate, with the owner map of the parallel phases below:
@@ -190,12 +200,16 @@ __device__ __forceinline__ void begin_body(const Lay &L, const Ptrs &P, const mp
 // copy inside the four-per-CU kernels' 128 registers measured slower in round 3); 0: from the layout.
 // scaled: also the scaled norms 7 .. 10, which only the rho estimate reads (every adaptive_rho_interval-th iteration: one check in four).
 template <int NXT = 0, int NUT = 0>
-__device__ __forceinline__ void check_norms_own(const Ctx &c, const double *X, const double *Z, const double *Y, const double *D, const double *E,
+__device__ __forceinline__ void check_norms_own(const Ctx &c, const double *Xg, const double *Zg, const double *Yg, const double *D, const double *E,
                                                 const double *Qv, double cc, double *nrm, double *vsum, const bool scaled) {
     const Lay &L = c.L;
     constexpr int UNR = NXT ? 16 : 4;                  // (compile-time dimensions: the nx-long sums fully unrolled)
     const int tid = threadIdx.x, nx = NXT ? NXT : L.nx, nu = NUT ? NUT : L.nu;
-    const double *Ad = c.Ad(), *Bd = c.Bd();
+    // Everything this pass reads a neighbour's value from sits in LDS -- the iterate's copy, the hot prefix, the weight matrices (staged with it,
+    // or copied behind W by check_body: mpcqp_create sizes the work area so that they fit) -- but reaches this function through pointers the
+    // compiler cannot place (selects of LDS and global bases): FLAT loads, 120 of them per thread, each waiting for every outstanding global
+    // load as well.  Explicit LDS views: plain ds_read, and the D / E / q requests above stay in flight behind them.
+    ldsd *X = as_lds(Xg), *Z = as_lds(Zg), *Y = as_lds(Yg), *Ad = as_lds(c.Ad()), *Bd = as_lds(c.Bd());
     auto row = [&](double ax, double z, double e) {
         const double d = ax - z;
         nrm[0] = fmax(nrm[0], fabs(d)); nrm[1] = fmax(nrm[1], fabs(ax)); nrm[2] = fmax(nrm[2], fabs(z));
@@ -229,7 +243,7 @@ __device__ __forceinline__ void check_norms_own(const Ctx &c, const double *X, c
             const double xe = X[e], ee = L.soft ? X[L.oe + e] : 0.0;
             double ax = -xe;                                           // dynamics row e  (mpc.py:537-552)
             if (k > 0) {
-                const double *xp = X + (k - 1) * nx, *up = X + L.ou + min(k - 1, L.Nc - 1) * nu;
+                ldsd *xp = X + (k - 1) * nx, *up = X + L.ou + min(k - 1, L.Nc - 1) * nu;
 #pragma unroll UNR
                 for (int i = 0; i < nx; ++i) ax += Ad[a * nx + i] * xp[i];
 #pragma unroll UNR
@@ -237,13 +251,13 @@ __device__ __forceinline__ void check_norms_own(const Ctx &c, const double *X, c
             }
             row(ax, Z[e], eDyn[j]);
             row(L.soft ? xe + ee : xe, Z[L.rs + e], eBox[j]);          // state-box row: x_k (+ eps_k)
-            const double *Q = (k < L.Np) ? c.Qx() : c.QxN();
-            const double *xk = X + k * nx;
+            ldsd *Q = as_lds((k < L.Np) ? c.Qx() : c.QxN());
+            ldsd *xk = X + k * nx;
             double px = 0.0, aty = -Y[e];
 #pragma unroll UNR
             for (int l = 0; l < nx; ++l) px += Q[min(a, l) * nx + max(a, l)] * xk[l];
             if (k < L.Np) {
-                const double *y1 = Y + (k + 1) * nx;
+                ldsd *y1 = Y + (k + 1) * nx;
 #pragma unroll UNR
                 for (int r = 0; r < nx; ++r) aty += Ad[r * nx + a] * y1[r];
             }
@@ -261,7 +275,7 @@ __device__ __forceinline__ void check_norms_own(const Ctx &c, const double *X, c
         row(ax, Z[L.rdu + nu + cu], eDu);
         if (cu < nu) row(ut, Z[L.rdu + cu], eD0);                      // first step: u_0 (- u_{-1} in the bounds)
         const double iu = (k == L.Nc - 1) ? (double)(L.Np - L.Nc + 1) : 1.0, dk = (k == L.Nc - 1) ? 1.0 : 2.0;
-        const double *Qu = c.Qu(), *QDu = c.QDu(), *uk = X + L.ou + k * nu;
+        ldsd *Qu = as_lds(c.Qu()), *QDu = as_lds(c.QDu()), *uk = X + L.ou + k * nu;
         double px = 0.0;
         for (int l = 0; l < nu; ++l) {
             const int lo = min(jj, l), hi = max(jj, l);
@@ -272,7 +286,7 @@ __device__ __forceinline__ void check_norms_own(const Ctx &c, const double *X, c
         double aty = 0.0;
         const int s_end = (k == L.Nc - 1) ? L.Np : k + 1;            // the last input is held to the end of the horizon
         for (int s = k + 1; s <= s_end; ++s) {
-            const double *y1 = Y + s * nx;
+            ldsd *y1 = Y + s * nx;
 #pragma unroll UNR
             for (int r = 0; r < nx; ++r) aty += Bd[r * nu + jj] * y1[r];
         }
@@ -296,11 +310,11 @@ __device__ __forceinline__ void check_norms_gown(const Ctx &c, const double *gX,
     constexpr int GU = 2;
     const Lay &L = c.L;
     const int tid = threadIdx.x, nx = L.nx, nu = L.nu;
-    const double *Ad = c.Ad(), *Bd = c.Bd();
+    ldsd *Ad = as_lds(c.Ad()), *Bd = as_lds(c.Bd());                   // (explicit LDS views, as in check_norms_own: plain ds_read instead of FLAT loads)
     cgdouble *Xg = (cgdouble *)gX, *Zg = (cgdouble *)gZ, *Yg = (cgdouble *)gY, *Dg = (cgdouble *)D, *Eg = (cgdouble *)E, *Qg = (cgdouble *)Qv;
-    double *Y = T, *X = T + L.m;                                        // X: the (x, u) part only; a slack is read by its owner alone
-    for (int i = tid; i < L.m; i += NT) Y[i] = Yg[i];
-    for (int i = tid; i < L.n_x + L.n_u; i += NT) X[i] = Xg[i];
+    for (int i = tid; i < L.m; i += NT) T[i] = Yg[i];
+    for (int i = tid; i < L.n_x + L.n_u; i += NT) T[L.m + i] = Xg[i];
+    ldsd *Y = as_lds(T), *X = as_lds(T + L.m);                          // X: the (x, u) part only; a slack is read by its owner alone
     __syncthreads();
     // Nc < Np: the held input's part of A'y is a sum over the Np - Nc + 1 stages it acts on.  Its owner used to walk them alone (76 stages of
     // dependent LDS reads at the reference's Kalman notebook: 4 of a check's 20 us); the last wave forms it beside the state items -- lane l the
@@ -311,7 +325,7 @@ __device__ __forceinline__ void check_norms_gown(const Ctx &c, const double *gX,
         for (int jj = 0; jj < nu; ++jj) {
             double a = 0.0;
             for (int s = L.Nc + lane; s <= L.Np; s += 64) {
-                const double *y1 = Y + s * nx;
+                ldsd *y1 = Y + s * nx;
                 double t = 0.0;
 #pragma unroll 4
                 for (int r = 0; r < nx; ++r) t += Bd[r * nu + jj] * y1[r];
@@ -352,7 +366,7 @@ __device__ __forceinline__ void check_norms_gown(const Ctx &c, const double *gX,
                 const double xe = X[e];
                 double ax = -xe;                                           // dynamics row e  (mpc.py:537-552)
                 if (k > 0) {
-                    const double *xp = X + (k - 1) * nx, *up = X + L.ou + min(k - 1, L.Nc - 1) * nu;
+                    ldsd *xp = X + (k - 1) * nx, *up = X + L.ou + min(k - 1, L.Nc - 1) * nu;
 #pragma unroll 4
                     for (int i = 0; i < nx; ++i) ax += Ad[a * nx + i] * xp[i];
 #pragma unroll 4
@@ -361,12 +375,12 @@ __device__ __forceinline__ void check_norms_gown(const Ctx &c, const double *gX,
                 row(ax, zD[u], eDyn[u]);
                 row(L.soft ? xe + ee[u] : xe, zB[u], eBox[u]);             // state-box row: x_k (+ eps_k)
                 const double *Q = (k < L.Np) ? c.Qx() : c.QxN();
-                const double *xk = X + k * nx;
+                ldsd *xk = X + k * nx;
                 double px = 0.0, aty = -Y[e];
 #pragma unroll 4
                 for (int l = 0; l < nx; ++l) px += Q[min(a, l) * nx + max(a, l)] * xk[l];
                 if (k < L.Np) {
-                    const double *y1 = Y + (k + 1) * nx;
+                    ldsd *y1 = Y + (k + 1) * nx;
 #pragma unroll 4
                     for (int r = 0; r < nx; ++r) aty += Ad[r * nx + a] * y1[r];
                 }
@@ -397,7 +411,7 @@ __device__ __forceinline__ void check_norms_gown(const Ctx &c, const double *gX,
                 row(ax, zU[u], eDu[u]);
                 if (cu < nu) row(ut, z0[u], eD0[u]);                       // first step: u_0 (- u_{-1} in the bounds)
                 const double iu = (k == L.Nc - 1) ? (double)(L.Np - L.Nc + 1) : 1.0, dk = (k == L.Nc - 1) ? 1.0 : 2.0;
-                const double *Qu = c.Qu(), *QDu = c.QDu(), *uk = X + L.ou + k * nu;
+                const double *Qu = c.Qu(), *QDu = c.QDu(); ldsd *uk = X + L.ou + k * nu;
                 double px = 0.0;
                 for (int l = 0; l < nu; ++l) {
                     const int lo = min(jj, l), hi = max(jj, l);
@@ -408,7 +422,7 @@ __device__ __forceinline__ void check_norms_gown(const Ctx &c, const double *gX,
                 double aty = 0.0;
                 if (held && k == L.Nc - 1) aty = hsy[jj];                  // the last input is held to the end of the horizon
                 else {
-                    const double *y1 = Y + (k + 1) * nx;
+                    ldsd *y1 = Y + (k + 1) * nx;
 #pragma unroll 4
                     for (int r = 0; r < nx; ++r) aty += Bd[r * nu + jj] * y1[r];
                 }
@@ -465,8 +479,8 @@ __device__ __forceinline__ int check_body(const Lay &L, const Ptrs &P, const mpc
     TICK(10)
     if (Xl) {                                                             // (LDS-resident iterate: owner-mapped passes)
         bool done = false;
-        if constexpr (kLatOnly) { if (L.nx == 12 && L.nu == 4) { check_norms_own<12, 4>(c, X, Z, Y, D, E, S.Qv, cc, nrm, vsum, scaled); done = true; } }      // (mpcqp_w8.hip: the BASELINE shape unrolled)
-        if (!done) check_norms_own(c, X, Z, Y, D, E, S.Qv, cc, nrm, vsum, scaled);
+        if constexpr (kLatOnly) { if (L.nx == 12 && L.nu == 4) { check_norms_own<12, 4>(c, Xl, Zl, Yl, D, E, S.Qv, cc, nrm, vsum, scaled); done = true; } }      // (mpcqp_w8.hip: the BASELINE shape unrolled)
+        if (!done) check_norms_own(c, Xl, Zl, Yl, D, E, S.Qv, cc, nrm, vsum, scaled);
     }
     else check_norms_gown(c, X, Z, Y, D, E, S.Qv, cc, S.T, S.tv, nrm, vsum, scaled);   // (iterate in global memory: staged, then the same passes)
     TICK(12)
@@ -570,11 +584,13 @@ __device__ __forceinline__ int check_body(const Lay &L, const Ptrs &P, const mpc
         for (int j = tid; j < L.n; j += NT) { double v = gx[j]; xo[j] = has_sol ? v : NAN; if (!has_sol) gx[j] = 0.0; }
         for (int r = tid; r < L.m; r += NT) { double v = gy[r]; yo[r] = has_sol ? v : NAN; if (!has_sol) { gy[r] = 0.0; gz[r] = 0.0; } }
     }
+    if (term && tid < L.nu) S.uo[tid] = X[L.ou + tid];                     // (the closed loop on the device: output() of the next step, with iflag[4])
     if (tid == 0) {
-        mpcqp_info inf = P.info[b];
-        inf.status = status; inf.iter = iter; inf.rho_updates += rho_upd; inf.reserved += 1;
+        mpcqp_info inf;                                                   // (written whole: the two running counts live in LDS, nothing is read back)
+        inf.status = status; inf.iter = iter; inf.rho_updates = (S.iflag[1] += rho_upd); inf.reserved = (S.iflag[3] += 1);
         inf.obj_val = obj_val; inf.pri_res = pri_res; inf.dua_res = dua_res; inf.rho = rho;
         P.rho[b] = rho;
+        S.iflag[4] = status;
         if (term) {
             atomicAdd(&P.stats[0], (unsigned long long)iter); atomicAdd(&P.stats[1], (unsigned long long)inf.reserved);
             atomicAdd(&P.stats[2], (unsigned long long)inf.rho_updates); atomicAdd(&P.stats[3], 1ULL);

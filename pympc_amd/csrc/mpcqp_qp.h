@@ -128,9 +128,10 @@ __device__ __forceinline__ void row_bounds(const Ctx &c, const double *x0s, cons
 }
 
 // Linear cost of the x and u variables (eps part is zero): mpc.py:489-526 / 411-452.
-__device__ __forceinline__ void build_q(const Ctx &c, const double *step, double *Qv) {
+// um1s / xrs: LDS copies of u_{-1} and of a constant reference (load_common; xrs = nullptr: the reference is a trajectory, read from the step blob).
+__device__ __forceinline__ void build_q(const Ctx &c, const double *step, double *Qv, const double *um1s = nullptr, const double *xrs = nullptr) {
     const Lay &L = c.L;
-    const double *um1 = step + L.nx, *xref = step + L.nx + L.nu;
+    const double *um1 = um1s ? um1s : step + L.nx, *xref = xrs ? xrs : step + L.nx + L.nu;
     const double *uref = c.hot + L.ouref;
     for (int j = threadIdx.x; j < L.n_x + L.n_u; j += NT) {
         double acc = 0.0;

@@ -125,10 +125,10 @@ __device__ __forceinline__ void admm_tiny(const Lay &L, const HotPtrs &P, Smem &
             for (int i = 0; i < MAXB; ++i) t[i] = nbr[i];
         }
         __builtin_amdgcn_sched_barrier(0);
-        double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;        // (four chains of four: a dependent FMA costs this lone wave 32 cycles)
+        double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
-        for (int i = 0; i < MAXB; i += 4) { acc0 = fma(cvec[i], t[i], acc0); acc1 = fma(cvec[i + 1], t[i + 1], acc1); acc2 = fma(cvec[i + 2], t[i + 2], acc2); acc3 = fma(cvec[i + 3], t[i + 3], acc3); }
-        return (acc0 + acc1) + (acc2 + acc3);
+        for (int i = 0; i < MAXB; i += 2) { acc0 = fma(cvec[i], t[i], acc0); acc1 = fma(cvec[i + 1], t[i + 1], acc1); }
+        return acc0 + acc1;
     };
     // Both lanes of a pair run ONE instruction stream per phase (a dot product, selects, one row step): roles differ in the
     // operands, not in the code -- a branch per role would execute both sides one after the other in every wave.
