@@ -247,21 +247,21 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     if (want < MPCQP_BACKEND_AUTO || want > MPCQP_BACKEND_BCRT) { mpcqp_destroy(h); return fail(MPCQP_ERR_ARG, "mpcqp_create: unknown mpcqp_settings.backend"); }
     const bool dense_shape = h->lds_state && L.NB == 16 && L.NR <= DenseFmt::ROWS;      // (Nc < Np included: the dense inverse holds the held input's couplings itself)
     if (want == MPCQP_BACKEND_DENSE && !dense_shape) return refuse("DENSE");
-    const bool dense = dense_shape && (want == MPCQP_BACKEND_AUTO || want == MPCQP_BACKEND_DENSE);
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->ncu = prop.multiProcessorCount; }
+    // (AUTO: up to six instances per compute unit -- measured on (3,1,30), (4,1,20), (2,2,12), (6,2,10), (12,4,7), device loop: ahead of both other backends by 1.2 - 2.3 x up to
+    //  512 instances, by 0.94 - 1.4 x at 1024, behind the bandwidth kernel by 0 - 18 % at 2048)
+    const bool dense = dense_shape && (want == MPCQP_BACKEND_DENSE || (want == MPCQP_BACKEND_AUTO && (h->ncu <= 0 || batch <= 6 * h->ncu)));
     h->L.dense = dense ? 1 : 0;
     if (dense) h->L.tsz += DenseFmt::SCRATCH;
-    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess) h->ncu = prop.multiProcessorCount; }
     // Up to three instances per compute unit (one resident, the others queued): the latency backend (block cyclic reduction, factor resident on the compute unit) for
     // 16 x 16 stages and horizons of up to 30 steps -- the BASELINE shape (12, 4, 30) with compile-time dimensions, anything else with nx + nu <= 16 through
     // the generic instantiations.  Larger batches stream the chain format (the bandwidth backend).
     const bool bcr_shape = !dense && h->lds_state && L.NB == 16 && !L.border && bcr_schedule(L.N) > 0;
     const bool want_bcr = want == MPCQP_BACKEND_BCR || want == MPCQP_BACKEND_BCR8 || want == MPCQP_BACKEND_BCRT;
     if (want_bcr && !bcr_shape) return refuse("BCR");
-    // (measured cross-over with the bandwidth kernel, device loop: three instances per compute unit for stages of 5 .. 16 variables -- at 768 instances (12,4,30) 1.31 against
-    //  1.14 M solves/s, (12,4,10) 2.32 / 2.21, (6,2,20) 1.71 / 1.61, (8,8,30) 1.66 / 1.21, and behind it at 1024 on every shape but full 31-stage schedules of wide stages (LAB_NOTES.md);
-    //  two per compute unit for stages of at most 4 variables, four of which share a 16 x 16 block of the bandwidth kernel's factor: (3,1,30) 1.28 / 1.25 at 512, 1.41 / 1.77 at 768)
-    const int bcr_per_cu = L.nb <= 4 ? 2 : 3;
-    const bool bcr = bcr_shape && (want == MPCQP_BACKEND_AUTO ? (h->ncu > 0 && batch <= bcr_per_cu * h->ncu) : want_bcr);
+    // (measured cross-over with the bandwidth kernel, device loop: three instances per compute unit -- at 768 instances (12,4,30) 1.31 against 1.14 M solves/s, (12,4,10)
+    //  2.32 / 2.21, (6,2,20) 1.71 / 1.61, (8,8,30) 1.66 / 1.21, and behind it at 1024 on every shape but full 31-stage schedules of wide stages (LAB_NOTES.md))
+    const bool bcr = bcr_shape && (want == MPCQP_BACKEND_AUTO ? (h->ncu > 0 && batch <= 3 * h->ncu) : want_bcr);
     h->L.bcr = bcr ? bcr_schedule(L.N) : 0;
     // What AUTO runs it on: 512-thread workgroups (two waves per SIMD) with a dense top (mpcqp_latw.h, mpcqp_w8.hip) -- 128 / 256 / 512 instances
     // 608 k / 1.03 M / 1.13 M solves/s against 506 k / 841 k / 935 k on four waves with the plain reduction (MPCQP_BACKEND_BCR, mpcqp_lat.h).

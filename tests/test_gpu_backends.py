@@ -200,6 +200,24 @@ def test_a_backend_the_shape_is_not_eligible_for_is_refused():
                 MPCController(**kw).setup(solve=False)
 
 
+def test_auto_follows_the_measured_cross_overs():
+    """mpcqp_create with backend AUTO: the dense register-resident inverse (N (nx+nu) <= 128) up to six instances per compute unit, block cyclic
+    reduction on 512-thread workgroups up to three, the bandwidth kernel beyond -- the cross-overs measured on (12,4,30), (12,4,10), (6,2,20),
+    (8,8,30) and on (3,1,30), (4,1,20), (2,2,12), (6,2,10), (12,4,7) (mpcqp.hip, LAB_NOTES.md).  Only handles are created: nothing is solved."""
+    import torch
+    from pympc_amd.solver import BatchProblem
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    mode = lambda kn: int(kn.split(',')[4])
+    for (nx, nu, Np) in ((12, 4, 30), (6, 2, 20)):
+        for B, latency in ((3 * ncu, True), (3 * ncu + 1, False)):
+            kn = BatchProblem(B, nx, nu, Np).kernel_name(True)
+            assert kn.startswith('w8::') == latency and (mode(kn) >= 200) == latency, (nx, nu, Np, B, kn)
+    for (nx, nu, Np) in ((4, 1, 20), (3, 1, 30)):
+        for B, dense in ((6 * ncu, True), (6 * ncu + 1, False)):
+            kn = BatchProblem(B, nx, nu, Np).kernel_name(True)
+            assert (mode(kn) == 2) == dense and not kn.startswith('w8::'), (nx, nu, Np, B, kn)
+
+
 @pytest.mark.parametrize('tag', ['bcr', 'bcr8', 'bcrt'])
 def test_cyclic_reduction_device_loop_is_the_stepwise_api(tag):
     """A batch of the BASELINE shape on each cyclic-reduction kernel: 12 closed-loop steps inside the device loop equal the same steps through
