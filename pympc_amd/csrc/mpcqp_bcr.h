@@ -22,6 +22,24 @@
 #pragma once
 #include <type_traits>
 
+// The dense top of the round on the VECTOR ALU (mpcqp_latw.h says why and what was measured): 0 = on the matrix cores (fragments), 1 = lane (i = lane & 15,
+// p = lane >> 4) of the wave that owns block row r holds row 16 r + i times columns [4 nt p, 4 nt (p + 1)), 2 = lane (q = lane >> 3, p = lane & 7) rows 16 r + 2 q,
+// 16 r + 2 q + 1 times columns [2 nt p, 2 nt (p + 1)).  Order of the inverse in 16-byte pairs: pair ((r * 2 nt + k) * 64 + lane), k < 2 nt, holds
+//   mode 1: T[16 r + (lane & 15)][4 nt (lane >> 4) + 2 k .. + 1]          mode 2: T[16 r + 2 (lane >> 3) + k / nt][2 nt (lane & 7) + 2 (k % nt) .. + 1]
+// -- a wave's read k is 64 consecutive pairs (conflict-free).  bcr_topv_rc: (row, first column) of a pair.
+#ifndef LATW_TOP_VALU
+#define LATW_TOP_VALU 2
+#endif
+__host__ __device__ inline void bcr_topv_rc(int nt, int pair, int &row, int &col) {
+    const int ln = pair & 63, rk = pair >> 6, r = rk / (2 * nt), k = rk - r * 2 * nt;
+#if LATW_TOP_VALU == 2
+    const int rr = k / nt, kc = k - rr * nt;
+    row = 16 * r + 2 * (ln >> 3) + rr; col = 2 * nt * (ln & 7) + 2 * kc;
+#else
+    row = 16 * r + (ln & 15); col = 4 * nt * (ln >> 4) + 2 * k;
+#endif
+}
+
 struct BcrFmt {
     static constexpr int NN = 256;                            // doubles per 16 x 16 fragment
     static constexpr int REC = 5 * NN;                        // [ D^-1 | -LbL | -LbR | -LbL' | -LbR' ]
@@ -32,9 +50,12 @@ struct BcrFmt {
     // tridiagonal Schur complement of order 16 nt (112 at N = 31) whose EXPLICIT inverse is stored as nt x nt fragments behind the stage records:
     // block (r, c) at TOPOFF(N) + (r nt + c) NN.  Levels 2 .. 4 of the plain reduction are a chain of five dependent level steps that one wave
     // walks alone (2 700 of an iteration's 11 000 cycles); the inverse is nt independent block rows of nt mat-vecs each.
+    // LATW_TOP_VALU (mpcqp_latw.h: the round applies the inverse on the vector ALU): a second copy of it behind the fragments, in the row-part order the
+    // round keeps it in LDS in -- TOPVOFF(N) + 2 pair + {0, 1}, pairs as bcr_topv_rc enumerates them -- so that the round's LDS copy is a straight, coalesced copy.
     static constexpr int top_count(int N) { return N / 4; }
     static constexpr long long top_off(int N) { return (long long)N * REC; }
-    static constexpr long long doubles(int N, bool top) { return (long long)N * REC + (top ? (long long)top_count(N) * top_count(N) * NN : 0); }
+    static constexpr long long topv_off(int N) { return top_off(N) + (long long)top_count(N) * top_count(N) * NN; }
+    static constexpr long long doubles(int N, bool top) { return (long long)N * REC + (top ? (LATW_TOP_VALU ? 2LL : 1LL) * top_count(N) * top_count(N) * NN : 0); }
     static constexpr int top_lds(int N) { return 16 * top_count(N) * (16 * top_count(N) + 1) + 2 * 16 * top_count(N); }      // LDS of the inversion: matrix (odd row stride), pivot row, pivot column
 };
 
@@ -193,13 +214,23 @@ __device__ __forceinline__ int factor_bcr(const Ctx &c, const double *om, const 
             __syncthreads();
         }
         double *Ft = F + BcrFmt::top_off(N);
-        for (int idx = tid; idx < nt * nt * NN; idx += NT) {
-            const int blk = idx / NN, e = idx - blk * NN, a = e / NB, b = e % NB, br = blk / nt, bc = blk - br * nt;
+        auto topval = [&](int br, int a, int bc, int b) {      // entry (16 br + a, 16 bc + b) of the symmetrised inverse, zero where a stage has no variable
             const int i = 4 * (br + 1) - 1, j = 4 * (bc + 1) - 1;
             const int nbi = i >= NR ? 0 : (i < L.NcT) ? L.nb : L.nx, nbj = j >= NR ? 0 : (j < L.NcT) ? L.nb : L.nx;
-            const double v = (a >= nbi || b >= nbj) ? 0.0 : 0.5 * (M[(br * NB + a) * ld + bc * NB + b] + M[(bc * NB + b) * ld + br * NB + a]);
-            Ft[(size_t)blk * NN + frag_pos<NB>(a, b)] = v;
+            return (a >= nbi || b >= nbj) ? 0.0 : 0.5 * (M[(br * NB + a) * ld + bc * NB + b] + M[(bc * NB + b) * ld + br * NB + a]);
+        };
+        for (int idx = tid; idx < nt * nt * NN; idx += NT) {
+            const int blk = idx / NN, e = idx - blk * NN, a = e / NB, b = e % NB, br = blk / nt, bc = blk - br * nt;
+            Ft[(size_t)blk * NN + frag_pos<NB>(a, b)] = topval(br, a, bc, b);
         }
+#if LATW_TOP_VALU
+        double *Fv = F + BcrFmt::topv_off(N);                 // the same in the round's row-part order
+        for (int idx = tid; idx < nt * nt * (NN / 2); idx += NT) {
+            int row, col; bcr_topv_rc(nt, idx, row, col);
+            Fv[2 * (size_t)idx] = topval(row / NB, row % NB, col / NB, col % NB);
+            Fv[2 * (size_t)idx + 1] = topval(row / NB, row % NB, (col + 1) / NB, (col + 1) % NB);
+        }
+#endif
         if (tid == 0) iflag[2] = 0;                          // (the rounds' LDS copy of the top is stale -- and this workspace has just run over it: admm_latw)
         __syncthreads();
     }

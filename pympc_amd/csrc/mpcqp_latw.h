@@ -50,9 +50,7 @@ constexpr int latw_top_stage(int r) { return 4 * (r + 1) - 1; }
 // Measured (one (12,4,30) instance alone, cycles of the top phase / of the iteration; 128 / 256 instances, driver's flags):
 //   matrix cores 2 043 / 8 138, 628 k / 1.04 M solves/s;  mode 1 (groups of 2, pipelined) 1 464 / 7 545, 654 k / 1.08 M;  mode 2 (the same) 1 214 / 7 310,
 //   682 k / 1.13 M;  larger groups (3 or 4 column pairs in flight twice) spill in the owner passes and lose more there than they gain here.
-#ifndef LATW_TOP_VALU
-#define LATW_TOP_VALU 2
-#endif
+// (LATW_TOP_VALU and the order of the inverse: mpcqp_bcr.h)
 #define LATW_TOP_LDS(N) ((BcrFmt::top_count(N) * BcrFmt::top_count(N) + 2) * BcrFmt::NN + 16 * BcrFmt::top_count(N))      /* LDS doubles of the top inverse and, behind it, of the fragments G and G' and of Xt */
 #if NT == 512
 #define LATW_DISPATCH(wv, CALL) switch (wv) { \
@@ -214,20 +212,7 @@ __device__ __forceinline__ void latw_top(const double *TopL, const LatwVecs &v, 
     });
 }
 
-// ---- the top on the vector ALU (LATW_TOP_VALU) ------------------------------------------------------------------------------------------
-// LDS order of the inverse, in 16-byte pairs: pair index ((r * 2 nt + k) * 64 + lane) holds
-//   mode 1: T[16 r + (lane & 15)][4 nt (lane >> 4) + 2 k .. + 1],                       k < 2 nt
-//   mode 2: T[16 r + 2 (lane >> 3) + k / nt][2 nt (lane & 7) + 2 (k % nt) .. + 1],      k < 2 nt
-// -- a wave's read k is 64 consecutive pairs (conflict-free).  latw_topv_rc: (row, first column) of a pair.
-__device__ __forceinline__ void latw_topv_rc(int nt, int pair, int &row, int &col) {
-    const int ln = pair & 63, rk = pair >> 6, r = rk / (2 * nt), k = rk - r * 2 * nt;
-#if LATW_TOP_VALU == 2
-    const int rr = k / nt, kc = k - rr * nt;
-    row = 16 * r + 2 * (ln >> 3) + rr; col = 2 * nt * (ln & 7) + 2 * kc;
-#else
-    row = 16 * r + (ln & 15); col = 4 * nt * (ln >> 4) + 2 * k;
-#endif
-}
+// ---- the top on the vector ALU (LATW_TOP_VALU; order of the inverse in LDS and in memory: bcr_topv_rc, mpcqp_bcr.h) ----------------------------------------
 template <int CTRL>
 __device__ __forceinline__ double latw_dpp(double x) {
     const long long xi = __builtin_bit_cast(long long, x);
@@ -376,12 +361,8 @@ __device__ __forceinline__ void admm_latw(const Lay &L, const HotPtrs &P, Smem &
         typedef __attribute__((address_space(1))) const d2 cgd2;
         cgd2 *Ft = (cgd2 *)(Fb + BcrFmt::top_off(N));
 #if LATW_TOP_VALU
-        cgdouble *Fs = (cgdouble *)(Fb + BcrFmt::top_off(N));
-        for (int idx = tid; idx < NTOP * NTOP * 128; idx += NT) {           // (the row-part order of latw_top_valu, gathered from the fragments)
-            int row, col; latw_topv_rc(NTOP, idx, row, col);
-            cgdouble *blk = Fs + (size_t)((row >> 4) * NTOP + (col >> 4)) * BcrFmt::NN;
-            *(d2 *)(TopL + 2 * idx) = d2{blk[frag_pos<16>(row & 15, col & 15)], blk[frag_pos<16>(row & 15, (col & 15) + 1)]};
-        }
+        cgd2 *Fv = (cgd2 *)(Fb + BcrFmt::topv_off(N));                      // (the copy factor_bcr left in this very order: 16 bytes per thread and trip, coalesced)
+        for (int idx = tid; idx < NTOP * NTOP * 128; idx += NT) *(d2 *)(TopL + 2 * idx) = Fv[idx];
         (void)Ft;
 #else
         for (int idx = tid; idx < NTOP * NTOP * 128; idx += NT) {           // (16 bytes per thread and trip: fragment element pairs (lane, j = 0,1 | 2,3))
