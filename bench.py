@@ -537,7 +537,10 @@ class Shard:
             flops = 512.0 * mfma * iters
             tail = self.tail_split(res, 512.0 * mfma, 0.0, 0.0) if path == 'device_loop' else None
             return {'bound': 'mfma', 'frac_excluding_tail': (tail['rate_before_tail'] / MFMA_F64_PEAK) if tail else None, 'tail': tail, 'achieved': flops / (admm_ms * 1e-3) / 1e12, 'peak': MFMA_F64_PEAK / 1e12, 'unit': 'TFLOP/s',
-                    'frac': flops / (admm_ms * 1e-3) / MFMA_F64_PEAK, 'traffic': None,
+                    'frac': flops / (admm_ms * 1e-3) / MFMA_F64_PEAK, 'traffic': traffic, 'measured_bytes_per_iter_per_qp': pmc_b,
+                    'traffic_source': ('from_profile: profiles/pmc_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE per ADMM iteration per QP, profiled at batch %s) x this run\'s iterations per launch'
+                                       % (pmc_batch if pmc_batch is not None else 'of the same command')) if pmc_b else None,
+                    'design_bytes_per_round_per_qp': per_round, 'design_bytes_per_solve_per_qp': per_solve,
                     'frac_is': 'executed v_mfma_f64_4x4x4_4b_f64 flops (512 per instruction, mpcqp_get_work x the device-side iteration count) / HIP-event kernel '
                                'time / the FP64 matrix peak; a mat-vec uses one of the four B-operand columns, so a quarter of these flops is useful; the dense top of the cyclic-reduction '
                                'backends (16 nt x 16 nt mat-vec per iteration) runs on the vector ALU and is not in this count',
@@ -693,6 +696,8 @@ def main():
                          'cfg2 / notebook: single-controller latency legs only')
     ap.add_argument('--hbm-leg-batch', type=int, default=4096, help='cfg3, 1 GPU: second leg with a working set beyond the Infinity Cache (0 = skip)')
     ap.add_argument('--cfg5-leg-batch', type=int, default=512, help='cfg3, 1 GPU: BASELINE configs[4] (512 x (20,8,100)) as a leg of the default line (0 = skip)')
+    ap.add_argument('--backend', default=None, choices=['sweeps', 'dense', 'bcr8'],
+                    help='force a KKT backend for the headline shard (mpcqp_settings.backend; default: the library chooses) -- profiling runs of the bandwidth kernel at the headline batch')
     ap.add_argument('--dry-run', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
     self_launch_if_needed(args)
@@ -717,7 +722,9 @@ def main():
     else:
         TOTAL, scaling = (args.batch if args.batch is not None else WORKLOADS[args.workload][4]) * world, 'weak'
 
-    sh = Shard(args, dims, None, rank, world, dev, 0, torch, dist, total=TOTAL)
+    from pympc_amd.solver import forced_settings
+    with forced_settings(**({'backend': args.backend} if args.backend else {})):
+        sh = Shard(args, dims, None, rank, world, dev, 0, torch, dist, total=TOTAL)
     B = sh.B                                                          # this rank's instances
     prob = sh.prob
     res = sh.measure(args.path, args.steps, args.warmup)
@@ -745,7 +752,7 @@ def main():
     # what one rho update costs: the block factorization of every instance, timed alone (mpcqp_refactor rewrites the factor
     # that is already in place); the steady-state loop above needs none, the cold solve a few per instance
     refactor_ms = None if args.no_refactor_timing else sh.refactor_ms()
-    roof_local = sh.roofline(res, args.path, args.workload)
+    roof_local = sh.roofline(res, args.path, args.workload + ('_' + args.backend if args.backend else '') + ('_b%d' % B if args.workload == 'cfg3' and B != WORKLOADS['cfg3'][4] else ''))
     roof = roof_local if rank == 0 else None
     # what every rank did, beside the job's line: its share, its own rate (its clock, before the max over ranks), its kernel's roofline fraction,
     # and what the two exchanges cost it -- the scatter of the problem data (one packed collective at setup) and the all-gathers of u*
@@ -774,11 +781,12 @@ def main():
             del s2
             torch.cuda.empty_cache()
         if world == 1 and args.workload == 'cfg3' and args.hbm_leg_batch and args.hbm_leg_batch != B:
-            # the same kernel on a working set beyond the 256 MiB Infinity Cache: an HBM-only roofline fraction; counter traffic from the
-            # profile of this very command shape (profiles/pmc_hbm_traffic.json, key cfg3_b<batch>: scripts/r4_profiles.sh)
-            s3 = Shard(args, dims, args.hbm_leg_batch, rank, world, dev, 0, torch, dist)
+            # the BANDWIDTH kernel (forced: since the second half of round 5 the library runs this shape on the register-resident kernel at every batch size) with
+            # finished slots refilling; counter traffic from the profile of this very command shape (profiles/pmc_hbm_traffic.json, key cfg3_sweeps_b<batch>)
+            with forced_settings(backend='sweeps'):
+                s3 = Shard(args, dims, args.hbm_leg_batch, rank, world, dev, 0, torch, dist)
             r3 = s3.measure(args.path, min(args.steps, 25), min(args.warmup, 25) or 5)
-            ro3 = s3.roofline(r3, args.path, 'cfg3_b%d' % args.hbm_leg_batch)
+            ro3 = s3.roofline(r3, args.path, 'cfg3_sweeps_b%d' % args.hbm_leg_batch)
             # the stepwise API at this batch: every solve walks all the instances (878 MB) -- but 25 iterations at a time, and an instance re-reads its
             # factor 25 times while it is resident: HBM delivers the first touch, the Infinity Cache the other 24 (active set: 1024 resident instances, 219 MB)
             r3s = s3.measure('stepwise', min(args.steps, 25), min(args.warmup, 25) or 5)
@@ -834,13 +842,13 @@ def main():
             s8 = Shard(args, dims, B // 8, rank, world, dev, 0, torch, dist)
             r8 = s8.measure(args.path, args.steps, args.warmup)
             v8 = (B // 8) * args.steps / r8['elapsed']
-            ro8 = s8.roofline(r8, args.path, None)
+            ro8 = s8.roofline(r8, args.path, 'cfg3_b%d' % (B // 8))
             extra['small_batch_legs'] = {'b%d' % (B // 8): {'batch': B // 8, 'value': v8, 'ms_per_step': 1e3 * r8['elapsed'] / args.steps, 'launch_spread': r8.get('launch_spread'), 'roofline': ro8}}
             if B % 4 == 0:
                 s4 = Shard(args, dims, B // 4, rank, world, dev, 0, torch, dist)
                 r4 = s4.measure(args.path, args.steps, args.warmup)
                 extra['small_batch_legs']['b%d' % (B // 4)] = {'batch': B // 4, 'value': (B // 4) * args.steps / r4['elapsed'], 'ms_per_step': 1e3 * r4['elapsed'] / args.steps,
-                                                               'launch_spread': r4.get('launch_spread'), 'roofline': s4.roofline(r4, args.path, None)}
+                                                               'launch_spread': r4.get('launch_spread'), 'roofline': s4.roofline(r4, args.path, 'cfg3_b%d' % (B // 4))}
                 del s4
                 torch.cuda.empty_cache()
             extra['strong_scaling_projection'] = {'total_batch': B, 'batch_per_gpu_at_8': B // 8, 'measured_1gpu_value_at_that_batch': v8, 'kernel': s8.prob.kernel_name(loop=True),
@@ -851,19 +859,17 @@ def main():
                                                           '--total-batch the strong reading on real GPUs' % (B // 8, B)}
             del s8
             torch.cuda.empty_cache()
-            # the register-resident kernel FORCED at the headline batch (AUTO runs it up to three instances per compute unit): since its top block row
-            # moved to the vector ALU it measures above the bandwidth kernel on this shape -- a full 31-stage schedule of 16-wide stages -- and below it on
-            # shorter horizons and narrower stages (LAB_NOTES.md), so AUTO's batch rule stands and the number is reported beside the headline
-            from pympc_amd.solver import forced_settings
+            # the BANDWIDTH kernel forced at the headline batch: the headline kernel of rounds 1-4 and of the first half of round 5 (HBM / Infinity-Cache bound: its
+            # own roofline, counter traffic from profiles key cfg3_sweeps); the library now runs this shape on the register-resident kernel at every batch size
             try:
-                with forced_settings(backend='bcr8'):
+                with forced_settings(backend='sweeps'):
                     sL = Shard(args, dims, B, rank, world, dev, 0, torch, dist)
                 rL = sL.measure(args.path, args.steps, args.warmup)
-                extra['small_batch_legs']['latency_backend_b%d' % B] = {'batch': B, 'value': B * args.steps / rL['elapsed'], 'ms_per_step': 1e3 * rL['elapsed'] / args.steps,
-                                                                        'launch_spread': rL.get('launch_spread'), 'roofline': sL.roofline(rL, args.path, None)}
+                extra['small_batch_legs']['bandwidth_kernel_b%d' % B] = {'batch': B, 'value': B * args.steps / rL['elapsed'], 'ms_per_step': 1e3 * rL['elapsed'] / args.steps,
+                                                                         'launch_spread': rL.get('launch_spread'), 'roofline': sL.roofline(rL, args.path, 'cfg3_sweeps')}
                 del sL
-            except Exception as e:                       # (a shape the backend is not eligible for: --workload cfg3 with other dimensions)
-                extra['small_batch_legs']['latency_backend_b%d' % B] = {'error': repr(e)}
+            except Exception as e:
+                extra['small_batch_legs']['bandwidth_kernel_b%d' % B] = {'error': repr(e)}
             torch.cuda.empty_cache()
         if rank == 0 and args.workload == 'cfg3':
             try:

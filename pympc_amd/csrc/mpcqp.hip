@@ -259,9 +259,16 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     const bool bcr_shape = !dense && h->lds_state && L.NB == 16 && !L.border && bcr_schedule(L.N) > 0;
     const bool want_bcr = want == MPCQP_BACKEND_BCR || want == MPCQP_BACKEND_BCR8 || want == MPCQP_BACKEND_BCRT;
     if (want_bcr && !bcr_shape) return refuse("BCR");
-    // (measured cross-over with the bandwidth kernel, device loop: three instances per compute unit -- at 768 instances (12,4,30) 1.31 against 1.14 M solves/s, (12,4,10)
-    //  2.32 / 2.21, (6,2,20) 1.71 / 1.61, (8,8,30) 1.66 / 1.21, and behind it at 1024 on every shape but full 31-stage schedules of wide stages (LAB_NOTES.md))
-    const bool bcr = bcr_shape && (want == MPCQP_BACKEND_AUTO ? (h->ncu > 0 && batch <= 3 * h->ncu) : want_bcr);
+    // AUTO, measured against the bandwidth kernel (device loop and stepwise path, 1024 .. 4096 instances; LAB_NOTES.md):
+    //   * horizons of 21 .. 30 steps (the 31-stage schedule: every wave owns one group of four stages and the kernel runs on five barriers per iteration, mpcqp_latw.h) with
+    //     stages too wide for the bandwidth kernel to pack two per block (nx + nu > 8): at EVERY batch size -- (12,4,30) 1.52 / 1.66 / 1.72 M solves/s against 1.28 / 1.37 /
+    //     1.47 M at 1024 / 2048 / 4096 instances, (12,4,25) 1.54 / 1.69 / 1.75 against 1.43 / 1.50 / 1.68, (8,8,30) 1.93 / 2.13 / 2.20 against 1.50 / 1.72 / 1.94, (6,3,28) 1.80 /
+    //     1.90 / 2.02 against 1.44 / 1.77 / 1.88, (10,6,24) 1.79 / 1.88 / 1.93 against 1.60 / 1.77 / 2.01, (12,4,21) level (1.56 / 1.69 / 1.75 against 1.59 / 1.70 / 1.84);
+    //   * anything else it is eligible for: up to three instances per compute unit -- at 768 instances (12,4,10) 2.32 against 2.21, (6,2,20) 1.71 / 1.61; beyond that the
+    //     bandwidth kernel is ahead on short or padded schedules ((12,4,10) 2.63 against 2.36 at 1024, (12,4,14) 2.17 / 1.80) and on stages it packs ((6,2,20) 2.63 / 2.04 and
+    //     (5,1,30) 1.72 / 1.63 at 2048).
+    const bool bcr_any_batch = bcr_schedule(L.N) == 31 && L.N >= 22 && L.nb > 8;
+    const bool bcr = bcr_shape && (want == MPCQP_BACKEND_AUTO ? (h->ncu > 0 && (bcr_any_batch || batch <= 3 * h->ncu)) : want_bcr);
     h->L.bcr = bcr ? bcr_schedule(L.N) : 0;
     // What AUTO runs it on: 512-thread workgroups (two waves per SIMD) with a dense top (mpcqp_latw.h, mpcqp_w8.hip) -- 128 / 256 / 512 instances
     // 608 k / 1.03 M / 1.13 M solves/s against 506 k / 841 k / 935 k on four waves with the plain reduction (MPCQP_BACKEND_BCR, mpcqp_lat.h).

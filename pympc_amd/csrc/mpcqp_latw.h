@@ -16,27 +16,50 @@
 //     they are stale) -- the latency kernels use 44 of the compute unit's 160 KB otherwise.  Since the second half of round 5 the top is a
 //     VECTOR-ALU mat-vec over that LDS copy (LATW_TOP_VALU below: 2 043 -> 1 214 cycles of an iteration's 8 138); the matrix-core form
 //     (fragments as [block][half][lane][2 doubles], a lane's 32 bytes two conflict-free 16-byte reads) remains as a build switch.
-// Seven barriers per iteration as before:  G'W + right-hand side | level 0 | level 1 | top | level 1 back | level 0 back | G v + row updates.
+// Barriers per iteration: seven as before (G'W + right-hand side | level 0 | level 1 | top | level 1 back | level 0 back | G v + row updates) where the waves share
+// groups of stages; FIVE where every wave owns exactly one group of four stages (31 stages on eight waves: LATW_FUSE0 below) -- a wave then runs the level-0 tasks of
+// its own stages straight behind its right-hand side, and both back substitutions of its own stages in one phase.
 #pragma once
 
 // ---- static schedule of levels 0 and 1 over NWAVES waves (task kinds as in mpcqp_lat.h: 0 kept stage forward, 1 eliminated stage forward, 2 back substitution)
 // kept stages (two mat-vecs each) are dealt from wave 0 up, eliminated ones (one mat-vec) from the last wave down
 constexpr int latw_owner(int /*N*/, int /*L*/, int kind, int t) { return kind == 1 ? NWAVES - 1 - t % NWAVES : t % NWAVES; }
+// LATW_FUSE0: level 0 forward WITHOUT the barrier behind the right-hand side, where every wave owns exactly one group of four stages (31 stages on
+// eight waves).  Wave w then runs the level-0 tasks of ITS stages 4w .. 4w+3 -- D^-1 of 4w and 4w+2, the kept stage 4w+1, the kept stage 4w+3 from
+// its left neighbour 4w+2 -- straight from the right-hand side it has just written (a wave reads its own LDS writes in order), plus the one
+// contribution that crosses into the previous group: the right neighbour 4w of the kept stage 4w-1, left in a second vector (x2) that level 1
+// forward adds when it starts that stage's chain.  Six fragments per wave as before; one barrier and the wait in front of it less per iteration.
+// LATW_FUSE0 >= 2: the same idea on the way back -- level 1 back and level 0 back of the wave's own stages in ONE phase: x(4w+1) from the top's solution
+// at 4w-1 and 4w+3 (read where the top left it), then x(4w) and x(4w+2) from those three -- nothing another wave computes in the same phase.
+// Five barriers per iteration: right-hand side + level 0 | level 1 | top | back | owner update.  Measured (one (12,4,30) instance alone, cycles per iteration; 128 / 256
+// instances): unfused 7 407, 690 k / 1.15 M solves/s; level 0 forward fused 6 966, 724 k / 1.21 M; back substitution fused too 6 372, 773 k / 1.29 M.  Level 1 forward
+// in the same phase as well (its tasks need only b'(4w+1), the top then adds two partial inputs as it reads them; four barriers): 6 938, 724 k / 1.19 M -- nine
+// dependent mat-vecs on one wave are longer than six and three with a barrier between them, and the extra live values spill in the owner passes; not kept.
+#ifndef LATW_FUSE0
+#define LATW_FUSE0 2
+#endif
+constexpr bool latw_fused(int N) { return LATW_FUSE0 && (N + 3) / 4 == NWAVES; }
+constexpr bool latw_fused_back(int N) { return LATW_FUSE0 >= 2 && latw_fused(N); }
+constexpr int LATW_F0 = 6;          // fragment slots of the fused level-0 forward: D^-1(4w), D^-1(4w+2), kept 4w+1 (left, right), kept 4w+3 (left), kept 4w-1 (right)
+constexpr int LATW_FB = 6;          // ... of the fused back substitution: x(4w+1) (left, right), x(4w) (left, right), x(4w+2) (left, right)
 // slot of a task's first fragment in its wave's register array: level 0 forward, level 1 forward, level 1 back, level 0 back
 constexpr int latw_slot(int N, int W, int Lq, int kq, int tq) {
-    int s = 0;
+    int s = latw_fused(N) ? LATW_F0 : 0;
     for (int pass = 0; pass < 2; ++pass)
         for (int li = 0; li < 2; ++li) {
             const int L = pass == 0 ? li : 1 - li;
             for (int kind = (pass == 0 ? 0 : 2); kind < (pass == 0 ? 2 : 3); ++kind)
                 for (int t = 0; t < lat_count(N, L, kind); ++t) {
+                    if (latw_fused(N) && L == 0 && kind < 2) continue;
+                    if (latw_fused_back(N) && kind == 2) continue;
                     if (L == Lq && kind == kq && t == tq) return s;
                     if (latw_owner(N, L, kind, t) == W) s += lat_nfr(N, L, kind, t);
                 }
         }
     return s;
 }
-constexpr int latw_slots(int N, int W) { return latw_slot(N, W, -1, -1, -1); }
+constexpr int latw_back_base(int N, int W) { return latw_slot(N, W, -1, -1, -1); }      // (fused back substitution: its six slots behind everything scheduled)
+constexpr int latw_slots(int N, int W) { return latw_slot(N, W, -1, -1, -1) + (latw_fused_back(N) ? LATW_FB : 0); }
 constexpr int latw_max_slots(int N) { int m = 0; for (int w = 0; w < NWAVES; ++w) m = latw_slots(N, w) > m ? latw_slots(N, w) : m; return m; }
 constexpr int latw_top_stage(int r) { return 4 * (r + 1) - 1; }
 
@@ -51,7 +74,7 @@ constexpr int latw_top_stage(int r) { return 4 * (r + 1) - 1; }
 //   matrix cores 2 043 / 8 138, 628 k / 1.04 M solves/s;  mode 1 (groups of 2, pipelined) 1 464 / 7 545, 654 k / 1.08 M;  mode 2 (the same) 1 214 / 7 310,
 //   682 k / 1.13 M;  larger groups (3 or 4 column pairs in flight twice) spill in the owner passes and lose more there than they gain here.
 // (LATW_TOP_VALU and the order of the inverse: mpcqp_bcr.h)
-#define LATW_TOP_LDS(N) ((BcrFmt::top_count(N) * BcrFmt::top_count(N) + 2) * BcrFmt::NN + 16 * BcrFmt::top_count(N))      /* LDS doubles of the top inverse and, behind it, of the fragments G and G' and of Xt */
+#define LATW_TOP_LDS(N) ((BcrFmt::top_count(N) * BcrFmt::top_count(N) + 2) * BcrFmt::NN + 32 * BcrFmt::top_count(N))      /* LDS doubles of the top inverse and, behind it, of the fragments G and G', of Xt and of x2 */
 #if NT == 512
 #define LATW_DISPATCH(wv, CALL) switch (wv) { \
     case 0: { constexpr int W = 0; CALL; } break; case 1: { constexpr int W = 1; CALL; } break; \
@@ -65,11 +88,24 @@ constexpr int latw_top_stage(int r) { return 4 * (r + 1) - 1; }
 template <int N, int W>
 __device__ __forceinline__ void latw_load(const double *F, d4 *fr) {
     const int lane = threadIdx.x & 63;
+    if constexpr (latw_fused(N)) {
+        constexpr int s0 = 4 * W;
+        if constexpr (s0 < N) { fr[0] = bcr_frag(F, s0, BcrFmt::ODINV, lane); fr[2] = bcr_frag(F, s0, BcrFmt::OLBRT, lane); }
+        if constexpr (s0 + 2 < N) { fr[1] = bcr_frag(F, s0 + 2, BcrFmt::ODINV, lane); fr[3] = bcr_frag(F, s0 + 2, BcrFmt::OLBLT, lane); }
+        if constexpr (s0 + 3 < N) fr[4] = bcr_frag(F, s0 + 2, BcrFmt::OLBRT, lane);
+        if constexpr (W > 0 && s0 < N) fr[5] = bcr_frag(F, s0, BcrFmt::OLBLT, lane);
+    }
+    if constexpr (latw_fused_back(N)) {
+        constexpr int bb = latw_back_base(N, W), e1 = 4 * W + 1, ea = 4 * W, eb = 4 * W + 2;
+        if constexpr (e1 < N) { if constexpr (e1 - 2 >= 0) fr[bb] = bcr_frag(F, e1, BcrFmt::OLBL, lane); if constexpr (e1 + 2 < N) fr[bb + 1] = bcr_frag(F, e1, BcrFmt::OLBR, lane); }
+        if constexpr (ea < N) { if constexpr (ea - 1 >= 0) fr[bb + 2] = bcr_frag(F, ea, BcrFmt::OLBL, lane); if constexpr (ea + 1 < N) fr[bb + 3] = bcr_frag(F, ea, BcrFmt::OLBR, lane); }
+        if constexpr (eb < N) { fr[bb + 4] = bcr_frag(F, eb, BcrFmt::OLBL, lane); if constexpr (eb + 1 < N) fr[bb + 5] = bcr_frag(F, eb, BcrFmt::OLBR, lane); }
+    }
     static_for<0, 2>([&](auto lc) {
         constexpr int L = decltype(lc)::value, h = 1 << L;
         static_for<0, lat_count(N, L, 0)>([&](auto tc) {
             constexpr int t = decltype(tc)::value, i = lat_stage(L, 0, t);
-            if constexpr (latw_owner(N, L, 0, t) == W) {
+            if constexpr (!(latw_fused(N) && L == 0) && latw_owner(N, L, 0, t) == W) {
                 constexpr int s = latw_slot(N, W, L, 0, t);
                 fr[s] = bcr_frag(F, i - h, BcrFmt::OLBRT, lane);
                 if constexpr (i + h < N) fr[s + 1] = bcr_frag(F, i + h, BcrFmt::OLBLT, lane);
@@ -77,8 +113,8 @@ __device__ __forceinline__ void latw_load(const double *F, d4 *fr) {
         });
         static_for<0, lat_count(N, L, 1)>([&](auto tc) {
             constexpr int t = decltype(tc)::value, e = lat_stage(L, 1, t);
-            if constexpr (latw_owner(N, L, 1, t) == W) { constexpr int s1 = latw_slot(N, W, L, 1, t); fr[s1] = bcr_frag(F, e, BcrFmt::ODINV, lane); }
-            if constexpr (latw_owner(N, L, 2, t) == W) {
+            if constexpr (!(latw_fused(N) && L == 0) && latw_owner(N, L, 1, t) == W) { constexpr int s1 = latw_slot(N, W, L, 1, t); fr[s1] = bcr_frag(F, e, BcrFmt::ODINV, lane); }
+            if constexpr (!latw_fused_back(N) && latw_owner(N, L, 2, t) == W) {
                 constexpr int s = latw_slot(N, W, L, 2, t);
                 if constexpr (e - h >= 0) fr[s] = bcr_frag(F, e, BcrFmt::OLBL, lane);
                 constexpr int s2 = s + (e - h >= 0 ? 1 : 0);
@@ -90,7 +126,7 @@ __device__ __forceinline__ void latw_load(const double *F, d4 *fr) {
 
 // LDS vectors of the round (stage-major, stride 16; mpcqp_lat.h): tb right-hand side / solution, cb c_e of the reduction -- and, at the top stages'
 // slots, the top's solution until level 1 back has copied it into tb; each seen through the lane bases of the four block rotations.
-struct LatwVecs { double *tb, *cb; const double *t1, *t2, *t3, *c1, *c2, *c3; double *xt; };      // (xt: LATW_TOP_VALU, the top's compact input, per-lane base as tb)
+struct LatwVecs { double *tb, *cb; const double *t1, *t2, *t3, *c1, *c2, *c3; double *xt, *x2; };      // (xt: LATW_TOP_VALU, the top's compact input, per-lane base as tb; x2: LATW_FUSE0, the top stages' contributions from the next group)
 #ifndef LATW_IN_DPP
 #define LATW_IN_DPP 0              // 1: one LDS read per input vector and three DPP block rotations instead of four reads (measured: see LAB_NOTES.md)
 #endif
@@ -115,6 +151,7 @@ __device__ __forceinline__ void latw_fwd(const d4 *fr, const LatwVecs &v) {
         if constexpr (latw_owner(N, L, 0, t) == W) {
             constexpr int s = latw_slot(N, W, L, 0, t);
             double p = v.tb[i * 16], q = 0.0;                 // (the stage's own right-hand side starts the chain)
+            if constexpr (latw_fused(N) && L == 1) p += v.x2[((i + 1) / 4 - 1) * 16];      // (its level-0 contribution from the next group's first stage)
             latw_mv_lds<false>(fr[s], v, (i - h) * 16, p, q);
             if constexpr (i + h < N) latw_mv_lds<false>(fr[s + 1], v, (i + h) * 16, p, q);
             // (level 1 keeps exactly the top stages 4 (r + 1) - 1: with the vector-ALU top their reduced right-hand side goes to the compact Xt --
@@ -132,6 +169,21 @@ __device__ __forceinline__ void latw_fwd(const d4 *fr, const LatwVecs &v) {
             v.cb[e * 16] = p + q;
         }
     });
+}
+// level 0 forward of wave W's own four stages (LATW_FUSE0), called right behind the right-hand side without a barrier
+template <int N, int W>
+__device__ __forceinline__ void latw_fwd0_own(const d4 *fr, const LatwVecs &v) {
+    constexpr int s0 = 4 * W;
+    if constexpr (s0 < N) { double p = 0.0, q = 0.0; latw_mv_lds<false>(fr[0], v, s0 * 16, p, q); v.cb[s0 * 16] = p + q; }
+    if constexpr (s0 + 2 < N) { double p = 0.0, q = 0.0; latw_mv_lds<false>(fr[1], v, (s0 + 2) * 16, p, q); v.cb[(s0 + 2) * 16] = p + q; }
+    if constexpr (s0 + 1 < N) {
+        double p = v.tb[(s0 + 1) * 16], q = 0.0;
+        latw_mv_lds<false>(fr[2], v, s0 * 16, p, q);
+        if constexpr (s0 + 2 < N) latw_mv_lds<false>(fr[3], v, (s0 + 2) * 16, p, q);
+        v.tb[(s0 + 1) * 16] = p + q;
+    }
+    if constexpr (s0 + 3 < N) { double p = v.tb[(s0 + 3) * 16], q = 0.0; latw_mv_lds<false>(fr[4], v, (s0 + 2) * 16, p, q); v.tb[(s0 + 3) * 16] = p + q; }
+    if constexpr (W > 0 && s0 < N) { double p = 0.0, q = 0.0; latw_mv_lds<false>(fr[5], v, s0 * 16, p, q); v.x2[(W - 1) * 16] = p + q; }
 }
 // back substitution of level L; TOPIN: the neighbours are top stages whose solution still sits in cb (level 1)
 template <int N, int W, int L, bool TOPIN>
@@ -156,6 +208,31 @@ __device__ __forceinline__ void latw_bwd1(const d4 *fr, const LatwVecs &v) {
         if constexpr (r % NWAVES == W) v.tb[latw_top_stage(r) * 16] = v.cb[latw_top_stage(r) * 16];
     });
     latw_bwd<N, W, 1, true>(fr, v);
+}
+
+// level 1 back and level 0 back of wave W's own stages in one phase (LATW_FUSE0 >= 2); the top's solution is read from cb where the neighbour is a top stage
+template <int N, int W>
+__device__ __forceinline__ void latw_bwd_own(const d4 *fr, const LatwVecs &v) {
+    constexpr int bb = latw_back_base(N, W), e1 = 4 * W + 1, ea = 4 * W, eb = 4 * W + 2;
+    if constexpr (W < BcrFmt::top_count(N)) v.tb[latw_top_stage(W) * 16] = v.cb[latw_top_stage(W) * 16];      // (the top's row W into tb, for the owner passes)
+    if constexpr (e1 < N) {
+        double p = v.cb[e1 * 16], q = 0.0;
+        if constexpr (e1 - 2 >= 0) latw_mv_lds<true>(fr[bb], v, (e1 - 2) * 16, p, q);
+        if constexpr (e1 + 2 < N) latw_mv_lds<true>(fr[bb + 1], v, (e1 + 2) * 16, p, q);
+        v.tb[e1 * 16] = p + q;
+    }
+    if constexpr (ea < N) {
+        double p = v.cb[ea * 16], q = 0.0;
+        if constexpr (ea - 1 >= 0) latw_mv_lds<true>(fr[bb + 2], v, (ea - 1) * 16, p, q);
+        if constexpr (ea + 1 < N) latw_mv_lds<false>(fr[bb + 3], v, (ea + 1) * 16, p, q);
+        v.tb[ea * 16] = p + q;
+    }
+    if constexpr (eb < N) {
+        double p = v.cb[eb * 16], q = 0.0;
+        latw_mv_lds<false>(fr[bb + 4], v, (eb - 1) * 16, p, q);
+        if constexpr (eb + 1 < N) latw_mv_lds<true>(fr[bb + 5], v, (eb + 1) * 16, p, q);
+        v.tb[eb * 16] = p + q;
+    }
 }
 
 // one fragment of the top inverse from its LDS copy: [block][half][lane][2]
@@ -312,14 +389,16 @@ template <int N>
 __device__ __forceinline__ void latw_solve(const d4 *fr, const double *TopL, const LatwVecs &v, double *Cc, int wv, int lane) {
     constexpr int NTOP = BcrFmt::top_count(N);
     static_assert(bcr_levels(N) >= 3 && NTOP >= 1, "two levels of reduction, then the dense top");
-    LATW_DISPATCH(wv, (latw_fwd<N, W, 0>(fr, v)))
-    __syncthreads();
+    if constexpr (!latw_fused(N)) {                       // (fused: done behind the right-hand side, the caller's barrier is this one)
+        LATW_DISPATCH(wv, (latw_fwd<N, W, 0>(fr, v)))
+        __syncthreads();
+    }
     TICK(1)
     LATW_DISPATCH(wv, (latw_fwd<N, W, 1>(fr, v)))
     __syncthreads();
     TICK(2)
 #if LATW_TOP_VALU
-    LATW_DISPATCH(wv, (latw_top_valu<N, W>(TopL, TopL + LATW_TOP_LDS(N) - 16 * NTOP, Cc, lane)))
+    LATW_DISPATCH(wv, (latw_top_valu<N, W>(TopL, TopL + LATW_TOP_LDS(N) - 32 * NTOP, Cc, lane)))
 #else
     LATW_DISPATCH(wv, (latw_top<N, W>(TopL, v, lane)))
 #endif
@@ -327,10 +406,15 @@ __device__ __forceinline__ void latw_solve(const d4 *fr, const double *TopL, con
     TICK(3)
     // level 1 back reads the top's solution from cb; on the way every top row's owner moves its stage into tb, where level 0 back (and the
     // owner passes) look for it -- nobody reads tb at a top stage during this phase
-    LATW_DISPATCH(wv, (latw_bwd1<N, W>(fr, v)))
-    __syncthreads();
-    TICK(4)
-    LATW_DISPATCH(wv, (latw_bwd<N, W, 0, false>(fr, v)))
+    if constexpr (latw_fused_back(N)) {
+        LATW_DISPATCH(wv, (latw_bwd_own<N, W>(fr, v)))
+        TICK(4)
+    } else {
+        LATW_DISPATCH(wv, (latw_bwd1<N, W>(fr, v)))
+        __syncthreads();
+        TICK(4)
+        LATW_DISPATCH(wv, (latw_bwd<N, W, 0, false>(fr, v)))
+    }
 }
 
 // ---- the round (as admm_lat, with ceil(NG / NWAVES) groups of four stages per wave) -----------------------------------------------------
@@ -388,7 +472,7 @@ __device__ __forceinline__ void admm_latw(const Lay &L, const HotPtrs &P, Smem &
     const int lo16 = vec_lane_offset(lane);
     const int lI = lane >> 4, lB = (lane >> 2) & 3;
     const int o1 = 4 * ((lB + 1) & 3) + lI, o2 = 4 * ((lB + 2) & 3) + lI, o3 = 4 * ((lB + 3) & 3) + lI;
-    const LatwVecs vec{Tc + lo16, Cc + lo16, Tc + o1, Tc + o2, Tc + o3, Cc + o1, Cc + o2, Cc + o3, TopL + LATW_TOP_LDS(N) - 16 * BcrFmt::top_count(N) + lo16};
+    const LatwVecs vec{Tc + lo16, Cc + lo16, Tc + o1, Tc + o2, Tc + o3, Cc + o1, Cc + o2, Cc + o3, TopL + LATW_TOP_LDS(N) - 32 * BcrFmt::top_count(N) + lo16, TopL + LATW_TOP_LDS(N) - 16 * BcrFmt::top_count(N) + lo16};
     // ---- owner map: lane (I, B, J), group g = wv + NWAVES q  ->  slot a = 4B + I of stage s = 4g + J
     const int a = 4 * ((lane >> 2) & 3) + (lane >> 4), J = lane & 3;
     const bool is_x = a < nx;
@@ -460,6 +544,7 @@ __device__ __forceinline__ void admm_latw(const Lay &L, const HotPtrs &P, Smem &
                 Tc[sl[q]] = ok[q] ? rhs : 0.0;
             }
         }
+        if constexpr (latw_fused(N)) { LATW_DISPATCH(wv, (latw_fwd0_own<N, W>(fr, vec))) }      // (level 0 forward of the wave's own stages: no barrier in between)
         __syncthreads();
         TICK(0)
         latw_solve<N>(fr, TopL, vec, Cc, wv, lane);

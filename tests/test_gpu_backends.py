@@ -201,14 +201,19 @@ def test_a_backend_the_shape_is_not_eligible_for_is_refused():
 
 
 def test_auto_follows_the_measured_cross_overs():
-    """mpcqp_create with backend AUTO: the dense register-resident inverse (N (nx+nu) <= 128) up to six instances per compute unit, block cyclic
-    reduction on 512-thread workgroups up to three, the bandwidth kernel beyond -- the cross-overs measured on (12,4,30), (12,4,10), (6,2,20),
-    (8,8,30) and on (3,1,30), (4,1,20), (2,2,12), (6,2,10), (12,4,7) (mpcqp.hip, LAB_NOTES.md).  Only handles are created: nothing is solved."""
+    """mpcqp_create with backend AUTO: the dense register-resident inverse (N (nx+nu) <= 128) up to six instances per compute unit; block cyclic
+    reduction on 512-thread workgroups at EVERY batch size for horizons of 21..30 steps with stages wider than 8 (its five-barrier form against the
+    bandwidth kernel: ahead on all six shapes measured), up to three instances per compute unit for anything else it is eligible for; the bandwidth
+    kernel beyond (mpcqp.hip, LAB_NOTES.md).  Only handles are created: nothing is solved."""
     import torch
     from pympc_amd.solver import BatchProblem
     ncu = torch.cuda.get_device_properties(0).multi_processor_count
     mode = lambda kn: int(kn.split(',')[4])
-    for (nx, nu, Np) in ((12, 4, 30), (6, 2, 20)):
+    for (nx, nu, Np) in ((12, 4, 30), (12, 4, 21), (6, 3, 28)):
+        for B in (1, 3 * ncu + 1, 4096):
+            kn = BatchProblem(B, nx, nu, Np).kernel_name(True)
+            assert kn.startswith('w8::') and mode(kn) == 231, (nx, nu, Np, B, kn)
+    for (nx, nu, Np) in ((12, 4, 20), (6, 2, 20), (6, 2, 28), (12, 4, 10)):
         for B, latency in ((3 * ncu, True), (3 * ncu + 1, False)):
             kn = BatchProblem(B, nx, nu, Np).kernel_name(True)
             assert kn.startswith('w8::') == latency and (mode(kn) >= 200) == latency, (nx, nu, Np, B, kn)

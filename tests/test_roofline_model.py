@@ -2,7 +2,7 @@
 ADMM iteration / round / solve.  The committed counter profiles of the same kernels (profiles/pmc_hbm_traffic.json: rocprofv3 FETCH_SIZE x 2
 + WRITE_SIZE per ADMM iteration per QP, scripts/r4_profiles.sh / scripts/profile_counters.sh + scripts/pmc_summary.py) are the measurement it must stay close to: if the
 factor format, the sweeps or the check phase change, the model changes with them and this test asks for a fresh profile instead of letting
-the headline fraction drift.  Five profiled command shapes: the headline batch, batch 4096, cfg-5 and the latency backend at 256 and 128 instances."""
+the headline fraction drift.  Six profiled command shapes: the headline batch as the library runs it (the register-resident kernel), the headline batch and batch 4096 with the bandwidth kernel forced, cfg-5, and 256 and 128 instances."""
 import json
 import os
 
@@ -11,16 +11,18 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-# key in the profile file, shape, batch, ADMM iterations per solve of the profiled launches, measured / model seen when the profile was taken
-CASES = [('cfg3', (12, 4, 30), 1024, 38.0, 1.01), ('cfg3_b4096', (12, 4, 30), 4096, 38.0, 1.02), ('cfg5', (20, 8, 100), 512, 27.5, 0.98),
-         ('cfg3_b256', (12, 4, 30), 256, 38.0, 1.25), ('cfg3_b128', (12, 4, 30), 128, 38.0, 1.10)]
+# key in the profile file, shape, batch, forced backend (None: what the library chooses), ADMM iterations per solve of the profiled launches, measured / model seen when the profile was taken
+CASES = [('cfg3', (12, 4, 30), 1024, None, 38.0, 1.26),
+         ('cfg3_sweeps', (12, 4, 30), 1024, 'sweeps', 38.0, 1.01), ('cfg3_sweeps_b4096', (12, 4, 30), 4096, 'sweeps', 38.0, 1.02), ('cfg5', (20, 8, 100), 512, None, 27.5, 0.98),
+         ('cfg3_b256', (12, 4, 30), 256, None, 38.0, 1.25), ('cfg3_b128', (12, 4, 30), 128, None, 38.0, 1.10)]
 
 
-@pytest.mark.parametrize('key,dims,batch,iters_per_solve,seen', CASES, ids=[c[0] for c in CASES])
-def test_stream_byte_model_matches_the_committed_counter_profile(key, dims, batch, iters_per_solve, seen):
-    from pympc_amd.solver import BatchProblem
+@pytest.mark.parametrize('key,dims,batch,forced,iters_per_solve,seen', CASES, ids=[c[0] for c in CASES])
+def test_stream_byte_model_matches_the_committed_counter_profile(key, dims, batch, forced, iters_per_solve, seen):
+    from pympc_amd.solver import BatchProblem, forced_settings
     nx, nu, Np = dims
-    bp = BatchProblem(batch, nx, nu, Np)
+    with forced_settings(**({'backend': forced} if forced else {})):
+        bp = BatchProblem(batch, nx, nu, Np)
     per_iter, per_round, per_solve = bp.stream_bytes()
     model = per_iter + per_round / 25.0 + per_solve / iters_per_solve        # one check per 25 iterations (OSQP's default)
     prof = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_hbm_traffic.json')))[key]['device_loop']
@@ -43,4 +45,4 @@ def test_stream_byte_model_matches_the_committed_counter_profile(key, dims, batc
     # 256 instances -- the model lost the weights' 2.5 KB per round, the kernel's ADMM phase gained spills (140 instead of 84 bytes per lane of scratch,
     # written before and read after the iteration loop of every round: ~ 3 KB per iteration and QP in the counters once an XCD's L2 no longer holds them).
     assert abs(ratio - seen) <= 0.08, (ratio, seen)
-    assert 0.85 <= ratio <= (1.30 if key in ('cfg3_b256', 'cfg3_b128') else 1.20), ratio
+    assert 0.85 <= ratio <= (1.35 if name.startswith('w8::') else 1.20), ratio
