@@ -3,7 +3,7 @@ profiles/pmc_hbm_traffic.json (one key per profiled command shape; tests/test_ro
 import json, os, shutil
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 O, P = os.path.join(R, 'gpurun_out'), os.path.join(R, 'profiles')
-shapes = {'cfg3': 'r5_cfg3', 'cfg3_b4096': 'r5b4096_cfg3', 'cfg3_sweeps': 'r5sw_cfg3', 'cfg3_sweeps_b4096': 'r5swb4096_cfg3', 'cfg3_b256': 'r5b256_cfg3', 'cfg3_b128': 'r5b128_cfg3',
+shapes = {'cfg3': 'r5_cfg3', 'cfg3_sweeps': 'r5sw_cfg3', 'cfg3_sweeps_b4096': 'r5swb4096_cfg3', 'cfg3_b256': 'r5b256_cfg3', 'cfg3_b128': 'r5b128_cfg3',
           'cfg5': 'r5_cfg5'}
 old = json.load(open(os.path.join(P, 'pmc_hbm_traffic.json')))
 new = {'round': '5: every entry taken on the final tree of round 5 with scripts/r5_profiles.sh (FETCH_SIZE, WRITE_SIZE and TCC_HIT/MISS in a pass each; '
