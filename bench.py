@@ -524,61 +524,178 @@ class Shard:
         ws = self.working_set_bytes()
         NX, NU = self.dims[0], self.dims[1]
         mode = int(kname.split('<')[1].split(',')[4])
-        # resident workgroup slots of the kernel: 4 per CU (16 x 16 sweeps), 2 (32 x 32), 1 (latency kernels, wide stages) x 256 CUs
-        slots = 256 * (1 if (mode >= 100 or mode == 2 or NX + NU > 32) else 4 if NX + NU <= 16 else 2)
+        # resident workgroup slots of the kernel: the library's own occupancy query (workgroups of this kernel a CU holds x the CUs of THIS device)
+        wg_per_cu, ncu, _ = prob.occupancy()
+        check_every = prob.settings_dict().get('check_termination', 25) or 25
+        slots = ncu * wg_per_cu
         # what the memory-side cache sees: the instances IN FLIGHT.  An instance re-reads its factor every iteration while it is resident -- for a whole
         # closed loop on the device-loop path, for a round of 25 iterations per launch on the stepwise one -- so the reuse distance of the stream is one
         # iteration of the resident instances, not the batch
         ws_active = self.working_set_bytes(slots)
+        secs = admm_ms * 1e-3
+        model_b = design_bytes / max(1, iters)                     # design bytes per ADMM iteration and QP, rounds and solves amortised
+        common = {'kernel': kname, 'kernel_ms': admm_ms / launches, 'launches': res['launches'], 'steps_per_launch': res.get('chunk', 1),
+                  'bytes_per_launch': design_bytes / launches, 'model_bytes_per_iter_per_qp': model_b, 'measured_bytes_per_iter_per_qp': pmc_b,
+                  'traffic': traffic, 'traffic_GBps': (traffic * launches / secs / 1e9) if traffic else None,
+                  'frac_counters': (traffic * launches / secs / HBM_PEAK) if traffic else None,
+                  'traffic_over_model': (pmc_b / model_b) if pmc_b else None,
+                  'traffic_profile': ('profiles/pmc_hbm_traffic.json:%s/%s (batch %s)' % (workload_key, path, pmc_batch if pmc_batch is not None else self.B)) if pmc_b else None,
+                  'design_bytes_per_iter_per_qp': per_iter, 'design_bytes_per_round_per_qp': per_round, 'design_bytes_per_solve_per_qp': per_solve,
+                  'working_set_bytes': ws, 'active_working_set_bytes': ws_active, 'fits_infinity_cache': bool(ws_active <= INFINITY_CACHE),
+                  'resident_slots': slots, 'compute_units': ncu, 'check_every': check_every}
         if mode >= 100:
-            # the latency backend (at most two instances per CU): factor and iterate live in registers, an iteration reads nothing from
-            # memory -- the kernel is bound by the matrix cores' issue rate and the dependent level steps, not by HBM
+            # the register-resident backends (one workgroup per CU at a time): factor and iterate live in registers and LDS, an ADMM iteration reads
+            # nothing from memory; what the kernel moves is per round (level fragments, owner values, check inputs) and per solve.  `frac` is those
+            # design bytes (mpcqp_get_stream_bytes x the device-side counters of the timed region) / HIP-event kernel time / 8 TB/s -- the same
+            # definition as for the bandwidth kernels -- and it is SMALL BY DESIGN: the kernel is bound by dependent level steps, not by HBM.
+            # Named separately: mfma_issue_frac = executed v_mfma_f64_4x4x4 flops (512 per instruction, mpcqp_get_work) / time / the FP64 matrix
+            # peak; useful_flop_frac = a quarter of that (a mat-vec uses one of the four B columns).
             mfma = prob.mfma_per_iter()
             flops = 512.0 * mfma * iters
-            tail = self.tail_split(res, 512.0 * mfma, 0.0, 0.0) if path == 'device_loop' else None
-            return {'bound': 'mfma', 'frac_excluding_tail': (tail['rate_before_tail'] / MFMA_F64_PEAK) if tail else None, 'tail': tail, 'achieved': flops / (admm_ms * 1e-3) / 1e12, 'peak': MFMA_F64_PEAK / 1e12, 'unit': 'TFLOP/s',
-                    'frac': flops / (admm_ms * 1e-3) / MFMA_F64_PEAK, 'traffic': traffic, 'measured_bytes_per_iter_per_qp': pmc_b,
-                    'traffic_source': ('from_profile: profiles/pmc_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE per ADMM iteration per QP, profiled at batch %s) x this run\'s iterations per launch'
-                                       % (pmc_batch if pmc_batch is not None else 'of the same command')) if pmc_b else None,
-                    'design_bytes_per_round_per_qp': per_round, 'design_bytes_per_solve_per_qp': per_solve,
-                    'frac_is': 'executed v_mfma_f64_4x4x4_4b_f64 flops (512 per instruction, mpcqp_get_work x the device-side iteration count) / HIP-event kernel '
-                               'time / the FP64 matrix peak; a mat-vec uses one of the four B-operand columns, so a quarter of these flops is useful; the dense top of the cyclic-reduction '
-                               'backends (16 nt x 16 nt mat-vec per iteration) runs on the vector ALU and is not in this count',
-                    'useful_frac': 0.25 * flops / (admm_ms * 1e-3) / MFMA_F64_PEAK, 'mfma_per_iter_per_qp': mfma,
-                    'occupancy_note': '%d instances on %d CUs: one workgroup per CU at a time (%s)' % (self.B, 256, 'w8:: kernels: 512 threads, two waves per SIMD' if kname.startswith('w8::') else '256 threads, one wave per SIMD'),
-                    'hbm_design_bytes_per_launch': design_bytes / launches, 'hbm_frac': achieved / HBM_PEAK,
-                    'working_set_bytes': ws, 'active_working_set_bytes': ws_active, 'fits_infinity_cache': bool(ws_active <= INFINITY_CACHE),
-                    'kernel': kname, 'kernel_ms': admm_ms / launches, 'launches': res['launches'], 'steps_per_launch': res.get('chunk', 1)}
-        tail = self.tail_split(res, per_iter, per_round, per_solve) if path == 'device_loop' else None
-        return {'bound': 'hbm', 'achieved': achieved / 1e9, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
-                'frac': achieved / HBM_PEAK, 'frac_is': 'model-based: design bytes (below) / HIP-event kernel time / 8 TB/s',
-                'frac_excluding_tail': (tail['rate_before_tail'] / HBM_PEAK) if tail else None, 'tail': tail,
-                'frac_of_achievable': achieved / HBM_ACHIEVABLE, 'achievable_GBps': HBM_ACHIEVABLE / 1e9,      # (MI355X_MICROARCH.md: 6.29 TB/s measured with a float4 copy)
-                'traffic': traffic,
-                'traffic_source': ('from_profile: profiles/pmc_hbm_traffic.json (FETCH_SIZE x2 + WRITE_SIZE per ADMM iteration per QP, profiled at batch %s) x this run\'s iterations per launch'
-                                   % (pmc_batch if pmc_batch is not None else 'of the same command')) if pmc_b else None,
-                'traffic_GBps': (traffic / (admm_ms / launches * 1e-3) / 1e9) if traffic else None,
-                'working_set_bytes': ws, 'active_working_set_bytes': ws_active, 'fits_infinity_cache': bool(ws_active <= INFINITY_CACHE),
-                'working_set_note': 'one instance per resident workgroup slot is in flight (%d slots) and re-reads its factor every iteration while it is: the ACTIVE set is what the '
-                                    '256 MiB Infinity Cache sees, whatever the batch (HBM delivers an instance\'s first touch per launch); cfg-5\'s active set (768 MB) is the one beyond it' % slots,
-                'frac_of_read_stream': achieved / (MALL_READ_STREAM if ws_active <= INFINITY_CACHE else HBM_READ_STREAM),
-                'read_stream_GBps': (MALL_READ_STREAM if ws_active <= INFINITY_CACHE else HBM_READ_STREAM) / 1e9,
-                'bytes_model': 'design: what k_mpc_run streams per instance (mpcqp_get_stream_bytes) -- per ADMM iteration the KKT factor '
-                               '(%s%s), per round the residual-evaluation inputs and the '
-                               'iterate in/out of LDS, per solve the QP refresh and the write-out'
-                               % ('forward matrices of N-1 stages, packed S^-1 of N stages and the stage tables once each, [G|G\'] once' if NX + NU <= 16
-                                  else 'packed S^-1 of N stages twice, one stage table per sweep, [G|G\'] by each sweeping wave',
-                                  '' if lds_state else '; iterate and metric vectors too: they do not fit LDS at this size'),
-                'design_bytes_per_iter_per_qp': per_iter, 'design_bytes_per_round_per_qp': per_round, 'design_bytes_per_solve_per_qp': per_solve,
-                'design_bytes_per_launch': design_bytes / launches,
-                'measured_bytes_per_iter_per_qp': pmc_b,
-                'kernel': kname, 'kernel_ms': admm_ms / launches, 'launches': res['launches'],
-                'steps_per_launch': res.get('chunk', 1),
-                'algorithmic_8d': {'bytes_per_launch': alg8d / launches, 'bytes_per_iter_per_qp': b_it8d, 'nnzL': prob.nnzL,
-                                   'GBps': alg8d / (admm_ms * 1e-3) / 1e9, 'frac_8d': alg8d / (admm_ms * 1e-3) / HBM_PEAK,
-                                   'note': 'SURVEY 8(d) generic sparse-LDL formula; charges 6n+10m vector doubles per iteration to HBM that this '
-                                           'kernel keeps in LDS/registers, so it exceeds the HBM peak BY CONSTRUCTION (frac_8d > 1 is not a '
-                                           'bandwidth claim) -- not used for frac'}}
+            tail = self.tail_split(res, per_iter, per_round, per_solve, check_every) if path == 'device_loop' else None
+            return dict(common, bound='hbm', achieved=achieved / 1e9, peak=HBM_PEAK / 1e9, unit='GB/s', frac=achieved / HBM_PEAK,
+                        frac_excluding_tail=(tail['rate_before_tail'] / HBM_PEAK) if tail else None, tail=tail,
+                        mfma_issue_frac=flops / secs / MFMA_F64_PEAK, useful_flop_frac=0.25 * flops / secs / MFMA_F64_PEAK,
+                        mfma_flops_executed_per_launch=flops / launches, mfma_per_iter_per_qp=mfma, mfma_peak_TFLOPs=MFMA_F64_PEAK / 1e12)
+        tail = self.tail_split(res, per_iter, per_round, per_solve, check_every) if path == 'device_loop' else None
+        stream = MALL_READ_STREAM if ws_active <= INFINITY_CACHE else HBM_READ_STREAM
+        return dict(common, bound='hbm', achieved=achieved / 1e9, peak=HBM_PEAK / 1e9, unit='GB/s', frac=achieved / HBM_PEAK,
+                    frac_excluding_tail=(tail['rate_before_tail'] / HBM_PEAK) if tail else None, tail=tail,
+                    frac_of_achievable=achieved / HBM_ACHIEVABLE, achievable_GBps=HBM_ACHIEVABLE / 1e9,      # (MI355X_MICROARCH.md: 6.29 TB/s measured with a float4 copy)
+                    frac_of_read_stream=achieved / stream, read_stream_GBps=stream / 1e9, lds_state=lds_state,
+                    algorithmic_8d={'bytes_per_launch': alg8d / launches, 'bytes_per_iter_per_qp': b_it8d, 'nnzL': prob.nnzL,
+                                    'GBps': alg8d / secs / 1e9, 'frac_8d': alg8d / secs / HBM_PEAK})
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the ONE line the driver parses: numbers only, a few kB (round 5's line carried every leg twice with its prose: 27.5 kB, and the
+# driver recorded `parsed: null`).  Everything else goes to the side file bench_legs.json (LEGS_FILE below).
+# ----------------------------------------------------------------------------------------------------------------------
+LINE_BUDGET = 6000          # bytes; tests/test_bench_line.py holds the assembled line to it
+
+
+def legs_path():
+    """Where the full record of a run goes: $MPCQP_BENCH_LEGS, else gpurun_out/ if this tree has one (it travels back from the GPU box), else the repo root."""
+    p = os.environ.get('MPCQP_BENCH_LEGS')
+    if p:
+        return p
+    d = os.path.join(ROOT, 'gpurun_out')
+    return os.path.join(d if os.path.isdir(d) else ROOT, 'bench_legs.json')
+
+
+def _num(v, nd=6):
+    """Numbers to `nd` significant digits (the line is read by a parser, not by the eye; the side file keeps every digit)."""
+    if isinstance(v, bool) or v is None or isinstance(v, (int, str)):
+        return v
+    if isinstance(v, float):
+        if v != v or v in (float('inf'), float('-inf')):
+            return None
+        return float('%.*g' % (nd, v))
+    return v
+
+
+def _pick(d, keys, nd=6):
+    return {k: _num(d[k], nd) for k in keys if isinstance(d, dict) and k in d and d[k] is not None and not isinstance(d[k], (dict, list))}
+
+
+ROOF_KEYS = ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'kernel', 'kernel_ms', 'launches', 'steps_per_launch',
+             'frac_counters', 'traffic_GBps', 'frac_excluding_tail', 'mfma_issue_frac', 'useful_flop_frac',
+             'bytes_per_launch', 'model_bytes_per_iter_per_qp', 'measured_bytes_per_iter_per_qp', 'traffic_over_model', 'traffic_profile')
+
+
+def compact_leg(leg, nd=5):
+    """value + what bounds it, numbers only (kernel names and the rest: the side file)."""
+    ro = leg.get('roofline') or {}
+    sp = leg.get('launch_spread') or {}
+    o = _pick(leg, ('batch', 'value', 'mean_admm_iters'), nd)
+    o.update(_pick(ro, ('frac', 'frac_excluding_tail', 'frac_counters', 'kernel_ms', 'mfma_issue_frac'), 4))
+    if sp.get('critical_path_ratio') is not None:
+        o['critical_path_ratio'] = _num(sp['critical_path_ratio'], 4)
+    return o
+
+
+def compact_line(out):
+    """The driver's line from the full record: every key of the bench contract, `roofline` and `cpu_baseline` as objects of numbers and short
+    identifiers, one small object per leg.  No prose.  Pure function of `out` (tests/test_bench_line.py feeds it canned records)."""
+    line = {k: _num(out.get(k)) for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                                          'vs_baseline', 'dtype', 'data', 'ranks_seen', 'devices_seen', 'collective_backend')}
+    cfg = out.get('config') or {}
+    line['config'] = _pick(cfg, ('workload', 'nx', 'nu', 'Np', 'n', 'm', 'batch_per_gpu', 'total_batch', 'eps_abs', 'eps_rel', 'path', 'parallelism'))
+    line.update(_pick(out, ('mean_admm_iters', 'solved_fraction_last_step', 'refactorizations_per_solve')))
+    line['roofline'] = _pick(out.get('roofline') or {}, ROOF_KEYS)
+    cpu = out.get('cpu_baseline')
+    if cpu:
+        c = _pick(cpu, ('value', 'unit', 'cores', 'kind'))
+        c['sample'] = str(cpu.get('sample', ''))[:160]
+        ac = cpu.get('all_cores') or {}
+        if 'value' in ac:
+            c['all_cores'] = _pick(ac, ('value', 'cores'))
+        line['cpu_baseline'] = c
+    ue = out.get('u_err')
+    if ue:
+        line['u_err'] = {k: _pick(v, ('max_abs', 'max_rel', 'instances'), 4) for k, v in ue.items() if isinstance(v, dict)}
+        line['u_err']['tolerance_rel'] = ue.get('north_star_tolerance_rel', 1e-6)
+    line['per_rank'] = [_pick(r, ('rank', 'instances', 'first_instance', 'value', 'ms_per_step', 'roofline_frac', 'kernel_ms', 'scatter_ms', 'gather_calls', 'gather_ms_per_call'), 5)
+                        for r in (out.get('per_rank') or [])]
+    line['cold'] = _pick(out.get('cold') or {}, ('setup_ms', 'first_solve_ms', 'iters_per_instance'), 4)
+    legs = {}
+    if out.get('other_path'):
+        legs[out['other_path']['path']] = _pick(out['other_path'], ('value', 'ms_per_step', 'mean_admm_iters'))
+    if out.get('parity_setting'):
+        legs['eps_1e-9'] = _pick(out['parity_setting'], ('value', 'ms_per_step', 'mean_admm_iters', 'solved_fraction_last_step'))
+    if out.get('strong_scaling'):
+        legs['strong_total1024'] = _pick(out['strong_scaling'], ('value', 'ms_per_step', 'batch_per_gpu', 'mean_admm_iters'))
+    if out.get('hbm_leg'):
+        legs['sweeps_b%d' % out['hbm_leg']['batch']] = compact_leg(out['hbm_leg'])
+        if out['hbm_leg'].get('stepwise'):
+            legs['sweeps_b%d_stepwise' % out['hbm_leg']['batch']] = compact_leg(out['hbm_leg']['stepwise'])
+    if out.get('cfg5_leg'):
+        c5 = compact_leg(out['cfg5_leg'])
+        c5['eps_1e-9_value'] = _num((out['cfg5_leg'].get('parity_setting') or {}).get('value'))
+        u5 = out['cfg5_leg'].get('u_err') or {}
+        if 'eps_1e-09' in u5:
+            c5['u_err_rel_eps_1e-9'] = _num(u5['eps_1e-09'].get('max_rel'), 4)
+        legs['cfg5_b%d' % out['cfg5_leg']['batch']] = c5
+    for k, v in (out.get('small_batch_legs') or {}).items():
+        if 'error' not in v:
+            legs[k] = compact_leg(v)
+    for k, v in (out.get('shared_model_legs') or {}).items():
+        if 'error' not in v:
+            legs[k] = dict(compact_leg(v), **_pick(v, ('useful_flop_frac', 'u_err_rel')))
+    pr = out.get('strong_scaling_projection')
+    if pr:
+        legs['projection_8gpu'] = _pick(pr, ('batch_per_gpu_at_8', 'projected_8gpu_value', 'projected_vs_1gpu_full_batch', 'weak_scaling_projection_8gpu_value'))
+    lat = out.get('latency') or {}
+    for k, v in lat.items():
+        if isinstance(v, dict) and 'update_us_median' in v:
+            legs['latency_' + k] = _pick(v, ('update_us_median', 'update_us_p95', 'kernel_us', 'raw_c_abi_step_us', 'cpu_oracle_update_us_median', 'mean_admm_iters'), 4)
+    line['legs'] = legs
+    ro = out.get('real_osqp') or {}
+    line['real_osqp'] = _pick(ro, ('osqp_available', 'osqp_version', 'all_equal'))
+    line['legs_file'] = out.get('legs_file')
+    # the budget is a hard one: shed detail (never the contract's keys) until the line fits
+    def fits():
+        return len(json.dumps(line)) <= LINE_BUDGET
+    if not fits():
+        line['legs'] = {k: _pick(v, ('batch', 'value', 'frac', 'update_us_median', 'projected_8gpu_value'), 4) for k, v in legs.items()}
+    for drop in ('cold', 'real_osqp', 'legs'):
+        if fits():
+            break
+        line.pop(drop, None)
+    return line
+
+
+def emit(out):
+    """Side file first (the whole record), then the compact line as the LAST line on stdout."""
+    path = legs_path()
+    out['legs_file'] = os.path.relpath(path, ROOT)
+    try:
+        with open(path, 'w') as f:
+            json.dump(out, f, default=lambda o: o.tolist() if hasattr(o, 'tolist') else repr(o))
+    except OSError as e:
+        out['legs_file'] = 'unwritable: %r' % (e,)
+    sys.stdout.flush()
+    print(json.dumps(compact_line(out)), flush=True)
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -796,17 +913,11 @@ def main():
                                 'launch_spread': r3.get('launch_spread'),
                                 'stepwise': {'value': args.hbm_leg_batch * min(args.steps, 25) / r3s['elapsed'], 'unit': 'QP-solves/s', 'ms_per_step': 1e3 * r3s['elapsed'] / min(args.steps, 25),
                                              'mean_admm_iters': r3s['iters'] / max(1, r3s['solves']),
-                                             'roofline': {k: ro3s[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'frac_of_read_stream', 'read_stream_GBps', 'working_set_bytes',
-                                                                               'active_working_set_bytes', 'fits_infinity_cache', 'kernel', 'kernel_ms', 'launches', 'design_bytes_per_launch')}},
-                                'roofline': {k: ro3[k] for k in ('active_working_set_bytes', 'working_set_note', 'frac_of_read_stream', 'read_stream_GBps', 'bound', 'achieved', 'peak', 'unit', 'frac', 'frac_excluding_tail', 'tail', 'frac_of_achievable', 'achievable_GBps', 'traffic', 'traffic_source', 'traffic_GBps',
-                                                                 'measured_bytes_per_iter_per_qp', 'design_bytes_per_iter_per_qp', 'working_set_bytes',
-                                                                 'fits_infinity_cache', 'kernel', 'kernel_ms', 'design_bytes_per_launch')},
-                                'note': '4096 instances pass through 1024 resident workgroup slots; an instance re-reads its factor every ADMM iteration while it is resident, so the stream '
-                                        're-reads an ACTIVE set of 219 MB whatever the batch -- inside the 256 MiB Infinity Cache, like the headline (rounds 2-4 called this leg "HBM-only": it is '
-                                        'not; what the larger batch removes is the idle tail, finished slots refill).  `stepwise` walks all 878 MB per solve, 25 iterations per launch: HBM serves '
-                                        'the first of them.  frac_of_read_stream compares with a whole-chip READ-ONLY stream of the same shape from the same place (profiles/r5_hbm_stream.txt: '
-                                        '6.9 TB/s from the Infinity Cache, 5.95 TB/s from HBM); frac is against the 8 TB/s HBM peak either way.  The leg whose active set (768 MB) IS beyond the '
-                                        'Infinity Cache is cfg5_leg'}
+                                             'roofline': ro3s},
+                                'roofline': ro3}
+            # (4096 instances pass through the resident workgroup slots; an instance re-reads its factor every ADMM iteration while it is resident, so the stream re-reads an
+            #  ACTIVE set of 219 MB whatever the batch -- inside the 256 MiB Infinity Cache, like the headline; what the larger batch removes is the idle tail.  `stepwise`
+            #  walks all 878 MB per solve, 25 iterations per launch: HBM serves the first of them.  The leg whose active set (768 MB) IS beyond the Infinity Cache is cfg5_leg.)
             del s3
             torch.cuda.empty_cache()
         if world == 1 and args.workload == 'cfg3' and args.cfg5_leg_batch:
@@ -828,10 +939,7 @@ def main():
                                  'value': B5 * 50 / r5['elapsed'], 'unit': 'QP-solves/s', 'ms_per_step': 1e3 * r5['elapsed'] / 50,
                                  'mean_admm_iters': r5['iters'] / max(1, r5['solves']), 'solved_fraction_last_step': sum(1 for i in inf5 if i.status == 1) / B5,
                                  'launch_spread': r5.get('launch_spread'), 'cold': s5.cold,
-                                 'roofline': {k: ro5[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'frac_is', 'frac_excluding_tail', 'tail', 'frac_of_achievable', 'traffic', 'traffic_source', 'traffic_GBps',
-                                                                  'measured_bytes_per_iter_per_qp', 'design_bytes_per_iter_per_qp', 'design_bytes_per_round_per_qp',
-                                                                  'design_bytes_per_solve_per_qp', 'working_set_bytes', 'fits_infinity_cache', 'kernel', 'kernel_ms',
-                                                                  'launches', 'steps_per_launch', 'design_bytes_per_launch')},
+                                 'roofline': ro5,
                                  'parity_setting': {'eps_abs': 1e-9, 'eps_rel': 1e-9, 'value': B5 * 50 / p5['elapsed'], 'ms_per_step': 1e3 * p5['elapsed'] / 50,
                                                     'mean_admm_iters': p5['iters'] / max(1, p5['solves']), 'launch_spread': p5.get('launch_spread')}}
             del s5
@@ -853,10 +961,9 @@ def main():
                 torch.cuda.empty_cache()
             extra['strong_scaling_projection'] = {'total_batch': B, 'batch_per_gpu_at_8': B // 8, 'measured_1gpu_value_at_that_batch': v8, 'kernel': s8.prob.kernel_name(loop=True),
                                                   'projected_8gpu_value': 8 * v8, 'projected_vs_1gpu_full_batch': 8 * v8 / (TOTAL * args.steps / elapsed),
-                                                  'weak_scaling_projection_8gpu_value': 8 * TOTAL * args.steps / elapsed,
-                                                  'note': 'strong scaling (total batch fixed) leaves %d instances on 256 CUs per GPU: one 512-thread workgroup (latency backend, mpcqp_w8.hip) per instance, '
-                                                          'half the CUs idle at 128, and a launch as long as its slowest instance; weak scaling (%d instances per GPU) is what --gpus N measures, '
-                                                          '--total-batch the strong reading on real GPUs' % (B // 8, B)}
+                                                  'weak_scaling_projection_8gpu_value': 8 * TOTAL * args.steps / elapsed}
+            # (strong scaling -- total batch fixed -- leaves B/8 instances per GPU: one 512-thread workgroup per instance, half the CUs idle at 128, and a launch as long as its
+            #  slowest instance; weak scaling -- B per GPU -- is what --gpus N measures, --total-batch the strong reading on real GPUs)
             del s8
             torch.cuda.empty_cache()
             # the BANDWIDTH kernel forced at the headline batch: the headline kernel of rounds 1-4 and of the first half of round 5 (HBM / Infinity-Cache bound: its
@@ -877,36 +984,6 @@ def main():
             except Exception as e:
                 extra['latency'] = {'error': repr(e)}
 
-    if rank == 0 and roof is not None:
-        # every BASELINE config's number inside the roofline object (compact: value, fraction of ITS roofline, kernel time, counter traffic, tail)
-        def compact(leg, ro=None):
-            ro = ro if ro is not None else leg.get('roofline') or {}
-            sp = leg.get('launch_spread') or {}
-            return {'value': leg.get('value'), 'unit': 'QP-solves/s', 'batch': leg.get('batch'), 'bound': ro.get('bound', 'hbm'), 'frac': ro.get('frac'),
-                    'frac_excluding_tail': ro.get('frac_excluding_tail'), 'kernel': ro.get('kernel'), 'kernel_ms': ro.get('kernel_ms'),
-                    'measured_bytes_per_iter_per_qp': ro.get('measured_bytes_per_iter_per_qp'), 'design_bytes_per_iter_per_qp': ro.get('design_bytes_per_iter_per_qp'),
-                    'critical_path_ratio': sp.get('critical_path_ratio'), 'ms_per_step': leg.get('ms_per_step')}
-        legs = {}
-        if 'hbm_leg' in extra:
-            sw = extra['hbm_leg']['stepwise']
-            legs['hbm_b%d' % extra['hbm_leg']['batch']] = dict(compact(extra['hbm_leg']), fits_infinity_cache=extra['hbm_leg']['roofline']['fits_infinity_cache'],
-                                                             frac_of_read_stream=extra['hbm_leg']['roofline']['frac_of_read_stream'],
-                                                             stepwise_value=sw['value'], stepwise_frac=sw['roofline']['frac'], stepwise_frac_of_read_stream=sw['roofline']['frac_of_read_stream'],
-                                                             stepwise_fits_infinity_cache=sw['roofline']['fits_infinity_cache'], stepwise_kernel_ms=sw['roofline']['kernel_ms'])
-        if 'cfg5_leg' in extra:
-            legs['cfg5_b%d' % extra['cfg5_leg']['batch']] = dict(compact(extra['cfg5_leg']), parity_setting_value=extra['cfg5_leg']['parity_setting']['value'])
-        for k, v in (extra.get('small_batch_legs') or {}).items():
-            legs[k] = compact(v)
-        if parity:
-            legs['parity_eps_1e-9'] = {'value': parity['value'], 'unit': 'QP-solves/s', 'batch': B, 'mean_admm_iters': parity['mean_admm_iters']}
-        if other:
-            legs[other['path']] = {'value': other['value'], 'unit': 'QP-solves/s', 'batch': B}
-        lat = extra.get('latency') or {}
-        for k in ('cfg2', 'notebook', 'kalman_np200'):
-            if k in lat:
-                legs['latency_' + k] = {'update_us_median': lat[k]['update_us_median'], 'update_us_p95': lat[k]['update_us_p95'], 'kernel_us': lat[k]['kernel_us'],
-                                        'cpu_oracle_update_us_median': lat[k]['cpu_oracle_update_us_median'], 'kernel': lat[k]['kernel']}
-        roof['legs'] = legs
     if rank == 0:
         out = {
             'metric': 'QP-solves/sec (MPC steps/sec) at nx=%d nu=%d Np=%d; max |u*-u*_ref|' % (NX, NU, NP),
@@ -917,8 +994,9 @@ def main():
             'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
             'ranks_seen': seen['ranks_seen'], 'devices_seen': seen['devices_seen'], 'collective_backend': seen['backend'],
-            'config': {'workload': '%s: %d random stable LTI MPC instances per GPU (nx=%d, nu=%d, Np=Nc=%d, n=%d, m=%d), '
-                                   'warm-started receding horizon x+=Ad x+Bd u*+w' % ('cfg-3' if args.workload == 'cfg3' else 'cfg-5', B, NX, NU, NP, n, m),
+            'config': {'workload': '%s: %d x (nx=%d, nu=%d, Np=Nc=%d) random stable LTI MPC instances per GPU, warm-started receding horizon'
+                                   % ('cfg-3' if args.workload == 'cfg3' else 'cfg-5', B, NX, NU, NP),
+                       'nx': NX, 'nu': NU, 'Np': NP, 'n': n, 'm': m,
                        'batch_per_gpu': B, 'total_batch': TOTAL, 'eps_abs': args.eps, 'eps_rel': args.eps, 'path': args.path,
                        'parallelism': 'instances sharded over %d GPU(s); RCCL scatter of data, all-gather of u*' % world},
             'mean_admm_iters': iters / max(1, solves),
@@ -957,7 +1035,7 @@ def main():
             _, refs5 = cpu_legs(WORKLOADS['cfg5'][:4], args.eps, cfg5_samples, want_baseline=False)
             out['cfg5_leg']['u_err'] = u_err_block(cfg5_samples, refs5)
         out['real_osqp'] = real_osqp_pin() if not args.no_cpu_baseline else {'osqp_available': osqp_available()}
-        print(json.dumps(out))
+        emit(out)
     if comm_on(world):
         dist.barrier()
         dist.destroy_process_group()

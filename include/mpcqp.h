@@ -82,7 +82,8 @@ enum mpcqp_backend {
     MPCQP_BACKEND_DENSE = 2,    /* explicit K^-1 in registers: N (nx+nu) <= 128 */
     MPCQP_BACKEND_BCR = 3,      /* block cyclic reduction, factor resident in registers, 256-thread workgroups: nx+nu <= 16, Np <= 30, Nc = Np -- at ANY batch */
     MPCQP_BACKEND_BCR8 = 4,     /* the same with 512-thread workgroups (two waves per SIMD) and the explicit inverse of what two levels of
-                                   reduction leave ("dense top"): what AUTO picks for such shapes at up to three instances per compute unit */
+                                   reduction leave ("dense top").  AUTO picks it for such shapes at EVERY batch when the horizon has 21..30 steps
+                                   and nx+nu > 8 (the BASELINE shape (12,4,30)), otherwise up to three instances per compute unit */
     MPCQP_BACKEND_BCRT = 5      /* the dense-top factor on 256-thread workgroups (the comparison BCR8 was measured against) */
 };
 enum mpcqp_tuning {
@@ -124,10 +125,13 @@ const char *mpcqp_last_error(void);
 int mpcqp_device_count(void);
 
 /* osqp.OSQP() (mpc.py:241) for `batch` controllers of one shape.  Np >= 2, 1 <= Nc <= Np, nx + nu <= 128 (MPCQP_ERR_UNSUPPORTED beyond:
- * the reference has no limit).  The KKT backend is chosen here from the shape and the batch: dense register-resident inverse
- * (N (nx+nu) <= 128), cyclic reduction (nx+nu <= 16, Np <= 30, Nc = Np, at most three instances per compute unit), grouped stages (nx+nu <= 8 on
- * longer horizons), block-tridiagonal sweeps (everything else up to 32 wide), plain block LDL' (33..128 wide).  Results do not depend on it
- * beyond rounding. */
+ * the reference has no limit).  The KKT backend is chosen here from the shape and the batch (#CU = compute units of `device`): dense
+ * register-resident inverse (N (nx+nu) <= 128, batch <= 6 #CU), cyclic reduction with a dense top on 512-thread workgroups (nx+nu <= 16,
+ * Np <= 30, Nc = Np: at every batch for 21 <= Np <= 30 with nx+nu > 8, else batch <= 3 #CU), grouped stages (nx+nu <= 8 on longer horizons),
+ * block-tridiagonal sweeps (everything else up to 32 wide), plain block LDL' (33..128 wide).  The cross-over points are measurements on one
+ * 256-CU MI355X (LAB_NOTES.md), expressed per compute unit.  Results do not depend on the backend beyond rounding.
+ * `s` must come from mpcqp_default_settings (then edited): the struct has no size field, and fields appended by later versions of this header
+ * (backend, tuning) are read unconditionally. */
 int mpcqp_create(mpcqp_handle **h, int device, int batch, int nx, int nu, int Np, int Nc,
                  const mpcqp_settings *s);
 void mpcqp_destroy(mpcqp_handle *h);
@@ -284,6 +288,10 @@ int mpcqp_get_stream_bytes(mpcqp_handle *h, int64_t *per_iter, int64_t *per_roun
 
 /* Matrix-core instructions (v_mfma_f64_4x4x4_4b_f64: 512 flop each) one instance issues per ADMM iteration with this handle's backend. */
 int mpcqp_get_work(mpcqp_handle *h, int64_t *mfma_per_iter);
+
+/* Workgroups of the handle's solve kernel one compute unit holds at a time, the compute units of its device, threads per workgroup
+ * (bench.py: instances in flight = the product of the first two -- the working set the memory-side cache sees). */
+int mpcqp_get_occupancy(mpcqp_handle *h, int *workgroups_per_cu, int *compute_units, int *threads_per_workgroup);
 
 /* Name of the solve-kernel instantiation this handle launches (loop = 0: mpcqp_solve; 1: mpcqp_mpc_loop), as profilers print it. */
 int mpcqp_kernel_name(mpcqp_handle *h, int loop, char *buf, int buflen);

@@ -74,6 +74,58 @@ def reference_inputs(args):
     return np.array(out)
 
 
+def alongside(args):
+    """Worker: the oracle stepping ALONGSIDE the device on the device's own closed-loop states.  For every instance index in `idx` (workload
+    recipe fixtures.random_lti): set up at tolerance `eps`, then for step k: output() against the input the device applied, update() with the
+    state the device's plant reached, and the solve's (status, ADMM iterations) against the device's.  Returns per instance
+    (index, largest rho the oracle worked with, [(k, oracle_iter, device_iter)] where counts differ, [(k, oracle_status, device_status)] where
+    statuses differ, worst relative input deviation, total oracle iterations)."""
+    idx, xs, us, its, sts, eps, nx, nu, Np, xbox = args
+    import numpy as np
+    from pympc_amd import MPCController, fixtures
+    from oracle.osqp_oracle import OSQP
+    out = []
+    for j, i in enumerate(idx):
+        kw = fixtures.random_lti(int(i), nx=nx, nu=nu, Np=Np, xbox=xbox)
+        kw.update(eps_abs=eps, eps_rel=eps)
+        K = MPCController(**kw); K.prob = OSQP()
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            K.setup()
+            rho = K.prob.iterate_state()[3]
+            bad_it, bad_st, worst, total = [], [], 0.0, 0
+            for k in range(us.shape[1]):
+                uo = K.output()
+                worst = max(worst, float(np.abs(us[j, k] - uo).max() / max(1e-3, np.abs(uo).max())))
+                K.update(xs[j, k + 1], us[j, k])
+                rho = max(rho, K.prob.iterate_state()[3])
+                total += int(K.res.info.iter)
+                if int(K.res.info.iter) != int(its[j, k]):
+                    bad_it.append((k, int(K.res.info.iter), int(its[j, k])))
+                if int(K.res.info.status_val) != int(sts[j, k]):
+                    bad_st.append((k, int(K.res.info.status_val), int(sts[j, k])))
+        out.append((int(i), float(rho), bad_it, bad_st, worst, total))
+    return out
+
+
+def alongside_pool(idx, tr, eps, nx, nu, Np, xbox, steps=None, workers=None):
+    """`alongside` for the instances `idx` of a device trajectory `tr` (dict with x [K+1,B,nx], u [K,B,nu], iter, status [K,B]) over the
+    usable cores (spawned workers).  Returns the per-instance tuples in index order."""
+    import multiprocessing as mp
+    import numpy as np
+    idx = np.asarray(idx, dtype=int)
+    K = tr['u'].shape[0] if steps is None else steps
+    ncores = max(1, min(workers or usable_cores(), len(idx)))
+    for v in ('OMP_NUM_THREADS', 'OPENBLAS_NUM_THREADS', 'MKL_NUM_THREADS'):
+        os.environ[v] = '1'
+    chunks = [c for c in np.array_split(idx, ncores * 4) if len(c)]
+    jobs = [(c, np.ascontiguousarray(tr['x'][:K + 1, c].transpose(1, 0, 2)), np.ascontiguousarray(tr['u'][:K, c].transpose(1, 0, 2)),
+             np.ascontiguousarray(tr['iter'][:K, c].T), np.ascontiguousarray(tr['status'][:K, c].T), eps, nx, nu, Np, xbox) for c in chunks]
+    with mp.get_context('spawn').Pool(ncores) as pool:
+        res = pool.map(alongside, jobs)
+    return sorted((r for chunk in res for r in chunk), key=lambda r: r[0])
+
+
 def usable_cores():
     """Cores this process may really use: affinity mask, capped by the cgroup CPU quota (a container on a 256-thread host is
     often limited to a fraction of it; more workers than that only time-slice)."""

@@ -495,6 +495,7 @@ int mpcqp_get_dims(mpcqp_handle *h, int *n, int *m, int64_t *factor_doubles, int
 }
 int mpcqp_get_stream_bytes(mpcqp_handle *h, int64_t *a, int64_t *b, int64_t *c) { (void)a; (void)b; (void)c; (void)h; return fail(MPCQP_ERR_UNSUPPORTED, "no kernels on a CPU"); }
 int mpcqp_get_work(mpcqp_handle *h, int64_t *v) { (void)h; (void)v; return fail(MPCQP_ERR_UNSUPPORTED, "no matrix cores on a CPU"); }
+int mpcqp_get_occupancy(mpcqp_handle *h, int *w, int *c, int *t) { (void)h; if (w) *w = 1; if (c) *c = 1; if (t) *t = 1; return MPCQP_OK; }
 int mpcqp_kernel_name(mpcqp_handle *h, int loop, char *buf, int buflen) { (void)h; (void)loop; if (buf && buflen > 0) snprintf(buf, (size_t)buflen, "cpu:osqp_ref"); return MPCQP_OK; }
 int mpcqp_export_qp(mpcqp_handle *h, double *Pm, double *Am, double *q, double *l, double *u) {
     if (!h) return fail(MPCQP_ERR_ARG, "null handle");

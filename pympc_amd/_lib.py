@@ -15,7 +15,7 @@ SYMBOLS = [
     'mpcqp_default_settings', 'mpcqp_status_string', 'mpcqp_last_error', 'mpcqp_device_count',
     'mpcqp_create', 'mpcqp_destroy', 'mpcqp_set_stream', 'mpcqp_synchronize',
     'mpcqp_setup', 'mpcqp_setup_qp', 'mpcqp_create_csc', 'mpcqp_setup_csc', 'mpcqp_update', 'mpcqp_update_vectors', 'mpcqp_warm_start', 'mpcqp_update_settings', 'mpcqp_solve',
-    'mpcqp_mpc_step', 'mpcqp_step_host', 'mpcqp_mpc_run', 'mpcqp_mpc_loop', 'mpcqp_get_solution', 'mpcqp_get_u0', 'mpcqp_get_shape', 'mpcqp_get_dims', 'mpcqp_get_stream_bytes', 'mpcqp_get_work', 'mpcqp_kernel_name', 'mpcqp_get_stats', 'mpcqp_get_launch_times', 'mpcqp_profile',
+    'mpcqp_mpc_step', 'mpcqp_step_host', 'mpcqp_mpc_run', 'mpcqp_mpc_loop', 'mpcqp_get_solution', 'mpcqp_get_u0', 'mpcqp_get_shape', 'mpcqp_get_dims', 'mpcqp_get_stream_bytes', 'mpcqp_get_work', 'mpcqp_get_occupancy', 'mpcqp_kernel_name', 'mpcqp_get_stats', 'mpcqp_get_launch_times', 'mpcqp_profile',
     'mpcqp_export_qp', 'mpcqp_get_scaling', 'mpcqp_debug_kkt_solve', 'mpcqp_get_iterate', 'mpcqp_iterate', 'mpcqp_refactor', 'mpcqp_eq_solve',
 ]
 
@@ -109,6 +109,7 @@ def load():
     L.mpcqp_get_dims.argtypes = [H, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.mpcqp_get_stream_bytes.argtypes = [H, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     L.mpcqp_get_work.argtypes = [H, C.POINTER(C.c_int64)]
+    L.mpcqp_get_occupancy.argtypes = [H] + [C.POINTER(C.c_int)] * 3
     L.mpcqp_kernel_name.argtypes = [H, C.c_int, C.c_char_p, C.c_int]
     L.mpcqp_get_stats.argtypes = [H, C.POINTER(C.c_uint64), C.c_int]
     L.mpcqp_get_launch_times.argtypes = [H, C.c_void_p, C.c_int]

@@ -345,6 +345,11 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     }
     h->smem_solve = h->smem_setup;
     if (h->smem_solve > 160 * 1024) { mpcqp_destroy(h); return fail(MPCQP_ERR_UNSUPPORTED, "problem too large for one workgroup's LDS"); }
+    // check_norms_own reads the weight matrices through LDS views (as_lds): with an LDS-resident iterate they must BE in LDS -- staged with the hot
+    // prefix, or behind W in the work area.  The sizing above guarantees it; a layout change that breaks it must fail here, not give wrong residuals.
+    if (h->lds_state && h->L.hot_lds == h->L.hot_sz && h->L.tsz - h->L.m < h->L.model_sz - h->L.hot_sz) {
+        mpcqp_destroy(h); return fail(MPCQP_ERR_UNSUPPORTED, "mpcqp_create: internal layout error: the weight matrices of an LDS-resident handle do not fit behind W");
+    }
     *out = h;
     return MPCQP_OK;
 }
@@ -1087,6 +1092,22 @@ extern "C" int mpcqp_get_work(mpcqp_handle *h, int64_t *mfma_per_iter) {
         mv = L.ffwd ? (int64_t)(L.N - 1) * blk * 3 + 3 * blk : (int64_t)(L.N - 1) * blk * 4 + 3 * blk;      // forward 1 (or 2) + backward 2 mat-vecs per stage, the middle stage
     }
     *mfma_per_iter = 4 * mv;
+    return MPCQP_OK;
+}
+
+// How many workgroups of the handle's solve kernel one compute unit holds at a time (the kernels' __launch_bounds__ occupancy, run_occupancy in
+// mpcqp_kernels.h, capped by what the dynamic LDS block leaves room for) and the compute units of the handle's device: bench.py's "instances in
+// flight" (what the memory-side cache sees) = the product.
+extern "C" int mpcqp_get_occupancy(mpcqp_handle *h, int *workgroups_per_cu, int *compute_units, int *threads_per_workgroup) {
+    if (!h) return fail(MPCQP_ERR_ARG, "null handle");
+    const Lay &L = h->L;
+    const bool one_at_a_time = L.bcr || L.dense || L.NB > 32 || L.nw == 8;
+    int occ = one_at_a_time ? 1 : (L.NB <= 16 ? 4 : 2);
+    const size_t lds_cu = 160 * 1024;
+    if (h->smem_solve > 0) occ = std::max(1, std::min(occ, (int)(lds_cu / h->smem_solve)));
+    if (workgroups_per_cu) *workgroups_per_cu = occ;
+    if (compute_units) *compute_units = h->ncu;
+    if (threads_per_workgroup) *threads_per_workgroup = L.nw == 8 ? 512 : 256;
     return MPCQP_OK;
 }
 

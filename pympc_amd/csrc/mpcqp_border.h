@@ -152,9 +152,8 @@ __device__ __forceinline__ void border_pre(const Lay &L, const double *Bb, const
     for (int idx = tid; idx < NP; idx += NT) {
         double a = Tc[idx];
         for (int j = 0; j < nu; ++j) a -= Bb[(size_t)j * NP + idx] * ubar[j];
-        Tc[idx] = a;
+        Tc[idx] = (idx >= slot && idx < slot + nu) ? 0.0 : a;      // (the r2 slots are cleared by their own writer: a separate store would race with this one across waves)
     }
-    if (tid < nu) Tc[slot + tid] = 0.0;
     __syncthreads();
 }
 __device__ __forceinline__ void border_post(const Lay &L, int NB, double *Tc, const double *ubar) {

@@ -21,6 +21,9 @@ _IGNORED_SETTINGS = ('verbose', 'polish', 'linsys_solver', 'time_limit', 'scaled
                      'polish_refine_iter', 'adaptive_rho_fraction')
 
 
+# fixed when the handle is created / set up: mpcqp_update_settings keeps the handle's own values (include/mpcqp.h)
+_FIXED_AT_CREATE = ('rho', 'sigma', 'scaling', 'soft_constraints', 'backend', 'tuning')
+
 _STATUS_STRINGS = {}       # status code -> OSQP's string (filled from mpcqp_status_string on first use)
 
 
@@ -275,6 +278,9 @@ class BatchProblem:
         for k, v in kw.items():
             if k not in _SETTING_NAMES:
                 raise TypeError('unknown solver setting %r' % k)
+            if k in _FIXED_AT_CREATE and v != getattr(self.settings, k):
+                # (mpcqp_update_settings keeps the handle's own value of these: they shape the problem, the factorization or the kernel choice)
+                raise ValueError('solver setting %r is fixed when the problem is created / set up; make a new problem to change it' % k)
             setattr(self.settings, k, v)
         _lib.check(self._L.mpcqp_update_settings(self._h, C.byref(self.settings)), 'mpcqp_update_settings')
 
@@ -408,6 +414,16 @@ class BatchProblem:
         v = C.c_int64()
         _lib.check(self._L.mpcqp_get_work(self._h, C.byref(v)), 'mpcqp_get_work')
         return v.value
+
+    def occupancy(self):
+        """(workgroups of the solve kernel a compute unit holds, compute units of the device, threads per workgroup) -- mpcqp_get_occupancy."""
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        _lib.check(self._L.mpcqp_get_occupancy(self._h, C.byref(a), C.byref(b), C.byref(c)), 'mpcqp_get_occupancy')
+        return a.value, b.value, c.value
+
+    def settings_dict(self):
+        """The handle's solver settings as a dict (what `update_settings` last sent, on top of what the handle was created with)."""
+        return {k: getattr(self.settings, k) for k in _SETTING_NAMES}
 
     def kernel_name(self, loop):
         buf = C.create_string_buffer(128)

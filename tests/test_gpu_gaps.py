@@ -39,12 +39,10 @@ def _oracle_u(kw, x0, um1):
 def test_benchmarked_batches_meet_the_north_star_tolerance(cfg):
     """The batches bench.py times, run as bench.py runs them (reference tolerance 1e-3, 50 warm closed-loop steps inside the device
     loop), then (i) at the parity tolerance the u* of 128 of the 1024 cfg-3 instances / 33 of the 512 cfg-5 instances against the
-    oracle at 1e-10 (north-star criterion: 1e-6 relative), and (ii) the 50 warm steps themselves at the default tolerance against
-    the oracle stepping alongside on the device's own states: same status and the same ADMM iteration count in EVERY step of the
-    sampled instances (what the headline throughput depends on), applied inputs to 1e-6."""
-    from pympc_amd import MPCController
-    from oracle.osqp_oracle import OSQP
-    B, nx, nu, Np, xbox, sample, alongside = (1024, 12, 4, 30, 10.0, 128, 24) if cfg == 'cfg3' else (512, 20, 8, 100, 1.0, 32, 8)
+    oracle at 1e-10 (north-star criterion: 1e-6 relative), and (ii) the warm steps themselves at the default tolerance against
+    the oracle stepping alongside on the device's own states: same status and the same ADMM iteration count in EVERY step of ALL
+    1024 cfg-3 instances (what the headline throughput depends on; 33 of the 512 at cfg-5), applied inputs to 1e-6."""
+    B, nx, nu, Np, xbox, sample, alongside = (1024, 12, 4, 30, 10.0, 128, 1024) if cfg == 'cfg3' else (512, 20, 8, 100, 1.0, 32, 32)
     K, kws = _bench_batch(B, nx, nu, Np, xbox, 1e-3)
     rng = np.random.default_rng(11)
     with warnings.catch_warnings():
@@ -66,30 +64,37 @@ def test_benchmarked_batches_meet_the_north_star_tolerance(cfg):
         assert so == 'solved' and st['status'][int(i)] == 'solved', (i, so, st['status'][int(i)])
         worst = max(worst, np.abs(U[i] - uo).max() / max(1e-3, np.abs(uo).max()))
     assert worst <= 1e-6, worst                                            # north_star: u* within 1e-6 relative of the reference solver's
-    # (ii) the warm steps at the default tolerance: the oracle on the same states, warm-starting from its own previous iterate.
-    # Where OSQP's rho adaptation has driven rho beyond 1e4 during the cold solve (cfg-5, tight state box: rho_eq = 1e3 rho against
-    # sigma = 1e-6 puts the KKT condition number beyond 1e13), a double-precision linear solve is only accurate to about the
-    # termination tolerance itself: two correct implementations then agree on the outcome, not on the round in which a residual
-    # test passes (seen: 175 vs 225 iterations).  Those instances are held to status equality and iteration counts within two rounds,
-    # all others to exact counts; the applied inputs -- ADMM iterates at tolerance 1e-3, not optima -- to the accuracy the KKT solve
-    # itself has at that rho, eps_machine * 1e3 rho / sigma ~ 2e-7 rho (seen: 1.1e-4 at rho = 3.5e3, 3.7e-3 at 3.8e4), 1e-6 at best.
-    exact = 0
-    for i in np.unique(np.linspace(0, B - 1, alongside).astype(int)):
-        kw = dict(kws[int(i)]); kw.update(eps_abs=1e-3, eps_rel=1e-3)
-        Ko = MPCController(**kw); Ko.prob = OSQP()
-        with warnings.catch_warnings():
-            warnings.simplefilter('ignore')
-            Ko.setup()
-            rho = Ko.prob.iterate_state()[3]                               # the largest rho this instance has worked with so far
-            for k in range(50):
-                uo = Ko.output()
-                assert np.abs(tr['u'][k, i] - uo).max() <= max(1e-6, 3e-7 * rho) * max(1e-3, np.abs(uo).max()), (cfg, i, k, rho)
-                Ko.update(tr['x'][k + 1, i], tr['u'][k, i])
-                rho = max(rho, Ko.prob.iterate_state()[3])
-                assert Ko.res.info.status_val == tr['status'][k, i], (cfg, i, k)
-                assert abs(Ko.res.info.iter - tr['iter'][k, i]) <= (0 if rho <= 1e4 else 50), (cfg, i, k, Ko.res.info.iter, tr['iter'][k, i], rho)
-        exact += int(rho <= 1e4)
-    assert exact >= alongside // 2, (exact, alongside)      # (most of the sample is held to exact counts)
+    # (ii) the warm steps at the default tolerance: the oracle on the same states, warm-starting from its own previous iterate -- on EVERY instance of
+    # the headline batch (cfg-3: all 1024, the first 20 steps = the driver's timed region; QP-solves/s = iterations/s / iterations per solve, and the
+    # second factor is what this pins), on a spread of 32 of the 512 cfg-5 instances (all 50 steps).  Worker processes (oracle/cpu_bench.alongside_pool).
+    # Where OSQP's rho adaptation has driven rho beyond 1e4 during the cold solve (cfg-5, tight state box: rho_eq = 1e3 rho against sigma = 1e-6 puts the
+    # KKT condition number beyond 1e13), a double-precision linear solve is only accurate to about the termination tolerance itself: two correct
+    # implementations then agree on the outcome, not on the round in which a residual test passes.  Rule: EVERY instance with rho <= 1e4 has the oracle's
+    # status and iteration count in every step and the applied inputs to 1e-6; the instances above are listed with their observed count differences,
+    # each within two rounds, inputs to the accuracy the KKT solve itself has at that rho (eps_machine * 1e3 rho / sigma ~ 3e-7 rho).
+    from oracle import cpu_bench
+    along = np.arange(B) if cfg == 'cfg3' else np.unique(np.append(np.linspace(0, B - 1, alongside).astype(int), 276))
+    steps = 20 if cfg == 'cfg3' else 50
+    res = cpu_bench.alongside_pool(along, tr, 1e-3, nx, nu, Np, xbox, steps=steps)
+    assert [r[0] for r in res] == list(along)
+    high, dev_iters, ora_iters = [], 0, 0
+    for i, rho, bad_it, bad_st, worst, total in res:
+        assert not bad_st, (cfg, i, rho, bad_st[:3])
+        dev_iters += int(tr['iter'][:steps, i].sum()); ora_iters += total
+        if rho <= 1e4:
+            assert not bad_it, (cfg, i, rho, bad_it[:3])
+            assert worst <= 1e-6, (cfg, i, rho, worst)
+        else:
+            high.append((i, rho, [(k, a - b_) for k, a, b_ in bad_it]))
+            assert all(abs(a - b_) <= 50 for _, a, b_ in bad_it), (cfg, i, rho, bad_it[:3])
+            assert worst <= 3e-7 * rho, (cfg, i, rho, worst)
+    print('%s: %d instances alongside for %d steps; %d with rho > 1e4: %s; ADMM iterations device %d / oracle %d'
+          % (cfg, len(res), steps, len(high), [(i, '%.3g' % r, d) for i, r, d in high][:12], dev_iters, ora_iters))
+    if cfg == 'cfg3':
+        assert not high, high[:5]                       # (the headline batch never gets there: every one of its 20 480 solves has the oracle's count)
+        assert dev_iters == ora_iters
+    else:
+        assert len(high) <= len(res) // 2, (len(high), len(res))
 
 
 @pytest.mark.parametrize('name', ['cart_pole', 'accel_brake', 'quadcopter'])

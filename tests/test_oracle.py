@@ -51,3 +51,35 @@ def test_oracle_update_rejects_crossed_bounds():
     prob.setup(golden_csc(g, 'P'), g['q'], golden_csc(g, 'A'), g['l'], g['u'])
     with pytest.raises(ValueError):
         prob.update(l=g['u'] + 1.0, u=g['u'])
+
+
+def test_alongside_worker_flags_what_differs_and_nothing_else():
+    """oracle/cpu_bench.alongside_pool (what tests/test_gpu_gaps.py checks the headline batch's iteration counts with, on every instance) on a
+    trajectory the oracle itself produced: no difference; with one count and one status tampered with: exactly those."""
+    from pympc_amd import MPCController, fixtures
+    from oracle import cpu_bench
+    nx, nu, Np, xbox, B, K = 5, 2, 8, 10.0, 3, 4
+    tr = dict(x=np.zeros((K + 1, B, nx)), u=np.zeros((K, B, nu)), iter=np.zeros((K, B), dtype=np.int32), status=np.zeros((K, B), dtype=np.int32))
+    for i in range(B):
+        kw = fixtures.random_lti(i, nx=nx, nu=nu, Np=Np, xbox=xbox); kw.update(eps_abs=1e-3, eps_rel=1e-3)
+        Ko = MPCController(**kw); Ko.prob = OSQP()
+        rng = fixtures.random_lti_noise_rng(i)
+        with warnings.catch_warnings():
+            warnings.simplefilter('ignore')
+            Ko.setup()
+            x = np.array(kw['x0'], dtype=float)
+            tr['x'][0, i] = x
+            for k in range(K):
+                u = Ko.output()
+                x = kw['Ad'] @ x + kw['Bd'] @ u + 0.01 * rng.standard_normal(nx)
+                Ko.update(x, u)
+                tr['u'][k, i], tr['x'][k + 1, i], tr['iter'][k, i], tr['status'][k, i] = u, x, Ko.res.info.iter, Ko.res.info.status_val
+    res = cpu_bench.alongside_pool(np.arange(B), tr, 1e-3, nx, nu, Np, xbox, workers=2)
+    assert [r[0] for r in res] == [0, 1, 2]
+    assert all(not r[2] and not r[3] and r[4] <= 1e-12 for r in res), res
+    assert sum(r[5] for r in res) == int(tr['iter'].sum())
+    tr['iter'][2, 1] += 25; tr['status'][3, 2] = 2
+    res = cpu_bench.alongside_pool(np.arange(B), tr, 1e-3, nx, nu, Np, xbox, workers=2)
+    assert res[0][2] == [] and res[0][3] == []
+    assert [k for k, _, _ in res[1][2]] == [2] and res[1][3] == []
+    assert res[2][2] == [] and [k for k, _, _ in res[2][3]] == [3]
