@@ -815,6 +815,7 @@ def main():
     ap.add_argument('--cfg5-leg-batch', type=int, default=512, help='cfg3, 1 GPU: BASELINE configs[4] (512 x (20,8,100)) as a leg of the default line (0 = skip)')
     ap.add_argument('--backend', default=None, choices=['sweeps', 'dense', 'bcr8'],
                     help='force a KKT backend for the headline shard (mpcqp_settings.backend; default: the library chooses) -- profiling runs of the bandwidth kernel at the headline batch')
+    ap.add_argument('--tuning', type=int, default=None, help='mpcqp_settings.tuning for the headline shard (development: switch a mechanism off, see enum mpcqp_tuning)')
     ap.add_argument('--dry-run', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
     self_launch_if_needed(args)
@@ -840,7 +841,7 @@ def main():
         TOTAL, scaling = (args.batch if args.batch is not None else WORKLOADS[args.workload][4]) * world, 'weak'
 
     from pympc_amd.solver import forced_settings
-    with forced_settings(**({'backend': args.backend} if args.backend else {})):
+    with forced_settings(**dict(({'backend': args.backend} if args.backend else {}), **({'tuning': args.tuning} if args.tuning is not None else {}))):
         sh = Shard(args, dims, None, rank, world, dev, 0, torch, dist, total=TOTAL)
     B = sh.B                                                          # this rank's instances
     prob = sh.prob

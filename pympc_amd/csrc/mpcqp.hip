@@ -72,10 +72,12 @@ static int fail(int code, const std::string &msg) { g_err = msg; return code; }
 #include "mpcqp_dense.h"
 #include "mpcqp_border.h"
 #include "mpcqp_phases.h"
+#include "mpcqp_run.h"
 #include "mpcqp_tiny.h"
 #include "mpcqp_lat.h"
 #include "mpcqp_latw.h"
 #include "mpcqp_kernels.h"
+#include "mpcqp_latw_check.h"
 #include "mpcqp_csc.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -645,6 +647,20 @@ static int rebalance(mpcqp_handle *h) {
         const int row = j / ncu, pos = j % ncu;
         const bool reversed = !one_at_a_time && (row & 1) && row < full_rows;      // a partial last row keeps forward order
         perm[row * ncu + (reversed ? ncu - 1 - pos : pos)] = order[j];
+    }
+    // Pacing (development switch, off unless mpcqp_settings.tuning bits 8..15 ask for it): in the bandwidth kernels with a global-memory iterate whose
+    // instances are ALL resident at once (B <= slots) the launch ends with its slowest instance.  Every instance that is NOT expected to need more than
+    // 1.15 x the median's iterations idles `units` x 3.5 us in each of its iterations, leaving its share of the memory system to the stragglers.
+    {
+        const int occ = one_at_a_time ? 1 : (h->L.NB <= 16 ? 4 : 2);
+        const int units = std::min((h->S.tuning >> 8) & 0xFF, 64);
+        if (units && !one_at_a_time && !h->lds_state && !h->L.lstage && B <= occ * ncu) {
+            const double wmed = h->work_ema[order[B / 2]];
+            for (int j = 0; j < B; ++j) {
+                const int inst = perm[j] & PERM_INST_MASK;
+                perm[j] = inst | ((h->work_ema[inst] > 1.15 * wmed ? 0 : units) << PERM_PACE_SHIFT);
+            }
+        }
     }
     HIPCHK(hipMemcpyAsync(h->perm_dev, perm.data(), sizeof(int) * (size_t)B, hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));                          // (perm is a stack-lifetime host buffer)

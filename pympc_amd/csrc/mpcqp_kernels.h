@@ -11,70 +11,8 @@
 // needs 25.  The same kernel with nsteps = 0 is
 // mpcqp_solve: begin, rounds of { admm, check } until this instance terminates -- no host loop, no batch barrier.
 // ------------------------------------------------------------------------------------------------
-struct RunArgs {
-    int nsteps;                   // closed-loop steps (LOOP kernels); 0 = one solve of the current data (mpcqp_solve)
-    int plain;                    // run exactly max_iter iterations, no termination test / rho adaptation (mpcqp_iterate)
-    int warm_x;                   // x was replaced by mpcqp_warm_start: begin with z = A x
-    int part;                     // LOOP = false only.  0: the whole solve.  1: begin + first round; instances that are not
-                                  // finished are appended to `pending`.  2: continue the `pending` instances to the end
-                                  // (the launch that follows part 1: its workgroup -> instance map IS the pending list, so
-                                  // the unfinished instances spread evenly over the CUs instead of staying where they were)
-                                  // 3: no solve at all -- refactor every instance with its current rho (mpcqp_refactor)
-    int *pending, *npending;      // [batch] instance list and its length (device)
-    int max_iter, chk, rho_every;
-    const double *w;              // [nsteps][batch][nx] additive plant disturbance, or null
-    const double *Ap, *Bp;        // [batch][nx*nx], [batch][nx*nu] plant matrices, or null (plant = model Ad, Bd)
-    const double *xref_traj;      // [nsteps][batch][xref_blk] reference for the solve after step k, or null (unchanged)
-    int xref_blk;                 // xref_rows * nx
-    int ny;                       // > 0: output feedback through a LinearStateEstimator (pyMPC/kalman.py:109-134)
-    const double *C, *Lg, *v;     // [batch][ny*nx], [batch][nx*ny], [nsteps][batch][ny] (or null)
-    double *x_true;               // [batch][nx] true plant state (in/out) when the controller only sees the estimate
-    double *x_traj;               // [nsteps+1][batch][nx] plant states
-    double *xhat_traj;            // [nsteps+1][batch][nx] estimates xhat[k|k-1] handed to update() (estimator only)
-    double *y_traj;               // [nsteps][batch][ny] measurements (estimator only)
-    double *u_traj;               // [nsteps][batch][nu]
-    int *status_traj, *iter_traj; // [nsteps][batch]: outcome of the solve that follows step k's update
-    int batch;
-    // host-resident exchange (mpcqp_step_host: one launch per control step, no copy calls, no stream synchronisation):
-    const double *pin_in;         // [batch][pin_stride] = [x0 | u_{-1} | xref] in mapped host memory, copied into the step blob first (null = off)
-    int pin_stride, pin_mask, pin_xref;   // mask: 1 x0, 2 u_{-1}, 4 xref (pin_xref doubles)
-    double *pub;                  // mapped host memory: [batch][n] x | [batch][m] y | [batch] info | flag; written when the solve is done (null = off)
-    unsigned *done;               // device counter of finished workgroups (the last one raises the flag)
-    unsigned long long seq;       // value the flag takes
-};
+// (RunArgs, RunKArgs, run_kargs(), next_stop / stop_mode: mpcqp_run.h -- the latency round reads them too)
 
-__host__ __device__ inline int next_stop(int iter, int max_iter, int chk, int rho_every) {
-    int nxt = max_iter;
-    if (chk) { int v = (iter / chk + 1) * chk; nxt = v < nxt ? v : nxt; }
-    if (rho_every) { int v = (iter / rho_every + 1) * rho_every; nxt = v < nxt ? v : nxt; }
-    return nxt;
-}
-__host__ __device__ inline int stop_mode(int iter, int max_iter, int chk, int rho_every, bool plain) {
-    int mode = plain ? COLD_PLAIN : 0;
-    if (chk && iter % chk == 0) mode |= COLD_CHECK;
-    if (rho_every && iter % rho_every == 0) mode |= COLD_RHO;
-    if (iter == max_iter && !plain) mode |= COLD_FINAL;
-    return mode;
-}
-
-// The three phases are separate (non-inlined) functions so that each gets a register allocation of its own --
-// inlined into one body, the cold code's live ranges pushed spill reloads into the ADMM sweep.  They take no
-// pointer arguments: everything is re-read from the kernel-argument segment, which is uniform, constant memory
-// (scalar loads), instead of travelling through the vector-register calling convention.
-struct RunKArgs { Lay L; Ptrs P; mpcqp_settings S; RunArgs R; };
-static_assert(sizeof(RunKArgs) % 8 == 0, "hidden kernel arguments start right behind RunKArgs");
-typedef const __attribute__((address_space(4))) RunKArgs *ckargs;
-// (In a non-kernel function the kernarg segment pointer itself is not available, the implicit-argument pointer is:
-//  the hidden arguments follow the explicit ones, here the single RunKArgs struct, at the next 8-byte boundary.)
-__device__ __forceinline__ const RunKArgs &run_kargs() {
-    typedef const __attribute__((address_space(4))) char *cbytes;
-    return *(const RunKArgs *)(ckargs)((cbytes)__builtin_amdgcn_implicitarg_ptr() - ((sizeof(RunKArgs) + 7) & ~size_t(7)));
-}
-
-// Every phase takes `frame_pin` (see run_admm_phase below: what keeps its calls from being marked `tail`, and with that the phase free of the
-// calling convention's callee-saved set); FRAME_PIN is the caller's side of it.
-#define PHASE_PIN_USE(p) asm volatile("" :: "v"(p) : "memory")
-struct FramePin { int v; __device__ __forceinline__ FramePin() : v(0) { asm volatile("" : "+v"(v)); } __device__ __forceinline__ ~FramePin() { asm volatile("" :: "v"(v)); } };
 struct RunSmem { Smem S; double *X, *Z, *Y; };
 template <bool LDSSTATE>
 __device__ __forceinline__ RunSmem run_smem(const Lay &L, const Ptrs &P) {
@@ -119,29 +57,35 @@ __device__ __noinline__ void run_factor_phase(int *frame_pin) {
                         border_ptrs(L, P, r.S));
 }
 
+// iter0: iterations of this solve done so far.  Returns 1 if the phase has FINISHED the solve itself (the latency round with a dense top runs OSQP's
+// termination test in its own layout, round after round: admm_latw) -- the iteration count reached is then in Smem::iflag[5], as it is whenever
+// that round returns -- and 0 if the generic check is to follow.
 template <int NB, bool LDSSTATE, int NXT, int NUT, int MODE>
-__device__ __forceinline__ void run_admm_phase_body(int iters) {
+__device__ __forceinline__ int run_admm_phase_body(int iters, int iter0) {
     const RunKArgs &A = run_kargs();
     const Lay &L = A.L; const Ptrs &P = A.P;
     RunSmem r = run_smem<LDSSTATE>(L, P);
     HotPtrs hp; hp.model = P.model; hp.step = P.step; hp.omega = P.omega; hp.s = P.s; hp.qv = P.qv; hp.F = P.F; hp.c = P.c;
     hp.Bb = P.Bb; hp.Zb = P.Zb; hp.Sig = P.Sig; hp.x = P.x; hp.z = P.z; hp.y = P.y; hp.dx = P.dx; hp.dy = P.dy; hp.perm = P.perm; hp.fsz = P.fsz;
+    if constexpr (MODE >= MODE_BCRT)
+        return admm_latw<NXT, NUT, MODE - MODE_BCRT>(L, hp, r.S, r.X, r.Z, r.Y, A.S.alpha, __builtin_amdgcn_readfirstlane(iters), __builtin_amdgcn_readfirstlane(iter0));
     admm_body<NB, LDSSTATE, NXT, NUT, MODE>(L, hp, r.S, r.X, r.Z, r.Y, A.S.alpha, __builtin_amdgcn_readfirstlane(iters));
+    return 0;
 }
 // (frame_pin: the address of a local of the CALLER, made opaque here.  A call that may reach into its caller's frame cannot be marked `tail`,
 //  and for an internal, non-recursive function none of whose calls is a tail call LLVM's interprocedural register allocation treats NO register
 //  as callee-saved (TargetFrameLowering::isSafeForNoCSROpt): the phase then starts without saving the ~ 340 (latency kernels) / 48 (bandwidth
 //  kernels) registers of the calling convention's callee-saved set -- the kernel keeps the handful of values it has live across the call itself.)
 template <int NB, bool LDSSTATE, int NXT, int NUT, int MODE>
-__device__ __noinline__ void run_admm_phase(int iters, int *frame_pin) {
+__device__ __noinline__ int run_admm_phase(int iters, int iter0, int *frame_pin) {
     PHASE_PIN_USE(frame_pin);
-    run_admm_phase_body<NB, LDSSTATE, NXT, NUT, MODE>(iters);
+    return run_admm_phase_body<NB, LDSSTATE, NXT, NUT, MODE>(iters, iter0);
 }
 // (History: as an ordinary call the latency kernels' phase saved and restored ~ 340 callee-saved registers per call -- 46 KB per iteration and
 //  instance in the write counters of a kernel that by design reads nothing; taking the phase INLINE removed that traffic but made the allocator
 //  spill inside the iteration loop, 914 k -> 885 k solves/s at 256 instances.  With frame_pin the call stays and the saves are gone: 941 k.)
 template <int NB, bool LDSSTATE, int NXT, int NUT, int MODE, int OCC>
-__device__ __forceinline__ void run_admm(int iters) { FramePin pin; run_admm_phase<NB, LDSSTATE, NXT, NUT, MODE>(iters, &pin.v); }
+__device__ __forceinline__ int run_admm(int iters, int iter0) { FramePin pin; return run_admm_phase<NB, LDSSTATE, NXT, NUT, MODE>(iters, iter0, &pin.v); }
 
 template <int NB, bool LDSSTATE, int OCC>
 __device__ __noinline__ void run_begin_phase(int plain, int warm_x, int *frame_pin) {
@@ -260,10 +204,12 @@ __global__ __launch_bounds__(NT, run_occupancy(NB, MODE)) void k_mpc_run(RunKArg
         PHASE_CLOCK(0)
         while (!term) {
             const int nxt = next_stop(iter, R.max_iter, R.chk, R.rho_every);
-            run_admm<NB, LDSSTATE, NXT, NUT, MODE, OCC>(nxt - iter);
+            term = __builtin_amdgcn_readfirstlane(run_admm<NB, LDSSTATE, NXT, NUT, MODE, OCC>(nxt - iter, R.plain ? -1 : iter));
             iter = nxt;
             __syncthreads();
+            if constexpr (MODE >= MODE_BCRT) { if (!R.plain) iter = S.iflag[5]; }      // (the latency round may have run several rounds, and finished the solve: admm_latw)
             PHASE_CLOCK(1)
+            if (term) break;
             { FramePin pin; term = run_check_phase<NB, LDSSTATE, OCC>(iter, stop_mode(iter, R.max_iter, R.chk, R.rho_every, R.plain != 0), &pin.v); }
             __syncthreads();
             PHASE_CLOCK(2)

@@ -418,9 +418,33 @@ __device__ __forceinline__ void latw_solve(const d4 *fr, const double *TopL, con
 }
 
 // ---- the round (as admm_lat, with ceil(NG / NWAVES) groups of four stages per wave) -----------------------------------------------------
+enum { LATW_CONTINUE = 0, LATW_SOLVED = 1, LATW_GENERIC = 2 };
 template <int NXT, int NUT, int NST>
-__device__ __forceinline__ void admm_latw(const Lay &L, const HotPtrs &P, Smem &S, double *Xl, double *Zl, double *Yl, double alpha, int iters) {
+__device__ int latw_check(double pv, double pv2, double ncq, double zA, double ysA, double omA, double zB, double ysB, double omB, double z0, double ys0, double om0,
+                          double loA, double hiA, double loB, double hiB, double cc, int iter, int *frame_pin);      // (mpcqp_latw_check.h)
+
+// FAST (iter0 >= 0): the round does not end with its iterations.  The termination test of OSQP (update_info + check_termination, mpcqp_phases.h:
+// check_body) is evaluated right here in the OWNER layout -- A x and A'y are the two MFMA groups of the iteration applied to x and y, P x a 16-long
+// dot product per lane against the weight matrices' LDS copy, the norms one block reduction (latw_check, a NON-INLINED function: compiled into this
+// one, its temporaries and the 220 registers that live across it fought for the same file, and the spill reloads -- each a memory round trip --
+// cost more than the generic check it replaced; as a call only the registers the callee really uses are saved around it) -- and
+//   * converged: the solve is finished here (solution, iterate, mpcqp_info, statistics: what check_body's tail writes), return 1;
+//   * not converged, and the cheap halves of both infeasibility certificates rule them out (|dy| or the support-function sum, |dx| or q'dx): the
+//     next round starts at once, with the fragments and the owner registers where they are -- no write-back, no generic check, no reload;
+//   * anything else (a rho estimate is due, the iteration limit, a certificate that needs its operator product, a non-finite residual, the first
+//     launch of a two-launch solve): write-back and return 0 -- the generic check does exactly what it did before.
+// Per round of one (12,4,30) instance this replaces write-back 1.5 k + generic check 15.2 k + owner registers 6.8 k + fragments 2.2 k cycles.
+// The iteration count reached is left in Smem::iflag[5].
+template <int NXT, int NUT, int NST>
+__device__ __forceinline__ int admm_latw(const Lay &L, const HotPtrs &P, Smem &S, double *Xl, double *Zl, double *Yl, double alpha, int iters, int iter0) {
     constexpr int NB = 16, N = NST, NG = (N + 3) / 4, QN = (NG + NWAVES - 1) / NWAVES;
+#ifdef MPCQP_RUN_TIMING
+    const unsigned long long tf0_ = clock64();            // (development: the whole function on thread 0's clock, slot 11)
+#endif
+#ifndef LATW_FAST
+#define LATW_FAST 1                // development: 0 = the in-function termination test compiled in but never taken; 2 = taken, but a converged solve is finished by the generic check
+#endif
+    const bool fast = LATW_FAST && iter0 >= 0 && L.hot_lds > L.hot_sz;      // (the check reads the weight matrices from their LDS copy)
     static_assert(NXT + NUT <= NB, "16 x 16 stages");
     const int nx = NXT ? NXT : L.nx, nu = NUT ? NUT : L.nu, NR = L.N;
     const int b = inst_of(P.perm), tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -435,6 +459,9 @@ __device__ __forceinline__ void admm_latw(const Lay &L, const HotPtrs &P, Smem &
     double *TopL = Yl + L.m + ((smem_common_doubles(L) + L.n + 2 * L.m) & 1);      // (the dynamic LDS block itself starts on one)
     TICK_RESET
     TICK_START
+#ifdef MPCQP_RUN_TIMING
+    if (tid == 0) atomicAdd(&g_ticks[12], clock64() - tf0_);      // (development: what precedes the first tick)
+#endif
     for (int i = tid; i < LAT_LDS_DOUBLES(N); i += NT) S.T[i] = 0.0;
     const double *Fb = P.F + (size_t)b * P.fsz;
     // The LDS-resident part of the factor -- the top inverse and the constant fragments G = [Ad Bd] (rows: dynamics rows, columns: (x, u)) and
@@ -467,8 +494,6 @@ __device__ __forceinline__ void admm_latw(const Lay &L, const HotPtrs &P, Smem &
         if (tid == 0) S.iflag[2] = 1;
     }
     d4 fr[latw_max_slots(N)];
-    LATW_DISPATCH(wv, (latw_load<N, W>(Fb, fr)))
-    TICK(7)
     const int lo16 = vec_lane_offset(lane);
     const int lI = lane >> 4, lB = (lane >> 2) & 3;
     const int o1 = 4 * ((lB + 1) & 3) + lI, o2 = 4 * ((lB + 2) & 3) + lI, o3 = 4 * ((lB + 3) & 3) + lI;
@@ -525,6 +550,13 @@ __device__ __forceinline__ void admm_latw(const Lay &L, const HotPtrs &P, Smem &
     for (int q = 0; q < QN; ++q) { WA[sl[q]] = rA[q].w; WB[sl[q]] = rB[q].w; }
     __syncthreads();
     TICK(8)
+    int iter = iter0 >= 0 ? iter0 : 0, term = 0;
+    for (;;) {
+    // (the level fragments are (re)loaded at the start of EVERY round -- 2 k cycles from L2 -- so that they are dead during the termination test between two
+    //  rounds: kept alive across it they leave the test no registers, and its spill reloads, each a memory round trip, cost several times the reload)
+    TICK_START
+    { const double *Fr = opaque_ptr(Fb); LATW_DISPATCH(wv, (latw_load<N, W>(Fr, fr))) }      // (opaque: a reload, not a loop-invariant the compiler may keep -- in scratch)
+    TICK(7)
     for (int it = 1; it <= iters; ++it) {
         const bool keep_delta = it == iters;
         TICK_START
@@ -577,18 +609,51 @@ __device__ __forceinline__ void admm_latw(const Lay &L, const HotPtrs &P, Smem &
         __syncthreads();
         TICK(6)
     }
+    iter += iters;
+    if (!fast) break;
     TICK_START
-    // ---- end of the round: the iterate back to memory (global: next round / warm start; LDS copy: the residual evaluation)
-    auto put_row = [&](const LatRow &r, int idx) { const double y = r.ys * (r.om * cinv); gz[idx] = r.z; gy[idx] = y; Zl[idx] = r.z; Yl[idx] = y; };
-#pragma unroll
-    for (int q = 0; q < QN; ++q) {
-        if (ok[q]) {
-            gx[pidx[q]] = pv[q]; Xl[pidx[q]] = pv[q];
-            if (is_x && L.soft) { gx[pidx[q] + L.oe] = pv2[q]; Xl[pidx[q] + L.oe] = pv2[q]; }
-            put_row(rA[q], aidx[q]); put_row(rB[q], bidx[q]);
-        }
+    if constexpr (QN != 1) break;      // (several groups of stages per wave -- the 256-thread build: the generic check)
+    else {
+        // ---- the termination test, in a function of its own (latw_check below): the owned values travel BY VALUE, in registers
+        const RunArgs &R = run_kargs().R;
+        if (stop_mode(iter, R.max_iter, R.chk, R.rho_every, R.plain != 0) != COLD_CHECK) break;      // (rho estimate / iteration limit / plain iterations: the generic check)
+        int verdict;
+        { FramePin pin; verdict = latw_check<NXT, NUT, NST>(pv[0], pv2[0], ncq[0], rA[0].z, rA[0].ys, rA[0].om, rB[0].z, rB[0].ys, rB[0].om, r0.z, r0.ys, r0.om,
+                                                               loA[0], hiA[0], loB[0], hiB[0], cc, iter, &pin.v); }
+        verdict = __builtin_amdgcn_readfirstlane(verdict);
+        if (verdict == LATW_SOLVED) { term = 1; break; }
+        if (verdict != LATW_CONTINUE) break;
+        iters = next_stop(iter, R.max_iter, R.chk, R.rho_every) - iter;
+        // The next round starts from exactly the state a write-back and a reload would give it -- y leaves as ys (om / c) and comes back as c y / om:
+        // the same two roundings here -- so that an instance's iterates do not depend on whether a round boundary was crossed in this function or through
+        // the generic check (which launch structure a solve runs under -- device loop, one launch, two launches -- never changes a result).
+        auto rt = [&](LatRow &r) { r.ys = cc * (r.ys * (r.om * cinv)) / r.om; r.w = r.om * (r.z - r.ys); };
+        rt(rA[0]); rt(rB[0]);
+        if (u0v) rt(r0);
+        WA[sl[0]] = ok[0] ? rA[0].w : 0.0; WB[sl[0]] = ok[0] ? rB[0].w : 0.0;      // (a slot without a variable contributes nothing)
+        __syncthreads();
     }
-    if (u0v) put_row(r0, L.rdu + jj);
+    TICK(9)
+    }
+    TICK_START
+    if (!term) {
+        // ---- end of the round: the iterate back to memory (global: next round / warm start; LDS copy: the residual evaluation)
+        auto put_row = [&](const LatRow &r, int idx) { const double y = r.ys * (r.om * cinv); gz[idx] = r.z; gy[idx] = y; Zl[idx] = r.z; Yl[idx] = y; };
+#pragma unroll
+        for (int q = 0; q < QN; ++q) {
+            if (ok[q]) {
+                gx[pidx[q]] = pv[q]; Xl[pidx[q]] = pv[q];
+                if (is_x && L.soft) { gx[pidx[q] + L.oe] = pv2[q]; Xl[pidx[q] + L.oe] = pv2[q]; }
+                put_row(rA[q], aidx[q]); put_row(rB[q], bidx[q]);
+            }
+        }
+        if (u0v) put_row(r0, L.rdu + jj);
+    }
+    if (tid == 0) S.iflag[5] = iter;
     TICK(9)
     TICK_FLUSH
+#ifdef MPCQP_RUN_TIMING
+    if (tid == 0) atomicAdd(&g_ticks[11], clock64() - tf0_);
+#endif
+    return term;
 }

@@ -70,7 +70,11 @@ struct HotPtrs {
 
 // The instance this workgroup works on.  (Which workgroup handles which instance never changes a result; the map
 // only decides which instances share a CU.)
-__device__ __forceinline__ int inst_of(const int *perm) { return perm ? perm[blockIdx.x] : (int)blockIdx.x; }
+// (The map's upper byte carries the instance's PACE: how many s_sleep(127) units -- 3.5 us each -- it idles per ADMM iteration in the co-resident
+//  bandwidth kernels, see rebalance() in mpcqp.hip: instances expected to need few iterations give way to the stragglers the launch waits for.)
+constexpr int PERM_INST_MASK = 0x00FFFFFF, PERM_PACE_SHIFT = 24;
+__device__ __forceinline__ int inst_of(const int *perm) { return perm ? (perm[blockIdx.x] & PERM_INST_MASK) : (int)blockIdx.x; }
+__device__ __forceinline__ int pace_of(const int *perm) { return perm ? (int)((unsigned)perm[blockIdx.x] >> PERM_PACE_SHIFT) : 0; }
 
 __device__ __forceinline__ int idiv(int r, float rcp) { return __float2int_rd(((float)r + 0.5f) * rcp); }
 __device__ __forceinline__ double limit_scaling(double v) { v = v < MIN_SCALING ? 1.0 : v; return v > MAX_SCALING ? MAX_SCALING : v; }

@@ -1024,7 +1024,7 @@ __device__ __forceinline__ void gown_update(const Lay &L, const double *hot, con
 enum { MODE_CHAIN = 0, MODE_BORDER = 1, MODE_DENSE = 2, MODE_BCR = 100, MODE_BCRT = 200 };
 template <int NB> __device__ __forceinline__ void admm_tiny(const Lay &, const HotPtrs &, Smem &, double *, double *, double *, double, int);      // mpcqp_tiny.h
 template <int NXT, int NUT, int NST> __device__ __forceinline__ void admm_lat(const Lay &, const HotPtrs &, Smem &, double *, double *, double *, double, int);      // mpcqp_lat.h
-template <int NXT, int NUT, int NST> __device__ __forceinline__ void admm_latw(const Lay &, const HotPtrs &, Smem &, double *, double *, double *, double, int);     // mpcqp_latw.h
+template <int NXT, int NUT, int NST> __device__ __forceinline__ int admm_latw(const Lay &, const HotPtrs &, Smem &, double *, double *, double *, double, int, int);     // mpcqp_latw.h
 // The ADMM round of a problem whose iterate does not live in LDS for the owner-mapped phases above (n_x > 2 NT, or too large for four workgroups
 // per CU).  INL = false: x, z, y, omega, s, q in global memory (L2 / HBM), every pass pays its round trips -- right for batches, where other
 // workgroups fill them.  INL = true (the handle holds at most one instance per compute unit, Lay::lstage): everything the passes read is STAGED
@@ -1066,8 +1066,12 @@ __device__ __forceinline__ void admm_round_global(const Lay &L, const HotPtrs &P
     gown_rows_w<NB, INL>(L, gom, cc, Z, Y, W, Tc);
 #endif
     TICK_RESET
+    const int pace = INL ? 0 : __builtin_amdgcn_readfirstlane(pace_of(P.perm));
     for (int it = 1; it <= iters; ++it) {
         const bool keep_delta = it == iters;         // the increments feed the infeasibility certificates of the check
+        // (all instances of the launch are resident at once and the launch ends with its slowest one: an instance expected to need few iterations
+        //  idles here, leaving its share of the memory system to the stragglers -- rebalance() in mpcqp.hip sets the pace, results do not depend on it)
+        for (int p = 0; p < pace; ++p) __builtin_amdgcn_s_sleep(127);
         TICK_START
 #ifndef MPCQP_ABL_NOPAR
         gown_rhs<NB, NXT, NUT, INL>(L, S.hot, gom, gsv, gqv, cc, X, W, Tc, S.tv);
@@ -1095,7 +1099,7 @@ __device__ __forceinline__ void admm_round_global(const Lay &L, const HotPtrs &P
 template <int NB, bool LDSSTATE, int NXT, int NUT, int MODE>
 __device__ __forceinline__ void admm_body(const Lay &L, const HotPtrs &P, Smem &S, double *X, double *Z, double *Y, double alpha, int iters) {
     if constexpr (MODE == MODE_DENSE) { admm_tiny<NB>(L, P, S, X, Z, Y, alpha, iters); return; }      // register-resident iterate and inverse
-    if constexpr (MODE >= MODE_BCRT) { admm_latw<NXT, NUT, MODE - MODE_BCRT>(L, P, S, X, Z, Y, alpha, iters); return; }   // ... and cyclic-reduction factor with a dense top
+    if constexpr (MODE >= MODE_BCRT) { admm_latw<NXT, NUT, MODE - MODE_BCRT>(L, P, S, X, Z, Y, alpha, iters, -1); return; }   // ... and cyclic-reduction factor with a dense top (k_mpc_run calls it directly, with its own termination test)
     else if constexpr (MODE >= MODE_BCR) { admm_lat<NXT, NUT, MODE - MODE_BCR>(L, P, S, X, Z, Y, alpha, iters); return; } // ... and cyclic-reduction factor
     if constexpr (!LDSSTATE) {          // iterate in global memory -- or staged in LDS for the round (generic kernels of small batches)
         if constexpr (NXT == 0 || NXT == 4) { if (L.lstage) { admm_round_global<NB, NXT, NUT, MODE, true>(L, P, S, alpha, iters); return; } }

@@ -33,10 +33,12 @@ namespace w8 {
 #include "mpcqp_dense.h"
 #include "mpcqp_border.h"
 #include "mpcqp_phases.h"
+#include "mpcqp_run.h"
 #include "mpcqp_tiny.h"
 #include "mpcqp_lat.h"
 #include "mpcqp_latw.h"
 #include "mpcqp_kernels.h"
+#include "mpcqp_latw_check.h"
 
 template <int NXT, int NUT, int MODE, bool LOOP, bool LDSS = true>
 static int launch(const RunKArgs &A, int grid, size_t smem, hipStream_t stream) {

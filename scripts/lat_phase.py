@@ -33,5 +33,6 @@ wall = [int(x) for x in re.search(r'begin (\d+) admm (\d+) check (\d+)', w).grou
 names = ['rhs', 'L0fwd', 'L1fwd', 'top', 'L1back', 'L0back', 'update']
 print('%s %s: %d iterations, %d rounds in 20 steps; %.0f cycles per iteration = ' % (os.path.basename(sys.argv[1]), backend, its, rounds, tot / its)
       + ' + '.join('%s %.0f' % (n, p / 100 * tot / its) for n, p in zip(names, pct)))
+print('   whole admm function (thread 0): %.0f cycles per step; sum of its slots: %.0f; before the first tick %.0f' % (chk[1] / 20.0, (tot + sum(outside)) / 20.0, chk[2] / 20.0))
 print('   per round: load %.0f  owner regs %.0f  write-back %.0f cycles;  per check: setup+tail %.0f vars %.0f reduce %.0f decide %.0f cycles;  wall (10 ns ticks) per step: begin %.0f admm %.0f check %.0f'
       % tuple([o / rounds for o in outside] + [chk[0] / rounds, chk[2] / rounds, chk[3] / rounds, chk[4] / rounds] + [x / 20.0 for x in wall]))
