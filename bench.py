@@ -17,7 +17,7 @@ pyMPC/mpc.py:80), synthetic data, FP64, all inputs resident in HBM when the time
 
 Two ways through the same library, both measured, `--path` chooses which one is `value` (the other is `other_path`):
   device_loop (default): the K steps run inside mpcqp_mpc_loop launches (output -> plant -> update -> solve per
-                         instance on the device, SURVEY 8f-1), at most 25 steps per launch (--chunk);
+                         instance on the device, SURVEY 8f-1), at most 50 steps per launch (--chunk);
   stepwise             : the reference's call pattern, update()/solve()/output() per step from the host.
 Both give bit-identical trajectories (tests/test_gpu_parity.py::test_device_loop_*).
 
@@ -382,13 +382,14 @@ class Shard:
         f64 = torch.float64
         # steps per launch: a launch ends when its slowest instance has finished its steps (no instance can run ahead of its
         # own closed loop), so short launches pay the spread of the per-instance iteration counts more often -- at cfg-3,
-        # 5-step launches cost 8 % against 20-step ones.  Default: the whole timed region in launches of at most 25 steps.
+        # 5-step launches cost 8 % against 20-step ones, and at cfg-5 50-step launches gain 2-3 % on 25-step ones (per-instance iteration totals
+        # average out over a longer launch).  Default: the whole timed region in equal launches of at most 50 steps.
         if self.args.chunk:
             chunk = self.args.chunk
         else:
             chunk = steps
-            while chunk > 25:
-                chunk = next((chunk // d for d in (2, 3, 5, 7) if chunk % d == 0), 25)
+            while chunk > 50:
+                chunk = next((chunk // d for d in (2, 3, 5, 7) if chunk % d == 0), 50)
         w_all = self.noise(warmup + steps)
         outs = (torch.empty((chunk + 1, B, NX), dtype=f64, device=dev), torch.empty((chunk, B, NU), dtype=f64, device=dev),
                 torch.empty((chunk, B), dtype=torch.int32, device=dev), torch.empty((chunk, B), dtype=torch.int32, device=dev))
@@ -801,7 +802,7 @@ def main():
     ap.add_argument('--batch', type=int, default=None, help='instances per GPU (weak scaling; default 1024, cfg5: 512)')
     ap.add_argument('--total-batch', type=int, default=None, help='instances in total, split evenly over the GPUs (strong scaling)')
     ap.add_argument('--eps', type=float, default=1e-3)
-    ap.add_argument('--chunk', type=int, default=None, help='device loop: steps per kernel launch (default: the timed steps in equal launches of at most 25)')
+    ap.add_argument('--chunk', type=int, default=None, help='device loop: steps per kernel launch (default: the timed steps in equal launches of at most 50)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-other-path', action='store_true', help='skip the secondary measurements (other path, parity setting, strong-scaling / HBM / latency legs)')
     ap.add_argument('--no-refactor-timing', action='store_true', help='skip the timing of the factorization alone (profiling runs: its launches carry the solve kernel\'s name)')

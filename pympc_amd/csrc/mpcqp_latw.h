@@ -597,12 +597,15 @@ __device__ __forceinline__ int admm_latw(const Lay &L, const HotPtrs &P, Smem &S
                 const double dA = lat_row_step(rA[q], ztA, loA[q], hiA[q], alpha, beta);
                 const double dB = lat_row_step(rB[q], ztB, loB[q], hiB[q], alpha, beta);
                 if (keep_delta && ok[q]) {
-                    dxg[pidx[q]] = vn - pv[q];
-                    if (is_x && L.soft) dxg[pidx[q] + L.oe] = en - pv2[q];
-                    dyg[aidx[q]] = (rA[q].om * cinv) * dA; dyg[bidx[q]] = (rB[q].om * cinv) * dB;
+                    // (indices made opaque HERE: left to itself the compiler forms the five 64-bit addresses once, outside the iteration loop, keeps them
+                    //  in scratch and reloads them in this branch -- ten registers' worth of spill traffic per round for five integer additions)
+                    const int ip = opaque_lane(pidx[q]), ia = opaque_lane(aidx[q]), ib = opaque_lane(bidx[q]);
+                    dxg[ip] = vn - pv[q];
+                    if (is_x && L.soft) dxg[ip + L.oe] = en - pv2[q];
+                    dyg[ia] = (rA[q].om * cinv) * dA; dyg[ib] = (rB[q].om * cinv) * dB;
                 }
                 pv[q] = vn; pv2[q] = en;
-                if (q == 0 && u0v) { const double d0 = lat_row_step(r0, xt, S.du0[jj], S.du0[nu + jj], alpha, beta); if (keep_delta) dyg[L.rdu + jj] = (r0.om * cinv) * d0; }
+                if (q == 0 && u0v) { const double d0 = lat_row_step(r0, xt, S.du0[jj], S.du0[nu + jj], alpha, beta); if (keep_delta) dyg[opaque_lane(L.rdu + jj)] = (r0.om * cinv) * d0; }
                 WA[sl[q]] = ok[q] ? rA[q].w : 0.0; WB[sl[q]] = ok[q] ? rB[q].w : 0.0;      // (a slot without a variable contributes nothing)
             }
         }
