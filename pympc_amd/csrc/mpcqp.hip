@@ -97,6 +97,7 @@ int mpcqp_w8_launch(const void *kargs, size_t kargs_bytes, int spec12_4, int sch
 void mpcqp_w8_ticks(unsigned long long *out16);
 #endif
 constexpr int BALANCE_EVERY = 16;  // solves between two rebuilds of the workgroup -> instance map
+constexpr int QUEUE_ITEMS_PER_SLOT = 16;   // persistent closed-loop launches: queue items per resident workgroup slot (run_kernel_args)
 constexpr int BALANCE_FIRST = 4;   // ... before the first one (an instance shows its character within a few solves; a short run should not end unbalanced)
 
 struct mpcqp_handle {
@@ -111,6 +112,7 @@ struct mpcqp_handle {
     double *u0_dev;
     int *pending_dev, *npending_dev;   // two-launch solve: instances that need more than the first round
     int *perm_dev;                // [batch] workgroup -> instance map (P.perm points here once a map has been built)
+    int *vcur_dev, *vdone_dev; unsigned *vqueue_dev;   // persistent launches: [slots] map entry each workgroup is working on; [batch] closed-loop steps done; the queue position
     std::vector<double> work_ema; // per instance: smoothed ADMM iterations per balancing interval (host)
     int ncu, solves_since_balance, auto_balance;
     void *run_buf; size_t run_bytes;     // staging of mpcqp_mpc_run (disturbances, plant, trajectories)
@@ -213,7 +215,7 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     if (device < 0 || device >= ndev) return fail(MPCQP_ERR_ARG, "mpcqp_create: bad device index");
     HIPCHK(hipSetDevice(device));
     mpcqp_handle *h = new mpcqp_handle();
-    h->device = device; h->batch = batch; h->is_setup = false; h->u0_dev = nullptr; h->run_buf = nullptr; h->run_bytes = 0; h->perm_dev = nullptr; h->solves_since_balance = 0; h->auto_balance = 1; h->ncu = 0;
+    h->device = device; h->batch = batch; h->is_setup = false; h->u0_dev = nullptr; h->run_buf = nullptr; h->run_bytes = 0; h->perm_dev = nullptr; h->vcur_dev = nullptr; h->vdone_dev = nullptr; h->vqueue_dev = nullptr; h->solves_since_balance = 0; h->auto_balance = 1; h->ncu = 0;
     h->profiling = false; h->run_ms = 0.0; h->run_launches = 0; h->ev_count = 0; h->nevents = 0; h->stream = nullptr; h->own_stream = false;
     h->warm_x_pending = false;
     h->csc = nullptr; h->vec_buf = nullptr; h->step_blank = false;
@@ -307,6 +309,7 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     rc |= dalloc(h, &P.ctype, B * L.m); rc |= dalloc(h, &P.info, B); rc |= dalloc(h, &P.stats, 8);
         rc |= dalloc(h, &h->u0_dev, B * L.nu);
     rc |= dalloc(h, &P.work, B); rc |= dalloc(h, &h->perm_dev, B);
+    rc |= dalloc(h, &h->vcur_dev, (size_t)std::max(4 * h->ncu, 1)); rc |= dalloc(h, &h->vqueue_dev, 4); rc |= dalloc(h, &h->vdone_dev, B);
     rc |= dalloc(h, &P.tstamp, (size_t)TS_STRIDE * B);
     rc |= dalloc(h, &h->pending_dev, B); rc |= dalloc(h, &h->npending_dev, 4);
     if (h->S.tuning & MPCQP_TUNE_NO_BALANCE) h->auto_balance = 0;
@@ -595,15 +598,45 @@ extern "C" int mpcqp_update_settings(mpcqp_handle *h, const mpcqp_settings *s) {
     return MPCQP_OK;
 }
 
+// The kernel arguments of a launch and its grid: one workgroup per instance, or -- batches beyond the resident workgroup slots -- the PERSISTENT form:
+// as many workgroups as there are slots, each taking instances off a queue (k_mpc_run in mpcqp_kernels.h says what that buys).
+static int run_grid(const mpcqp_handle *h) {
+    const Lay &L = h->L;
+    const bool one_at_a_time = L.bcr || L.dense || L.NB > 32 || L.nw == 8;
+    int occ = one_at_a_time ? 1 : (L.NB <= 16 ? 4 : 2);
+    if (h->smem_solve > 0) occ = std::max(1, std::min(occ, (int)((size_t)160 * 1024 / h->smem_solve)));
+    return h->ncu * occ;
+}
+static RunKArgs run_kernel_args(mpcqp_handle *h, const RunArgs &R0, int *grid) {
+    RunKArgs A; A.L = h->L; A.P = h->P; A.S = h->S; A.R = R0;
+    *grid = h->batch;
+    const int slots = run_grid(h);
+    if (h->ncu > 0 && h->batch > slots && h->vcur_dev && !R0.pin_in && !R0.pub && !(h->S.tuning & MPCQP_TUNE_NO_QUEUE)) {
+        A.R.vcur = h->vcur_dev; A.R.vperm = h->P.perm; A.R.vqueue = h->vqueue_dev;
+        A.P.perm = h->vcur_dev;
+        *grid = slots;
+        // closed loop: an instance's steps in parts, about QUEUE_ITEMS_PER_SLOT items per slot in all (a launch ends within half an item of its ideal
+        // length; an item costs a kernel prologue, ~ 10 us)
+        if (R0.nsteps > 1 && !(h->S.tuning & MPCQP_TUNE_NO_PARTS)) {
+            const int per_slot = ((h->S.tuning >> 16) & 0xFF) ? ((h->S.tuning >> 16) & 0xFF) : QUEUE_ITEMS_PER_SLOT;      // (bits 16..23: development override)
+            const int parts = std::min(R0.nsteps, (per_slot * slots + h->batch - 1) / h->batch);
+            if (parts > 1) { A.R.vchunk = (R0.nsteps + parts - 1) / parts; A.R.vdone = h->vdone_dev; }
+        }
+    }
+    return A;
+}
 template <int NB, bool LDSS, int NXT, int NUT, int MODE>
 static int launch_run_t(mpcqp_handle *h, const RunArgs &R) {
-    RunKArgs A; A.L = h->L; A.P = h->P; A.S = h->S; A.R = R;
+    int grid;
+    const RunKArgs A = run_kernel_args(h, R, &grid);
+    if (A.R.vcur && hipMemsetAsync(h->vqueue_dev, 0, sizeof(unsigned), h->stream) != hipSuccess) return MPCQP_ERR_HIP;
+    if (A.R.vdone && hipMemsetAsync(h->vdone_dev, 0, sizeof(int) * (size_t)h->batch, h->stream) != hipSuccess) return MPCQP_ERR_HIP;
     if (R.nsteps > 0) {
         if (set_smem(k_mpc_run<NB, LDSS, NXT, NUT, MODE, true>, h->smem_solve)) return MPCQP_ERR_HIP;
-        hipLaunchKernelGGL((k_mpc_run<NB, LDSS, NXT, NUT, MODE, true>), dim3(h->batch), dim3(NT), h->smem_solve, h->stream, A);
+        hipLaunchKernelGGL((k_mpc_run<NB, LDSS, NXT, NUT, MODE, true>), dim3(grid), dim3(NT), h->smem_solve, h->stream, A);
     } else {
         if (set_smem(k_mpc_run<NB, LDSS, NXT, NUT, MODE, false>, h->smem_solve)) return MPCQP_ERR_HIP;
-        hipLaunchKernelGGL((k_mpc_run<NB, LDSS, NXT, NUT, MODE, false>), dim3(h->batch), dim3(NT), h->smem_solve, h->stream, A);
+        hipLaunchKernelGGL((k_mpc_run<NB, LDSS, NXT, NUT, MODE, false>), dim3(grid), dim3(NT), h->smem_solve, h->stream, A);
     }
     return 0;
 }
@@ -642,10 +675,11 @@ static int rebalance(mpcqp_handle *h) {
     // One workgroup per compute unit at a time (the latency kernels, wide stages): workgroups start in index order as compute units come
     // free, so the map is the longest-expected-work-first list -- the classic greedy schedule, makespan within one instance of the mean.
     const bool one_at_a_time = h->L.bcr || h->L.dense || h->L.NB > 32 || h->L.nw == 8;
+    const bool queued = B > run_grid(h) && h->vcur_dev && !(h->S.tuning & MPCQP_TUNE_NO_QUEUE);      // (persistent launch: the map is the queue -- longest expected work first)
     const int full_rows = B / ncu;
     for (int j = 0; j < B; ++j) {
         const int row = j / ncu, pos = j % ncu;
-        const bool reversed = !one_at_a_time && (row & 1) && row < full_rows;      // a partial last row keeps forward order
+        const bool reversed = !one_at_a_time && !queued && (row & 1) && row < full_rows;      // a partial last row keeps forward order
         perm[row * ncu + (reversed ? ncu - 1 - pos : pos)] = order[j];
     }
     // Pacing (development switch, off unless mpcqp_settings.tuning bits 8..15 ask for it): in the bandwidth kernels with a global-memory iterate whose
@@ -690,14 +724,13 @@ static int launch_run(mpcqp_handle *h, RunArgs R, int plain_iters) {
     }
     int rc;
     if (L.dense) rc = launch_run_t<16, true, 0, 0, MODE_DENSE>(h, R);
-    else if (!L.bcr && L.nw == 8) {                 // 512-thread workgroups (one long-horizon controller on grouped stages): the other translation unit
-        RunKArgs A; A.L = h->L; A.P = h->P; A.S = h->S; A.R = R;
-        rc = mpcqp_w8_launch(&A, sizeof(A), L.border, 0, R.nsteps > 0, h->batch, h->smem_solve, h->stream);
-        if (rc) return fail(MPCQP_ERR_HIP, "mpcqp_w8_launch failed");
-    }
-    else if (L.bcr && L.nw == 8) {                  // 512-thread workgroups: the other translation unit
-        RunKArgs A; A.L = h->L; A.P = h->P; A.S = h->S; A.R = R;
-        rc = mpcqp_w8_launch(&A, sizeof(A), L.bcr == 31 && L.nx == 12 && L.nu == 4, L.bcr, R.nsteps > 0, h->batch, h->smem_solve, h->stream);
+    else if (L.nw == 8) {                           // 512-thread workgroups: the other translation unit (cyclic reduction with a dense top, or one long-horizon controller on grouped stages)
+        int grid;
+        const RunKArgs A = run_kernel_args(h, R, &grid);
+        if (A.R.vcur) HIPCHK(hipMemsetAsync(h->vqueue_dev, 0, sizeof(unsigned), h->stream));
+        if (A.R.vdone) HIPCHK(hipMemsetAsync(h->vdone_dev, 0, sizeof(int) * (size_t)h->batch, h->stream));
+        rc = L.bcr ? mpcqp_w8_launch(&A, sizeof(A), L.bcr == 31 && L.nx == 12 && L.nu == 4, L.bcr, R.nsteps > 0, grid, h->smem_solve, h->stream)
+                   : mpcqp_w8_launch(&A, sizeof(A), L.border, 0, R.nsteps > 0, grid, h->smem_solve, h->stream);
         if (rc) return fail(MPCQP_ERR_HIP, "mpcqp_w8_launch failed");
     }
     else if (L.bcrtop && L.bcr == 31 && L.nx == 12 && L.nu == 4) rc = launch_run_t<16, true, 12, 4, MODE_BCRT + 31>(h, R);

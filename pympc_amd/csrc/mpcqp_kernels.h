@@ -104,17 +104,28 @@ __device__ __noinline__ int run_check_phase(int iter, int mode, int *frame_pin) 
 }
 
 constexpr int run_occupancy(int NB, int MODE) { return (NT > 256 || MODE == MODE_DENSE || MODE >= MODE_BCR || NB > 32) ? 1 : NB <= 16 ? 4 : 2; }      // workgroups per CU (512-thread kernels: one, two waves per SIMD)
+// One instance from the kernel's prologue to its last store: what a workgroup of k_mpc_run does ONCE when the grid is the batch, and once per instance it
+// takes off the queue when the launch is persistent (below).
+// LOOP: the closed-loop steps [k0, k1) of the launch's nsteps (the whole launch, or the part of it one queue item covers: the state an instance carries
+// from step to step is in memory at every step boundary -- step blob, iterate, mpcqp_info -- exactly as between two launches).
 template <int NB, bool LDSSTATE, int NXT, int NUT, int MODE, bool LOOP>
-__global__ __launch_bounds__(NT, run_occupancy(NB, MODE)) void k_mpc_run(RunKArgs A_) {
+__device__ __forceinline__ void run_instance(const int k0, const int k1) {
     constexpr int OCC = run_occupancy(NB, MODE);
     const RunKArgs &A = run_kargs();
     const Lay &L = A.L; const Ptrs &P = A.P; const RunArgs &R = A.R;
-    if (!LOOP && R.part == 2 && (int)blockIdx.x >= *R.npending) return;
     RunSmem rs = run_smem<LDSSTATE>(L, P);
     Smem &S = rs.S;
     const int b = inst_of(P.perm), tid = threadIdx.x;
     double *step = P.step + (size_t)b * L.step_sz;
-    if (LOOP && tid == 0) P.tstamp[(size_t)TS_STRIDE * b] = wall_clock64();
+    if (LOOP && tid == 0 && k0 == 0) P.tstamp[(size_t)TS_STRIDE * b] = wall_clock64();
+#ifdef MPCQP_RUN_TIMING
+    if (LOOP && tid == 0 && k0 == 0) {      // (development: WHERE this workgroup runs -- XCC and HW_ID in the last step's slot of its stamps; scripts/diag_makespan.py)
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        P.tstamp[(size_t)TS_STRIDE * b + 2 + TS_STEPS - 1] = ((unsigned long long)(xcc & 15) << 32) | hw;
+    }
+#endif
     if (MODE >= MODE_BCRT && tid == 0) S.iflag[2] = 0;      // (the rounds' LDS-resident part of the factor is not loaded yet: admm_latw; a barrier follows in load_common)
     if (!LOOP && R.pin_in) {                     // update(x0, u_{-1}, xref) straight from the caller's (mapped) memory: one PCIe round trip
         const double *src = R.pin_in + (size_t)b * R.pin_stride;
@@ -130,8 +141,7 @@ __global__ __launch_bounds__(NT, run_occupancy(NB, MODE)) void k_mpc_run(RunKArg
         return;
     }
     const int nx = L.nx, nu = L.nu;
-    const int nrun = LOOP ? R.nsteps : 1;        // LOOP = false: one solve of the current data (mpcqp_solve)
-    for (int k = 0; k < nrun; ++k) {
+    for (int k = k0; k < k1; ++k) {              // (LOOP = false: [0, 1), one solve of the current data -- mpcqp_solve)
         if (LOOP) {
             // scratch in the (idle) work area: un | xn | xt | ym | inn | xu, 128 doubles each (nx + nu <= 128, ny <= 64)
             double *un = S.T, *xn = S.T + 128, *xt = S.T + 256, *ym = S.T + 384, *inn = S.T + 512, *xu = S.T + 640;
@@ -139,8 +149,8 @@ __global__ __launch_bounds__(NT, run_occupancy(NB, MODE)) void k_mpc_run(RunKArg
             const int ny = R.ny;
             // ---- output(): first input of the current solution, or u_failure
             // (from the second step on, status and first input of the solve that just ended are where its last check left them in LDS)
-            const int status = k ? S.iflag[4] : P.info[b].status;
-            if (tid < nu) un[tid] = status == MPCQP_SOLVED ? (k ? S.uo[tid] : P.xo[(size_t)b * L.n + L.ou + tid]) : S.hot[L.ouref + tid];
+            const int status = k > k0 ? S.iflag[4] : P.info[b].status;
+            if (tid < nu) un[tid] = status == MPCQP_SOLVED ? (k > k0 ? S.uo[tid] : P.xo[(size_t)b * L.n + L.ou + tid]) : S.hot[L.ouref + tid];
             if (tid < nx) xt[tid] = ny ? R.x_true[(size_t)b * nx + tid] : S.x0s[tid];      // the plant state
             __syncthreads();
             if (ny && tid < ny) {                            // measurement y = C x + v and innovation y - C xhat
@@ -234,18 +244,69 @@ __global__ __launch_bounds__(NT, run_occupancy(NB, MODE)) void k_mpc_run(RunKArg
         __threadfence_system();
         __syncthreads();
         if (tid == 0) {
-            if (atomicAdd(R.done, 1u) == gridDim.x - 1) {
+            if (atomicAdd(R.done, 1u) == (unsigned)R.batch - 1u) {      // (one workgroup per instance on this path: never persistent)
                 *R.done = 0;
                 __threadfence_system();
                 *(volatile unsigned long long *)(pi + R.batch) = R.seq;
             }
         }
     }
+    if (LOOP && k1 < R.nsteps) return;           // (a queue item that is not the instance's last)
     if (LOOP && tid == 0) P.tstamp[(size_t)TS_STRIDE * b + 1] = wall_clock64();
     if (LOOP && tid < nx) {
         const size_t e = ((size_t)R.nsteps * R.batch + b) * nx + tid;
         R.x_traj[e] = R.ny ? R.x_true[(size_t)b * nx + tid] : S.x0s[tid];
         if (R.ny && R.xhat_traj) R.xhat_traj[e] = S.x0s[tid];
+    }
+}
+
+// The kernel.  Grid = batch: one workgroup per instance (inst_of: the workgroup -> instance map).  PERSISTENT (RunArgs::vcur, batches beyond the
+// resident slots): the grid is the number of resident slots and every workgroup takes ITEMS off a queue until it is empty.  An item is an instance --
+// position v of the map is instance vperm[v], the map is the longest-expected-work-first list (rebalance() in mpcqp.hip): the greedy schedule -- or, in
+// the closed loop, `vchunk` consecutive steps of an instance: the items of part p + 1 follow all items of part p in the queue, an item waits for its
+// instance's previous part through a per-instance progress counter (vdone; its producer was taken off the queue earlier and never waits for a later
+// item, so this cannot deadlock), and the launch ends within a fraction of an instance's closed loop of its ideal length instead of within a whole one.
+// Measured on the hardware's own dispatch of 1024 one-at-a-time workgroups (scripts/diag_makespan.py, HW_ID stamps): every compute unit gets exactly
+// four of them whatever they last, 54 us (median; mean 116) pass between two workgroups on a compute unit, and the units idle 1.3 ms of a 12.6 ms
+// launch at its end -- 13 % of the slots' time.  The instance a workgroup works on reaches the phases the way it always did, through inst_of(P.perm):
+// P.perm points at vcur, one entry per workgroup, which thread 0 rewrites per item (fence, barrier, scalar-cache invalidate: the phases read it with
+// scalar loads).
+template <int NB, bool LDSSTATE, int NXT, int NUT, int MODE, bool LOOP>
+__global__ __launch_bounds__(NT, run_occupancy(NB, MODE)) void k_mpc_run(RunKArgs A_) {
+    const RunArgs &R = run_kargs().R;
+    const int nrun = LOOP ? R.nsteps : 1;
+    if (R.vcur == nullptr) {
+        if (!LOOP && R.part == 2 && (int)blockIdx.x >= *R.npending) return;
+        run_instance<NB, LDSSTATE, NXT, NUT, MODE, LOOP>(0, nrun);
+        return;
+    }
+    __shared__ int s_item[3];                                  // map entry (-1: the queue is empty), first step, end step
+    const int nvirt = (!LOOP && R.part == 2) ? *R.npending : R.batch;
+    const int chunk = (LOOP && R.vchunk > 0) ? R.vchunk : nrun, nparts = (nrun + chunk - 1) / chunk;
+    for (;;) {
+        if (threadIdx.x == 0) {
+            const int v = (int)atomicAdd(R.vqueue, 1u);
+            int entry = -1, ka = 0, kb = nrun;
+            if (v < nvirt * nparts) {
+                const int part = v / nvirt, idx = v - part * nvirt;
+                entry = R.vperm ? R.vperm[idx] : idx;
+                ka = part * chunk; kb = min(nrun, ka + chunk);
+                if (part > 0) {                                // the instance's previous part must be done (and its writes visible: acquire below)
+                    volatile int *done = R.vdone + (entry & PERM_INST_MASK);
+                    while (*done < ka) __builtin_amdgcn_s_sleep(16);
+                }
+                R.vcur[blockIdx.x] = entry; __threadfence();
+            }
+            s_item[0] = entry; s_item[1] = ka; s_item[2] = kb;
+        }
+        __syncthreads();
+        const int entry = s_item[0], ka = s_item[1], kb = s_item[2];
+        if (entry < 0) break;
+        __builtin_amdgcn_s_dcache_inv();                       // (inst_of's load of vcur[blockIdx.x] is a scalar load in most phases)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // (... and a vector load in the others; with parts: everything the previous part wrote)
+        run_instance<NB, LDSSTATE, NXT, NUT, MODE, LOOP>(ka, kb);
+        __syncthreads();
+        if (nparts > 1 && threadIdx.x == 0) { __threadfence(); *(volatile int *)(R.vdone + (entry & PERM_INST_MASK)) = kb; }
     }
 }
 

@@ -27,6 +27,12 @@ struct RunArgs {
     double *u_traj;               // [nsteps][batch][nu]
     int *status_traj, *iter_traj; // [nsteps][batch]: outcome of the solve that follows step k's update
     int batch;
+    // persistent launch (k_mpc_run: the grid is the resident slots, workgroups take instances off a queue); null = one workgroup per instance
+    int *vcur;                    // [grid] the map entry (instance | pace bits) each workgroup is working on: what Ptrs::perm points at
+    const int *vperm;             // [batch] queue position -> map entry, or null = identity
+    unsigned *vqueue;             // next queue position (zeroed before the launch)
+    int vchunk;                   // closed loop: steps per queue item (0 = an instance's whole loop is one item)
+    int *vdone;                   // [batch] steps of this launch an instance has completed (zeroed before the launch; vchunk > 0)
     // host-resident exchange (mpcqp_step_host: one launch per control step, no copy calls, no stream synchronisation):
     const double *pin_in;         // [batch][pin_stride] = [x0 | u_{-1} | xref] in mapped host memory, copied into the step blob first (null = off)
     int pin_stride, pin_mask, pin_xref;   // mask: 1 x0, 2 u_{-1}, 4 xref (pin_xref doubles)
