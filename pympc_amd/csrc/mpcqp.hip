@@ -112,6 +112,7 @@ struct mpcqp_handle {
     double *u0_dev;
     int *pending_dev, *npending_dev;   // two-launch solve: instances that need more than the first round
     int *perm_dev;                // [batch] workgroup -> instance map (P.perm points here once a map has been built)
+    int *qperm_dev; bool qperm_set;     // [batch] the queue order of persistent launches (longest expected work first), once a map has been built
     int *vcur_dev, *vdone_dev; unsigned *vqueue_dev;   // persistent launches: [slots] map entry each workgroup is working on; [batch] closed-loop steps done; the queue position
     std::vector<double> work_ema; // per instance: smoothed ADMM iterations per balancing interval (host)
     int ncu, solves_since_balance, auto_balance;
@@ -215,7 +216,7 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     if (device < 0 || device >= ndev) return fail(MPCQP_ERR_ARG, "mpcqp_create: bad device index");
     HIPCHK(hipSetDevice(device));
     mpcqp_handle *h = new mpcqp_handle();
-    h->device = device; h->batch = batch; h->is_setup = false; h->u0_dev = nullptr; h->run_buf = nullptr; h->run_bytes = 0; h->perm_dev = nullptr; h->vcur_dev = nullptr; h->vdone_dev = nullptr; h->vqueue_dev = nullptr; h->solves_since_balance = 0; h->auto_balance = 1; h->ncu = 0;
+    h->device = device; h->batch = batch; h->is_setup = false; h->u0_dev = nullptr; h->run_buf = nullptr; h->run_bytes = 0; h->perm_dev = nullptr; h->vcur_dev = nullptr; h->vdone_dev = nullptr; h->vqueue_dev = nullptr; h->qperm_dev = nullptr; h->qperm_set = false; h->solves_since_balance = 0; h->auto_balance = 1; h->ncu = 0;
     h->profiling = false; h->run_ms = 0.0; h->run_launches = 0; h->ev_count = 0; h->nevents = 0; h->stream = nullptr; h->own_stream = false;
     h->warm_x_pending = false;
     h->csc = nullptr; h->vec_buf = nullptr; h->step_blank = false;
@@ -309,7 +310,7 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     rc |= dalloc(h, &P.ctype, B * L.m); rc |= dalloc(h, &P.info, B); rc |= dalloc(h, &P.stats, 8);
         rc |= dalloc(h, &h->u0_dev, B * L.nu);
     rc |= dalloc(h, &P.work, B); rc |= dalloc(h, &h->perm_dev, B);
-    rc |= dalloc(h, &h->vcur_dev, (size_t)std::max(4 * h->ncu, 1)); rc |= dalloc(h, &h->vqueue_dev, 4); rc |= dalloc(h, &h->vdone_dev, B);
+    rc |= dalloc(h, &h->vcur_dev, (size_t)std::max(4 * h->ncu, 1)); rc |= dalloc(h, &h->vqueue_dev, 4); rc |= dalloc(h, &h->vdone_dev, B); rc |= dalloc(h, &h->qperm_dev, B);
     rc |= dalloc(h, &P.tstamp, (size_t)TS_STRIDE * B);
     rc |= dalloc(h, &h->pending_dev, B); rc |= dalloc(h, &h->npending_dev, 4);
     if (h->S.tuning & MPCQP_TUNE_NO_BALANCE) h->auto_balance = 0;
@@ -611,8 +612,10 @@ static RunKArgs run_kernel_args(mpcqp_handle *h, const RunArgs &R0, int *grid) {
     RunKArgs A; A.L = h->L; A.P = h->P; A.S = h->S; A.R = R0;
     *grid = h->batch;
     const int slots = run_grid(h);
-    if (h->ncu > 0 && h->batch > slots && h->vcur_dev && !R0.pin_in && !R0.pub && !(h->S.tuning & MPCQP_TUNE_NO_QUEUE)) {
-        A.R.vcur = h->vcur_dev; A.R.vperm = h->P.perm; A.R.vqueue = h->vqueue_dev;
+    // (closed-loop launches only: a single solve's workgroups last ~ 100 us, and the queue's per-item cost -- an atomic, two fences, a barrier -- and the
+    //  counter's memset in front of each of a solve's two launches cost the stepwise path more than the hardware's dispatch gaps: 1.49 -> 1.25 M solves/s)
+    if (h->ncu > 0 && h->batch > slots && h->vcur_dev && R0.nsteps > 0 && !(h->S.tuning & MPCQP_TUNE_NO_QUEUE)) {
+        A.R.vcur = h->vcur_dev; A.R.vperm = h->qperm_set ? h->qperm_dev : h->P.perm; A.R.vqueue = h->vqueue_dev;
         A.P.perm = h->vcur_dev;
         *grid = slots;
         // closed loop: an instance's steps in parts, about QUEUE_ITEMS_PER_SLOT items per slot in all (a launch ends within half an item of its ideal
@@ -675,13 +678,15 @@ static int rebalance(mpcqp_handle *h) {
     // One workgroup per compute unit at a time (the latency kernels, wide stages): workgroups start in index order as compute units come
     // free, so the map is the longest-expected-work-first list -- the classic greedy schedule, makespan within one instance of the mean.
     const bool one_at_a_time = h->L.bcr || h->L.dense || h->L.NB > 32 || h->L.nw == 8;
-    const bool queued = B > run_grid(h) && h->vcur_dev && !(h->S.tuning & MPCQP_TUNE_NO_QUEUE);      // (persistent launch: the map is the queue -- longest expected work first)
     const int full_rows = B / ncu;
     for (int j = 0; j < B; ++j) {
         const int row = j / ncu, pos = j % ncu;
-        const bool reversed = !one_at_a_time && !queued && (row & 1) && row < full_rows;      // a partial last row keeps forward order
+        const bool reversed = !one_at_a_time && (row & 1) && row < full_rows;      // a partial last row keeps forward order
         perm[row * ncu + (reversed ? ncu - 1 - pos : pos)] = order[j];
     }
+    // (the closed loop's persistent launches take instances off a QUEUE: for them the longest-expected-work-first list itself, whatever the kernel)
+    HIPCHK(hipMemcpyAsync(h->qperm_dev, order.data(), sizeof(int) * (size_t)B, hipMemcpyHostToDevice, h->stream));
+    h->qperm_set = true;
     // Pacing (development switch, off unless mpcqp_settings.tuning bits 8..15 ask for it): in the bandwidth kernels with a global-memory iterate whose
     // instances are ALL resident at once (B <= slots) the launch ends with its slowest instance.  Every instance that is NOT expected to need more than
     // 1.15 x the median's iterations idles `units` x 3.5 us in each of its iterations, leaving its share of the memory system to the stragglers.

@@ -548,6 +548,29 @@ def test_load_balancing_map_never_changes_results(monkeypatch):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize('B,steps', [(300, 12), (1100, 7)])
+def test_persistent_queue_never_changes_results(B, steps):
+    """Beyond one workgroup per resident slot a closed-loop launch is PERSISTENT: as many workgroups as slots, each taking (instance, step range)
+    items off a queue (k_mpc_run, mpcqp_kernels.h).  Pure scheduling: the trajectories, statuses and iteration counts of two consecutive launches are
+    bit-identical with the queue and its step-range parts (default), with whole closed loops as items (TUNE_NO_PARTS), and with the hardware's own
+    dispatch of one workgroup per instance (TUNE_NO_QUEUE).  300 instances: more than the 256 one-at-a-time slots of the register-resident kernel;
+    1100 with the bandwidth kernel forced: more than its 1024."""
+    from pympc_amd import fixtures, _lib
+    from pympc_amd.solver import forced_settings
+    kws = [fixtures.random_lti(2000 + i) for i in range(B)]
+    rng = np.random.default_rng(8)
+    w = 0.02 * rng.standard_normal((2 * steps, B, 12))
+    out = []
+    for tuning in (0, _lib.TUNE_NO_PARTS, _lib.TUNE_NO_QUEUE):
+        with forced_settings(tuning=tuning, **({'backend': 'sweeps'} if B > 1024 else {})):
+            K = _stacked_batch(kws); K.setup()
+        parts = [K.run(steps, w=w[steps * i:steps * (i + 1)]) for i in range(2)]
+        out.append(tuple(np.concatenate([p[k] for p in parts]) for k in ('u', 'x', 'iter', 'status')) + (K.prob.solution()[0],))
+    for other in out[1:]:
+        for a, b in zip(out[0], other):
+            assert np.array_equal(a, b)
+
+
 def _random_case(seed):
     """A seeded random controller: dimensions, horizon split, bound pattern (finite / one-sided / absent), weights
     (including semidefinite ones) and reference shape are all drawn."""
