@@ -657,6 +657,9 @@ def compact_line(out):
         if 'eps_1e-09' in u5:
             c5['u_err_rel_eps_1e-9'] = _num(u5['eps_1e-09'].get('max_rel'), 4)
         legs['cfg5_b%d' % out['cfg5_leg']['batch']] = c5
+        db = out['cfg5_leg'].get('double_batch') or {}
+        if 'value' in db:
+            legs['cfg5_b%d' % db['batch']] = compact_leg(db)
     for k, v in (out.get('small_batch_legs') or {}).items():
         if 'error' not in v:
             legs[k] = compact_leg(v)
@@ -945,6 +948,17 @@ def main():
                                  'parity_setting': {'eps_abs': 1e-9, 'eps_rel': 1e-9, 'value': B5 * 50 / p5['elapsed'], 'ms_per_step': 1e3 * p5['elapsed'] / 50,
                                                     'mean_admm_iters': p5['iters'] / max(1, p5['solves']), 'launch_spread': p5.get('launch_spread')}}
             del s5
+            torch.cuda.empty_cache()
+            # ... and twice that batch: beyond the 512 resident slots of this kernel a closed-loop launch is persistent (workgroups take (instance, step
+            # range) items off a queue) and the stragglers' tail is filled by other instances -- what the 512-batch cannot have (all of it is resident at once)
+            try:
+                s5b = Shard(args, d5, 2 * B5, rank, world, dev, 0, torch, dist)
+                r5b = s5b.measure('device_loop', 50, 25)
+                extra['cfg5_leg']['double_batch'] = {'batch': 2 * B5, 'value': 2 * B5 * 50 / r5b['elapsed'], 'ms_per_step': 1e3 * r5b['elapsed'] / 50, 'mean_admm_iters': r5b['iters'] / max(1, r5b['solves']),
+                                                     'launch_spread': r5b.get('launch_spread'), 'roofline': s5b.roofline(r5b, 'device_loop', None)}
+                del s5b
+            except Exception as e:
+                extra['cfg5_leg']['double_batch'] = {'error': repr(e)}
             torch.cuda.empty_cache()
         if world == 1 and args.workload == 'cfg3' and scaling == 'weak' and B >= 8 and B % 8 == 0 and args.path == 'device_loop':
             # BASELINE configs[3] read literally (the SAME batch split over 8 GPUs): what ONE GPU does with its eighth, measured here --

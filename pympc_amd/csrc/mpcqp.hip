@@ -1114,14 +1114,26 @@ extern "C" int mpcqp_get_stream_bytes(mpcqp_handle *h, int64_t *per_iter, int64_
     int64_t rd = (L.model_sz - L.hot_lds) /* the weight matrices, unless they are staged with the hot prefix */ + 2 * n + 2 * m /* D, s, E, omega */ + n + m /* dx, dy */;
     if (L.dense) rd += DenseFmt::DOUBLES;               // the round's load of K^-1 into registers
     if (L.bcr && !L.bcrtop) rd += (int64_t)L.bcr * BcrFmt::REC - 4 * BcrFmt::NN;      // ... of the cyclic-reduction fragments (the two end stages have one neighbour)
-    if (L.bcrtop) {                                     // ... of levels 0 and 1 (the top inverse and G, G' enter LDS once per LAUNCH: admm_latw)
-        int64_t fr = 0;
+    int64_t fr = 0;
+    if (L.bcrtop) {                                     // ... of levels 0 and 1 (the top inverse and G, G' enter LDS once per kernel prologue: admm_latw)
         for (int l = 0; l < 2; ++l) for (int kind = 0; kind < 3; ++kind) for (int t = 0; t < lat_count(L.bcr, l, kind); ++t) fr += lat_nfr(L.bcr, l, kind, t);
         rd += fr * BcrFmt::NN;
     }
     rd += (h->lds_state || L.lstage) ? 2 * (n + 2 * m) /* iterate in and out of LDS */ + (m + L.n_x) + (n + L.n_x) + nq : (n + 2 * m);
     if (L.lstage && L.border) rd += 2 * (int64_t)L.nu * L.N * NB;      // the border matrices staged with it
     int64_t sv = L.hot_lds + L.step_sz + 3 * m /* E, types, omega */ + nq + 2 * (n + m) /* solution out, iterate read */;
+    if (L.bcrtop && L.nw == 8 && (L.bcr + 3) / 4 <= 8 && L.hot_lds > L.hot_sz) {
+        // The 512-thread latency round with its own termination test (latw_check): a round boundary moves the level fragments, the increments (written by
+        // the last iteration, read back by the test) and the three scalings per lane the test clips the certificates with; the owners' registers are
+        // loaded once per SOLVE (iterate, metric, linear cost), the iterate, the solution and the record written once per solve; the top inverse and the hot
+        // prefix enter LDS once per kernel prologue -- per queue item of a persistent closed-loop launch, about every fifth solve (QUEUE_ITEMS_PER_SLOT).
+        // (Spill traffic around the non-inlined test -- ~ 110 bytes per lane and round in the write counter -- is NOT design traffic and not in here.)
+        rd = fr * BcrFmt::NN + 2 * (n + m) /* dx, dy out and back */ + 3 * 64 * 8 /* E of the owned rows */;
+        sv = L.step_sz + 3 * m + nq                                            /* begin: E, types, omega looked at, q written */
+           + (2 * n + 3 * m + nq)                                              /* the round's prologue: x, s, q, omega, z, y */
+           + (n + 2 * m) + (n + m)                                             /* the solve's end: iterate, reported solution */
+           + ((int64_t)L.bcrtop * L.bcrtop * BcrFmt::NN + L.hot_lds) / 5;     /* kernel prologue, amortised */
+    }
     if (per_iter) *per_iter = 8 * it;
     if (per_round) *per_round = 8 * rd;
     if (per_solve) *per_solve = 8 * sv;

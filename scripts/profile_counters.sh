@@ -12,7 +12,8 @@ case "$*" in *--steps*) STEPS="";; esac
 CMD="python $R/bench.py $STEPS --no-cpu-baseline --no-other-path --no-refactor-timing --workload $wl --path device_loop $*"
 timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${T}_stats -o ks -- $CMD > $O/${T}_bench_under_rocprof.json 2> $O/${T}_stats.log
 cp $O/${T}_stats/ks_kernel_stats.csv $O/${T}_kernel_stats.csv
-timeout 150 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${T}_pmc_f -o f -- $CMD > $O/${T}_bench_under_pmc.json 2> $O/${T}_pmc_f.log
+# (the full record of the FETCH pass -- bench.py's side file -- carries the per-kernel iteration totals pmc_summary.py divides by; stdout is the compact line)
+MPCQP_BENCH_LEGS=$O/${T}_bench_under_pmc.json timeout 150 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${T}_pmc_f -o f -- $CMD > /dev/null 2> $O/${T}_pmc_f.log
 timeout 150 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${T}_pmc_w -o w -- $CMD > /dev/null 2> $O/${T}_pmc_w.log
 TCCCSV=""
 if [ "${TCC:-1}" != "0" ]; then

@@ -17,3 +17,5 @@ bash scripts/pmc_sq.sh r6b128 128 > $O/r6_sq_b128.log 2>&1
 bash scripts/pmc_sq.sh r6b256 256 > $O/r6_sq_b256.log 2>&1
 bash scripts/pmc_sq.sh r6b1024 1024 > $O/r6_sq_b1024.log 2>&1
 for f in b256 b128 sw swb4096 cfg5; do tail -n 3 $O/r6_profile_$f.log; done; tail -n 12 $O/r6_sq_b1024.log
+( cd scripts/diag && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o mix_rate mix_rate.hip 2>/dev/null; timeout 60 ./mix_rate ) > $O/r6_mix_rate.txt 2>&1
+cat $O/r6_mix_rate.txt
