@@ -5,14 +5,16 @@ instance give the time per iteration, early and late in the launch."""
 import argparse, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-ap = argparse.ArgumentParser(); ap.add_argument('batch', type=int, nargs='?', default=1024); ap.add_argument('steps', type=int, nargs='?', default=20); ap.add_argument('--lib')
+ap = argparse.ArgumentParser(); ap.add_argument('batch', type=int, nargs='?', default=1024); ap.add_argument('steps', type=int, nargs='?', default=20); ap.add_argument('--lib'); ap.add_argument('--tuning', type=int, default=16, help='mpcqp_settings.tuning (default 16 = TUNE_NO_QUEUE: the hardware dispatch this script was written to look at)')
 a = ap.parse_args()
 from pympc_amd import _lib
 if a.lib: _lib.LIB_PATH = os.path.abspath(a.lib)
 import numpy as np, torch
 import bench
 dev = torch.device('cuda', 0)
-sh = bench.Shard(argparse.Namespace(eps=1e-3, chunk=None), bench.WORKLOADS['cfg3'][:4], a.batch, 0, 1, dev, 0, torch, None)
+from pympc_amd.solver import forced_settings
+with forced_settings(tuning=a.tuning):
+    sh = bench.Shard(argparse.Namespace(eps=1e-3, chunk=None), bench.WORKLOADS['cfg3'][:4], a.batch, 0, 1, dev, 0, torch, None)
 r = sh.measure('device_loop', a.steps, 5)
 ll = r['last_launch']
 t = ll['t'].astype(np.float64) * 1e-8

@@ -1,9 +1,11 @@
 """The evidence under profiles/ that bench.py and the docs point at exists: every counter-profile key bench.py looks up (roofline.traffic of the headline, of the
 forced bandwidth-kernel legs, of the small-batch legs and of cfg-5) has an entry for a closed-loop k_mpc_run kernel with bytes per iteration and QP, and every
-round-5 file the index (profiles/README.md) names is there."""
+round-6 file the index (profiles/README.md) names is there."""
 import json
 import os
 import re
+
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, 'profiles')
@@ -21,9 +23,9 @@ def test_counter_profile_has_the_keys_bench_looks_up():
 
 def test_files_named_in_the_index_exist():
     text = open(os.path.join(P, 'README.md')).read()
-    round5 = text.split('`r1/`, `r2_*`')[0]
-    names = set(re.findall(r'`(r5[a-z0-9]*_[A-Za-z0-9_.*]+)`', round5))
-    assert names, 'no round-5 entries found in profiles/README.md'
+    current = text.split('`r1/`, `r2_*`')[0]
+    names = set(re.findall(r'`(r6[a-z0-9]*_[A-Za-z0-9_.*]+)`', current))
+    assert names, 'no round-6 entries found in profiles/README.md'
     files = os.listdir(P)
     for n in sorted(names):
         if n.endswith('*'):
@@ -33,12 +35,17 @@ def test_files_named_in_the_index_exist():
 
 
 def test_bench_lines_of_the_round_are_the_final_kernels():
-    d = json.load(open(os.path.join(P, 'r5_bench_driver.json')))
+    """The driver's command on the final tree: the compact line (what the driver parses) and the full record beside it."""
+    d = json.load(open(os.path.join(P, 'r6_bench_driver.json')))
     assert d['steps'] == 20 and d['warmup'] == 5 and d['n_gpus'] == 1
+    assert len(json.dumps(d)) < 6000
     ro = d['roofline']
-    assert ro['kernel'] == 'w8::k_mpc_run<16,true,12,4,231,true>' and ro['bound'] == 'mfma' and 0.0 < ro['frac'] < 1.0
-    legs = ro['legs']
-    for k in ('bandwidth_kernel_b1024', 'hbm_b4096', 'cfg5_b512', 'b128', 'b256', 'latency_cfg2', 'latency_notebook', 'latency_kalman_np200'):
+    assert ro['kernel'] == 'w8::k_mpc_run<16,true,12,4,231,true>' and ro['bound'] == 'hbm' and 0.0 < ro['frac'] < 1.0
+    assert abs(ro['frac'] - ro['achieved'] / ro['peak']) < 1e-3 and ro['traffic'] > 0
+    legs = d['legs']
+    for k in ('bandwidth_kernel_b1024', 'sweeps_b4096', 'cfg5_b512', 'cfg5_b1024', 'b128', 'b256', 'latency_cfg2', 'latency_notebook', 'latency_kalman_np200', 'stepwise', 'eps_1e-9'):
         assert k in legs, k
-    assert legs['bandwidth_kernel_b1024']['bound'] == 'hbm' and legs['cfg5_b512']['bound'] == 'hbm'
     assert d['cpu_baseline']['kind'] == 'port' and d['cpu_baseline']['cores'] == 1
+    full = json.load(open(os.path.join(P, 'r6_bench_driver_legs.json')))
+    assert full['value'] == pytest.approx(d['value'], rel=1e-5) and full['roofline']['kernel'] == ro['kernel']
+    assert full['cfg5_leg']['roofline']['bound'] == 'hbm' and full['small_batch_legs']['bandwidth_kernel_b1024']['roofline']['bound'] == 'hbm'

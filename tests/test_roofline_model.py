@@ -12,9 +12,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # key in the profile file, shape, batch, forced backend (None: what the library chooses), ADMM iterations per solve of the profiled launches, measured / model seen when the profile was taken
-CASES = [('cfg3', (12, 4, 30), 1024, None, 38.0, 1.26),
-         ('cfg3_sweeps', (12, 4, 30), 1024, 'sweeps', 38.0, 1.01), ('cfg3_sweeps_b4096', (12, 4, 30), 4096, 'sweeps', 38.0, 1.02), ('cfg5', (20, 8, 100), 512, None, 27.5, 0.98),
-         ('cfg3_b256', (12, 4, 30), 256, None, 38.0, 1.25), ('cfg3_b128', (12, 4, 30), 128, None, 38.0, 1.10)]
+CASES = [('cfg3', (12, 4, 30), 1024, None, 38.0, 1.28),
+         ('cfg3_sweeps', (12, 4, 30), 1024, 'sweeps', 38.0, 1.01), ('cfg3_sweeps_b4096', (12, 4, 30), 4096, 'sweeps', 38.0, 1.03), ('cfg5', (20, 8, 100), 512, None, 27.5, 0.98),
+         ('cfg3_b256', (12, 4, 30), 256, None, 38.0, 1.19), ('cfg3_b128', (12, 4, 30), 128, None, 38.0, 0.98)]
 
 
 @pytest.mark.parametrize('key,dims,batch,forced,iters_per_solve,seen', CASES, ids=[c[0] for c in CASES])
@@ -27,7 +27,7 @@ def test_stream_byte_model_matches_the_committed_counter_profile(key, dims, batc
     model = per_iter + per_round / 25.0 + per_solve / iters_per_solve        # one check per 25 iterations (OSQP's default)
     prof = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_hbm_traffic.json')))[key]['device_loop']
     name = bp.kernel_name(loop=True)
-    assert name in prof, 'profiles/pmc_hbm_traffic.json has no entry for %s: re-profile (scripts/r5_profiles.sh + scripts/r5_collect.py)' % name
+    assert name in prof, 'profiles/pmc_hbm_traffic.json has no entry for %s: re-profile (scripts/r6_profiles.sh + scripts/r6_collect.py)' % name
     entry = prof[name]
     assert entry['batch'] == batch
     ratio = entry['hbm_bytes_per_iter_per_qp'] / model
@@ -44,5 +44,9 @@ def test_stream_byte_model_matches_the_committed_counter_profile(key, dims, batc
     # Second half of round 5 (the top of the latency kernel on the vector ALU, the weight matrices staged with the hot prefix): 1.10 at 128 and 1.25 at
     # 256 instances -- the model lost the weights' 2.5 KB per round, the kernel's ADMM phase gained spills (140 instead of 84 bytes per lane of scratch,
     # written before and read after the iteration loop of every round: ~ 3 KB per iteration and QP in the counters once an XCD's L2 no longer holds them).
+    # Round 6 (profiles/r6*): the register-resident kernel ends a round with its own termination test (latw_check) and its model changed with it -- per round the
+    # level fragments, the increments out and back, the owned rows' scalings; per SOLVE the owners' registers, the iterate, the solution; per kernel prologue the
+    # top inverse.  Counters / model 1.28 at 1024 instances, 1.19 at 256, 0.98 at 128: what the model leaves out is the spill traffic around the non-inlined test
+    # (~ 230 bytes per lane and round trip: 3.8 KB per iteration and QP once an XCD's L2 no longer holds it) -- register spills, not design traffic.
     assert abs(ratio - seen) <= 0.08, (ratio, seen)
     assert 0.85 <= ratio <= (1.35 if name.startswith('w8::') else 1.20), ratio
