@@ -612,10 +612,8 @@ static RunKArgs run_kernel_args(mpcqp_handle *h, const RunArgs &R0, int *grid) {
     RunKArgs A; A.L = h->L; A.P = h->P; A.S = h->S; A.R = R0;
     *grid = h->batch;
     const int slots = run_grid(h);
-    // (closed-loop launches only: a single solve's workgroups last ~ 100 us, and the queue's per-item cost -- an atomic, two fences, a barrier -- and the
-    //  counter's memset in front of each of a solve's two launches cost the stepwise path more than the hardware's dispatch gaps: 1.49 -> 1.25 M solves/s)
-    if (h->ncu > 0 && h->batch > slots && h->vcur_dev && R0.nsteps > 0 && !(h->S.tuning & MPCQP_TUNE_NO_QUEUE)) {
-        A.R.vcur = h->vcur_dev; A.R.vperm = h->qperm_set ? h->qperm_dev : h->P.perm; A.R.vqueue = h->vqueue_dev;
+    if (h->ncu > 0 && h->batch > slots && h->vcur_dev && !R0.pin_in && !R0.pub && (R0.nsteps > 0 || (h->S.tuning & MPCQP_TUNE_QUEUE_SOLVES)) && !(h->S.tuning & MPCQP_TUNE_NO_QUEUE)) {
+        A.R.vcur = h->vcur_dev; A.R.vperm = (R0.nsteps > 0 && h->qperm_set) ? h->qperm_dev : h->P.perm;      /* (a solve's second launch walks the pending list: P.perm) */ A.R.vqueue = h->vqueue_dev;
         A.P.perm = h->vcur_dev;
         *grid = slots;
         // closed loop: an instance's steps in parts, about QUEUE_ITEMS_PER_SLOT items per slot in all (a launch ends within half an item of its ideal
@@ -632,7 +630,6 @@ template <int NB, bool LDSS, int NXT, int NUT, int MODE>
 static int launch_run_t(mpcqp_handle *h, const RunArgs &R) {
     int grid;
     const RunKArgs A = run_kernel_args(h, R, &grid);
-    if (A.R.vcur && hipMemsetAsync(h->vqueue_dev, 0, sizeof(unsigned), h->stream) != hipSuccess) return MPCQP_ERR_HIP;
     if (A.R.vdone && hipMemsetAsync(h->vdone_dev, 0, sizeof(int) * (size_t)h->batch, h->stream) != hipSuccess) return MPCQP_ERR_HIP;
     if (R.nsteps > 0) {
         if (set_smem(k_mpc_run<NB, LDSS, NXT, NUT, MODE, true>, h->smem_solve)) return MPCQP_ERR_HIP;
@@ -732,7 +729,6 @@ static int launch_run(mpcqp_handle *h, RunArgs R, int plain_iters) {
     else if (L.nw == 8) {                           // 512-thread workgroups: the other translation unit (cyclic reduction with a dense top, or one long-horizon controller on grouped stages)
         int grid;
         const RunKArgs A = run_kernel_args(h, R, &grid);
-        if (A.R.vcur) HIPCHK(hipMemsetAsync(h->vqueue_dev, 0, sizeof(unsigned), h->stream));
         if (A.R.vdone) HIPCHK(hipMemsetAsync(h->vdone_dev, 0, sizeof(int) * (size_t)h->batch, h->stream));
         rc = L.bcr ? mpcqp_w8_launch(&A, sizeof(A), L.bcr == 31 && L.nx == 12 && L.nu == 4, L.bcr, R.nsteps > 0, grid, h->smem_solve, h->stream)
                    : mpcqp_w8_launch(&A, sizeof(A), L.border, 0, R.nsteps > 0, grid, h->smem_solve, h->stream);

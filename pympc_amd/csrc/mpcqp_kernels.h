@@ -295,13 +295,17 @@ __global__ __launch_bounds__(NT, run_occupancy(NB, MODE)) void k_mpc_run(RunKArg
                     volatile int *done = R.vdone + (entry & PERM_INST_MASK);
                     while (*done < ka) __builtin_amdgcn_s_sleep(16);
                 }
-                R.vcur[blockIdx.x] = entry; __threadfence();
+                R.vcur[blockIdx.x] = entry;                   // (read by this workgroup only: the barrier below orders it)
             }
             s_item[0] = entry; s_item[1] = ka; s_item[2] = kb;
         }
         __syncthreads();
         const int entry = s_item[0], ka = s_item[1], kb = s_item[2];
-        if (entry < 0) break;
+        if (entry < 0) {
+            // the last workgroup to leave puts the queue back to zero for the next launch (vqueue[1] counts the leavers): no memset between launches
+            if (threadIdx.x == 0 && atomicAdd(R.vqueue + 1, 1u) == gridDim.x - 1) { R.vqueue[1] = 0; __threadfence(); R.vqueue[0] = 0; }
+            break;
+        }
         __builtin_amdgcn_s_dcache_inv();                       // (inst_of's load of vcur[blockIdx.x] is a scalar load in most phases)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // (... and a vector load in the others; with parts: everything the previous part wrote)
         run_instance<NB, LDSSTATE, NXT, NUT, MODE, LOOP>(ka, kb);
