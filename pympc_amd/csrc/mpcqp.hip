@@ -621,7 +621,20 @@ static RunKArgs run_kernel_args(mpcqp_handle *h, const RunArgs &R0, int *grid) {
         if (R0.nsteps > 1 && !(h->S.tuning & MPCQP_TUNE_NO_PARTS)) {
             const int per_slot = ((h->S.tuning >> 16) & 0xFF) ? ((h->S.tuning >> 16) & 0xFF) : QUEUE_ITEMS_PER_SLOT;      // (bits 16..23: development override)
             const int parts = std::min(R0.nsteps, (per_slot * slots + h->batch - 1) / h->batch);
-            if (parts > 1) { A.R.vchunk = (R0.nsteps + parts - 1) / parts; A.R.vdone = h->vdone_dev; }
+            if (parts > 1) {
+                // part lengths fall off towards the end of the loop (each takes about 2 / (parts left + 1) of what is left: 20 steps in 4 parts = 8, 6, 4, 2): the
+                // launch's end is as fine-grained as many small parts would make it, for the prologues of few
+                const int np = std::min(parts, 16);
+                int off = 0;
+                for (int p = 0; p < np; ++p) {
+                    A.R.voff[p] = off;
+                    const int left = R0.nsteps - off, pl = np - p;
+                    int len = pl == 1 ? left : std::max(1, std::min(left - (pl - 1), (2 * left + pl) / (pl + 1)));
+                    if (h->S.tuning & MPCQP_TUNE_EVEN_PARTS) len = pl == 1 ? left : (left + pl - 1) / pl;
+                    off += len;
+                }
+                A.R.voff[np] = R0.nsteps; A.R.vparts = np; A.R.vdone = h->vdone_dev;
+            }
         }
     }
     return A;

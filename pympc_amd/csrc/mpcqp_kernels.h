@@ -263,7 +263,7 @@ __device__ __forceinline__ void run_instance(const int k0, const int k1) {
 // The kernel.  Grid = batch: one workgroup per instance (inst_of: the workgroup -> instance map).  PERSISTENT (RunArgs::vcur, batches beyond the
 // resident slots): the grid is the number of resident slots and every workgroup takes ITEMS off a queue until it is empty.  An item is an instance --
 // position v of the map is instance vperm[v], the map is the longest-expected-work-first list (rebalance() in mpcqp.hip): the greedy schedule -- or, in
-// the closed loop, `vchunk` consecutive steps of an instance: the items of part p + 1 follow all items of part p in the queue, an item waits for its
+// the closed loop, a few consecutive steps of an instance (long parts first, short ones last): the items of part p + 1 follow all items of part p in the queue, an item waits for its
 // instance's previous part through a per-instance progress counter (vdone; its producer was taken off the queue earlier and never waits for a later
 // item, so this cannot deadlock), and the launch ends within a fraction of an instance's closed loop of its ideal length instead of within a whole one.
 // Measured on the hardware's own dispatch of 1024 one-at-a-time workgroups (scripts/diag_makespan.py, HW_ID stamps): every compute unit gets exactly
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(NT, run_occupancy(NB, MODE)) void k_mpc_run(RunKArg
     }
     __shared__ int s_item[3];                                  // map entry (-1: the queue is empty), first step, end step
     const int nvirt = (!LOOP && R.part == 2) ? *R.npending : R.batch;
-    const int chunk = (LOOP && R.vchunk > 0) ? R.vchunk : nrun, nparts = (nrun + chunk - 1) / chunk;
+    const int nparts = (LOOP && R.vparts > 1) ? R.vparts : 1;
     for (;;) {
         if (threadIdx.x == 0) {
             const int v = (int)atomicAdd(R.vqueue, 1u);
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(NT, run_occupancy(NB, MODE)) void k_mpc_run(RunKArg
             if (v < nvirt * nparts) {
                 const int part = v / nvirt, idx = v - part * nvirt;
                 entry = R.vperm ? R.vperm[idx] : idx;
-                ka = part * chunk; kb = min(nrun, ka + chunk);
+                if (nparts > 1) { ka = R.voff[part]; kb = R.voff[part + 1]; }
                 if (part > 0) {                                // the instance's previous part must be done (and its writes visible: acquire below)
                     volatile int *done = R.vdone + (entry & PERM_INST_MASK);
                     while (*done < ka) __builtin_amdgcn_s_sleep(16);

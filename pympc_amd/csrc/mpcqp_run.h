@@ -31,8 +31,8 @@ struct RunArgs {
     int *vcur;                    // [grid] the map entry (instance | pace bits) each workgroup is working on: what Ptrs::perm points at
     const int *vperm;             // [batch] queue position -> map entry, or null = identity
     unsigned *vqueue;             // next queue position (zeroed before the launch)
-    int vchunk;                   // closed loop: steps per queue item (0 = an instance's whole loop is one item)
-    int *vdone;                   // [batch] steps of this launch an instance has completed (zeroed before the launch; vchunk > 0)
+    int vparts, voff[17];         // closed loop: queue items per instance (0 / 1: the whole loop is one item) and their first steps (voff[p] .. voff[p + 1])
+    int *vdone;                   // [batch] steps of this launch an instance has completed (zeroed before the launch; vparts > 1)
     // host-resident exchange (mpcqp_step_host: one launch per control step, no copy calls, no stream synchronisation):
     const double *pin_in;         // [batch][pin_stride] = [x0 | u_{-1} | xref] in mapped host memory, copied into the step blob first (null = off)
     int pin_stride, pin_mask, pin_xref;   // mask: 1 x0, 2 u_{-1}, 4 xref (pin_xref doubles)
