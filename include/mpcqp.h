@@ -275,7 +275,8 @@ int mpcqp_profile(mpcqp_handle *h, int enable, double *run_ms, int64_t *run_laun
 /* When each instance's workgroup entered and left the last mpcqp_mpc_loop / mpcqp_mpc_run launch and when it finished each of its first
  * nsteps closed-loop steps (0 <= nsteps <= 64): out [batch][2 + nsteps] = { entry, exit, end of step 0, end of step 1, ... } in ticks of the
  * GPU's constant 100 MHz clock (s_memrealtime: one time base for the whole chip).  A launch ends with its slowest instance; this is what says
- * how much work was done while the compute units were still full (bench.py: roofline.frac_excluding_tail).  Synchronises. */
+ * how much work was done while the compute units were still full (bench.py: roofline.frac_excluding_tail).  Launches of fewer than 64 steps: slot
+ * [2 + 63] holds (XCC_ID << 32 | HW_ID) of the workgroup that ran the instance's first steps (scripts/diag_makespan.py).  Synchronises. */
 int mpcqp_get_launch_times(mpcqp_handle *h, uint64_t *out, int nsteps);
 
 /* The controller's dimensions (what mpcqp_create was given, or what mpcqp_create_csc read out of the patterns). */

@@ -118,14 +118,12 @@ __device__ __forceinline__ void run_instance(const int k0, const int k1) {
     const int b = inst_of(P.perm), tid = threadIdx.x;
     double *step = P.step + (size_t)b * L.step_sz;
     if (LOOP && tid == 0 && k0 == 0) P.tstamp[(size_t)TS_STRIDE * b] = wall_clock64();
-#ifdef MPCQP_RUN_TIMING
-    if (LOOP && tid == 0 && k0 == 0) {      // (development: WHERE this workgroup runs -- XCC and HW_ID in the last step's slot of its stamps; scripts/diag_makespan.py)
+    if (LOOP && tid == 0 && k0 == 0 && R.nsteps < TS_STEPS) {      // (WHERE the instance's first steps ran -- XCC and HW_ID in the last step's slot of its stamps; scripts/diag_makespan.py)
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         P.tstamp[(size_t)TS_STRIDE * b + 2 + TS_STEPS - 1] = ((unsigned long long)(xcc & 15) << 32) | hw;
     }
-#endif
     if (MODE >= MODE_BCRT && tid == 0) S.iflag[2] = 0;      // (the rounds' LDS-resident part of the factor is not loaded yet: admm_latw; a barrier follows in load_common)
     if (!LOOP && R.pin_in) {                     // update(x0, u_{-1}, xref) straight from the caller's (mapped) memory: one PCIe round trip
         const double *src = R.pin_in + (size_t)b * R.pin_stride;

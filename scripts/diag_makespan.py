@@ -1,4 +1,4 @@
-"""How full are the compute units during a device-loop launch of the headline batch?  python scripts/diag_makespan.py [batch] [steps] [--lib x.so]
+"""How full are the compute units during a device-loop launch of the headline batch?  python scripts/diag_makespan.py [batch] [steps] [--lib x.so] [--tuning 16 | 0]
 From the per-instance entry / exit stamps of the last launch (mpcqp_get_launch_times): sum of the instances' residence times / #CU = the mean busy
 time of a compute unit (one workgroup per CU at a time for the register-resident kernel), against the launch's length; the iteration counts per
 instance give the time per iteration, early and late in the launch."""
@@ -33,7 +33,7 @@ for name, idx in (('first quarter to start', order[:q]), ('second', order[q:2 * 
           % (name, 1e3 * entry[idx].min(), 1e3 * entry[idx].max(), 1e3 * res[idx].mean(), its[idx].mean(), us_it[idx].mean()))
 print('  %.0f solves/s' % (a.batch * a.steps / r['elapsed']))
 hw = sh.prob.launch_times(64)[:, -1]
-if hw.any():          # (a -DMPCQP_RUN_TIMING build stamps XCC / HW_ID there)
+if hw.any() and a.tuning & 16:          # (XCC / HW_ID of the workgroup that ran an instance's first steps: per-CU timelines make sense with one workgroup per instance only)
     xcc = (hw >> np.uint64(32)).astype(int) & 15; h = hw.astype(np.uint64) & np.uint64(0xFFFFFFFF); h = h.astype(np.int64)
     cu = (h >> 8) & 15; shh = (h >> 12) & 1; se = (h >> 13) & 7
     key = (xcc << 12) | (se << 8) | (shh << 4) | cu

@@ -706,3 +706,32 @@ def test_refactor_rewrites_the_same_factor(name):
         x = kw['Ad'] @ x + kw['Bd'] @ u
         K.prob.batch_problem.refactor()
         K.update(x, u); K2.update(x, u)
+
+
+def test_persistent_queue_with_output_feedback_and_a_moving_reference():
+    """The same invariance for the closed loop's optional inputs: 300 cart-pole controllers (more than the 256 one-at-a-time slots of their dense kernel) with a
+    LinearStateEstimator in the loop, measurement and process noise and a reference that changes every step -- an instance's estimate, true state, previous input and
+    reference cross from one queue item to the next through memory exactly as they cross from one launch to the next."""
+    from pympc_amd import fixtures, _lib
+    from pympc_amd.kalman import BatchLinearStateEstimator
+    from pympc_amd.solver import forced_settings
+    B, steps = 300, 9
+    kw0 = fixtures.cart_pole()
+    kw0.setdefault('uref', np.zeros(1)); kw0.setdefault('uminus1', kw0['uref']); kw0.setdefault('QxN', kw0['Qx'])
+    rng = np.random.default_rng(21)
+    kws = [dict(kw0, x0=kw0['x0'] + 0.02 * rng.standard_normal(4)) for _ in range(B)]
+    C = np.tile(np.array([[1.0, 0, 0, 0], [0, 0, 1.0, 0]]), (B, 1, 1))
+    Lg = np.tile(0.3 * np.array([[1.0, 0], [0.5, 0], [0, 1.0], [0, 0.5]]), (B, 1, 1))
+    st = lambda k: np.stack([np.asarray(d[k], dtype=float) for d in kws])
+    w, v = 1e-3 * rng.standard_normal((steps, B, 4)), 1e-3 * rng.standard_normal((steps, B, 2))
+    xref = np.tile(np.asarray(kw0['xref'], dtype=float), (steps, B, 1)); xref[:, :, 0] += 0.01 * np.arange(steps)[:, None]
+    out = []
+    for tuning in (0, _lib.TUNE_NO_QUEUE):
+        with forced_settings(tuning=tuning):
+            K = _stacked_batch(kws); K.setup()
+        est = BatchLinearStateEstimator(st('x0'), st('Ad'), st('Bd'), C, Lg, x_true=st('x0').copy(), v=v)
+        tr = K.run(steps, w=w, xref_traj=xref, estimator=est)
+        out.append((tr['u'], tr['x'], tr['xhat'], tr['y'], tr['iter'], tr['status'], est.x_true.copy()))
+    for a, b in zip(*out):
+        assert np.array_equal(a, b)
+
