@@ -72,7 +72,9 @@ def test_scratch_of_the_hot_kernels_stays_where_it_was():
     68 for the 512-thread cart-pole kernels."""
     ks = _kernels()
     rk = _run_kernels(ks)
-    lim = {(16, 1, 12, 4, 0, 1): 800, (16, 1, 12, 4, 0, 0): 640, (32, 0, 20, 8, 0, 1): 128, (32, 0, 20, 8, 0, 0): 128}
+    # (round 6: the kernel's own frame grew by ~ 60 bytes -- the persistent loop around the instance -- 780 / 668 for the four-per-CU kernels, 316 / 204 for the
+    #  512-thread latency kernels, whose ADMM phase itself went from 148 to 80 bytes)
+    lim = {(16, 1, 12, 4, 0, 1): 832, (16, 1, 12, 4, 0, 0): 704, (32, 0, 20, 8, 0, 1): 192, (32, 0, 20, 8, 0, 0): 192}
     for key, bound in lim.items():
         assert int(rk[key]['ScratchSize']) <= bound, (key, rk[key])
     for n, v in ks.items():
