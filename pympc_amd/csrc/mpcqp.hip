@@ -318,7 +318,7 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     // The factorization's workspace starts at the work area T, the last part of the common block,
     // and may run on into the iterate area (dead while a factorization runs); T is widened only where even that is short.
     const int toplds = bcrt ? LATW_TOP_LDS(NS) + 2 : 0;      // the round's LDS copy of the top inverse, behind the iterate (+ alignment slack)
-    const int fws = dense ? L.NR * L.dld + 2 * DenseFmt::ROWS + L.m + L.n : bcr ? std::max(BcrFmt::LDSW + L.m + L.n, bcrt ? BcrFmt::top_lds(NS) : 0) : (L.NB == 16 ? FactorCfg<16>::WS : L.NB == 32 ? FactorCfg<32>::WS : L.NB == 64 ? WideFmt::WS : HugeFmt::WS);
+    const int fws = dense ? L.NR * L.dld + 2 * DenseFmt::ROWS + L.m + L.n : bcr ? BcrFmt::lds_doubles(h->L.nw, L.m + L.n, bcrt ? BcrFmt::top_count(NS) : 0) : (L.NB == 16 ? FactorCfg<16>::WS : L.NB == 32 ? FactorCfg<32>::WS : L.NB == 64 ? WideFmt::WS : HugeFmt::WS);
     // (a held input, Nc < Np: border_factor also forms Sigma and its inverse, 2 nu^2 doubles, at the start of T -- more than any factorization
     //  workspace once nu is large: (30, 40, 3, 2) needs 3 200 doubles where the 128-wide factorization asks for 264)
     const int need = std::max(fws, (L.border && !dense) ? 2 * L.nu * L.nu : 0);
@@ -438,6 +438,26 @@ static int step_upload(mpcqp_handle *h, const double *x0, const double *um1, con
     return 0;
 }
 
+// k_setup: one launch -- or two where the factorization's LDS would hold the equilibration passes to one workgroup per compute unit (mpcqp_phases.h)
+static int launch_setup(mpcqp_handle *h) {
+    const Lay &L = h->L;
+    if (L.NB == 16 && L.bcr) {
+        const size_t lean = sizeof(double) * (size_t)(smem_common_doubles(L) - L.tsz);      // (T is carved last and not touched by PART 1)
+        if (set_smem(k_setup<16, 1>, lean)) return MPCQP_ERR_HIP;
+        hipLaunchKernelGGL((k_setup<16, 1>), dim3(h->batch), dim3(NT), lean, h->stream, h->L, h->P, h->S);
+        const size_t fac = lean + sizeof(double) * (size_t)BcrFmt::lds_doubles(NT / 64, L.m + L.n, L.bcrtop);      // (the work area as far as THIS launch's factorization uses it: three workgroups per compute unit at (12,4,30))
+        if (set_smem(k_setup_factor_bcr, fac)) return MPCQP_ERR_HIP;
+        hipLaunchKernelGGL(k_setup_factor_bcr, dim3(h->batch), dim3(NT), fac, h->stream, h->L, h->P);
+    } else {
+        DISPATCH_NB(L.NB, {
+            if (set_smem(k_setup<NB, 0>, h->smem_setup)) return MPCQP_ERR_HIP;
+            hipLaunchKernelGGL((k_setup<NB, 0>), dim3(h->batch), dim3(NT), h->smem_setup, h->stream, h->L, h->P, h->S);
+        });
+    }
+    HIPCHK(hipGetLastError());
+    return MPCQP_OK;
+}
+
 extern "C" int mpcqp_setup(mpcqp_handle *h, const mpcqp_model *M, const double *x0, const double *um1, const double *xref, int xref_rows) {
     if (!h || !M || !x0 || !um1 || !xref) return fail(MPCQP_ERR_ARG, "mpcqp_setup: null argument");
     if (!M->Ad || !M->Bd || !M->Qx || !M->QxN || !M->Qu || !M->QDu || !M->xmin || !M->xmax || !M->umin || !M->umax ||
@@ -455,11 +475,7 @@ extern "C" int mpcqp_setup(mpcqp_handle *h, const mpcqp_model *M, const double *
     rc |= put(h, mb, ms, L.oQu, M->Qu, nu * nu); rc |= put(h, mb, ms, L.oQDu, M->QDu, nu * nu);
     if (rc) return MPCQP_ERR_HIP;
     if ((rc = step_upload(h, x0, um1, xref, xref_rows))) return rc;
-    DISPATCH_NB(L.NB, {
-        if (set_smem(k_setup<NB>, h->smem_setup)) return MPCQP_ERR_HIP;
-        hipLaunchKernelGGL(k_setup<NB>, dim3(h->batch), dim3(NT), h->smem_setup, h->stream, h->L, h->P, h->S);
-    });
-    HIPCHK(hipGetLastError());
+    if ((rc = launch_setup(h))) return rc;
     h->is_setup = true;
     return MPCQP_OK;
 }
@@ -531,11 +547,7 @@ extern "C" int mpcqp_setup_qp(mpcqp_handle *h, const mpcqp_model *M, const doubl
     if (rc) return MPCQP_ERR_HIP;
     h->L.raw = 1; h->step_blank = true;
     if ((rc = upload_vectors(h, q, l, u))) return rc;
-    DISPATCH_NB(L.NB, {
-        if (set_smem(k_setup<NB>, h->smem_setup)) return MPCQP_ERR_HIP;
-        hipLaunchKernelGGL(k_setup<NB>, dim3(h->batch), dim3(NT), h->smem_setup, h->stream, h->L, h->P, h->S);
-    });
-    HIPCHK(hipGetLastError());
+    if ((rc = launch_setup(h))) return rc;
     h->is_setup = true;
     return MPCQP_OK;
 }

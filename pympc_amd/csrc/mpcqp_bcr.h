@@ -40,12 +40,24 @@ __host__ __device__ inline void bcr_topv_rc(int nt, int pair, int &row, int &col
 #endif
 }
 
+// ... and the position (in doubles) of entry (row, col) in that order
+__host__ __device__ inline long long bcr_topv_pos(int nt, int row, int col) {
+    const int r = row >> 4, rl = row & 15;
+#if LATW_TOP_VALU == 2
+    const int ln = (rl >> 1) * 8 + col / (2 * nt), k = (rl & 1) * nt + (col % (2 * nt)) / 2;
+#else
+    const int ln = rl + 16 * (col / (4 * nt)), k = (col % (4 * nt)) / 2;
+#endif
+    return 2LL * ((long long)(r * 2 * nt + k) * 64 + ln) + (col & 1);
+}
+
 struct BcrFmt {
     static constexpr int NN = 256;                            // doubles per 16 x 16 fragment
     static constexpr int REC = 5 * NN;                        // [ D^-1 | -LbL | -LbR | -LbL' | -LbR' ]
     static constexpr int ODINV = 0, OLBL = NN, OLBR = 2 * NN, OLBLT = 3 * NN, OLBRT = 4 * NN;
     static constexpr int WSTAGE = 4 * NN;                     // global workspace per stage of the factorization: K_ii | K_{i,next} | dK_L | dK_R
-    static constexpr int LDSW = 4 * 5 * NN;                   // LDS of the factorization: four groups x [ D | B_L | B_R | Lb_L | Lb_R ]
+    // LDS of the factorization: per wave [ D | B_L | B_R | Lb_L | Lb_R ] for the levels; omega and s during the assembly; two block rows of the top inverse + two blocks
+    static constexpr int lds_doubles(int waves, int m_plus_n, int nt) { const int a = waves * 5 * NN, b = (2 * nt + 2) * NN; return (a > b ? a : b) > m_plus_n ? (a > b ? a : b) : m_plus_n; }
     // Dense top (Lay::bcrtop = nt > 0): the reduction stops after levels 0 and 1; the nt = N / 4 stages i = 4 (r + 1) - 1 that are left form a block
     // tridiagonal Schur complement of order 16 nt (112 at N = 31) whose EXPLICIT inverse is stored as nt x nt fragments behind the stage records:
     // block (r, c) at TOPOFF(N) + (r nt + c) NN.  Levels 2 .. 4 of the plain reduction are a chain of five dependent level steps that one wave
@@ -56,119 +68,127 @@ struct BcrFmt {
     static constexpr long long top_off(int N) { return (long long)N * REC; }
     static constexpr long long topv_off(int N) { return top_off(N) + (long long)top_count(N) * top_count(N) * NN; }
     static constexpr long long doubles(int N, bool top) { return (long long)N * REC + (top ? (LATW_TOP_VALU ? 2LL : 1LL) * top_count(N) * top_count(N) * NN : 0); }
-    static constexpr int top_lds(int N) { return 16 * top_count(N) * (16 * top_count(N) + 1) + 2 * 16 * top_count(N); }      // LDS of the inversion: matrix (odd row stride), pivot row, pivot column
 };
 
 // ------------------------------------------------------------------------------------------------
-// Factorization (run time N).  Wg: this instance's global workspace, N * WSTAGE doubles; W: LDS, BcrFmt::LDSW doubles.
-// Four thread groups (one wave each) eliminate four stages of a level side by side; barriers are workgroup-wide, every
-// thread makes the same calls.  Returns 1 on a non-positive pivot.
+// Factorization (run time N).  Wg: this instance's global workspace, N * WSTAGE doubles; W: LDS, BcrFmt::lds_doubles(waves, m + n).
+// Every 16 x 16 block operation belongs to ONE wave (lane (a0 = lane >> 4, b = lane & 15) holds the elements (a0 + 4u, b), u < 4, of a block):
+// a wave eliminates a stage of a level on its own -- inversion, the two products with the couplings, the Schur contributions -- in its own five
+// LDS blocks, ordered by the wave's in-order LDS pipe (wave_sync: no workgroup barrier inside a task; round 5's version ran four stages side by
+// side behind 38 workgroup barriers each and cost 130 us per instance).  Workgroup barriers separate the levels.  Returns 1 on a non-positive pivot.
 // N = L.bcr >= L.N is the stage count of the elimination tree (the register-resident schedule of mpcqp_lat.h exists for a few sizes): the
 // stages beyond the problem's own are identity blocks without couplings -- they cost the schedule a few idle mat-vecs and change nothing.
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+
+// in-place Gauss-Jordan inversion of an SPD 16 x 16 block in LDS by one wave (step p uses the OLD pivot row and column), then symmetrised
+__device__ __forceinline__ int wave_inv16(double *D, int lane) {
+    const int b = lane & 15, a0 = lane >> 4;
+    double v[4];
+    int bad = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = D[(a0 + 4 * u) * 16 + b];
+#pragma unroll 2
+    for (int pv = 0; pv < 16; ++pv) {
+        double d = D[pv * 17];
+        const double rpj = D[pv * 16 + b];
+        double rip[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) rip[u] = D[(a0 + 4 * u) * 16 + pv];
+        if (!(d > 0.0)) { bad = 1; d = 1e-300; }
+        const double inv = 1.0 / d;
+        wave_sync();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = a0 + 4 * u;
+            v[u] = (i == pv) ? (b == pv ? inv : rpj * inv) : (b == pv ? -rip[u] * inv : v[u] - rip[u] * rpj * inv);
+            D[i * 16 + b] = v[u];
+        }
+        wave_sync();
+    }
+    double sy[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) sy[u] = 0.5 * (v[u] + D[b * 16 + a0 + 4 * u]);
+    wave_sync();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) D[(a0 + 4 * u) * 16 + b] = sy[u];
+    wave_sync();
+    return bad;
+}
+// o(a, b) += sum_l X(a, l) Y(l, b), X read as X[a][l] or (XT) as X[l][a]: broadcast reads of X, row reads of Y -- no bank conflicts
+template <bool XT>
+__device__ __forceinline__ void wave_mul16(const double *X, const double *Y, int lane, double (&o)[4]) {
+    const int b = lane & 15, a0 = lane >> 4;
+#pragma unroll 8
+    for (int l = 0; l < 16; ++l) {
+        const double y = Y[l * 16 + b];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) o[u] = fma(XT ? X[l * 16 + a0 + 4 * u] : X[(a0 + 4 * u) * 16 + l], y, o[u]);
+    }
+}
+
 __device__ __forceinline__ int factor_bcr(const Ctx &c, const double *om, const double *sv, double cc, double *F, double *Wg, double *W, int *iflag) {
-    constexpr int NN = BcrFmt::NN, G = 4, T = NT / G, EPT = NN / T, NB = 16;
+    constexpr int NN = BcrFmt::NN, G = NT / 64, NB = 16;
     const Lay &L = c.L;
-    const int N = L.bcr, NR = L.N, tid = threadIdx.x, g = tid / T, lt = tid % T;
+    const int N = L.bcr, NR = L.N, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63, b = lane & 15, a0 = lane >> 4;
     double *Kd = Wg, *Up = Wg + (size_t)N * NN, *dKL = Up + (size_t)N * NN, *dKR = dKL + (size_t)N * NN;
     if (tid == 0) *iflag = 0;
-    // (omega and s through an LDS copy behind the workspace: every entry of a diagonal block sums nx products of them)
-    double *oml = W + BcrFmt::LDSW, *svl = oml + L.m;
+    // (omega and s through an LDS copy at the start of the workspace -- every entry of a diagonal block sums nx products of them; the levels' blocks take its place)
+    double *oml = W, *svl = oml + L.m;
     for (int r = tid; r < L.m; r += NT) oml[r] = om[r];
     for (int r = tid; r < L.n; r += NT) svl[r] = sv[r];
     __syncthreads();
     for (int idx = tid; idx < N * NN; idx += NT) {
-        const int k = idx / NN, r = idx % NN, a = r / NB, b = r % NB;
-        Kd[idx] = k < NR ? kkt_diag_entry(c, oml, svl, cc, k, a, b) : (a == b ? 1.0 : 0.0);
-        Up[idx] = (k + 1 < NR) ? kkt_sub_entry(c, oml, cc, k, b, a) : 0.0;     // K_{k,k+1}[a][b] = K_{k+1,k}[b][a]
+        const int k = idx / NN, r = idx % NN, a = r / NB, bb = r % NB;
+        Kd[idx] = k < NR ? kkt_diag_entry(c, oml, svl, cc, k, a, bb) : (a == bb ? 1.0 : 0.0);
+        Up[idx] = (k + 1 < NR) ? kkt_sub_entry(c, oml, cc, k, bb, a) : 0.0;     // K_{k,k+1}[a][b] = K_{k+1,k}[b][a]
     }
     __syncthreads();
-    double *D = W + g * 5 * NN, *BL = D + NN, *BR = D + 2 * NN, *LL = D + 3 * NN, *LR = D + 4 * NN;
+    int bad = 0;
+    double *D = W + wv * 5 * NN, *BL = D + NN, *BR = D + 2 * NN, *LL = D + 3 * NN, *LR = D + 4 * NN;
+    auto nvar = [&](int e) { return e >= NR ? 0 : (e < L.NcT) ? L.nb : L.nx; };      // variables of a stage; the rest is padding (identity in K, zero in the factor)
     for (int h = 1; h - 1 < N; h <<= 1) {
         if (L.bcrtop && h == 4) break;                        // (dense top: what is left after levels 0 and 1 is inverted explicitly below)
         const int ne = (N + h) / (2 * h);                     // stages e = h (2t+1) - 1 < N
-        for (int t0 = 0; t0 < ne; t0 += G) {
-            const int t = t0 + g;
-            const bool on = t < ne;
+        for (int t = wv; t < ne; t += G) {
             const int e = h * (2 * t + 1) - 1, i1 = e - h, i2 = e + h;
-            const bool hasL = on && i1 >= 0, hasR = on && i2 < N;
-            if (on) {
+            const bool hasL = i1 >= 0, hasR = i2 < N;
 #pragma unroll
-                for (int u = 0; u < EPT; ++u) {
-                    const int idx = lt + T * u, a = idx / NB, b = idx % NB;
-                    D[idx] = Kd[(size_t)e * NN + idx];
-                    BL[idx] = hasL ? Up[(size_t)i1 * NN + b * NB + a] : 0.0;     // K_{e,i1} = K_{i1,e}'
-                    BR[idx] = hasR ? Up[(size_t)e * NN + idx] : 0.0;            // K_{e,i2}
-                }
+            for (int u = 0; u < 4; ++u) {
+                const int a = a0 + 4 * u, idx = a * NB + b;
+                D[idx] = Kd[(size_t)e * NN + idx];
+                BL[idx] = hasL ? Up[(size_t)i1 * NN + b * NB + a] : 0.0;     // K_{e,i1} = K_{i1,e}'
+                BR[idx] = hasR ? Up[(size_t)e * NN + idx] : 0.0;            // K_{e,i2}
             }
-            __syncthreads();
-            // in-place Gauss-Jordan inversion of the SPD block (as in factor_all): step p uses the OLD pivot row and column
-            for (int pv = 0; pv < NB; ++pv) {
-                double rip[EPT], rpj[EPT], d = 1.0;
-                if (on) {
-                    d = D[pv * NB + pv];
+            wave_sync();
+            bad |= wave_inv16(D, lane);
+            double accL[4] = {0.0, 0.0, 0.0, 0.0}, accR[4] = {0.0, 0.0, 0.0, 0.0};      // Lb = D^-1 B
+            wave_mul16<false>(D, BL, lane, accL);
+            wave_mul16<false>(D, BR, lane, accR);
 #pragma unroll
-                    for (int u = 0; u < EPT; ++u) { const int idx = lt + T * u; rip[u] = D[(idx / NB) * NB + pv]; rpj[u] = D[pv * NB + (idx % NB)]; }
-                }
-                if (on && !(d > 0.0)) { if (lt == 0) *iflag = 1; d = 1e-300; }
-                __syncthreads();
-                if (on) {
-                    const double inv = 1.0 / d;
+            for (int u = 0; u < 4; ++u) { const int idx = (a0 + 4 * u) * NB + b; LL[idx] = accL[u]; LR[idx] = accR[u]; }
+            wave_sync();
+            double *rec = F + (size_t)e * BcrFmt::REC;
+            const int nbk = nvar(e);
+            double sL[4] = {0.0, 0.0, 0.0, 0.0}, sR[4] = {0.0, 0.0, 0.0, 0.0}, sU[4] = {0.0, 0.0, 0.0, 0.0};      // K_{i1,e} Lb_L,  K_{i2,e} Lb_R,  K_{i1,e} Lb_R
+            wave_mul16<true>(BL, LL, lane, sL);
+            wave_mul16<true>(BR, LR, lane, sR);
+            if (hasL && hasR) wave_mul16<true>(BL, LR, lane, sU);
 #pragma unroll
-                    for (int u = 0; u < EPT; ++u) {
-                        const int idx = lt + T * u, i = idx / NB, j = idx % NB;
-                        D[idx] = (i == pv) ? (j == pv ? inv : rpj[u] * inv) : (j == pv ? -rip[u] * inv : D[idx] - rip[u] * rpj[u] * inv);
-                    }
-                }
-                __syncthreads();
+            for (int u = 0; u < 4; ++u) {
+                const int a = a0 + 4 * u, idx = a * NB + b, fp = frag_pos<NB>(a, b);
+                rec[BcrFmt::ODINV + fp] = (a >= nbk || b >= nbk) ? 0.0 : D[idx];
+                rec[BcrFmt::OLBL + fp] = -accL[u];
+                rec[BcrFmt::OLBR + fp] = -accR[u];
+                rec[BcrFmt::OLBLT + fp] = -LL[b * NB + a];
+                rec[BcrFmt::OLBRT + fp] = -LR[b * NB + a];
+                dKL[(size_t)e * NN + idx] = sL[u];
+                dKR[(size_t)e * NN + idx] = sR[u];
+                if (hasL && hasR) Up[(size_t)i1 * NN + idx] = -sU[u];          // the coupling i1 <-> i2 of the next level
             }
-            double sy[EPT];
-            if (on) {
-#pragma unroll
-                for (int u = 0; u < EPT; ++u) { const int idx = lt + T * u, a = idx / NB, b = idx % NB; sy[u] = 0.5 * (D[a * NB + b] + D[b * NB + a]); }
-            }
-            __syncthreads();
-            if (on) {
-#pragma unroll
-                for (int u = 0; u < EPT; ++u) D[lt + T * u] = sy[u];
-            }
-            __syncthreads();
-            if (on) {
-#pragma unroll
-                for (int u = 0; u < EPT; ++u) {              // Lb = D^-1 B
-                    const int idx = lt + T * u, a = idx / NB, b = idx % NB;
-                    double accL = 0.0, accR = 0.0;
-#pragma unroll 8
-                    for (int l = 0; l < NB; ++l) { const double dv = D[a * NB + l]; accL += dv * BL[l * NB + b]; accR += dv * BR[l * NB + b]; }
-                    LL[idx] = accL; LR[idx] = accR;
-                }
-            }
-            __syncthreads();
-            if (on) {
-                double *rec = F + (size_t)e * BcrFmt::REC;
-                const int nbk = e >= NR ? 0 : (e < L.NcT) ? L.nb : L.nx;     // variables of this stage; the rest is padding (identity in K, zero in the factor)
-#pragma unroll
-                for (int u = 0; u < EPT; ++u) {
-                    const int idx = lt + T * u, a = idx / NB, b = idx % NB;
-                    const int fp = frag_pos<NB>(a, b);
-                    rec[BcrFmt::ODINV + fp] = (a >= nbk || b >= nbk) ? 0.0 : D[idx];
-                    rec[BcrFmt::OLBL + fp] = -LL[idx];
-                    rec[BcrFmt::OLBR + fp] = -LR[idx];
-                    rec[BcrFmt::OLBLT + fp] = -LL[b * NB + a];
-                    rec[BcrFmt::OLBRT + fp] = -LR[b * NB + a];
-                    double sL = 0.0, sR = 0.0, sU = 0.0;      // K_{i1,e} Lb_L,  K_{i2,e} Lb_R,  K_{i1,e} Lb_R
-#pragma unroll 8
-                    for (int l = 0; l < NB; ++l) {
-                        const double bl = BL[l * NB + a], br = BR[l * NB + a];
-                        sL += bl * LL[l * NB + b]; sR += br * LR[l * NB + b]; sU += bl * LR[l * NB + b];
-                    }
-                    dKL[(size_t)e * NN + idx] = sL;
-                    dKR[(size_t)e * NN + idx] = sR;
-                    if (hasL && hasR) Up[(size_t)i1 * NN + idx] = -sU;          // the coupling i1 <-> i2 of the next level
-                }
-            }
-            __syncthreads();
+            wave_sync();                                      // (the next task of this wave overwrites the blocks)
         }
+        __syncthreads();
         // kept stages: Schur updates from the (one or two) eliminated neighbours, in a fixed order
         for (int idx = tid;; idx += NT) {
             const int t = idx / NN, r = idx % NN, i = 2 * h * (t + 1) - 1;
@@ -180,60 +200,97 @@ __device__ __forceinline__ int factor_bcr(const Ctx &c, const double *om, const 
         __syncthreads();
     }
     if (L.bcrtop) {
-        // ---- the top: stages i_r = 4 (r + 1) - 1, r < nt, with the Schur complements the two levels left in Kd (diagonal blocks) and Up (Up[i] =
-        // K_{i,i+4} for a kept i).  Assembled dense in LDS (odd row stride), inverted in place by Gauss-Jordan sweeps -- SPD: no pivoting, a
-        // non-positive pivot is reported as everywhere else -- with thread t owning column t mod 128 of every (NT / 128)-th row, then written as
-        // fragments with zero rows and columns where a stage has no variable (as D^-1 above).
-        const int nt = L.bcrtop, NRt = nt * NB, ld = NRt + 1;
-        double *M = W, *prow = M + NRt * ld, *pcol = prow + NRt;
-        for (int idx = tid; idx < NRt * NRt; idx += NT) {
-            const int r = idx / NRt, cx = idx - r * NRt, br = r / NB, a = r % NB, bc = cx / NB, b = cx % NB;
-            const int i = 4 * (br + 1) - 1, j = 4 * (bc + 1) - 1;
-            double v = 0.0;
-            if (br == bc) v = Kd[(size_t)i * NN + a * NB + b];
-            else if (bc == br + 1) v = Up[(size_t)i * NN + a * NB + b];          // K_{i,j}, j = i + 4
-            else if (bc + 1 == br) v = Up[(size_t)j * NN + b * NB + a];          // K_{i,j} = K_{j,i}'
-            M[r * ld + cx] = v;
+        // ---- the top: stages i_r = 4 (r + 1) - 1, r < nt, with the Schur complements the two levels left in Kd (diagonal blocks A_r) and Up (Up[i_r] = B_r =
+        // K_{i_r, i_{r+1}}): a block tridiagonal SPD matrix of order 16 nt whose EXPLICIT inverse the round applies.  Block LDL' down the chain,
+        //     S_0 = A_0,   L_r = B_r' S_r^-1,   S_{r+1} = A_{r+1} - L_r B_r                     (one wave; S_r^-1 and L_r parked in the dead workspace dKL / dKR)
+        // then the inverse from its last block row upwards (Sigma = D^-1 L^-1 + (I - L') Sigma, upper triangle):
+        //     Sigma_{nt-1,nt-1} = S_{nt-1}^-1,   Sigma_{r,j} = -L_r' Sigma_{r+1,j} (j > r),   Sigma_{r,r} = S_r^-1 - Sigma_{r,r+1} L_r
+        // with two block rows in LDS at a time (16 blocks = 32 KB; round 5 inverted the assembled 112 x 112 matrix by Gauss-Jordan sweeps in 103 KB of LDS --
+        // one workgroup per compute unit, 224 barriers, seven times the arithmetic: 660 us per instance).  Every finished row goes out in both formats,
+        // mirrored into the lower triangle, with zero rows and columns where a stage has no variable (as D^-1 above).
+        const int nt = L.bcrtop;
+        double *SinvG = dKL, *LG = dKR;
+        if (wv == 0) {
+            double *Sb = W, *Bb = W + NN, *Lb = W + 2 * NN;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int idx = (a0 + 4 * u) * NB + b; Sb[idx] = Kd[(size_t)3 * NN + idx]; }
+            wave_sync();
+            for (int r = 0; r < nt; ++r) {
+                const int i = 4 * (r + 1) - 1;
+                bad |= wave_inv16(Sb, lane);
+                double sn[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = (a0 + 4 * u) * NB + b;
+                    SinvG[(size_t)r * NN + idx] = Sb[idx];
+                    if (r + 1 < nt) { Bb[idx] = Up[(size_t)i * NN + idx]; sn[u] = Kd[(size_t)(i + 4) * NN + idx]; }
+                }
+                if (r + 1 == nt) break;
+                wave_sync();
+                double lacc[4] = {0.0, 0.0, 0.0, 0.0};
+                wave_mul16<true>(Bb, Sb, lane, lacc);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int idx = (a0 + 4 * u) * NB + b; Lb[idx] = lacc[u]; LG[(size_t)r * NN + idx] = lacc[u]; }
+                wave_sync();
+                double prod[4] = {0.0, 0.0, 0.0, 0.0};
+                wave_mul16<false>(Lb, Bb, lane, prod);
+                wave_sync();
+#pragma unroll
+                for (int u = 0; u < 4; ++u) Sb[(a0 + 4 * u) * NB + b] = sn[u] - prod[u];
+                wave_sync();
+            }
         }
         __syncthreads();
-        const int jc = tid & 127, i0 = tid >> 7;
-        constexpr int RG = NT / 128;                          // row groups
-        for (int pv = 0; pv < NRt; ++pv) {
-            for (int t = tid; t < NRt; t += NT) { prow[t] = M[pv * ld + t]; pcol[t] = M[t * ld + pv]; }
-            __syncthreads();
-            double d = prow[pv];
-            if (!(d > 0.0)) { if (tid == 0) *iflag = 1; d = 1e-300; }
-            const double inv = 1.0 / d;
-            if (jc < NRt) {
-                const double rpj = prow[jc];
-                for (int i = i0; i < NRt; i += RG) {
-                    const double rip = pcol[i], cur = M[i * ld + jc];
-                    M[i * ld + jc] = (i == pv) ? (jc == pv ? inv : rpj * inv) : (jc == pv ? -rip * inv : cur - rip * rpj * inv);
+        double *rowP = W, *rowC = W + (size_t)nt * NN, *Lc = W + (size_t)2 * nt * NN, *Sc = Lc + NN;
+        double *Ft = F + BcrFmt::top_off(N);
+#if LATW_TOP_VALU
+        double *Fv = F + BcrFmt::topv_off(N);                 // the same in the round's row-part order
+#endif
+        for (int idx = tid; idx < NN; idx += NT) rowC[(size_t)(nt - 1) * NN + idx] = SinvG[(size_t)(nt - 1) * NN + idx];
+        for (int r = nt - 1; r >= 0; --r) {
+            if (r < nt - 1) {
+                for (int idx = tid; idx < NN; idx += NT) { Lc[idx] = LG[(size_t)r * NN + idx]; Sc[idx] = SinvG[(size_t)r * NN + idx]; }
+                __syncthreads();
+                for (int j = r + 1 + wv; j < nt; j += G) {
+                    double o[4] = {0.0, 0.0, 0.0, 0.0};
+                    wave_mul16<true>(Lc, rowP + (size_t)j * NN, lane, o);
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) rowC[(size_t)j * NN + (a0 + 4 * u) * NB + b] = -o[u];
+                    if (j == r + 1) {                         // ... and the diagonal block behind its right-hand neighbour, by the wave that has just written that one
+                        wave_sync();
+                        double dg[4] = {0.0, 0.0, 0.0, 0.0};
+                        wave_mul16<false>(rowC + (size_t)j * NN, Lc, lane, dg);
+                        double *Cd = rowC + (size_t)r * NN;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) { const int idx = (a0 + 4 * u) * NB + b; dg[u] = Sc[idx] - dg[u]; Cd[idx] = dg[u]; }
+                        wave_sync();
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) dg[u] = 0.5 * (dg[u] + Cd[b * NB + a0 + 4 * u]);
+                        wave_sync();
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) Cd[(a0 + 4 * u) * NB + b] = dg[u];
+                    }
                 }
             }
             __syncthreads();
-        }
-        double *Ft = F + BcrFmt::top_off(N);
-        auto topval = [&](int br, int a, int bc, int b) {      // entry (16 br + a, 16 bc + b) of the symmetrised inverse, zero where a stage has no variable
-            const int i = 4 * (br + 1) - 1, j = 4 * (bc + 1) - 1;
-            const int nbi = i >= NR ? 0 : (i < L.NcT) ? L.nb : L.nx, nbj = j >= NR ? 0 : (j < L.NcT) ? L.nb : L.nx;
-            return (a >= nbi || b >= nbj) ? 0.0 : 0.5 * (M[(br * NB + a) * ld + bc * NB + b] + M[(bc * NB + b) * ld + br * NB + a]);
-        };
-        for (int idx = tid; idx < nt * nt * NN; idx += NT) {
-            const int blk = idx / NN, e = idx - blk * NN, a = e / NB, b = e % NB, br = blk / nt, bc = blk - br * nt;
-            Ft[(size_t)blk * NN + frag_pos<NB>(a, b)] = topval(br, a, bc, b);
-        }
+            const int nbr = nvar(4 * (r + 1) - 1);
+            for (int idx = tid; idx < (nt - r) * NN; idx += NT) {
+                const int j = r + idx / NN, e = idx % NN, a = e / NB, bb = e % NB;
+                const double v = (a >= nbr || bb >= nvar(4 * (j + 1) - 1)) ? 0.0 : rowC[(size_t)j * NN + e];
+                Ft[(size_t)(r * nt + j) * NN + frag_pos<NB>(a, bb)] = v;
+                if (j != r) Ft[(size_t)(j * nt + r) * NN + frag_pos<NB>(bb, a)] = v;
 #if LATW_TOP_VALU
-        double *Fv = F + BcrFmt::topv_off(N);                 // the same in the round's row-part order
-        for (int idx = tid; idx < nt * nt * (NN / 2); idx += NT) {
-            int row, col; bcr_topv_rc(nt, idx, row, col);
-            Fv[2 * (size_t)idx] = topval(row / NB, row % NB, col / NB, col % NB);
-            Fv[2 * (size_t)idx + 1] = topval(row / NB, row % NB, (col + 1) / NB, (col + 1) % NB);
-        }
+                Fv[bcr_topv_pos(nt, NB * r + a, NB * j + bb)] = v;
+                if (j != r) Fv[bcr_topv_pos(nt, NB * j + bb, NB * r + a)] = v;
 #endif
+            }
+            __syncthreads();
+            double *sw = rowP; rowP = rowC; rowC = sw;
+        }
         if (tid == 0) iflag[2] = 0;                          // (the rounds' LDS copy of the top is stale -- and this workspace has just run over it: admm_latw)
-        __syncthreads();
     }
+    if (bad) *iflag = 1;
+    __syncthreads();
     return *iflag;
 }
 

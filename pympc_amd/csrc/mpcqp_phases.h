@@ -67,7 +67,10 @@ __device__ __forceinline__ void load_common(const Lay &L, const double *model, c
 // ------------------------------------------------------------------------------------------------
 // setup kernel: Ruiz equilibration (OSQP, 10 passes), rho vector, metric, first factorization.
 // ------------------------------------------------------------------------------------------------
-template <int NB>
+// PART 0: all of it in one launch.  Handles whose factorization needs most of a compute unit's LDS (the dense top of the cyclic reduction: 103 KB, one workgroup
+// per compute unit) run it as two launches instead: PART 1 = everything but the factorization, launched with the common block WITHOUT the work area T (a few KB:
+// the equilibration is ten passes of dependent global round trips -- latency, hidden by co-resident workgroups), then k_setup_factor_bcr with the full block.
+template <int NB, int PART>
 __global__ __launch_bounds__(NT) void k_setup(Lay L, Ptrs P, mpcqp_settings S_) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     double *p = sh; Smem S; smem_common(L, P, p, S);
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(NT) void k_setup(Lay L, Ptrs P, mpcqp_settings S_) 
     for (int j = tid; j < L.n; j += NT) sv[j] = S_.sigma / (D[j] * D[j]);
     if (tid == 0) { P.c[b] = cc; P.rho[b] = rho; }
     __syncthreads();
-    int bad = NB == 16 && L.grp > 1 ? factor_grouped(c, om, sv, cc, P.F + (size_t)b * P.fsz, S.T, S.iflag, border_ptrs(L, P, S))
+    int bad = PART == 1 ? 0 : NB == 16 && L.grp > 1 ? factor_grouped(c, om, sv, cc, P.F + (size_t)b * P.fsz, S.T, S.iflag, border_ptrs(L, P, S))
             : NB == 16 && L.dense ? factor_dense(c, om, sv, cc, P.F + (size_t)b * P.fsz, S.T, S.iflag)
             : NB == 16 && L.bcr ? factor_bcr(c, om, sv, cc, P.F + (size_t)b * P.fsz, P.bws + (size_t)b * L.bcr * BcrFmt::WSTAGE, S.T, S.iflag)
                       : factor_all<NB>(c, om, sv, cc, P.F + (size_t)b * P.fsz, S.T, S.iflag, border_ptrs(L, P, S));
@@ -137,6 +140,18 @@ __global__ __launch_bounds__(NT) void k_setup(Lay L, Ptrs P, mpcqp_settings S_) 
         inf.obj_val = 0; inf.pri_res = 0; inf.dua_res = 0; inf.rho = rho;
         P.info[b] = inf;
     }
+}
+
+// the second launch of a split setup: the cyclic-reduction factorization from the metric k_setup<16, 1> left in memory
+__global__ __launch_bounds__(NT) void k_setup_factor_bcr(Lay L, Ptrs P) {
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    double *p = sh; Smem S; smem_common(L, P, p, S);
+    const int b = inst_of(P.perm);
+    const double *model = P.model + (size_t)b * L.model_sz;
+    load_common(L, model, P.step + (size_t)b * L.step_sz, S);
+    Ctx c{L, S.hot, model + L.hot_sz};
+    const int bad = factor_bcr(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], P.F + (size_t)b * P.fsz, P.bws + (size_t)b * L.bcr * BcrFmt::WSTAGE, S.T, S.iflag);
+    if (bad && threadIdx.x == 0) P.info[b].status = MPCQP_NON_CVX;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,3 +1,12 @@
-for rep in 1 2; do for ps in 8 12 16 20; do python bench.py --steps 20 --warmup 5 --tuning $((ps*65536)) --no-other-path --no-cpu-baseline 2>/dev/null | tail -n 1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('loop 1024 items/slot',$ps, int(d['value']), d['roofline']['kernel_ms'])"; done; done
-for ps in 8 16 32; do python bench.py --steps 20 --warmup 5 --batch 512 --tuning $((ps*65536)) --no-other-path --no-cpu-baseline 2>/dev/null | tail -n 1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('loop 512 items/slot',$ps, int(d['value']), d['roofline']['kernel_ms'])"; done
-for ps in 8 16 32; do python bench.py --steps 20 --warmup 5 --batch 2048 --tuning $((ps*65536)) --no-other-path --no-cpu-baseline 2>/dev/null | tail -n 1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('loop 2048 items/slot',$ps, int(d['value']), d['roofline']['kernel_ms'])"; done
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+for lib in ${LIBS:-pympc_amd/libmpcqp_hip.so}; do
+echo "--- $lib"
+rm -rf /tmp/ks; ( cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -o s -- python $GRAFT_REPO_ROOT/scripts/with_lib.py $GRAFT_REPO_ROOT/$lib $GRAFT_REPO_ROOT/scripts/setup_only.py 2>&1 | grep "setup " | tail -1 )
+python - <<'PY'
+import csv, glob
+for f in glob.glob('/tmp/ks/**/*kernel_stats.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        if 'setup' in r['Name']:
+            print('   ', r['Name'][:60], 'calls', r['Calls'], 'avg us %.1f' % (float(r['AverageNs']) / 1e3), 'min us %.1f' % (float(r['MinNs']) / 1e3))
+PY
+done
