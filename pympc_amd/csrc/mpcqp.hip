@@ -438,20 +438,22 @@ static int step_upload(mpcqp_handle *h, const double *x0, const double *um1, con
     return 0;
 }
 
-// k_setup: one launch -- or two where the factorization's LDS would hold the equilibration passes to one workgroup per compute unit (mpcqp_phases.h)
+// setup's two launches (mpcqp_phases.h): equilibration, rho vector and cold start with a lean LDS block; then the first factorization
 static int launch_setup(mpcqp_handle *h) {
     const Lay &L = h->L;
+    const size_t lean = sizeof(double) * (size_t)(smem_common_doubles(L) - L.tsz);      // (the work area T is carved last and not touched by k_setup)
+    if (set_smem(k_setup, lean)) return MPCQP_ERR_HIP;
+    hipLaunchKernelGGL(k_setup, dim3(h->batch), dim3(NT), lean, h->stream, h->L, h->P, h->S);
+    // the cyclic reduction's factorization at 256 threads uses the work area only as far as BcrFmt::lds_doubles says (three workgroups per compute unit at (12,4,30)
+    // where the solve kernel's block -- iterate, top inverse -- would allow one); everything else factors in the block it solves in
     if (L.NB == 16 && L.bcr) {
-        const size_t lean = sizeof(double) * (size_t)(smem_common_doubles(L) - L.tsz);      // (T is carved last and not touched by PART 1)
-        if (set_smem(k_setup<16, 1>, lean)) return MPCQP_ERR_HIP;
-        hipLaunchKernelGGL((k_setup<16, 1>), dim3(h->batch), dim3(NT), lean, h->stream, h->L, h->P, h->S);
-        const size_t fac = lean + sizeof(double) * (size_t)BcrFmt::lds_doubles(NT / 64, L.m + L.n, L.bcrtop);      // (the work area as far as THIS launch's factorization uses it: three workgroups per compute unit at (12,4,30))
+        const size_t fac = lean + sizeof(double) * (size_t)BcrFmt::lds_doubles(NT / 64, L.m + L.n, L.bcrtop);
         if (set_smem(k_setup_factor_bcr, fac)) return MPCQP_ERR_HIP;
         hipLaunchKernelGGL(k_setup_factor_bcr, dim3(h->batch), dim3(NT), fac, h->stream, h->L, h->P);
     } else {
         DISPATCH_NB(L.NB, {
-            if (set_smem(k_setup<NB, 0>, h->smem_setup)) return MPCQP_ERR_HIP;
-            hipLaunchKernelGGL((k_setup<NB, 0>), dim3(h->batch), dim3(NT), h->smem_setup, h->stream, h->L, h->P, h->S);
+            if (set_smem(k_setup_factor<NB>, h->smem_setup)) return MPCQP_ERR_HIP;
+            hipLaunchKernelGGL(k_setup_factor<NB>, dim3(h->batch), dim3(NT), h->smem_setup, h->stream, h->L, h->P);
         });
     }
     HIPCHK(hipGetLastError());
@@ -613,17 +615,27 @@ extern "C" int mpcqp_update_settings(mpcqp_handle *h, const mpcqp_settings *s) {
 
 // The kernel arguments of a launch and its grid: one workgroup per instance, or -- batches beyond the resident workgroup slots -- the PERSISTENT form:
 // as many workgroups as there are slots, each taking instances off a queue (k_mpc_run in mpcqp_kernels.h says what that buys).
-static int run_grid(const mpcqp_handle *h) {
+// nsteps: closed-loop steps of the launch (0: a solve).
+// Fewer slots than fit for the bandwidth kernel of 32 x 32 stages with its iterate in memory (BASELINE configs[4]) where a closed-loop launch would otherwise hold
+// (nearly) every instance resident at once: such a launch ends with its slowest instance, which -- sharing the memory system with 511 others -- runs at 104 us per
+// iteration where it could run at 75.  Three quarters of the slots and a queue of (instance, step range) items, longest expected work first: the stragglers start
+// first and run faster all along, the memory system stays saturated.  Measured (50-step launches, k solves/s, 4 / 5 / 6 / 7 / 8 quarters of a workgroup per unit):
+// 512 instances 121 / 138 / 148-150 / 141-144 / 137-138; 768 instances - / - / 153 / - / 145; 1024 instances 119 / - / 153 / 166 / 177 (two full rounds: all slots).
+static int run_grid(const mpcqp_handle *h, int nsteps) {
     const Lay &L = h->L;
     const bool one_at_a_time = L.bcr || L.dense || L.NB > 32 || L.nw == 8;
     int occ = one_at_a_time ? 1 : (L.NB <= 16 ? 4 : 2);
     if (h->smem_solve > 0) occ = std::max(1, std::min(occ, (int)((size_t)160 * 1024 / h->smem_solve)));
-    return h->ncu * occ;
+    const int full = h->ncu * occ;
+    const int q = (h->S.tuning >> MPCQP_TUNE_SLOTS_SHIFT) & 0x1F;      // (development: resident workgroups in quarters of a workgroup per compute unit)
+    if (q) return std::max(1, std::min(full, h->ncu * q / 4));
+    if (L.NB == 32 && occ == 2 && !h->lds_state && !L.lstage && nsteps >= 8 && 2 * h->batch <= 3 * full && 4 * h->batch > 3 * full && !(h->S.tuning & MPCQP_TUNE_NO_QUEUE)) return 3 * full / 4;
+    return full;
 }
 static RunKArgs run_kernel_args(mpcqp_handle *h, const RunArgs &R0, int *grid) {
     RunKArgs A; A.L = h->L; A.P = h->P; A.S = h->S; A.R = R0;
     *grid = h->batch;
-    const int slots = run_grid(h);
+    const int slots = run_grid(h, R0.nsteps);
     if (h->ncu > 0 && h->batch > slots && h->vcur_dev && !R0.pin_in && !R0.pub && (R0.nsteps > 0 || (h->S.tuning & MPCQP_TUNE_QUEUE_SOLVES)) && !(h->S.tuning & MPCQP_TUNE_NO_QUEUE)) {
         A.R.vcur = h->vcur_dev; A.R.vperm = (R0.nsteps > 0 && h->qperm_set) ? h->qperm_dev : h->P.perm;      /* (a solve's second launch walks the pending list: P.perm) */ A.R.vqueue = h->vqueue_dev;
         A.P.perm = h->vcur_dev;

@@ -67,10 +67,9 @@ __device__ __forceinline__ void load_common(const Lay &L, const double *model, c
 // ------------------------------------------------------------------------------------------------
 // setup kernel: Ruiz equilibration (OSQP, 10 passes), rho vector, metric, first factorization.
 // ------------------------------------------------------------------------------------------------
-// PART 0: all of it in one launch.  Handles whose factorization needs most of a compute unit's LDS (the dense top of the cyclic reduction: 103 KB, one workgroup
-// per compute unit) run it as two launches instead: PART 1 = everything but the factorization, launched with the common block WITHOUT the work area T (a few KB:
-// the equilibration is ten passes of dependent global round trips -- latency, hidden by co-resident workgroups), then k_setup_factor_bcr with the full block.
-template <int NB, int PART>
+// Two launches.  k_setup: everything but the factorization -- ten passes of dependent global round trips (latency, hidden by co-resident workgroups: 52 registers,
+// the common block WITHOUT the work area T, a few KB of LDS); k_setup_factor<NB>: the first factorization with its own registers and LDS.  (One kernel until round 6:
+// 219 registers and, for the cyclic reduction with a dense top, 142 KB of LDS held the equilibration passes to two / one workgroup per compute unit.)
 __global__ __launch_bounds__(NT) void k_setup(Lay L, Ptrs P, mpcqp_settings S_) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     double *p = sh; Smem S; smem_common(L, P, p, S);
@@ -128,21 +127,34 @@ __global__ __launch_bounds__(NT) void k_setup(Lay L, Ptrs P, mpcqp_settings S_) 
     for (int j = tid; j < L.n; j += NT) sv[j] = S_.sigma / (D[j] * D[j]);
     if (tid == 0) { P.c[b] = cc; P.rho[b] = rho; }
     __syncthreads();
-    int bad = PART == 1 ? 0 : NB == 16 && L.grp > 1 ? factor_grouped(c, om, sv, cc, P.F + (size_t)b * P.fsz, S.T, S.iflag, border_ptrs(L, P, S))
-            : NB == 16 && L.dense ? factor_dense(c, om, sv, cc, P.F + (size_t)b * P.fsz, S.T, S.iflag)
-            : NB == 16 && L.bcr ? factor_bcr(c, om, sv, cc, P.F + (size_t)b * P.fsz, P.bws + (size_t)b * L.bcr * BcrFmt::WSTAGE, S.T, S.iflag)
-                      : factor_all<NB>(c, om, sv, cc, P.F + (size_t)b * P.fsz, S.T, S.iflag, border_ptrs(L, P, S));
     // cold start
     for (int j = tid; j < L.n; j += NT) { P.x[(size_t)b * L.n + j] = 0.0; P.xo[(size_t)b * L.n + j] = 0.0; }
     for (int r = tid; r < L.m; r += NT) { P.z[(size_t)b * L.m + r] = 0.0; P.y[(size_t)b * L.m + r] = 0.0; P.yo[(size_t)b * L.m + r] = 0.0; }
     if (tid == 0) {
-        mpcqp_info inf; inf.status = bad ? MPCQP_NON_CVX : MPCQP_UNSOLVED; inf.iter = 0; inf.rho_updates = 0; inf.reserved = 0;
+        mpcqp_info inf; inf.status = MPCQP_UNSOLVED; inf.iter = 0; inf.rho_updates = 0; inf.reserved = 0;      // (k_setup_factor: MPCQP_NON_CVX on a non-positive pivot)
         inf.obj_val = 0; inf.pri_res = 0; inf.dua_res = 0; inf.rho = rho;
         P.info[b] = inf;
     }
 }
 
-// the second launch of a split setup: the cyclic-reduction factorization from the metric k_setup<16, 1> left in memory
+// the second launch of setup: the first factorization, from the metric k_setup left in memory
+template <int NB>
+__global__ __launch_bounds__(NT) void k_setup_factor(Lay L, Ptrs P) {
+    extern __shared__ __attribute__((aligned(16))) double sh[];
+    double *p = sh; Smem S; smem_common(L, P, p, S);
+    const int b = inst_of(P.perm);
+    const double *model = P.model + (size_t)b * L.model_sz;
+    load_common(L, model, P.step + (size_t)b * L.step_sz, S);
+    Ctx c{L, S.hot, model + L.hot_sz};
+    const double *om = P.omega + (size_t)b * L.m, *sv = P.s + (size_t)b * L.n;
+    const double cc = P.c[b];
+    const int bad = NB == 16 && L.grp > 1 ? factor_grouped(c, om, sv, cc, P.F + (size_t)b * P.fsz, S.T, S.iflag, border_ptrs(L, P, S))
+                  : NB == 16 && L.dense ? factor_dense(c, om, sv, cc, P.F + (size_t)b * P.fsz, S.T, S.iflag)
+                            : factor_all<NB>(c, om, sv, cc, P.F + (size_t)b * P.fsz, S.T, S.iflag, border_ptrs(L, P, S));
+    if (bad && threadIdx.x == 0) P.info[b].status = MPCQP_NON_CVX;
+}
+
+// ... of the cyclic reduction (a kernel of its own: 130 registers and 47 KB of LDS at (12,4,30) -- three workgroups per compute unit)
 __global__ __launch_bounds__(NT) void k_setup_factor_bcr(Lay L, Ptrs P) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     double *p = sh; Smem S; smem_common(L, P, p, S);
