@@ -100,6 +100,8 @@ constexpr int BALANCE_EVERY = 16;  // solves between two rebuilds of the workgro
 constexpr int QUEUE_ITEMS_PER_SLOT = 16;   // persistent closed-loop launches: queue items per resident workgroup slot (run_kernel_args)
 constexpr int BALANCE_FIRST = 4;   // ... before the first one (an instance shows its character within a few solves; a short run should not end unbalanced)
 
+struct PackItem { const double *src; double *dst; int w, stride; };
+struct PackArgs { PackItem it[24]; int n, batch; };
 struct mpcqp_handle {
     int device, batch;
     Lay L;
@@ -127,6 +129,7 @@ struct mpcqp_handle {
     // mpcqp_step_host: mapped, coherent host memory the kernel reads its step data from and writes its results to
     double *pin_in, *pin_out; void *pin_in_dev, *pin_out_dev;
     unsigned *done_dev; unsigned long long host_seq; int pin_stride; bool pin_tried;
+    PackArgs pack;                       // device-resident sources of put() waiting for flush_puts
     CscSeam *csc;                        // patterns of P and A of a handle made by mpcqp_create_csc
     double *vec_buf;                     // staging of mpcqp_update_vectors' host arrays [q | l | u], allocated on first use, kept
     bool step_blank;                     // set up through mpcqp_setup_qp: the step blob holds no x0 / u_{-1} / xref yet
@@ -407,8 +410,37 @@ struct Scratch {
     }
 };
 
-// strided upload: src [batch][w] -> dst [batch][stride] at column offset off
+// strided upload: src [batch][w] -> dst [batch][stride] at column offset off.  Host sources: one 2-D copy each.  DEVICE sources (a caller that keeps its
+// data on the GPU: bench.py, the RCCL shards) are collected and moved by ONE kernel launch (flush_puts) -- a device-to-device hipMemcpy2DAsync costs
+// ~ 0.2 ms of host time each, and setup() issues seventeen of them: 4 of the 5.2 ms a cold setup() of 1024 instances took.
+__global__ __launch_bounds__(256) void k_pack_rows(PackArgs A) {
+    for (int i = 0; i < A.n; ++i) {
+        const PackItem t = A.it[i];
+        const int total = A.batch * t.w;
+        for (int idx = blockIdx.x * 256 + threadIdx.x; idx < total; idx += gridDim.x * 256) {
+            const int b = idx / t.w, c = idx - b * t.w;
+            t.dst[(size_t)b * t.stride + c] = t.src[idx];
+        }
+    }
+}
+static int flush_puts(mpcqp_handle *h) {
+    PackArgs &A = h->pack;
+    if (A.n == 0) return 0;
+    A.batch = h->batch;
+    int most = 1;
+    for (int i = 0; i < A.n; ++i) most = std::max(most, A.it[i].w);
+    const int grid = std::max(1, std::min(1024, (h->batch * most + 255) / 256));
+    hipLaunchKernelGGL(k_pack_rows, dim3(grid), dim3(256), 0, h->stream, A);
+    A.n = 0;
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 static int put(mpcqp_handle *h, double *dst, int stride, int off, const double *src, int w) {
+    if (is_device_ptr(src)) {
+        if (h->pack.n == 24 && flush_puts(h)) return MPCQP_ERR_HIP;
+        h->pack.it[h->pack.n++] = PackItem{src, dst + off, w, stride};
+        return 0;
+    }
     HIPCHK(hipMemcpy2DAsync(dst + off, sizeof(double) * (size_t)stride, src, sizeof(double) * (size_t)w,
                             sizeof(double) * (size_t)w, (size_t)h->batch, hipMemcpyDefault, h->stream));
     return 0;
@@ -435,15 +467,18 @@ static int step_upload(mpcqp_handle *h, const double *x0, const double *um1, con
         h->L.xref_rows = xref_rows;
         if (put(h, h->P.step, L.step_sz, L.nx + L.nu, xref, xref_rows * L.nx)) return MPCQP_ERR_HIP;
     }
-    return 0;
+    return flush_puts(h) ? MPCQP_ERR_HIP : 0;
 }
 
 // setup's two launches (mpcqp_phases.h): equilibration, rho vector and cold start with a lean LDS block; then the first factorization
 static int launch_setup(mpcqp_handle *h) {
     const Lay &L = h->L;
+    if (flush_puts(h)) return MPCQP_ERR_HIP;
     const size_t lean = sizeof(double) * (size_t)(smem_common_doubles(L) - L.tsz);      // (the work area T is carved last and not touched by k_setup)
-    if (set_smem(k_setup, lean)) return MPCQP_ERR_HIP;
-    hipLaunchKernelGGL(k_setup, dim3(h->batch), dim3(NT), lean, h->stream, h->L, h->P, h->S);
+    const size_t de = sizeof(double) * (size_t)(L.n + L.m);
+    const int lds_de = lean + de <= 96 * 1024 ? 1 : 0;      // (cfg-5: 91 KB -- one workgroup per compute unit, still well ahead of two walking memory)
+    if (set_smem(k_setup, lean + (lds_de ? de : 0))) return MPCQP_ERR_HIP;
+    hipLaunchKernelGGL(k_setup, dim3(h->batch), dim3(NT), lean + (lds_de ? de : 0), h->stream, h->L, h->P, h->S, lds_de);
     // the cyclic reduction's factorization at 256 threads uses the work area only as far as BcrFmt::lds_doubles says (three workgroups per compute unit at (12,4,30)
     // where the solve kernel's block -- iterate, top inverse -- would allow one); everything else factors in the block it solves in
     if (L.NB == 16 && L.bcr) {
@@ -468,6 +503,7 @@ extern "C" int mpcqp_setup(mpcqp_handle *h, const mpcqp_model *M, const double *
     const Lay &L = h->L; const int nx = L.nx, nu = L.nu, ms = L.model_sz;
     double *mb = h->P.model;
     int rc = 0;
+    h->pack.n = 0;                                  // (nothing left over from a call that failed half-way)
     rc |= put(h, mb, ms, L.oAd, M->Ad, nx * nx); rc |= put(h, mb, ms, L.oBd, M->Bd, nx * nu);
     rc |= put(h, mb, ms, L.oxmin, M->xmin, nx); rc |= put(h, mb, ms, L.oxmax, M->xmax, nx);
     rc |= put(h, mb, ms, L.oumin, M->umin, nu); rc |= put(h, mb, ms, L.oumax, M->umax, nu);
@@ -489,6 +525,7 @@ extern "C" int mpcqp_update(mpcqp_handle *h, const double *x0, const double *um1
     HIPCHK(hipSetDevice(h->device));
     h->step_blank = false;
     h->L.raw = 0;                                   // q, l, u are rebuilt from (x0, u_{-1}, xref) again
+    h->pack.n = 0;
     return step_upload(h, x0, um1, xref, xref_rows);
 }
 
@@ -541,6 +578,7 @@ extern "C" int mpcqp_setup_qp(mpcqp_handle *h, const mpcqp_model *M, const doubl
     const Lay &L = h->L; const int nx = L.nx, nu = L.nu, ms = L.model_sz;
     double *mb = h->P.model;
     int rc = 0;
+    h->pack.n = 0;                                  // (nothing left over from a call that failed half-way)
     rc |= put(h, mb, ms, L.oAd, M->Ad, nx * nx); rc |= put(h, mb, ms, L.oBd, M->Bd, nx * nu);
     rc |= put(h, mb, ms, L.oeps, M->eps_feas, 1);
     if (M->uref) rc |= put(h, mb, ms, L.ouref, M->uref, nu);          // (only output()'s u_failure reads it; zeros otherwise)

@@ -70,7 +70,9 @@ __device__ __forceinline__ void load_common(const Lay &L, const double *model, c
 // Two launches.  k_setup: everything but the factorization -- ten passes of dependent global round trips (latency, hidden by co-resident workgroups: 52 registers,
 // the common block WITHOUT the work area T, a few KB of LDS); k_setup_factor<NB>: the first factorization with its own registers and LDS.  (One kernel until round 6:
 // 219 registers and, for the cyclic reduction with a dense top, 142 KB of LDS held the equilibration passes to two / one workgroup per compute unit.)
-__global__ __launch_bounds__(NT) void k_setup(Lay L, Ptrs P, mpcqp_settings S_) {
+// lds_de: the scaling vectors D, E live in LDS during the passes (where the work area T would start; the launch provides n + m doubles there) -- every term of
+// every row norm reads one of them, through a visitor the compiler cannot hoist the loads out of: a memory round trip per term otherwise.
+__global__ __launch_bounds__(NT) void k_setup(Lay L, Ptrs P, mpcqp_settings S_, int lds_de) {
     extern __shared__ __attribute__((aligned(16))) double sh[];
     double *p = sh; Smem S; smem_common(L, P, p, S);
     const int b = inst_of(P.perm), tid = threadIdx.x;
@@ -78,7 +80,8 @@ __global__ __launch_bounds__(NT) void k_setup(Lay L, Ptrs P, mpcqp_settings S_) 
     load_common(L, model, step, S);
     Ctx c{L, S.hot, model + L.hot_sz};
     if (!L.raw) build_q(c, step, S.Qv, S.um1s, L.xref_rows == 1 ? S.xrs : nullptr);      // (raw vectors: q was uploaded by mpcqp_update_vectors)
-    double *D = P.D + (size_t)b * L.n, *E = P.E + (size_t)b * L.m, *Dt = P.Dt + (size_t)b * L.n, *Et = P.Et + (size_t)b * L.m;
+    double *Dg = P.D + (size_t)b * L.n, *Eg = P.E + (size_t)b * L.m, *Dt = P.Dt + (size_t)b * L.n, *Et = P.Et + (size_t)b * L.m;
+    double *D = lds_de ? S.T : Dg, *E = lds_de ? S.T + L.n : Eg;
     for (int j = tid; j < L.n; j += NT) D[j] = 1.0;
     for (int r = tid; r < L.m; r += NT) E[r] = 1.0;
     double cc = 1.0;
@@ -113,6 +116,10 @@ __global__ __launch_bounds__(NT) void k_setup(Lay L, Ptrs P, mpcqp_settings S_) 
         double qn = limit_scaling(vmax[0]);
         ct = limit_scaling(fmax(ct, qn));
         cc *= 1.0 / ct;
+    }
+    if (lds_de) {
+        for (int j = tid; j < L.n; j += NT) Dg[j] = D[j];
+        for (int r = tid; r < L.m; r += NT) Eg[r] = E[r];
     }
     // rho vector / metric
     double rho = S_.rho;
