@@ -10,20 +10,22 @@
 // Per round the instance reads its K^-1 once (128 KB); per iteration nothing.
 //
 // Variable order of the dense system: stage-major COMPACT, v = k (nx + nu) + a (the padded order of Tc without the padding).
-// Factor record (DenseFmt): F[j * NT + t] = K^-1[row(t)][64 half(t) + j],  row(t) = t >> 1, half(t) = t & 1, j < 64 --
-// the order the threads load it in (coalesced), zero beyond NR and in rows/columns of absent inputs (stages >= NcT carry no u).
-// The two halves of a row sit in NEIGHBOURING LANES: their sums meet through one DPP swap, not through LDS and a barrier.
+// Factor record (DenseFmt): F[j * NT + t] = K^-1[2 (t >> 2) + (j >> 5)][32 (t & 3) + (j & 31)], j < 64 -- a QUAD of lanes holds two rows, each lane a
+// quarter of their columns, in the order the threads load it (coalesced); zero beyond NR and in rows/columns of absent inputs (stages >= NcT carry
+// no u).  (Until round 6 a lane pair held one row, each lane half of it: 64 broadcast reads of the right-hand side per lane and mat-vec -- 128 KB
+// through the LDS return path per iteration, 1 024 of the mat-vec's 1 314 cycles.  Two rows per lane use every value read twice: 32 reads.)
+// The four partial sums of a row meet through two DPP steps inside the quad, not through LDS and a barrier; the lane pair (2v, 2v+1) ends up with row v.
 #pragma once
 
 struct DenseFmt {
     static constexpr int ROWS = 128, JW = 64;                 // row slots, columns per thread
     static constexpr int DOUBLES = JW * NT;                   // doubles per instance
-    static constexpr int HPAD = 2;                            // the second half of the compact vector starts HPAD doubles late: lanes
-                                                              // of the two halves read cv[j] and cv[64 + HPAD + j] in one instruction -- other banks
-    static constexpr int CV = ROWS + HPAD + 6;                // compact right-hand side (16-byte multiples)
+    static constexpr int QW = 32, HPAD = 2;                   // columns per lane and row; quarter p of the compact vector starts p * HPAD doubles late: the
+                                                              // lanes of the four quarters read cv[j + (QW + HPAD) p] in one instruction -- four different banks
+    static constexpr int CV = ROWS + 3 * HPAD + 2;            // compact right-hand side (16-byte multiples; the last entry is never written)
     static constexpr int SCRATCH = 4 * ROWS + 64;             // LDS doubles: rhs | solution | two exchange vectors of the small-problem iteration
 };
-__device__ __forceinline__ int dense_cv_index(int v) { return v + (v >= DenseFmt::JW ? DenseFmt::HPAD : 0); }
+__device__ __forceinline__ int dense_cv_index(int v) { return v + DenseFmt::HPAD * (v / DenseFmt::QW); }
 // swap with the neighbouring lane (lane ^ 1): DPP quad_perm [1,0,3,2]
 __device__ __forceinline__ double lane_swap1(double x) {
     const long long xi = __builtin_bit_cast(long long, x);
@@ -129,12 +131,10 @@ __device__ __forceinline__ int factor_dense(const Ctx &c, const double *om, cons
         __syncthreads();
     }
     TICK(1)
-    const int ro = tid >> 1, co = DenseFmt::JW * (tid & 1);   // register order: row, first column of this thread
-    const bool dead_r = ro >= NR || dense_dead(L, ro);
-    for (int j = 0; j < DenseFmt::JW; ++j) {
-        const int cidx = co + j;
+    for (int j = 0; j < DenseFmt::JW; ++j) {                  // register order (DenseFmt): rows 2 (tid >> 2), + 1; columns 32 (tid & 3) ..
+        const int ro = 2 * (tid >> 2) + (j >> 5), cidx = DenseFmt::QW * (tid & 3) + (j & 31);
         double v = 0.0;
-        if (!dead_r && cidx < NR) {
+        if (ro < NR && !dense_dead(L, ro) && cidx < NR) {
             // (Nc < Np: the column of an input slot behind the held input is a copy of the held input's column -- admm_tiny puts the slot's
             //  share of the held input's A'W into the right-hand side there, the mat-vec adds the shares up)
             const int kc = cidx / nb, ac = cidx - kc * nb;
@@ -156,36 +156,44 @@ __device__ __forceinline__ void dense_load(const double *F, double *Kreg) {
     for (int j = 0; j < DenseFmt::JW; ++j) Kreg[j] = Fg[(size_t)j * NT + threadIdx.x];
 }
 
-// The half-row dot product of this thread with the compact vector cvec (LDS), both halves summed: every lane pair (2v, 2v+1)
+template <int CTRL>
+__device__ __forceinline__ double quad_perm(double x) {
+    const long long xi = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_mov_dpp((int)xi, CTRL, 0xF, 0xF, false), hi = __builtin_amdgcn_mov_dpp((int)(xi >> 32), CTRL, 0xF, 0xF, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+// This thread's two quarter-rows times its quarter of the compact vector cvec (LDS), summed over the quad: every lane pair (2v, 2v+1)
 // returns row v of K^-1 cvec.  REGS: K^-1 from the registers loaded by dense_load; else streamed from F.
 template <bool REGS>
 __device__ __forceinline__ double dense_row(const double *Kreg, const double *F, const double *cvec) {
-    constexpr int BATCH = 16;                                 // LDS values in flight
+    constexpr int BATCH = 16, QW = DenseFmt::QW;              // LDS values in flight
     const int tid = threadIdx.x;
-    const double *cv = cvec + (tid & 1) * (DenseFmt::JW + DenseFmt::HPAD);
+    const double *cv = cvec + (tid & 3) * (QW + DenseFmt::HPAD);
     cgdouble *Fg = (cgdouble *)F;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    auto kk = [&](int j) { return REGS ? Kreg[j] : Fg[(size_t)j * NT + tid]; };
+    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
     // The reads are issued in groups and fenced: left alone, a scheduler that is short of registers (the inverse takes 128 of
-    // them) waits for every single read before the two FMAs that use it -- 32 LDS round trips per mat-vec instead of 4.
-    // 8-byte reads on purpose: every lane of a half reads the SAME address, which the LDS serves as a broadcast for 4- and 8-byte
-    // reads; 16-byte reads of one address by 32 lanes are serialised (measured: 260 cycles per instruction).
+    // them) waits for every single read before the FMAs that use it -- a round trip per read instead of one per group.
+    // 8-byte reads on purpose: every lane of a quarter reads the SAME address, which the LDS serves as a broadcast for 4- and 8-byte
+    // reads; 16-byte reads of one address by many lanes are serialised (measured: 260 cycles per instruction).
 #pragma unroll
-    for (int jb = 0; jb < DenseFmt::JW; jb += BATCH) {
+    for (int jb = 0; jb < QW; jb += BATCH) {
         double c[BATCH];
 #pragma unroll
         for (int q = 0; q < BATCH; ++q) c[q] = cv[jb + q];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int q = 0; q < BATCH; q += 4) {
+        for (int q = 0; q < BATCH; q += 2) {
             const int j = jb + q;
-            const double k0 = REGS ? Kreg[j] : Fg[(size_t)j * NT + tid], k1 = REGS ? Kreg[j + 1] : Fg[(size_t)(j + 1) * NT + tid];
-            const double k2 = REGS ? Kreg[j + 2] : Fg[(size_t)(j + 2) * NT + tid], k3 = REGS ? Kreg[j + 3] : Fg[(size_t)(j + 3) * NT + tid];
-            a0 = fma(k0, c[q], a0); a1 = fma(k1, c[q + 1], a1); a2 = fma(k2, c[q + 2], a2); a3 = fma(k3, c[q + 3], a3);
+            a0 = fma(kk(j), c[q], a0); a1 = fma(kk(j + 1), c[q + 1], a1);
+            b0 = fma(kk(QW + j), c[q], b0); b1 = fma(kk(QW + j + 1), c[q + 1], b1);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    const double part = (a0 + a1) + (a2 + a3);
-    return part + lane_swap1(part);
+    double r0 = a0 + a1, r1 = b0 + b1;
+    r0 += quad_perm<0xB1>(r0); r1 += quad_perm<0xB1>(r1);    // lane ^ 1
+    r0 += quad_perm<0x4E>(r0); r1 += quad_perm<0x4E>(r1);    // lane ^ 2: every lane of the quad holds both rows' sums (the same bits)
+    return (tid & 2) ? r1 : r0;
 }
 
 // Tc <- K^-1 Tc on the padded stage-major vector Tc (stride NB): gather to compact order, row dot products, scatter
