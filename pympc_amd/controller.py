@@ -272,7 +272,7 @@ class MPCController:
         if isinstance(self.prob, DeviceProblem):
             self._stale = True                    # refreshed on first read, from a snapshot of this call's inputs
             self._snap = (np.array(self.x0_rh, dtype=float), np.array(self.uminus1_rh, dtype=float), np.array(self.xref, dtype=float))
-            self.prob.update(mpc_step=self._step_data())
+            self.prob.update(mpc_step=self._snap)      # (the snapshot itself: private copies, float64, contiguous -- nothing to convert again on the way down)
         else:                                     # a solver that wants the vectors (the oracle in the tests)
             self._stale = False
             self.q, self.J_CNST = qp_build.refresh_vectors(self)

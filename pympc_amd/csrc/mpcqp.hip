@@ -1067,14 +1067,19 @@ extern "C" int mpcqp_step_host(mpcqp_handle *h, const double *x0, const double *
     h->L.raw = 0;
     if (xref) h->L.xref_rows = xref_rows;
     const int nxr = xref ? xref_rows * L.nx : 0;
-    for (size_t b = 0; b < B; ++b) {
+    const bool inl = B == 1 && x0 && uminus1 && xref && L.nx + L.nu + nxr <= 32;      // (a single controller's few doubles travel in the kernel arguments instead)
+    for (size_t b = 0; b < B && !inl; ++b) {
         double *dst = h->pin_in + b * h->pin_stride;
         if (x0) memcpy(dst, x0 + b * L.nx, sizeof(double) * L.nx);
         if (uminus1) memcpy(dst + L.nx, uminus1 + b * L.nu, sizeof(double) * L.nu);
         if (xref) memcpy(dst + L.nx + L.nu, xref + b * nxr, sizeof(double) * nxr);
     }
     RunArgs R; memset(&R, 0, sizeof(R));
-    R.pin_in = (x0 || uminus1 || xref) ? (const double *)h->pin_in_dev : nullptr;
+    if (inl) {
+        memcpy(R.inl, x0, sizeof(double) * L.nx); memcpy(R.inl + L.nx, uminus1, sizeof(double) * L.nu); memcpy(R.inl + L.nx + L.nu, xref, sizeof(double) * nxr);
+        R.inl_n = L.nx + L.nu + nxr;
+    }
+    R.pin_in = (!inl && (x0 || uminus1 || xref)) ? (const double *)h->pin_in_dev : nullptr;
     R.pin_stride = h->pin_stride; R.pin_mask = (x0 ? 1 : 0) | (uminus1 ? 2 : 0) | (xref ? 4 : 0); R.pin_xref = nxr;
     R.pub = (double *)h->pin_out_dev; R.done = (unsigned *)h->npending_dev + 2; R.seq = ++h->host_seq;
     int rc = launch_run(h, R, 0);

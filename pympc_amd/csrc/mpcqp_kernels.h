@@ -125,14 +125,18 @@ __device__ __forceinline__ void run_instance(const int k0, const int k1) {
         P.tstamp[(size_t)TS_STRIDE * b + 2 + TS_STEPS - 1] = ((unsigned long long)(xcc & 15) << 32) | hw;
     }
     if (MODE >= MODE_BCRT && tid == 0) S.iflag[2] = 0;      // (the rounds' LDS-resident part of the factor is not loaded yet: admm_latw; a barrier follows in load_common)
-    if (!LOOP && R.pin_in) {                     // update(x0, u_{-1}, xref) straight from the caller's (mapped) memory: one PCIe round trip
+    const double *step_src = step;
+    if (!LOOP && R.inl_n) {                      // update(x0, u_{-1}, xref) from the kernel arguments: into the step blob for the phases that follow (behind load_common's
+        for (int i = tid; i < R.inl_n; i += NT) step[i] = R.inl[i];      // barrier), while load_common reads the very same values from the arguments -- no round trip at all
+        step_src = R.inl;
+    } else if (!LOOP && R.pin_in) {              // ... or straight from the caller's (mapped) memory: one PCIe round trip
         const double *src = R.pin_in + (size_t)b * R.pin_stride;
         if (R.pin_mask & 1) for (int i = tid; i < L.nx; i += NT) step[i] = src[i];
         if (R.pin_mask & 2) for (int i = tid; i < L.nu; i += NT) step[L.nx + i] = src[L.nx + i];
         if (R.pin_mask & 4) for (int i = tid; i < R.pin_xref; i += NT) step[L.nx + L.nu + i] = src[L.nx + L.nu + i];
         __syncthreads();
     }
-    load_common(L, P.model + (size_t)b * L.model_sz, step, S);
+    load_common(L, P.model + (size_t)b * L.model_sz, step_src, S);
     if (!LOOP && R.part == 3) {                  // mpcqp_refactor: the factorization alone (what one rho update costs)
         __syncthreads();
         { FramePin pin; run_factor_phase<NB, OCC>(&pin.v); }

@@ -514,6 +514,8 @@ __device__ __forceinline__ int check_body(const Lay &L, const Ptrs &P, const mpc
     if (Xl) {                                                             // (LDS-resident iterate: owner-mapped passes)
         bool done = false;
         if constexpr (kLatOnly) { if (L.nx == 12 && L.nu == 4) { check_norms_own<12, 4>(c, Xl, Zl, Yl, D, E, S.Qv, cc, nrm, vsum, scaled); done = true; } }      // (mpcqp_w8.hip: the BASELINE shape unrolled)
+        // (the reference's cart pole on the dense backend: its nx-long sums unrolled -- one workgroup per compute unit has the registers for it)
+        if constexpr (!kLatOnly && OCC == 1 && NB == 16) { if (L.dense && L.nx == 4 && L.nu == 1) { check_norms_own<4, 1>(c, Xl, Zl, Yl, D, E, S.Qv, cc, nrm, vsum, scaled); done = true; } }
         if (!done) check_norms_own(c, Xl, Zl, Yl, D, E, S.Qv, cc, nrm, vsum, scaled);
     }
     else check_norms_gown(c, X, Z, Y, D, E, S.Qv, cc, S.T, S.tv, nrm, vsum, scaled);   // (iterate in global memory: staged, then the same passes)
@@ -1056,7 +1058,7 @@ __device__ __forceinline__ void gown_update(const Lay &L, const double *hot, con
 // MODE_BCR + N: block cyclic reduction with the factor of an N-stage problem resident in registers (mpcqp_bcr.h).
 // MODE_BCRT + N: the same with a dense top instead of the levels above 1, for any number of waves per workgroup (mpcqp_latw.h).
 enum { MODE_CHAIN = 0, MODE_BORDER = 1, MODE_DENSE = 2, MODE_BCR = 100, MODE_BCRT = 200 };
-template <int NB> __device__ __forceinline__ void admm_tiny(const Lay &, const HotPtrs &, Smem &, double *, double *, double *, double, int);      // mpcqp_tiny.h
+template <int NB, int MAXB> __device__ __forceinline__ void admm_tiny(const Lay &, const HotPtrs &, Smem &, double *, double *, double *, double, int);      // mpcqp_tiny.h
 template <int NXT, int NUT, int NST> __device__ __forceinline__ void admm_lat(const Lay &, const HotPtrs &, Smem &, double *, double *, double *, double, int);      // mpcqp_lat.h
 template <int NXT, int NUT, int NST> __device__ __forceinline__ int admm_latw(const Lay &, const HotPtrs &, Smem &, double *, double *, double *, double, int, int);     // mpcqp_latw.h
 // The ADMM round of a problem whose iterate does not live in LDS for the owner-mapped phases above (n_x > 2 NT, or too large for four workgroups
@@ -1132,7 +1134,7 @@ __device__ __forceinline__ void admm_round_global(const Lay &L, const HotPtrs &P
 
 template <int NB, bool LDSSTATE, int NXT, int NUT, int MODE>
 __device__ __forceinline__ void admm_body(const Lay &L, const HotPtrs &P, Smem &S, double *X, double *Z, double *Y, double alpha, int iters) {
-    if constexpr (MODE == MODE_DENSE) { admm_tiny<NB>(L, P, S, X, Z, Y, alpha, iters); return; }      // register-resident iterate and inverse
+    if constexpr (MODE == MODE_DENSE) { if (L.nb <= 8) admm_tiny<NB, 8>(L, P, S, X, Z, Y, alpha, iters); else admm_tiny<NB, 16>(L, P, S, X, Z, Y, alpha, iters); return; }      // register-resident iterate and inverse
     if constexpr (MODE >= MODE_BCRT) { admm_latw<NXT, NUT, MODE - MODE_BCRT>(L, P, S, X, Z, Y, alpha, iters, -1); return; }   // ... and cyclic-reduction factor with a dense top (k_mpc_run calls it directly, with its own termination test)
     else if constexpr (MODE >= MODE_BCR) { admm_lat<NXT, NUT, MODE - MODE_BCR>(L, P, S, X, Z, Y, alpha, iters); return; } // ... and cyclic-reduction factor
     if constexpr (!LDSSTATE) {          // iterate in global memory -- or staged in LDS for the round (generic kernels of small batches)

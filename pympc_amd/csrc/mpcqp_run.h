@@ -39,6 +39,9 @@ struct RunArgs {
     double *pub;                  // mapped host memory: [batch][n] x | [batch][m] y | [batch] info | flag; written when the solve is done (null = off)
     unsigned *done;               // device counter of finished workgroups (the last one raises the flag)
     unsigned long long seq;       // value the flag takes
+    // ... or, a single controller whose [x0 | u_{-1} | xref] is a few doubles: in the kernel arguments themselves (no PCIe read in front of the solve)
+    int inl_n;                    // doubles in inl (0 = off)
+    double inl[32];
 };
 
 __host__ __device__ inline int next_stop(int iter, int max_iter, int chk, int rho_every) {

@@ -32,9 +32,10 @@ __device__ __forceinline__ double tiny_row_step(TinyRow &r, double zt, double al
     return (r.om * cinv) * d;
 }
 
-template <int NB>
+// MAXB: length the coefficient vectors are zero-padded to (nx + nu <= MAXB <= 16; 8 for the reference's own small examples: half the LDS reads and FMAs of the two 16-long products)
+template <int NB, int MAXB>
 __device__ __forceinline__ void admm_tiny(const Lay &L, const HotPtrs &P, Smem &S, double *Xl, double *Zl, double *Yl, double alpha, int iters) {
-    constexpr int MAXB = 16;                                  // nx + nu <= 16: coefficient vectors are zero-padded to this length
+    constexpr int VPAD = 16;                                  // padding of the exchange vectors (a lane's reads run up to MAXB entries past its stage)
     const int b = inst_of(P.perm), tid = threadIdx.x;
     const int nx = L.nx, nu = L.nu, nb = L.nb;
     gdouble *gx = (gdouble *)(P.x + (size_t)b * L.n), *gz = (gdouble *)(P.z + (size_t)b * L.m), *gy = (gdouble *)(P.y + (size_t)b * L.m);
@@ -42,10 +43,10 @@ __device__ __forceinline__ void admm_tiny(const Lay &L, const HotPtrs &P, Smem &
     gdouble *dxg = (gdouble *)(P.dx + (size_t)b * L.n), *dyg = (gdouble *)(P.dy + (size_t)b * L.m);
     const double cc = P.c[b], cinv = 1.0 / cc, beta = 1.0 - alpha;
     const double *hot = S.hot;
+    TICK_RESET
+    TICK_START
     // LDS exchange vectors (in the work area T; nothing else lives there during a round)
-    double *Cv = S.T, *Xt = Cv + DenseFmt::CV, *Wd = Xt + DenseFmt::ROWS + MAXB, *Wu = Wd + DenseFmt::ROWS + MAXB;
-    double Kreg[DenseFmt::JW];
-    dense_load(P.F + (size_t)b * P.fsz, Kreg);
+    double *Cv = S.T, *Xt = Cv + DenseFmt::CV, *Wd = Xt + DenseFmt::ROWS + VPAD, *Wu = Wd + DenseFmt::ROWS + VPAD;
     for (int i = tid; i < DenseFmt::SCRATCH; i += NT) S.T[i] = 0.0;
     // ---- who am I
     const int v = tid >> 1, k = v / nb, a = v - k * nb;
@@ -111,6 +112,10 @@ __device__ __forceinline__ void admm_tiny(const Lay &L, const HotPtrs &P, Smem &
     const bool has_unext = is_u && cu + 1 < L.n_u;
     const bool has_uprev = is_u && cu > 0;
     const int cvi = dense_cv_index(v);
+    // (the inverse is requested BEHIND the owners' values: the memory counter retires in order, and 64 loads in front of them kept the first exchange waiting for
+    //  the whole 128 KB; now it streams in under the two barriers and the first right-hand side)
+    double Kreg[DenseFmt::JW];
+    dense_load(P.F + (size_t)b * P.fsz, Kreg);
     __syncthreads();
     if (is_x && !odd) Wd[e] = r1.w;
     if (is_u && odd) Wu[cu] = r1.w;
@@ -138,7 +143,7 @@ __device__ __forceinline__ void admm_tiny(const Lay &L, const HotPtrs &P, Smem &
     const double *upp = has_uprev && odd ? Wu + (cu - 1) : Cv + DenseFmt::CV - 1;  // Delta-u row of the previous flattened input
     const double s_uprev = has_uprev && odd ? 1.0 : 0.0, s_unext = has_unext && odd ? 1.0 : 0.0;
     const double okap = odd_x ? r1.om * kap : 0.0;
-    TICK_RESET
+    TICK(7)
     for (int it = 1; it <= iters; ++it) {
         const bool keep_delta = it == iters;
         TICK_START
@@ -179,7 +184,7 @@ __device__ __forceinline__ void admm_tiny(const Lay &L, const HotPtrs &P, Smem &
         __syncthreads();
         TICK(5)
     }
-    TICK_FLUSH
+    TICK_START
     // ---- end of the round: the iterate back to memory (global: the next round / warm start; LDS copy: the residual evaluation)
     auto put_row = [&](const TinyRow &r, int idx) { const double y = r.ys * (r.om * cinv); gz[idx] = r.z; gy[idx] = y; Zl[idx] = r.z; Yl[idx] = y; };
     if (is_x || is_u) {
@@ -187,4 +192,6 @@ __device__ __forceinline__ void admm_tiny(const Lay &L, const HotPtrs &P, Smem &
         put_row(r1, r1idx);
         if (first_u && !odd) put_row(r2, L.rdu + cu);
     }
+    TICK(9)
+    TICK_FLUSH
 }

@@ -314,12 +314,14 @@ class BatchProblem:
         """update(x0, uminus1, xref) + warm-started solve + solution in ONE library call with host arrays (mpcqp_step_host):
         the latency path of a single controller.  Returns ``(x [B,n], y [B,m], info[B])`` like ``solution()``."""
         B, nx, nu = self.batch, self.nx, self.nu
-        a = None if x0 is None else np.ascontiguousarray(np.asarray(x0, dtype=np.float64).reshape(B, nx))
-        b = None if uminus1 is None else np.ascontiguousarray(np.asarray(uminus1, dtype=np.float64).reshape(B, nu))
+        f64 = lambda v, cols: v if (type(v) is np.ndarray and v.dtype == np.float64 and v.flags.c_contiguous and v.size == B * cols) \
+            else np.ascontiguousarray(np.asarray(v, dtype=np.float64).reshape(B, cols))      # (a conforming array goes down as it is: same memory, whatever its shape)
+        a = None if x0 is None else f64(x0, nx)
+        b = None if uminus1 is None else f64(uminus1, nu)
         c, rows = None, 1
         if xref is not None:
             rows = self._xref_rows(xref)
-            c = np.ascontiguousarray(np.asarray(xref, dtype=np.float64).reshape(B, rows * nx))
+            c = f64(xref, rows * nx)
         x, y = np.empty((B, self.n)), np.empty((B, self.m))
         info = (_lib.Info * B)()
         _lib.check(self._L.mpcqp_step_host(self._h, _ptr(a), _ptr(b), _ptr(c), rows, _ptr(x), _ptr(y), C.cast(info, C.c_void_p)), 'mpcqp_step_host')
@@ -566,8 +568,11 @@ class DeviceProblem:
             self._bp.update_vectors(None if q is None else np.asarray(q, dtype=float)[None], clip(l), clip(u))
             return
         # kept on the host until the solve that follows (mpc.py:338-364: update() = refresh + solve): one library call, one launch
-        self._pending = (np.array(mpc_step['x0'], dtype=float).reshape(1, -1), np.array(mpc_step['uminus1'], dtype=float).reshape(1, -1),
-                         np.array(mpc_step['xref'], dtype=float).reshape(1, -1))
+        if isinstance(mpc_step, tuple):                   # (x0, uminus1, xref) as private float64 copies: MPCController's snapshot
+            self._pending = mpc_step
+        else:
+            self._pending = (np.array(mpc_step['x0'], dtype=float).reshape(1, -1), np.array(mpc_step['uminus1'], dtype=float).reshape(1, -1),
+                             np.array(mpc_step['xref'], dtype=float).reshape(1, -1))
 
     def update_settings(self, **kw):
         self._bp.update_settings(**kw)

@@ -1,2 +1,4 @@
 cd $GRAFT_REPO_ROOT
-MPCQP_LIB=build_abl/timing.so python scripts/diag_small.py cart_pole 200 2>&1 | grep -v amdgpu.ids | tail -3
+python scripts/latency_single.py 2>&1 | grep -v amdgpu.ids | tail -3
+python scripts/latency_single.py 2>&1 | grep -v amdgpu.ids | tail -3 | head -2
+timeout 1200 python -m pytest tests -m gpu -q -x 2>&1 | tail -3
