@@ -10,6 +10,7 @@ Arrays may be numpy ndarrays (host) or torch CUDA tensors (device-resident); bot
 raw pointers, PyTorch being used only as a device-memory container.
 """
 import ctypes as C
+import math
 
 import numpy as np
 
@@ -178,6 +179,8 @@ class BatchProblem:
             raise NotAnMPCQP(self._L.mpcqp_last_error().decode())
         _lib.check(rc, 'mpcqp_setup_csc')
 
+    _hin = None                # (step_host of a single controller: input buffer, made on first use)
+
     def _finish_init(self, stream):
         n, m, fd, nnzL = C.c_int(), C.c_int(), C.c_int64(), C.c_int64()
         _lib.check(self._L.mpcqp_get_dims(self._h, C.byref(n), C.byref(m), C.byref(fd), C.byref(nnzL)), 'mpcqp_get_dims')
@@ -252,7 +255,7 @@ class BatchProblem:
 
     def _xref_rows(self, xref):
         shape = tuple(xref.shape)
-        per = int(np.prod(shape[1:])) if len(shape) > 1 and shape[0] == self.batch else int(np.prod(shape))
+        per = math.prod(shape[1:]) if len(shape) > 1 and shape[0] == self.batch else math.prod(shape)
         if per == self.nx:
             return 1
         if per == (self.Np + 1) * self.nx:
@@ -314,6 +317,8 @@ class BatchProblem:
         """update(x0, uminus1, xref) + warm-started solve + solution in ONE library call with host arrays (mpcqp_step_host):
         the latency path of a single controller.  Returns ``(x [B,n], y [B,m], info[B])`` like ``solution()``."""
         B, nx, nu = self.batch, self.nx, self.nu
+        if B == 1 and x0 is not None and uminus1 is not None and xref is not None:
+            return self._step_host_one(x0, uminus1, xref)
         f64 = lambda v, cols: v if (type(v) is np.ndarray and v.dtype == np.float64 and v.flags.c_contiguous and v.size == B * cols) \
             else np.ascontiguousarray(np.asarray(v, dtype=np.float64).reshape(B, cols))      # (a conforming array goes down as it is: same memory, whatever its shape)
         a = None if x0 is None else f64(x0, nx)
@@ -326,6 +331,29 @@ class BatchProblem:
         info = (_lib.Info * B)()
         _lib.check(self._L.mpcqp_step_host(self._h, _ptr(a), _ptr(b), _ptr(c), rows, _ptr(x), _ptr(y), C.cast(info, C.c_void_p)), 'mpcqp_step_host')
         return x, y, info
+
+    def _step_host_one(self, x0, uminus1, xref):
+        """step_host for ONE controller with the Python side trimmed (a step is ~ 60 us in all: every microsecond here shows): the inputs are
+        copied into a buffer the problem keeps -- its three addresses are plain integers computed once -- and x, y come back as views of one
+        ctypes block (``ndarray.ctypes.data`` costs ~ 1 us per array, ``np.prod`` of a shape more)."""
+        nx, nu, n, m = self.nx, self.nu, self.n, self.m
+        hb = self._hin
+        if hb is None:
+            hb = self._hin = np.empty(nx + nu + (self.Np + 1) * nx)
+            p = hb.ctypes.data
+            self._hin_p = (p, p + 8 * nx, p + 8 * (nx + nu))
+            self._out_t = C.c_double * (n + m)
+        xr = xref if type(xref) is np.ndarray else np.asarray(xref, dtype=np.float64)
+        nxr = xr.size
+        if nxr != nx and nxr != (self.Np + 1) * nx:
+            raise ValueError('xref must hold nx or (Np+1)*nx values per instance')
+        hb[:nx] = np.reshape(x0, nx); hb[nx:nx + nu] = np.reshape(uminus1, nu); hb[nx + nu:nx + nu + nxr] = xr.reshape(nxr)
+        cb = self._out_t()
+        info = (_lib.Info * 1)()
+        a, b, c = self._hin_p
+        _lib.check(self._L.mpcqp_step_host(self._h, a, b, c, nxr // nx, cb, C.addressof(cb) + 8 * n, info), 'mpcqp_step_host')
+        buf = np.frombuffer(cb, dtype=np.float64)
+        return buf[:n].reshape(1, n), buf[n:].reshape(1, m), info
 
     def mpc_run(self, nsteps, w=None, Ap=None, Bp=None, out=None, xref_traj=None, estimator=None):
         """Device-side receding-horizon loop (mpcqp_mpc_loop): ``nsteps`` closed-loop steps
