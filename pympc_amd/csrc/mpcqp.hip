@@ -665,8 +665,8 @@ static int run_grid(const mpcqp_handle *h, int nsteps) {
     int occ = one_at_a_time ? 1 : (L.NB <= 16 ? 4 : 2);
     if (h->smem_solve > 0) occ = std::max(1, std::min(occ, (int)((size_t)160 * 1024 / h->smem_solve)));
     const int full = h->ncu * occ;
-    const int q = (h->S.tuning >> MPCQP_TUNE_SLOTS_SHIFT) & 0x1F;      // (development: resident workgroups in quarters of a workgroup per compute unit)
-    if (q) return std::max(1, std::min(full, h->ncu * q / 4));
+    const int q = (h->S.tuning >> MPCQP_TUNE_SLOTS_SHIFT) & 0x1F;      // (development: resident workgroups in eighths of a workgroup per compute unit)
+    if (q) return std::max(1, std::min(full, h->ncu * q / 8));
     if (L.NB == 32 && occ == 2 && !h->lds_state && !L.lstage && nsteps >= 8 && 2 * h->batch <= 3 * full && 4 * h->batch > 3 * full && !(h->S.tuning & MPCQP_TUNE_NO_QUEUE)) return 3 * full / 4;
     return full;
 }
