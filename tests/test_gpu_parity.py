@@ -571,6 +571,29 @@ def test_persistent_queue_never_changes_results(B, steps):
             assert np.array_equal(a, b)
 
 
+def test_three_quarter_slots_never_change_results():
+    """Round 6: closed-loop launches of the 32 x 32 bandwidth kernel with its iterate in memory (BASELINE configs[4]'s kernel) that would hold (nearly) every
+    instance resident at once run on three quarters of their slots with the (instance, step range) queue instead (run_grid, mpcqp.hip: the stragglers start
+    first and run faster).  400 instances of a (20, 8, 40) controller on a 256-unit part: 384 slots instead of 512.  Bit-identical to the hardware's dispatch of
+    one workgroup per instance (TUNE_NO_QUEUE) and to a forced slot count (the development switch, 10 eighths per unit)."""
+    from pympc_amd import fixtures, _lib
+    from pympc_amd.solver import forced_settings
+    B, steps = 400, 8
+    kws = [fixtures.random_lti(4000 + i, nx=20, nu=8, Np=40, xbox=2.0) for i in range(B)]
+    rng = np.random.default_rng(9)
+    w = 0.02 * rng.standard_normal((2 * steps, B, 20))
+    out = []
+    for tuning in (0, _lib.TUNE_NO_QUEUE, 10 << 24):
+        with forced_settings(tuning=tuning):
+            K = _stacked_batch(kws); K.setup()
+        assert K.prob.kernel_name(True).replace(' ', '').startswith('k_mpc_run<32,false'), K.prob.kernel_name(True)
+        parts = [K.run(steps, w=w[steps * i:steps * (i + 1)]) for i in range(2)]
+        out.append(tuple(np.concatenate([p[k] for p in parts]) for k in ('u', 'x', 'iter', 'status')) + (K.prob.solution()[0],))
+    for other in out[1:]:
+        for a, b in zip(out[0], other):
+            assert np.array_equal(a, b)
+
+
 def _random_case(seed):
     """A seeded random controller: dimensions, horizon split, bound pattern (finite / one-sided / absent), weights
     (including semidefinite ones) and reference shape are all drawn."""
