@@ -74,12 +74,15 @@ def reference_inputs(args):
     return np.array(out)
 
 
+LATE_FROM = 8        # steps of a closed loop behind its cold-start transient (rho adaptation settles within the first solves)
+
+
 def alongside(args):
     """Worker: the oracle stepping ALONGSIDE the device on the device's own closed-loop states.  For every instance index in `idx` (workload
     recipe fixtures.random_lti): set up at tolerance `eps`, then for step k: output() against the input the device applied, update() with the
     state the device's plant reached, and the solve's (status, ADMM iterations) against the device's.  Returns per instance
     (index, largest rho the oracle worked with, [(k, oracle_iter, device_iter)] where counts differ, [(k, oracle_status, device_status)] where
-    statuses differ, worst relative input deviation, total oracle iterations)."""
+    statuses differ, worst relative input deviation, total oracle iterations, worst relative input deviation from step LATE_FROM on)."""
     idx, xs, us, its, sts, eps, nx, nu, Np, xbox = args
     import numpy as np
     from pympc_amd import MPCController, fixtures
@@ -93,10 +96,12 @@ def alongside(args):
             warnings.simplefilter('ignore')
             K.setup()
             rho = K.prob.iterate_state()[3]
-            bad_it, bad_st, worst, total = [], [], 0.0, 0
+            bad_it, bad_st, worst, total, worst_late = [], [], 0.0, 0, 0.0
             for k in range(us.shape[1]):
                 uo = K.output()
-                worst = max(worst, float(np.abs(us[j, k] - uo).max() / max(1e-3, np.abs(uo).max())))
+                dev = float(np.abs(us[j, k] - uo).max() / max(1e-3, np.abs(uo).max()))
+                worst = max(worst, dev)
+                if k >= LATE_FROM: worst_late = max(worst_late, dev)
                 K.update(xs[j, k + 1], us[j, k])
                 rho = max(rho, K.prob.iterate_state()[3])
                 total += int(K.res.info.iter)
@@ -104,7 +109,7 @@ def alongside(args):
                     bad_it.append((k, int(K.res.info.iter), int(its[j, k])))
                 if int(K.res.info.status_val) != int(sts[j, k]):
                     bad_st.append((k, int(K.res.info.status_val), int(sts[j, k])))
-        out.append((int(i), float(rho), bad_it, bad_st, worst, total))
+        out.append((int(i), float(rho), bad_it, bad_st, worst, total, worst_late))
     return out
 
 

@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-run() { python bench.py --path stepwise --steps 40 --warmup 10 --tuning $1 --no-other-path --no-cpu-baseline 2>/dev/null | tail -n 1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('stepwise tuning', $1, 'value', int(d['value']), 'ms/step', d['ms_per_step'], 'kernel_ms', r.get('kernel_ms'), 'launches', r.get('launches'), 'iters', d.get('mean_admm_iters'))"; }
-run 0; run 64; run 0; run 64
+timeout 900 python -m pytest tests/test_gpu_gaps.py -m gpu -q -x -s -k "north_star" 2>&1 | grep -v amdgpu.ids | tail -6 | cut -c1-600
