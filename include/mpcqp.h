@@ -216,7 +216,8 @@ int mpcqp_mpc_step(mpcqp_handle *h, const double *x0, const double *uminus1, con
 
 /* The drop-in class's update() in one call with HOST arrays (mpc.py:338-375: prob.update(l=, u=, q=) + prob.solve() + res.x / res.y /
  * res.info): mpcqp_update(x0, uminus1, xref) (any of them may be NULL = unchanged), a warm-started solve and mpcqp_get_solution.
- * x0 / uminus1 / xref are copied into mapped host memory which the solve kernel reads itself, x [batch][n], y [batch][m],
+ * x0 / uminus1 / xref travel in the kernel's arguments (one controller, all three given, at most 32 doubles) or are copied into mapped host
+ * memory which the solve kernel reads itself; x [batch][n], y [batch][m],
  * info [batch] (any may be NULL) come back the same way and the call waits on a flag in that memory: one kernel launch, no copy
  * calls, no stream synchronisation -- the latency path of a single small controller.  All pointers are HOST pointers. */
 int mpcqp_step_host(mpcqp_handle *h, const double *x0, const double *uminus1, const double *xref, int xref_rows,
