@@ -95,6 +95,7 @@ enum mpcqp_tuning {
     MPCQP_TUNE_NO_PARTS = 32,   /* persistent closed-loop launches: an instance's whole loop is ONE queue item (no parts) */
     MPCQP_TUNE_QUEUE_SOLVES = 64, /* development: persistent launches for single solves (mpcqp_solve) too, not only for the closed loop */
     MPCQP_TUNE_EVEN_PARTS = 128, /* development: persistent closed-loop launches cut an instance's steps into EQUAL parts (default: decreasing) */
+    MPCQP_TUNE_ONE_LAUNCH_SOLVES = 1 << 29, /* development: a solve of more instances than resident slots as ONE persistent launch (instances off the queue, longest expected work first, each run to its end) instead of two launches (one round for everybody, then the unfinished ones re-dealt) */
     MPCQP_TUNE_SLOTS_SHIFT = 24, /* development: tuning bits 24..28 = resident workgroup slots of a persistent closed-loop launch in eighths of a workgroup per compute unit (8 = one per unit); 0 = the library's choice */
     MPCQP_TUNE_PACE_SHIFT = 8   /* development: tuning bits 8..15 = pacing units (x 3.5 us idled per ADMM iteration by the instances of a fully resident launch of the bandwidth kernels that are not expected to straggle); 0 = off */
 };

@@ -674,8 +674,8 @@ static RunKArgs run_kernel_args(mpcqp_handle *h, const RunArgs &R0, int *grid) {
     RunKArgs A; A.L = h->L; A.P = h->P; A.S = h->S; A.R = R0;
     *grid = h->batch;
     const int slots = run_grid(h, R0.nsteps);
-    if (h->ncu > 0 && h->batch > slots && h->vcur_dev && !R0.pin_in && !R0.pub && (R0.nsteps > 0 || (h->S.tuning & MPCQP_TUNE_QUEUE_SOLVES)) && !(h->S.tuning & MPCQP_TUNE_NO_QUEUE)) {
-        A.R.vcur = h->vcur_dev; A.R.vperm = (R0.nsteps > 0 && h->qperm_set) ? h->qperm_dev : h->P.perm;      /* (a solve's second launch walks the pending list: P.perm) */ A.R.vqueue = h->vqueue_dev;
+    if (h->ncu > 0 && h->batch > slots && h->vcur_dev && !R0.pin_in && !R0.pub && (R0.nsteps > 0 || (h->S.tuning & (MPCQP_TUNE_QUEUE_SOLVES | MPCQP_TUNE_ONE_LAUNCH_SOLVES))) && !(h->S.tuning & MPCQP_TUNE_NO_QUEUE)) {
+        A.R.vcur = h->vcur_dev; A.R.vperm = ((R0.nsteps > 0 || (R0.part == 0 && (h->S.tuning & MPCQP_TUNE_ONE_LAUNCH_SOLVES))) && h->qperm_set) ? h->qperm_dev : h->P.perm;      /* (a solve's second launch walks the pending list: P.perm) */ A.R.vqueue = h->vqueue_dev;
         A.P.perm = h->vcur_dev;
         *grid = slots;
         // closed loop: an instance's steps in parts, about QUEUE_ITEMS_PER_SLOT items per slot in all (a launch ends within half an item of its ideal
@@ -852,7 +852,7 @@ static int launch_solve(mpcqp_handle *h, int plain_iters) {
     if (!h->is_setup) return fail(MPCQP_ERR_STATE, "solve before mpcqp_setup");
     HIPCHK(hipSetDevice(h->device));
     RunArgs R; memset(&R, 0, sizeof(R));
-    const bool split = plain_iters == 0 && h->auto_balance && h->ncu > 0 && h->batch > h->ncu;
+    const bool split = plain_iters == 0 && h->auto_balance && h->ncu > 0 && h->batch > h->ncu && !(h->S.tuning & MPCQP_TUNE_ONE_LAUNCH_SOLVES);
     if (!split) return launch_run(h, R, plain_iters);
     R.pending = h->pending_dev; R.npending = h->npending_dev;
     HIPCHK(hipMemsetAsync(h->npending_dev, 0, sizeof(int), h->stream));

@@ -473,7 +473,15 @@ __device__ __forceinline__ int admm_latw(const Lay &L, const HotPtrs &P, Smem &S
         cgd2 *Ft = (cgd2 *)(Fb + BcrFmt::top_off(N));
 #if LATW_TOP_VALU
         cgd2 *Fv = (cgd2 *)(Fb + BcrFmt::topv_off(N));                      // (the copy factor_bcr left in this very order: 16 bytes per thread and trip, coalesced)
-        for (int idx = tid; idx < NTOP * NTOP * 128; idx += NT) *(d2 *)(TopL + 2 * idx) = Fv[idx];
+        {   // every trip's load requested before the first store: the stores go through a generic pointer, behind which the compiler keeps the next load --
+            // thirteen dependent memory round trips (~ 12 us per kernel prologue, i.e. per queue item and per stepwise solve) instead of one
+            constexpr int PAIRS = NTOP * NTOP * 128, TRIPS = (PAIRS + NT - 1) / NT;
+            d2 buf[TRIPS];
+#pragma unroll
+            for (int t = 0; t < TRIPS; ++t) { const int idx = tid + t * NT; buf[t] = Fv[idx < PAIRS ? idx : PAIRS - 1]; }
+#pragma unroll
+            for (int t = 0; t < TRIPS; ++t) { const int idx = tid + t * NT; if (idx < PAIRS) *(d2 *)(TopL + 2 * idx) = buf[t]; }
+        }
         (void)Ft;
 #else
         for (int idx = tid; idx < NTOP * NTOP * 128; idx += NT) {           // (16 bytes per thread and trip: fragment element pairs (lane, j = 0,1 | 2,3))
