@@ -677,7 +677,7 @@ def compact_line(out):
             legs[k] = compact_leg(v)
     for k, v in (out.get('shared_model_legs') or {}).items():
         if 'error' not in v:
-            legs[k] = dict(compact_leg(v), **_pick(v, ('useful_flop_frac', 'u_err_rel')))
+            legs[k] = _pick(v, ('batch', 'value', 'own_factor_value', 'register_resident_value', 'bit_identical_to_own_factor', 'mean_admm_iters', 'useful_flop_frac'), 5)
     pr = out.get('strong_scaling_projection')
     if pr:
         legs['projection_8gpu'] = _pick(pr, ('batch_per_gpu_at_8', 'projected_8gpu_value', 'projected_vs_1gpu_full_batch', 'weak_scaling_projection_8gpu_value'))
@@ -717,6 +717,58 @@ def emit(out):
 # ----------------------------------------------------------------------------------------------------------------------
 # single-controller latency legs (BASELINE configs[1] and the reference notebook's shape)
 # ----------------------------------------------------------------------------------------------------------------------
+def shared_model_leg(args, dims, B, torch, dev, steps=40, warmup=20, chunk=20):
+    """One model, many states (test_scripts/example_mpc_function.py:105-111, SURVEY 8(e) last paragraph): B instances of ONE random model of the workload's shape,
+    set up from one common state (what one reference controller's setup() is), then scattered states and per-instance noise in the closed device loop.  The
+    bandwidth kernel with every instance streaming its own factor, the same with mpcqp_share_factor (one copy, out of L2), and the register-resident kernel."""
+    from pympc_amd.solver import BatchProblem
+    from pympc_amd import fixtures
+    NX, NU, NP, XBOX = dims
+    f64 = torch.float64
+    kw = fixtures.random_lti(0, nx=NX, nu=NU, Np=NP, xbox=XBOX)
+    Ad, Bd, x_common = (np.asarray(kw[k], dtype=float) for k in ('Ad', 'Bd', 'x0'))
+    rng = np.random.default_rng(1)
+    X0 = x_common[None, :] * rng.uniform(0.2, 1.0, size=(B, 1)) * rng.choice([-1.0, 1.0], size=(B, NX))
+    W = torch.from_numpy(0.01 * rng.standard_normal((warmup + steps, B, NX))).to(dev)
+    ones = lambda k, v: np.full((B, k), v)
+    outs = (torch.empty((chunk + 1, B, NX), dtype=f64, device=dev), torch.empty((chunk, B, NU), dtype=f64, device=dev),
+            torch.empty((chunk, B), dtype=torch.int32, device=dev), torch.empty((chunk, B), dtype=torch.int32, device=dev))
+
+    def run(backend, share):
+        prob = BatchProblem(B, NX, NU, NP, device=dev.index, stream=torch.cuda.current_stream(dev).cuda_stream, eps_abs=args.eps, eps_rel=args.eps, warm_start=1, backend=backend)
+        prob.setup(Ad, Bd, np.eye(NX), np.eye(NX), 0.1 * np.eye(NU), 0.1 * np.eye(NU), ones(NX, -XBOX), ones(NX, XBOX), ones(NU, -1.0), ones(NU, 1.0),
+                   ones(NU, -0.5), ones(NU, 0.5), ones(NU, 0.0), np.full((B, 1), 1e6), np.broadcast_to(x_common, (B, NX)), ones(NU, 0.0), np.zeros((B, NX)))
+        prob.solve_async(); prob.synchronize()
+        nshared = prob.share_factor() if share else 0
+        prob.update(X0, np.zeros((B, NU)))
+        hist = []
+        for c in range(0, warmup, chunk):
+            prob.mpc_run(chunk, w=W[c:c + chunk], out=outs); hist.append(outs[1].clone())
+        torch.cuda.synchronize()
+        prob.stats(reset=True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for c in range(warmup, warmup + steps, chunk):
+            prob.mpc_run(chunk, w=W[c:c + chunk], out=outs); hist.append(outs[1].clone())
+        e1.record(); torch.cuda.synchronize()
+        secs = 1e-3 * e0.elapsed_time(e1)
+        st = prob.stats(reset=True)
+        flops = 512.0 * prob.mfma_per_iter() * st[0]
+        r = {'batch': B, 'backend': backend, 'shared_factor': bool(share), 'instances_sharing': nshared, 'value': B * steps / secs, 'unit': 'QP-solves/s', 'ms_per_step': 1e3 * secs / steps,
+             'mean_admm_iters': st[0] / max(1, st[3]), 'refactorizations': st[2], 'kernel': prob.kernel_name(True), 'solved_fraction_last_step': float((outs[2][-1] == 1).double().mean()),
+             'mfma_issue_frac': flops / secs / MFMA_F64_PEAK, 'useful_flop_frac': 0.25 * flops / secs / MFMA_F64_PEAK}
+        prob.close()
+        return r, torch.cat(hist)
+
+    own, U0 = run('sweeps', False)
+    shr, U1 = run('sweeps', True)
+    reg, U2 = run('auto', False)
+    return dict(shr, own_factor_value=own['value'], speedup_over_own_factor=shr['value'] / own['value'], bit_identical_to_own_factor=bool(torch.equal(U0, U1)),
+                register_resident_value=reg['value'], register_resident_kernel=reg['kernel'],
+                max_abs_input_difference_to_register_resident=float((U1 - U2).abs().max()),
+                definition='device loop, %d timed steps in launches of %d after %d warm-up steps; value = the bandwidth kernel with ONE shared factor (mpcqp_share_factor)' % (steps, chunk, warmup))
+
+
 def latency_leg(kind, nsim=300):
     """One controller through the drop-in class, `MPCController.update()` per step (pyMPC/mpc.py:338-364), median microseconds;
     beside it the CPU oracle on the same loop.  kind = 'cfg2': examples/example_inverted_pendulum.py:10-69 (4,1,20);
@@ -819,6 +871,7 @@ def main():
     ap.add_argument('--eps', type=float, default=1e-3)
     ap.add_argument('--chunk', type=int, default=None, help='device loop: steps per kernel launch (default: the timed steps in equal launches of at most 50)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-shared-model-leg', action='store_true', help='skip the one-model-many-states legs (mpcqp_share_factor)')
     ap.add_argument('--no-other-path', action='store_true', help='skip the secondary measurements (other path, parity setting, strong-scaling / HBM / latency legs)')
     ap.add_argument('--no-refactor-timing', action='store_true', help='skip the timing of the factorization alone (profiling runs: its launches carry the solve kernel\'s name)')
     ap.add_argument('--path', default='device_loop', choices=['stepwise', 'device_loop'],
@@ -1006,6 +1059,14 @@ def main():
             except Exception as e:
                 extra['small_batch_legs']['bandwidth_kernel_b%d' % B] = {'error': repr(e)}
             torch.cuda.empty_cache()
+        if world == 1 and args.workload == 'cfg3' and args.path == 'device_loop' and not args.no_shared_model_leg:
+            extra['shared_model_legs'] = {}
+            for Bs in (B, 4 * B):
+                try:
+                    extra['shared_model_legs']['shared_model_b%d' % Bs] = shared_model_leg(args, dims, Bs, torch, dev)
+                except Exception as e:
+                    extra['shared_model_legs']['shared_model_b%d' % Bs] = {'error': repr(e)}
+                torch.cuda.empty_cache()
         if rank == 0 and args.workload == 'cfg3':
             try:
                 extra['latency'] = {'cfg2': latency_leg('cfg2', nsim=200), 'notebook': latency_leg('notebook', nsim=100), 'kalman_np200': latency_leg('kalman_np200', nsim=60)}

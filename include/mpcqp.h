@@ -322,6 +322,15 @@ int mpcqp_iterate(mpcqp_handle *h, int iters);
  * place: nothing observable changes.  Asynchronous on the handle's stream; bench.py times it to report what a refactorization
  * costs per instance. */
 int mpcqp_refactor(mpcqp_handle *h);
+/* One model, many states -- the caller of test_scripts/example_mpc_function.py:105-111 (10 000 random (x, u_{-1}) through ONE controller) and SURVEY 8(e)'s
+ * last paragraph (broadcast the model, scatter only x0): every instance whose factorization inputs (model, rho vector, scaling, cost scale) are bit-identical
+ * to instance 0's solves from now on with ONE shared copy of instance 0's factor instead of its own -- the streaming backends then read the factor out of
+ * L2 instead of HBM.  Call it after mpcqp_setup (same model and same x0 / u_{-1} / xref for every instance: what ONE reference controller's setup() is),
+ * then scatter the states with mpcqp_update.  Results are bit-identical to the unshared batch: the factorization is deterministic, and an instance that
+ * refactors later (a rho update, changed constraint types, mpcqp_refactor) writes its own slot and solves with that from then on.  Any setup call ends the
+ * sharing.  *nshared (may be NULL; non-NULL makes the call synchronous): instances sharing, 0 for the register-resident backends (MPCQP_BACKEND_DENSE / BCR*:
+ * they read their factor once per launch, there is nothing to share). */
+int mpcqp_share_factor(mpcqp_handle *h, int *nshared);
 
 /* The EQUALITY-constrained part of the handle's QP -- minimise 1/2 w'P w + q'w subject to the dynamics rows alone, every other row
  * ignored -- by sweeps of the method of multipliers in residual form, each one KKT solve with the handle's factor (one factorization,

@@ -603,4 +603,6 @@ int mpcqp_eq_solve(mpcqp_handle *h, int sweeps, int cold, double tol, double *re
     free(D); free(E); free(xs); free(zs); free(ys); free(xp);
     return MPCQP_OK;
 }
+/* (the CPU twin keeps one factor per instance: nothing is shared, nothing changes) */
+int mpcqp_share_factor(mpcqp_handle *h, int *nshared) { if (nshared) *nshared = 0; return h && h->is_setup ? MPCQP_OK : fail(MPCQP_ERR_STATE, "mpcqp_share_factor before mpcqp_setup"); }
 int mpcqp_refactor(mpcqp_handle *h) { return h && h->is_setup ? MPCQP_OK : fail(MPCQP_ERR_STATE, "mpcqp_refactor before mpcqp_setup"); }

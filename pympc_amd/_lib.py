@@ -16,7 +16,7 @@ SYMBOLS = [
     'mpcqp_create', 'mpcqp_destroy', 'mpcqp_set_stream', 'mpcqp_synchronize',
     'mpcqp_setup', 'mpcqp_setup_qp', 'mpcqp_create_csc', 'mpcqp_setup_csc', 'mpcqp_update', 'mpcqp_update_vectors', 'mpcqp_warm_start', 'mpcqp_update_settings', 'mpcqp_solve',
     'mpcqp_mpc_step', 'mpcqp_step_host', 'mpcqp_mpc_run', 'mpcqp_mpc_loop', 'mpcqp_get_solution', 'mpcqp_get_u0', 'mpcqp_get_shape', 'mpcqp_get_dims', 'mpcqp_get_stream_bytes', 'mpcqp_get_work', 'mpcqp_get_occupancy', 'mpcqp_kernel_name', 'mpcqp_get_stats', 'mpcqp_get_launch_times', 'mpcqp_profile',
-    'mpcqp_export_qp', 'mpcqp_get_scaling', 'mpcqp_debug_kkt_solve', 'mpcqp_get_iterate', 'mpcqp_iterate', 'mpcqp_refactor', 'mpcqp_eq_solve',
+    'mpcqp_export_qp', 'mpcqp_get_scaling', 'mpcqp_debug_kkt_solve', 'mpcqp_get_iterate', 'mpcqp_iterate', 'mpcqp_refactor', 'mpcqp_share_factor', 'mpcqp_eq_solve',
 ]
 
 
@@ -121,6 +121,7 @@ def load():
     L.mpcqp_get_iterate.argtypes = [H, C.c_void_p, C.c_void_p, C.c_void_p]
     L.mpcqp_iterate.argtypes = [H, C.c_int]
     L.mpcqp_refactor.argtypes = [H]
+    L.mpcqp_share_factor.argtypes = [H, C.POINTER(C.c_int)]
     L.mpcqp_eq_solve.argtypes = [H, C.c_int, C.c_int, C.c_double, C.c_void_p]
     for name in SYMBOLS:
         getattr(L, name)           # AttributeError here = header and library out of sync

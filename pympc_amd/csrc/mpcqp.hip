@@ -133,6 +133,7 @@ struct mpcqp_handle {
     CscSeam *csc;                        // patterns of P and A of a handle made by mpcqp_create_csc
     double *vec_buf;                     // staging of mpcqp_update_vectors' host arrays [q | l | u], allocated on first use, kept
     bool step_blank;                     // set up through mpcqp_setup_qp: the step blob holds no x0 / u_{-1} / xref yet
+    int *fown_dev; unsigned *nshared_dev;   // mpcqp_share_factor: [batch] factor slot per instance (P.fown points here while sharing is on); how many share
 };
 
 extern "C" void mpcqp_default_settings(mpcqp_settings *s) {
@@ -301,7 +302,8 @@ extern "C" int mpcqp_create(mpcqp_handle **out, int device, int batch, int nx, i
     rc |= dalloc(h, &P.model, B * L.model_sz); rc |= dalloc(h, &P.step, B * L.step_sz);
     rc |= dalloc(h, &P.D, B * L.n); rc |= dalloc(h, &P.E, B * L.m); rc |= dalloc(h, &P.c, B);
     rc |= dalloc(h, &P.omega, B * L.m); rc |= dalloc(h, &P.s, B * L.n); rc |= dalloc(h, &P.rho, B);
-    rc |= dalloc(h, &P.F, B * (size_t)P.fsz);
+    rc |= dalloc(h, &P.F, (B + 1) * (size_t)P.fsz);      // (slot B: the shared factor of mpcqp_share_factor)
+    rc |= dalloc(h, &h->fown_dev, B); rc |= dalloc(h, &h->nshared_dev, 4);
     rc |= dalloc(h, &P.x, B * L.n); rc |= dalloc(h, &P.z, B * L.m); rc |= dalloc(h, &P.y, B * L.m);
     rc |= dalloc(h, &P.xo, B * L.n); rc |= dalloc(h, &P.yo, B * L.m);
     rc |= dalloc(h, &P.dx, B * L.n); rc |= dalloc(h, &P.dy, B * L.m);
@@ -473,6 +475,7 @@ static int step_upload(mpcqp_handle *h, const double *x0, const double *um1, con
 // setup's two launches (mpcqp_phases.h): equilibration, rho vector and cold start with a lean LDS block; then the first factorization
 static int launch_setup(mpcqp_handle *h) {
     const Lay &L = h->L;
+    h->P.fown = nullptr;                            // (every instance factors into its own slot: sharing is off until mpcqp_share_factor is asked again)
     if (flush_puts(h)) return MPCQP_ERR_HIP;
     const size_t lean = sizeof(double) * (size_t)(smem_common_doubles(L) - L.tsz);      // (the work area T is carved last and not touched by k_setup)
     const size_t de = sizeof(double) * (size_t)(L.n + L.m);
@@ -881,6 +884,45 @@ extern "C" int mpcqp_refactor(mpcqp_handle *h) {
     const int rc = launch_run(h, R, 0);
     h->profiling = prof; h->solves_since_balance = since;
     return rc;
+}
+// One model, many states (test_scripts/example_mpc_function.py:105-111): instances whose factorization inputs are bit-identical to instance 0's solve with ONE
+// copy of its factor -- a streamed factor then comes out of L2 instead of HBM.  k_share_map decides per instance; results cannot change: the factorization is a
+// deterministic function of (model, rho vector, scaling, cost scale), and an instance that refactors (rho update, changed constraint types) leaves the shared
+// slot for its own before it writes.
+__global__ __launch_bounds__(NT) void k_share_map(Lay L, Ptrs P, int *fown, unsigned *nshared, int batch) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    typedef const unsigned long long cu64;
+    int diff = 0;
+    auto cmp = [&](const double *base, size_t len) {
+        cu64 *a = (cu64 *)(base + (size_t)b * len), *r = (cu64 *)base;
+        for (size_t i = tid; i < len; i += NT) diff |= a[i] != r[i];
+    };
+    cmp(P.model, L.model_sz); cmp(P.omega, L.m); cmp(P.s, L.n); cmp(P.c, 1);
+    if (P.info[b].status == MPCQP_NON_CVX && P.info[b].iter == 0) diff = 1;      // (a factorization k_setup reported bad stays where it is)
+    diff = __syncthreads_or(diff);
+    if (tid == 0) { fown[b] = diff ? b : batch; if (!diff) atomicAdd(nshared, 1u); }
+}
+extern "C" int mpcqp_share_factor(mpcqp_handle *h, int *nshared) {
+    if (!h) return fail(MPCQP_ERR_ARG, "null handle");
+    if (!h->is_setup) return fail(MPCQP_ERR_STATE, "mpcqp_share_factor before mpcqp_setup");
+    HIPCHK(hipSetDevice(h->device));
+    if (nshared) *nshared = 0;
+    h->P.fown = nullptr;
+    // the register-resident backends read their factor once per launch (nothing to gain); the shared slot holds instance 0's factor as of NOW
+    if (h->L.dense || h->L.bcr) return MPCQP_OK;
+    if (flush_puts(h)) return MPCQP_ERR_HIP;
+    HIPCHK(hipMemcpyAsync(h->P.F + (size_t)h->batch * h->P.fsz, h->P.F, sizeof(double) * (size_t)h->P.fsz, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(h->nshared_dev, 0, sizeof(unsigned), h->stream));
+    hipLaunchKernelGGL(k_share_map, dim3(h->batch), dim3(NT), 0, h->stream, h->L, h->P, h->fown_dev, h->nshared_dev, h->batch);
+    HIPCHK(hipGetLastError());
+    h->P.fown = h->fown_dev;
+    if (nshared) {
+        unsigned n = 0;
+        HIPCHK(hipMemcpyAsync(&n, h->nshared_dev, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+        *nshared = (int)n;
+    }
+    return MPCQP_OK;
 }
 extern "C" int mpcqp_iterate(mpcqp_handle *h, int iters) {
     if (!h || iters < 1) return fail(MPCQP_ERR_ARG, "mpcqp_iterate: bad argument");

@@ -33,6 +33,7 @@ __device__ __noinline__ void run_group_factor_phase(int *frame_pin) {
     const Lay &L = A.L; const Ptrs &P = A.P;
     RunSmem r = run_smem<false>(L, P);
     const int b = inst_of(P.perm);
+    factor_unshare(P, b);
     Ctx c{L, r.S.hot, P.model + (size_t)b * L.model_sz + L.hot_sz};
     factor_grouped(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], P.F + (size_t)b * P.fsz, r.S.T, r.S.iflag, border_ptrs(L, P, r.S));
 }
@@ -45,6 +46,7 @@ __device__ __noinline__ void run_factor_phase(int *frame_pin) {
     if constexpr (NB == 16 && !kLatOnly) { if (L.grp > 1) { FramePin pin; run_group_factor_phase<OCC>(&pin.v); return; } }
     RunSmem r = run_smem<false>(L, P);                       // (the common LDS area comes first in both layouts)
     const int b = inst_of(P.perm);
+    factor_unshare(P, b);
     Ctx c{L, r.S.hot, P.model + (size_t)b * L.model_sz + L.hot_sz};
     if constexpr (kLatOnly) {                                // (mpcqp_w8.hip: cyclic-reduction handles, or grouped small stages)
         if (L.bcr) factor_bcr(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], P.F + (size_t)b * P.fsz, P.bws + (size_t)b * L.bcr * BcrFmt::WSTAGE, r.S.T, r.S.iflag);
@@ -66,7 +68,7 @@ __device__ __forceinline__ int run_admm_phase_body(int iters, int iter0) {
     const Lay &L = A.L; const Ptrs &P = A.P;
     RunSmem r = run_smem<LDSSTATE>(L, P);
     HotPtrs hp; hp.model = P.model; hp.step = P.step; hp.omega = P.omega; hp.s = P.s; hp.qv = P.qv; hp.F = P.F; hp.c = P.c;
-    hp.Bb = P.Bb; hp.Zb = P.Zb; hp.Sig = P.Sig; hp.x = P.x; hp.z = P.z; hp.y = P.y; hp.dx = P.dx; hp.dy = P.dy; hp.perm = P.perm; hp.fsz = P.fsz;
+    hp.Bb = P.Bb; hp.Zb = P.Zb; hp.Sig = P.Sig; hp.x = P.x; hp.z = P.z; hp.y = P.y; hp.dx = P.dx; hp.dy = P.dy; hp.perm = P.perm; hp.fsz = P.fsz; hp.fown = P.fown;
     if constexpr (MODE >= MODE_BCRT)
         return admm_latw<NXT, NUT, MODE - MODE_BCRT>(L, hp, r.S, r.X, r.Z, r.Y, A.S.alpha, __builtin_amdgcn_readfirstlane(iters), __builtin_amdgcn_readfirstlane(iter0));
     admm_body<NB, LDSSTATE, NXT, NUT, MODE>(L, hp, r.S, r.X, r.Z, r.Y, A.S.alpha, __builtin_amdgcn_readfirstlane(iters));
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(NT) void k_kkt_solve(Lay L, Ptrs P, const double *r
     const double *model = P.model + (size_t)b * L.model_sz, *step = P.step + (size_t)b * L.step_sz;
     load_common(L, model, step, S);
     Ctx c{L, S.hot, model + L.hot_sz};
-    kkt_solve<NB>(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], P.F + (size_t)b * P.fsz, rhs + (size_t)b * L.n, S.T + L.m, sol + (size_t)b * L.n, border_ptrs(L, P, S), S.tv);
+    kkt_solve<NB>(c, P.omega + (size_t)b * L.m, P.s + (size_t)b * L.n, P.c[b], factor_of(P, b), rhs + (size_t)b * L.n, S.T + L.m, sol + (size_t)b * L.n, border_ptrs(L, P, S), S.tv);
     (void)tid;
 }
 
@@ -401,7 +403,7 @@ __global__ __launch_bounds__(NT) void k_eq_solve(Lay L, Ptrs P, int sweeps, int 
         }
         __syncthreads();
         if (sw == sweeps || settled) break;
-        kkt_solve<NB>(c, om, sv, cc, P.F + (size_t)b * P.fsz, r, S.T + L.m, d, border_ptrs(L, P, S), S.tv);
+        kkt_solve<NB>(c, om, sv, cc, factor_of(P, b), r, S.T + L.m, d, border_ptrs(L, P, S), S.tv);
         double mx[2] = {0.0, 0.0}, dsum[1] = {0.0};
         for (int j = tid; j < L.n; j += NT) { const double dj = d[j], xj = x[j] + dj; x[j] = xj; mx[0] = fmax(mx[0], fabs(dj)); mx[1] = fmax(mx[1], fabs(xj)); dsum[0] += dj; }
         block_reduce<2, 1>(mx, dsum, S.red);

@@ -58,6 +58,8 @@ struct Ptrs {
     unsigned *work;               // per instance: ADMM iterations since the map was last rebuilt
     unsigned long long *tstamp;   // per instance [TS_STRIDE]: { entry, exit, end of step 0 .. TS_STEPS-1 } of the last closed-loop launch, 100 MHz ticks (mpcqp_get_launch_times)
     long long fsz;                // factor doubles per instance
+    int *fown;                    // null, or (mpcqp_share_factor) per instance the factor slot it SOLVES with: its own (b) or the shared one (slot `batch`, a copy of
+                                  // instance 0's factor that no kernel writes); an instance that refactors writes its own slot and points itself back at it
 };
 
 // The hot kernel gets only the pointers it uses (fewer scalar registers -> no SGPR spills into vector lanes).
@@ -66,7 +68,22 @@ struct HotPtrs {
     double *x, *z, *y, *dx, *dy;
     const int *perm;
     long long fsz;
+    const int *fown;
 };
+
+// The factor an instance's KKT solves read (streaming backends): its own slot, or the shared one (Ptrs::fown).  The map entry is read past the
+// vector L1 (another workgroup may have handled the instance's previous step range of the same launch and un-shared it there).
+template <class PT>
+__device__ __forceinline__ const double *factor_of(const PT &P, int b) {
+    long long slot = b;
+    if (P.fown) slot = __builtin_amdgcn_readfirstlane(__hip_atomic_load(P.fown + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    return P.F + (size_t)slot * P.fsz;
+}
+// An instance that is about to rewrite its factor (rho update, changed constraint types, mpcqp_refactor) solves with its own slot from then on.
+template <class PT>
+__device__ __forceinline__ void factor_unshare(const PT &P, int b) {
+    if (P.fown && threadIdx.x == 0) { __hip_atomic_store(P.fown + b, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __threadfence(); }
+}
 
 // The instance this workgroup works on.  (Which workgroup handles which instance never changes a result; the map
 // only decides which instances share a CU.)

@@ -1096,7 +1096,7 @@ __device__ __forceinline__ void admm_round_global(const Lay &L, const HotPtrs &P
     __syncthreads();
     cptr *gom = (cptr *)omp, *gsv = (cptr *)svp, *gqv = (cptr *)qvp;
     gdouble *dxg = (gdouble *)(P.dx + (size_t)b * L.n), *dyg = (gdouble *)(P.dy + (size_t)b * L.m);
-    const double *F = P.F + (size_t)b * P.fsz;
+    const double *F = factor_of(P, b);
     const double cc = P.c[b];
 #ifndef MPCQP_ABL_NOPAR
     gown_rows_w<NB, INL>(L, gom, cc, Z, Y, W, Tc);
@@ -1151,7 +1151,7 @@ __device__ __forceinline__ void admm_body(const Lay &L, const HotPtrs &P, Smem &
     __syncthreads();
     cgdouble *gom = (cgdouble *)(P.omega + (size_t)b * L.m), *gsv = (cgdouble *)(P.s + (size_t)b * L.n), *gqv = (cgdouble *)S.Qv;
     gdouble *dxg = (gdouble *)(P.dx + (size_t)b * L.n), *dyg = (gdouble *)(P.dy + (size_t)b * L.m);
-    const double *F = P.F + (size_t)b * P.fsz;
+    const double *F = factor_of(P, b);
     const double cc = P.c[b];
     constexpr bool BORDER = MODE == MODE_BORDER;
     OwnRegs hr;

@@ -511,6 +511,15 @@ class BatchProblem:
         _lib.check(self._L.mpcqp_eq_solve(self._h, int(sweeps), int(bool(cold)), float(tol), _ptr(res)), 'mpcqp_eq_solve')
         return res
 
+    def share_factor(self):
+        """One model, many states (test_scripts/example_mpc_function.py:105-111): every instance whose factorization inputs are bit-identical to
+        instance 0's solves with ONE shared copy of its factor from now on (mpcqp_share_factor) -- call after ``setup`` with the same model and step
+        data for every instance, then scatter the states with ``update``.  Results do not change.  Returns the number of instances sharing
+        (0 for the register-resident backends)."""
+        n = C.c_int(0)
+        _lib.check(self._L.mpcqp_share_factor(self._h, C.byref(n)), 'mpcqp_share_factor')
+        return int(n.value)
+
     def refactor(self):
         """Recompute every instance's KKT factor from its current rho (asynchronous; what one rho update costs)."""
         _lib.check(self._L.mpcqp_refactor(self._h), 'mpcqp_refactor')

@@ -1,3 +1,5 @@
 cd $GRAFT_REPO_ROOT
-run() { python bench.py --path stepwise --steps 40 --warmup 20 --tuning $1 --no-other-path --no-cpu-baseline 2>/dev/null | tail -n 1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); r=d['roofline']; print('stepwise tuning', hex($1), 'value', int(d['value']), 'ms/step', d['ms_per_step'], 'kernel_ms', r.get('kernel_ms'), 'launches', r.get('launches'), 'iters', d.get('mean_admm_iters'))"; }
-run 0; run $(((1<<29)|16)); run 0; run $(((1<<29)|16))
+timeout 900 python -m pytest tests/test_gpu_share_factor.py -q 2>&1 | grep -v "amdgpu.ids" | tail -15
+timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_sm.log 2> gpurun_out/bench_sm.err; tail -n 1 gpurun_out/bench_sm.log | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print(len(json.dumps(d)), d['value'], d['roofline']['frac'], {k:v for k,v in d['legs'].items() if 'shared' in k})"
+tail -3 gpurun_out/bench_sm.err
