@@ -86,6 +86,12 @@ class BatchMPCController:
         if solve:
             self.solve()
 
+    def share_factor(self):
+        """One model, many states (test_scripts/example_mpc_function.py:105-111): after ``setup()`` of a batch whose instances all carry the same model, every
+        instance whose factorization inputs equal instance 0's solves with ONE shared copy of its KKT factor (``mpcqp_share_factor``); scatter the states with
+        ``update()`` afterwards.  Results do not change; returns how many instances share (0 on the register-resident backends)."""
+        return self.prob.share_factor()
+
     def update(self, x, u=None, xref=None, solve=True):
         self.x0_rh = x
         if u is not None:
