@@ -722,7 +722,7 @@ def shared_model_leg(args, dims, B, torch, dev, steps=40, warmup=20, chunk=20):
     set up from one common state (what one reference controller's setup() is), then scattered states and per-instance noise in the closed device loop.  The
     bandwidth kernel with every instance streaming its own factor, the same with mpcqp_share_factor (one copy, out of L2), and the register-resident kernel."""
     from pympc_amd.solver import BatchProblem
-    from pympc_amd import fixtures
+    from pympc_amd import fixtures, _lib
     NX, NU, NP, XBOX = dims
     f64 = torch.float64
     kw = fixtures.random_lti(0, nx=NX, nu=NU, Np=NP, xbox=XBOX)
@@ -735,7 +735,8 @@ def shared_model_leg(args, dims, B, torch, dev, steps=40, warmup=20, chunk=20):
             torch.empty((chunk, B), dtype=torch.int32, device=dev), torch.empty((chunk, B), dtype=torch.int32, device=dev))
 
     def run(backend, share):
-        prob = BatchProblem(B, NX, NU, NP, device=dev.index, stream=torch.cuda.current_stream(dev).cuda_stream, eps_abs=args.eps, eps_rel=args.eps, warm_start=1, backend=backend)
+        prob = BatchProblem(B, NX, NU, NP, device=dev.index, stream=torch.cuda.current_stream(dev).cuda_stream, eps_abs=args.eps, eps_rel=args.eps, warm_start=1, backend=backend,
+                            tuning=0 if share else _lib.TUNE_NO_SHARE)      # (setup shares by itself unless told not to)
         prob.setup(Ad, Bd, np.eye(NX), np.eye(NX), 0.1 * np.eye(NU), 0.1 * np.eye(NU), ones(NX, -XBOX), ones(NX, XBOX), ones(NU, -1.0), ones(NU, 1.0),
                    ones(NU, -0.5), ones(NU, 0.5), ones(NU, 0.0), np.full((B, 1), 1e6), np.broadcast_to(x_common, (B, NX)), ones(NU, 0.0), np.zeros((B, NX)))
         prob.solve_async(); prob.synchronize()

@@ -96,6 +96,7 @@ enum mpcqp_tuning {
     MPCQP_TUNE_QUEUE_SOLVES = 64, /* development: persistent launches for single solves (mpcqp_solve) too, not only for the closed loop */
     MPCQP_TUNE_EVEN_PARTS = 128, /* development: persistent closed-loop launches cut an instance's steps into EQUAL parts (default: decreasing) */
     MPCQP_TUNE_ONE_LAUNCH_SOLVES = 1 << 29, /* development: a solve of more instances than resident slots as ONE persistent launch (instances off the queue, longest expected work first, each run to its end) instead of two launches (one round for everybody, then the unfinished ones re-dealt) */
+    MPCQP_TUNE_NO_SHARE = 1 << 30, /* every instance solves with its own factor even where mpcqp_setup finds instances identical to instance 0 (mpcqp_share_factor; measurement switch: results are the same either way) */
     MPCQP_TUNE_SLOTS_SHIFT = 24, /* development: tuning bits 24..28 = resident workgroup slots of a persistent closed-loop launch in eighths of a workgroup per compute unit (8 = one per unit); 0 = the library's choice */
     MPCQP_TUNE_PACE_SHIFT = 8   /* development: tuning bits 8..15 = pacing units (x 3.5 us idled per ADMM iteration by the instances of a fully resident launch of the bandwidth kernels that are not expected to straggle); 0 = off */
 };
@@ -324,12 +325,13 @@ int mpcqp_iterate(mpcqp_handle *h, int iters);
 int mpcqp_refactor(mpcqp_handle *h);
 /* One model, many states -- the caller of test_scripts/example_mpc_function.py:105-111 (10 000 random (x, u_{-1}) through ONE controller) and SURVEY 8(e)'s
  * last paragraph (broadcast the model, scatter only x0): every instance whose factorization inputs (model, rho vector, scaling, cost scale) are bit-identical
- * to instance 0's solves from now on with ONE shared copy of instance 0's factor instead of its own -- the streaming backends then read the factor out of
- * L2 instead of HBM.  Call it after mpcqp_setup (same model and same x0 / u_{-1} / xref for every instance: what ONE reference controller's setup() is),
- * then scatter the states with mpcqp_update.  Results are bit-identical to the unshared batch: the factorization is deterministic, and an instance that
- * refactors later (a rho update, changed constraint types, mpcqp_refactor) writes its own slot and solves with that from then on.  Any setup call ends the
- * sharing.  *nshared (may be NULL; non-NULL makes the call synchronous): instances sharing, 0 for the register-resident backends (MPCQP_BACKEND_DENSE / BCR*:
- * they read their factor once per launch, there is nothing to share). */
+ * to instance 0's solves with ONE shared copy of instance 0's factor instead of its own -- the streaming backends then read the factor out of L2 instead of
+ * HBM.  Every setup call does this by itself (one map kernel; mpcqp_settings.tuning & MPCQP_TUNE_NO_SHARE: not): a batch set up with the same model and the
+ * same x0 / u_{-1} / xref in every instance -- what ONE reference controller's setup() is -- shares from the start, and mpcqp_update then scatters the states.
+ * Results are bit-identical to the unshared batch: the factorization is deterministic, and an instance that refactors later (a rho update, changed
+ * constraint types, mpcqp_refactor) writes its own slot and solves with that from then on.  This call rebuilds the map against instance 0's factor as of
+ * NOW (e.g. after the whole batch has adapted rho the same way) and reports it.  *nshared (may be NULL; non-NULL makes the call synchronous): instances
+ * sharing, 0 for the register-resident backends (MPCQP_BACKEND_DENSE / BCR*: they read their factor once per launch, there is nothing to share). */
 int mpcqp_share_factor(mpcqp_handle *h, int *nshared);
 
 /* The EQUALITY-constrained part of the handle's QP -- minimise 1/2 w'P w + q'w subject to the dynamics rows alone, every other row

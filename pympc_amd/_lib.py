@@ -33,6 +33,7 @@ class Settings(C.Structure):
 # enum mpcqp_backend / mpcqp_tuning of include/mpcqp.h
 BACKEND_AUTO, BACKEND_SWEEPS, BACKEND_DENSE, BACKEND_BCR, BACKEND_BCR8, BACKEND_BCRT = 0, 1, 2, 3, 4, 5
 TUNE_NO_BALANCE, TUNE_NO_LSTAGE, TUNE_NO_GROUPING, TUNE_NO_W8, TUNE_NO_QUEUE, TUNE_NO_PARTS = 1, 2, 4, 8, 16, 32
+TUNE_NO_SHARE = 1 << 30    # every instance keeps to its own factor (mpcqp_share_factor)
 TUNE_PACE_SHIFT = 8        # development: tuning bits 8..15 = pacing units (include/mpcqp.h)
 
 

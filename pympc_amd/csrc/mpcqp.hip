@@ -472,6 +472,7 @@ static int step_upload(mpcqp_handle *h, const double *x0, const double *um1, con
     return flush_puts(h) ? MPCQP_ERR_HIP : 0;
 }
 
+static int share_factor_async(mpcqp_handle *h);
 // setup's two launches (mpcqp_phases.h): equilibration, rho vector and cold start with a lean LDS block; then the first factorization
 static int launch_setup(mpcqp_handle *h) {
     const Lay &L = h->L;
@@ -495,6 +496,9 @@ static int launch_setup(mpcqp_handle *h) {
         });
     }
     HIPCHK(hipGetLastError());
+    // a batch of copies of ONE controller (the reference's one-model-many-states caller) is detected here: instances whose factorization inputs equal
+    // instance 0's share one copy of its factor from the start (mpcqp_share_factor says what that means; one map kernel and a 0.5 MB copy per setup)
+    if (h->batch > 1 && !(h->S.tuning & MPCQP_TUNE_NO_SHARE)) return share_factor_async(h);
     return MPCQP_OK;
 }
 
@@ -902,11 +906,7 @@ __global__ __launch_bounds__(NT) void k_share_map(Lay L, Ptrs P, int *fown, unsi
     diff = __syncthreads_or(diff);
     if (tid == 0) { fown[b] = diff ? b : batch; if (!diff) atomicAdd(nshared, 1u); }
 }
-extern "C" int mpcqp_share_factor(mpcqp_handle *h, int *nshared) {
-    if (!h) return fail(MPCQP_ERR_ARG, "null handle");
-    if (!h->is_setup) return fail(MPCQP_ERR_STATE, "mpcqp_share_factor before mpcqp_setup");
-    HIPCHK(hipSetDevice(h->device));
-    if (nshared) *nshared = 0;
+static int share_factor_async(mpcqp_handle *h) {
     h->P.fown = nullptr;
     // the register-resident backends read their factor once per launch (nothing to gain); the shared slot holds instance 0's factor as of NOW
     if (h->L.dense || h->L.bcr) return MPCQP_OK;
@@ -916,7 +916,16 @@ extern "C" int mpcqp_share_factor(mpcqp_handle *h, int *nshared) {
     hipLaunchKernelGGL(k_share_map, dim3(h->batch), dim3(NT), 0, h->stream, h->L, h->P, h->fown_dev, h->nshared_dev, h->batch);
     HIPCHK(hipGetLastError());
     h->P.fown = h->fown_dev;
-    if (nshared) {
+    return MPCQP_OK;
+}
+extern "C" int mpcqp_share_factor(mpcqp_handle *h, int *nshared) {
+    if (!h) return fail(MPCQP_ERR_ARG, "null handle");
+    if (!h->is_setup) return fail(MPCQP_ERR_STATE, "mpcqp_share_factor before mpcqp_setup");
+    HIPCHK(hipSetDevice(h->device));
+    if (nshared) *nshared = 0;
+    const int rc = share_factor_async(h);
+    if (rc) return rc;
+    if (nshared && h->P.fown) {
         unsigned n = 0;
         HIPCHK(hipMemcpyAsync(&n, h->nshared_dev, sizeof(unsigned), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));

@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def run(args, B, backend, share, torch, dev):
     from pympc_amd.solver import BatchProblem
-    from pympc_amd import fixtures
+    from pympc_amd import fixtures, _lib
     NX, NU, NP, XBOX = args.nx, args.nu, args.np, args.xbox
     f64 = torch.float64
     kw = fixtures.random_lti(args.seed, nx=NX, nu=NU, Np=NP, xbox=XBOX)
@@ -23,7 +23,8 @@ def run(args, B, backend, share, torch, dev):
     X0 = x_common[None, :] * rng.uniform(0.2, 1.0, size=(B, 1)) * rng.choice([-1.0, 1.0], size=(B, NX))      # scattered states
     W = torch.from_numpy(0.01 * rng.standard_normal((args.warmup + args.steps, B, NX))).to(dev)
     stream = torch.cuda.current_stream(dev)
-    prob = BatchProblem(B, NX, NU, NP, device=dev.index, stream=stream.cuda_stream, eps_abs=args.eps, eps_rel=args.eps, warm_start=1, backend=backend)
+    prob = BatchProblem(B, NX, NU, NP, device=dev.index, stream=stream.cuda_stream, eps_abs=args.eps, eps_rel=args.eps, warm_start=1, backend=backend,
+                        tuning=0 if share else _lib.TUNE_NO_SHARE)      # (setup shares by itself unless told not to)
     ones = lambda k, s: np.full((B, k), s)
     prob.setup(Ad, Bd, np.eye(NX), np.eye(NX), 0.1 * np.eye(NU), 0.1 * np.eye(NU), ones(NX, -XBOX), ones(NX, XBOX), ones(NU, -1.0), ones(NU, 1.0),
                ones(NU, -0.5), ones(NU, 0.5), ones(NU, 0.0), np.full((B, 1), 1e6), np.broadcast_to(x_common, (B, NX)), ones(NU, 0.0), np.zeros((B, NX)))

@@ -1,10 +1,12 @@
-"""mpcqp_share_factor: one model, many states (test_scripts/example_mpc_function.py:105-111; SURVEY 8(e): broadcast the model, scatter only x0).  Instances
+"""mpcqp_share_factor / the map every setup builds: one model, many states (test_scripts/example_mpc_function.py:105-111; SURVEY 8(e): broadcast the model, scatter only x0).  Instances
 whose factorization inputs equal instance 0's solve with ONE shared copy of its factor.  Sharing must not change a single bit of any result -- not when an
 instance adapts rho in the middle of a launch and leaves the shared slot, not in the closed loop -- and it must not share what is not identical."""
 import warnings
 
 import numpy as np
 import pytest
+
+from pympc_amd import _lib
 
 pytestmark = pytest.mark.gpu
 
@@ -48,10 +50,11 @@ def test_shared_factor_changes_no_bit(shape):
     for share in (False, True):
         with warnings.catch_warnings():
             warnings.simplefilter('ignore')
-            prob = _setup(B, kw, 'sweeps', eps_abs=1e-8, eps_rel=1e-8, max_iter=20000)      # (tight: solves long enough for OSQP's rho adaptation to act)
+            # (tight: solves long enough for OSQP's rho adaptation to act; setup shares by itself unless told not to)
+            prob = _setup(B, kw, 'sweeps', eps_abs=1e-8, eps_rel=1e-8, max_iter=20000, tuning=0 if share else _lib.TUNE_NO_SHARE)
             prob.solve_async(); prob.synchronize()
             if share:
-                assert prob.share_factor() == B
+                assert prob.share_factor() == B                  # (the map again, against instance 0's factor after the cold solve: identical instances adapted alike)
             res.append(_walk(prob, X0, W, 12))
             prob.close()
     (a, sa), (b, sb) = res
@@ -72,18 +75,18 @@ def test_only_identical_instances_share_and_setup_ends_it():
     Bd[5, 0, 0] = np.nextafter(Bd[5, 0, 0], 10.0)                # one ulp in the model: not the same factorization any more
     x0[9] *= 0.5                                                 # the state at setup enters the bounds only, not the factor: instance 9 shares
 
-    def make():
-        prob = BatchProblem(B, 12, 4, kw['Np'], backend='sweeps', warm_start=1)
+    def make(tuning=0):
+        prob = BatchProblem(B, 12, 4, kw['Np'], backend='sweeps', warm_start=1, tuning=tuning)
         prob.setup(bc(kw['Ad']), Bd, bc(kw['Qx']), bc(kw['QxN']), bc(kw['Qu']), bc(kw['QDu']), bc(kw['xmin']), bc(kw['xmax']), bc(kw['umin']),
                    bc(kw['umax']), bc(kw['Dumin']), bc(kw['Dumax']), bc(kw['uref']), np.full((B, 1), kw['eps_feas']), x0, bc(kw['uminus1']), bc(kw['xref']))
         return prob
 
-    prob, ref = make(), make()
+    prob, ref = make(), make(_lib.TUNE_NO_SHARE)
     assert prob.share_factor() == B - 1
     for p in (prob, ref):
         p.solve_async(); p.synchronize()
     assert np.array_equal(prob.solution()[0], ref.solution()[0])
-    # any setup call ends the sharing (every instance factors into its own slot again); asking again shares again
+    # every setup call factors every instance into its own slot and builds the map anew
     prob.setup(bc(kw['Ad']), bc(kw['Bd']), bc(kw['Qx']), bc(kw['QxN']), bc(kw['Qu']), bc(kw['QDu']), bc(kw['xmin']), bc(kw['xmax']), bc(kw['umin']),
                bc(kw['umax']), bc(kw['Dumin']), bc(kw['Dumax']), bc(kw['uref']), np.full((B, 1), kw['eps_feas']), x0, bc(kw['uminus1']), bc(kw['xref']))
     assert prob.share_factor() == B
