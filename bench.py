@@ -264,11 +264,23 @@ class Shard:
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        loc = sharding.scatter_instances(full, {'Ad': (NX, NX), 'Bd': (NX, NU), 'x0': (NX,)}, None, dev, total=total)      # one packed collective
+        self.shared = bool(getattr(args, 'shared_model', False))
+        if self.shared:
+            # ONE model for every instance of every rank (last paragraph; test_scripts/example_mpc_function.py:105-111): the first instance's model and
+            # state are broadcast once, the states alone are scattered; every rank sets its shard up as copies of that ONE controller (its instances then
+            # share one KKT factor, mpcqp_share_factor) and update() scatters the states
+            mdl = sharding.broadcast_model({k: full[k][0] for k in ('Ad', 'Bd', 'x0')} if rank == 0 else None, {'Ad': (NX, NX), 'Bd': (NX, NU), 'x0': (NX,)}, dev)
+            loc = sharding.scatter_instances({'x0': full['x0']} if rank == 0 else None, {'x0': (NX,)}, None, dev, total=total)
+            loc['Ad'], loc['Bd'] = mdl['Ad'].expand(B, NX, NX).contiguous(), mdl['Bd'].expand(B, NX, NU).contiguous()
+            x_setup = mdl['x0'].expand(B, NX).contiguous()
+        else:
+            loc = sharding.scatter_instances(full, {'Ad': (NX, NX), 'Bd': (NX, NU), 'x0': (NX,)}, None, dev, total=total)      # one packed collective
         torch.cuda.synchronize()
         self.scatter_ms = 1e3 * (time.perf_counter() - t0)
         self.gather_ms, self.gathers = 0.0, 0
         self.Ad, self.Bd, self.x = loc['Ad'], loc['Bd'], loc['x0'].clone()
+        if not self.shared:
+            x_setup = self.x
         stream = torch.cuda.current_stream(dev)
         self.prob = prob = BatchProblem(B, NX, NU, NP, device=dev.index, stream=stream.cuda_stream,
                                         eps_abs=args.eps, eps_rel=args.eps, warm_start=1)
@@ -279,7 +291,7 @@ class Shard:
         setup_args = (self.Ad, self.Bd, eye(NX, 1.0), eye(NX, 1.0), eye(NU, 0.1), eye(NU, 0.1),
                       ones(NX, -XBOX), ones(NX, XBOX), ones(NU, -1.0), ones(NU, 1.0), ones(NU, -0.5), ones(NU, 0.5),
                       ones(NU, 0.0), torch.full((B, 1), 1e6, dtype=f64, device=dev),
-                      self.x, ones(NU, 0.0), torch.zeros((B, NX), dtype=f64, device=dev))      # (built first: torch's fill kernels load lazily, ~100 ms the first time)
+                      x_setup, ones(NU, 0.0), torch.zeros((B, NX), dtype=f64, device=dev))      # (built first: torch's fill kernels load lazily, ~100 ms the first time)
         torch.cuda.synchronize()
         ev[0].record()
         prob.setup(*setup_args)
@@ -300,6 +312,13 @@ class Shard:
         ev2[2].record()
         torch.cuda.synchronize()
         st2 = prob.stats(reset=True)
+        self.instances_sharing = None
+        if self.shared:
+            self.instances_sharing = prob.share_factor()      # (setup has built the map already; this reports it)
+            prob.update(self.x, ones(NU, 0.0))                # the scattered states
+            prob.solve_async()
+            prob.u0(out=self.u)
+            torch.cuda.synchronize()
         self.cold = dict(setup_ms=ev[0].elapsed_time(ev[1]), first_solve_ms=ev[1].elapsed_time(ev[2]),
                          setup_ms_repeat=ev2[0].elapsed_time(ev2[1]), first_solve_ms_repeat=ev2[1].elapsed_time(ev2[2]), repeat_same_iterations=bool(st2[0] == st[0]),
                          iters_per_instance=st[0] / B, refactorizations_per_instance=st[2] / B, instances=B,
@@ -524,6 +543,12 @@ class Shard:
         iters, checks, solves = res['iters'], res['checks'], res['solves']
         admm_ms, launches = res['run_ms'], max(1, res['launches'])
         per_iter, per_round, per_solve = prob.stream_bytes()
+        shared_frac = (self.instances_sharing or 0) / self.B if getattr(self, 'shared', False) else 0.0
+        if shared_frac:
+            # copies of ONE controller on a shared factor (mpcqp_share_factor): the factor stream of the sharing instances is ONE 8 * factor_doubles block that stays
+            # in L2 -- not memory traffic, and no committed counter profile is of this command (profiles/r6_shared_factor_fetch.txt: 312 -> 9.4 GB per launch)
+            per_iter = max(0, per_iter - int(shared_frac * 8 * prob.factor_doubles))
+            workload_key = None
         design_bytes = iters * per_iter + checks * per_round + solves * per_solve
         achieved = design_bytes / (admm_ms * 1e-3)
         alg8d, b_it8d = algorithmic_bytes_8d(self.dims, prob.n, prob.m, prob.nnzL, iters, checks, solves)
@@ -555,7 +580,7 @@ class Shard:
                   'traffic_profile': ('profiles/pmc_hbm_traffic.json:%s/%s (batch %s)' % (workload_key, path, pmc_batch if pmc_batch is not None else self.B)) if pmc_b else None,
                   'design_bytes_per_iter_per_qp': per_iter, 'design_bytes_per_round_per_qp': per_round, 'design_bytes_per_solve_per_qp': per_solve,
                   'working_set_bytes': ws, 'active_working_set_bytes': ws_active, 'fits_infinity_cache': bool(ws_active <= INFINITY_CACHE),
-                  'resident_slots': slots, 'compute_units': ncu, 'check_every': check_every}
+                  'resident_slots': slots, 'compute_units': ncu, 'check_every': check_every, 'shared_factor_fraction': shared_frac or None}
         if mode >= 100:
             # the register-resident backends (one workgroup per CU at a time): factor and iterate live in registers and LDS, an ADMM iteration reads
             # nothing from memory; what the kernel moves is per round (level fragments, owner values, check inputs) and per solve.  `frac` is those
@@ -648,7 +673,7 @@ def compact_line(out):
     if ue:
         line['u_err'] = {k: _pick(v, ('max_abs', 'max_rel', 'instances'), 4) for k, v in ue.items() if isinstance(v, dict)}
         line['u_err']['tolerance_rel'] = ue.get('north_star_tolerance_rel', 1e-6)
-    line['per_rank'] = [_pick(r, ('rank', 'instances', 'first_instance', 'value', 'ms_per_step', 'roofline_frac', 'kernel_ms', 'scatter_ms', 'gather_calls', 'gather_ms_per_call'), 5)
+    line['per_rank'] = [_pick(r, ('rank', 'instances', 'first_instance', 'value', 'ms_per_step', 'roofline_frac', 'kernel_ms', 'scatter_ms', 'gather_calls', 'gather_ms_per_call', 'instances_sharing_factor'), 5)
                         for r in (out.get('per_rank') or [])]
     line['cold'] = _pick(out.get('cold') or {}, ('setup_ms', 'first_solve_ms', 'setup_ms_repeat', 'first_solve_ms_repeat', 'iters_per_instance'), 4)
     legs = {}
@@ -872,6 +897,8 @@ def main():
     ap.add_argument('--eps', type=float, default=1e-3)
     ap.add_argument('--chunk', type=int, default=None, help='device loop: steps per kernel launch (default: the timed steps in equal launches of at most 50)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--shared-model', action='store_true', help='every instance (on every rank) is a copy of ONE controller -- the first instance\'s model, broadcast once -- and only the states are scattered '
+                                                                '(test_scripts/example_mpc_function.py:105-111, SURVEY 8e last paragraph); implies --no-cpu-baseline')
     ap.add_argument('--no-shared-model-leg', action='store_true', help='skip the one-model-many-states legs (mpcqp_share_factor)')
     ap.add_argument('--no-other-path', action='store_true', help='skip the secondary measurements (other path, parity setting, strong-scaling / HBM / latency legs)')
     ap.add_argument('--no-refactor-timing', action='store_true', help='skip the timing of the factorization alone (profiling runs: its launches carry the solve kernel\'s name)')
@@ -888,6 +915,8 @@ def main():
     ap.add_argument('--tuning', type=int, default=None, help='mpcqp_settings.tuning for the headline shard (development: switch a mechanism off, see enum mpcqp_tuning)')
     ap.add_argument('--dry-run', action='store_true', help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.shared_model:
+        args.no_cpu_baseline = args.no_other_path = True      # (the CPU legs and the u* references rebuild instance i's OWN model from its seed)
     self_launch_if_needed(args)
 
     import torch
@@ -919,7 +948,7 @@ def main():
     elapsed, iters, refacts, solves = res['elapsed'], res['iters'], res['refacts'], res['solves']
     infos = prob.infos()
     n_solved = sum(1 for i in infos if i.status == 1)
-    samples = [dict(sh.sample_point(), eps=args.eps)]
+    samples = [] if args.shared_model else [dict(sh.sample_point(), eps=args.eps)]
     other = None
     if not args.no_other_path:
         oname = 'stepwise' if args.path == 'device_loop' else 'device_loop'
@@ -946,7 +975,7 @@ def main():
     # and what the two exchanges cost it -- the scatter of the problem data (one packed collective at setup) and the all-gathers of u*
     mine = {'rank': rank, 'instances': B, 'first_instance': sh.first_local, 'value': B * args.steps / res['elapsed_local'], 'ms_per_step': 1e3 * res['elapsed_local'] / args.steps,
             'roofline_bound': roof_local['bound'], 'roofline_frac': roof_local['frac'], 'kernel': roof_local['kernel'], 'kernel_ms': roof_local['kernel_ms'],
-            'scatter_ms': sh.scatter_ms, 'gather_calls': sh.gathers, 'gather_ms_per_call': (sh.gather_ms / sh.gathers) if sh.gathers else None}
+            'instances_sharing_factor': sh.instances_sharing, 'scatter_ms': sh.scatter_ms, 'gather_calls': sh.gathers, 'gather_ms_per_call': (sh.gather_ms / sh.gathers) if sh.gathers else None}
     per_rank = [mine]
     if comm_on(world):
         per_rank = [None] * world
@@ -1084,7 +1113,8 @@ def main():
             'higher_is_better': True, 'scaling': scaling, 'vs_baseline': None,
             'dtype': 'f64', 'data': 'synthetic',
             'ranks_seen': seen['ranks_seen'], 'devices_seen': seen['devices_seen'], 'collective_backend': seen['backend'],
-            'config': {'workload': '%s: %d x (nx=%d, nu=%d, Np=Nc=%d) random stable LTI MPC instances per GPU, warm-started receding horizon'
+            'config': {'workload': ('%s: %d copies per GPU of ONE (nx=%d, nu=%d, Np=Nc=%d) random stable LTI MPC controller, states scattered, warm-started receding horizon' if args.shared_model else
+                                    '%s: %d x (nx=%d, nu=%d, Np=Nc=%d) random stable LTI MPC instances per GPU, warm-started receding horizon')
                                    % ('cfg-3' if args.workload == 'cfg3' else 'cfg-5', B, NX, NU, NP),
                        'nx': NX, 'nu': NU, 'Np': NP, 'n': n, 'm': m,
                        'batch_per_gpu': B, 'total_batch': TOTAL, 'eps_abs': args.eps, 'eps_rel': args.eps, 'path': args.path,

@@ -5,6 +5,10 @@ The instances are independent (no coupling, no reduction -- SURVEY.md section 8e
 Collectives (RCCL on GPUs, gloo in the CPU tests) are used only where the path has a real exchange:
   * ``scatter_instances``: the problem data (Ad, Bd, x0, ...) is generated on rank 0, PACKED into one [world*per, width] buffer and
                            scattered once, at setup -- ONE collective whatever the number of arrays (17 per-array scatters before);
+  * ``broadcast_model``:   ONE model for every instance of every rank (last paragraph: instances that share (Ad, Bd, Q*, bounds) and differ only in
+                           x0 -- the reference's one-controller-many-states caller, test_scripts/example_mpc_function.py:105-111): the model is packed and
+                           broadcast once, ``scatter_instances`` then carries the states alone; set up with the model and ONE common state on every
+                           rank, the shard's instances share one KKT factor (mpcqp_share_factor), and ``update`` scatters the states;
   * ``gather_inputs``:     the first optimal inputs u* of every shard are all-gathered after each solve;
   * ``gather_trajectory``: the applied inputs of a whole device-loop launch are all-gathered at once.
 Short shards are padded to ``per`` rows for the collectives (all_gather_into_tensor wants equal pieces) and trimmed afterwards.
@@ -64,6 +68,24 @@ def scatter_instances(full, shapes, per_rank=None, device=None, dtype=torch.floa
     out, off = {}, 0
     for k, w in zip(names, widths):
         out[k] = loc[:hi - lo, off:off + w].reshape((hi - lo,) + tuple(shapes[k])).contiguous()
+        off += w
+    return out
+
+
+def broadcast_model(model, shapes, device=None, dtype=torch.float64, src=0):
+    """``model``: dict name -> tensor of shape ``shapes[name]`` on rank ``src`` (None elsewhere).  Returns the same dict on every rank: ONE
+    ``dist.broadcast`` of a packed buffer whatever the number of arrays."""
+    rank, _ = world()
+    names = list(shapes)
+    widths = [int(math.prod(shapes[k])) if len(tuple(shapes[k])) else 1 for k in names]
+    buf = torch.empty((sum(widths),), dtype=dtype, device=device)
+    if _no_group() or rank == src:
+        buf.copy_(torch.cat([torch.as_tensor(model[k]).to(device=device, dtype=dtype).reshape(-1) for k in names]))
+    if not _no_group():
+        dist.broadcast(buf, src=src)
+    out, off = {}, 0
+    for k, w in zip(names, widths):
+        out[k] = buf[off:off + w].reshape(tuple(shapes[k])).clone()
         off += w
     return out
 

@@ -1,3 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 300 python -m pytest tests/test_gpu_share_factor.py -q 2>&1 | grep -v "amdgpu.ids" | tail -5
-bash scripts/shared_factor_fetch.sh 4096
+timeout 900 python -m pytest tests/test_gpu_rccl_single_rank.py -q -x 2>&1 | grep -v "amdgpu.ids" | tail -15
+timeout 300 python bench.py --shared-model --backend sweeps --batch 4096 --steps 40 --warmup 20 | tail -n 1 | cut -c1-1500

@@ -37,3 +37,14 @@ def test_single_rank_rccl_group_runs_and_changes_nothing(path):
     assert forced['value'] > 0 and forced['steps'] == 4
     # the same seeded workload with and without the process group: the same ADMM work, iteration for iteration
     assert forced['mean_admm_iters'] == plain['mean_admm_iters']
+
+
+@pytest.mark.timeout(600)
+def test_shared_model_broadcast_over_rccl_with_a_communicator_of_one():
+    """bench.py --shared-model: ONE controller broadcast (sharding.broadcast_model: a packed RCCL broadcast), the states alone scattered, every instance of the
+    shard on one shared KKT factor -- and the same ADMM work with and without the process group."""
+    forced, plain = _bench(True, '--shared-model', '--backend', 'sweeps'), _bench(False, '--shared-model', '--backend', 'sweeps')
+    assert forced['collective_backend'] == 'nccl' and plain.get('collective_backend') is None
+    assert forced['per_rank'][0]['instances_sharing_factor'] == 64 == plain['per_rank'][0]['instances_sharing_factor']
+    assert forced['mean_admm_iters'] == plain['mean_admm_iters'] and forced['solved_fraction_last_step'] == 1.0
+    assert 'ONE' in forced['config']['workload']

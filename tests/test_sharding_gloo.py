@@ -128,3 +128,53 @@ def test_packed_scatter_and_padded_gathers_with_a_short_last_rank_world3():
     full = _make(total)
     ref = (full['x0'][:, :3] + full['Ad'][:, 0, :3] * 2.0 + full['Bd'][:, 4, :]).numpy()
     assert np.array_equal(got, ref)
+
+
+def _worker_shared(rank, world_size, port, total, q):
+    """One model, many states over the ranks (last paragraph): broadcast the model once, scatter only x0, solve, gather u*."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world_size)
+    sys.path.insert(0, ROOT)
+    from pympc_amd import sharding
+    full = _make(total) if rank == 0 else None
+    model = {k: full[k][0] for k in ('Ad', 'Bd')} if rank == 0 else None
+    mdl = sharding.broadcast_model(model, {'Ad': (5, 5), 'Bd': (5, 3)}, torch.device('cpu'))
+    loc = sharding.scatter_instances({'x0': full['x0']} if rank == 0 else None, {'x0': (5,)}, None, torch.device('cpu'), total=total)
+    lo, hi = sharding.shard_range(total, rank, world_size)
+    assert loc['x0'].shape == (hi - lo, 5) and mdl['Ad'].shape == (5, 5) and mdl['Bd'].shape == (5, 3)
+    n = hi - lo
+    u = _solve_shard(mdl['Ad'].expand(n, 5, 5), mdl['Bd'].expand(n, 5, 3), loc['x0']) if n else torch.zeros((0, 3), dtype=torch.float64)
+    u_all = sharding.gather_inputs(u, total=total)
+    if rank == 0:
+        q.put((mdl['Ad'].numpy(), u_all.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_broadcast_model_scatter_states_world3():
+    total, ws = 7, 3                                    # shards of 3, 3, 1
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_shared, args=(r, ws, port, total, q)) for r in range(ws)]
+    for p in procs:
+        p.start()
+    Ad, got = q.get(timeout=240)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    full = _make(total)
+    assert np.array_equal(Ad, full['Ad'][0].numpy())
+    ref = _solve_shard(full['Ad'][:1].expand(total, 5, 5), full['Bd'][:1].expand(total, 5, 3), full['x0']).numpy()
+    assert got.shape == (total, 3)
+    assert np.allclose(got, ref, rtol=1e-9, atol=1e-12)
+
+
+def test_broadcast_model_without_a_process_group_is_a_copy():
+    sys.path.insert(0, ROOT)
+    from pympc_amd import sharding
+    m = {'Ad': torch.arange(6.0, dtype=torch.float64).reshape(2, 3), 'c': torch.tensor(4.0, dtype=torch.float64)}
+    out = sharding.broadcast_model(m, {'Ad': (2, 3), 'c': ()})
+    assert torch.equal(out['Ad'], m['Ad']) and out['c'].shape == () and float(out['c']) == 4.0
