@@ -45,6 +45,23 @@ def controller_map(kw, X, Um1, max_iter=None):
     return K.output(), K
 
 
+def controller_map_one_controller(kw, X, Um1, x_setup, um1_setup, max_iter=None, backend=None):
+    """The same map the way the reference's loop runs it: ONE controller is set up (at x_setup, um1_setup -- example_mpc_function.py:62-64), then only its
+    state moves.  Here: B copies of that one controller (same model, same setup state: the batch shares ONE KKT factor, mpcqp_share_factor -- setup()
+    arranges it on the streaming backends), update() scatters the states, every instance warm-starts from the setup solution."""
+    B = X.shape[0]
+    stack = lambda a: np.broadcast_to(np.asarray(a, dtype=float), (B,) + np.shape(a))
+    K = BatchMPCController(stack(kw['Ad']), stack(kw['Bd']), Np=kw['Np'], x0=stack(x_setup), uminus1=stack(um1_setup), xref=stack(kw['xref']), uref=stack(kw['uref']),
+                           Qx=stack(kw['Qx']), QxN=stack(kw['QxN']), Qu=stack(kw['Qu']), QDu=stack(kw['QDu']),
+                           xmin=stack(kw['xmin']), xmax=stack(kw['xmax']), umin=stack(kw['umin']), umax=stack(kw['umax']),
+                           Dumin=stack(kw['Dumin']), Dumax=stack(kw['Dumax']), eps_abs=kw['eps_abs'], eps_rel=kw['eps_rel'])
+    K.solver_settings = dict(({'max_iter': max_iter} if max_iter else {}), **({'backend': backend} if backend else {}))
+    K.setup()
+    sharing = K.share_factor()
+    K.update(X, Um1)
+    return K.output(), K, sharing
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--n', type=int, default=10000); ap.add_argument('--eps', type=float, default=1e-3)
@@ -68,6 +85,11 @@ def main():
     print('batched map : %d states in %.1f ms (%.0f per second; setup of %d instances included)' % (a.n, 1e3 * t_batch, a.n / t_batch, a.n))
     print('sequential  : %d states in %.1f ms (%.0f per second; warm-started from the previous, unrelated state as in the reference loop)' % (m, 1e3 * t_seq, m / t_seq))
     print('largest |u_batched - u_sequential| over those %d: %.2e (solver tolerance %.0e)' % (m, np.abs(U[:m] - Us).max(), a.eps))
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        t = time.perf_counter(); U1, _, sharing = controller_map_one_controller(kw, X, Um1, X[0], Um1[0], **big); t_one = time.perf_counter() - t
+    print('one controller, many states: %d states in %.1f ms (%.0f per second; %d instances on one shared KKT factor); largest |u - u_batched| %.2e'
+          % (a.n, 1e3 * t_one, a.n / t_one, sharing, np.abs(U1 - U).max()))
 
 
 if __name__ == '__main__':

@@ -1,3 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_rccl_single_rank.py -q -x 2>&1 | grep -v "amdgpu.ids" | tail -15
-timeout 300 python bench.py --shared-model --backend sweeps --batch 4096 --steps 40 --warmup 20 | tail -n 1 | cut -c1-1500
+timeout 900 python -m pytest tests/test_gpu_controller_map.py -q -x 2>&1 | grep -v "amdgpu.ids" | tail -15
+timeout 300 python examples/controller_map_monte_carlo.py 2>&1 | grep -v amdgpu.ids
+timeout 300 python examples/controller_map_monte_carlo.py --eps 1e-9 2>&1 | grep -v amdgpu.ids

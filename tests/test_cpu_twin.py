@@ -149,3 +149,25 @@ def test_unconstrained_gains_host_logic_through_the_twin(twin):
             args[which] = np.eye(size)[j]
             u_seq, _ = unconstrained_mpc(kw['Ad'], kw['Bd'], Np, Qx=kw['Qx'], QxN=kw.get('QxN'), Qu=kw['Qu'], QDu=kw['QDu'], **args)
             assert np.abs(G[key][:, j] - u_seq.ravel()).max() <= 1e-8 * max(1.0, np.abs(u_seq).max()), (key, j)
+
+
+def test_batch_host_layer_one_model_many_states_through_the_abi(twin):
+    """BatchMPCController.share_factor() (mpcqp_share_factor) through the ABI: the twin keeps a factor per instance and says so (0 share), and the
+    one-model-many-states call order -- setup with ONE common state, share, scatter the states -- gives each state the controller's own answer."""
+    from pympc_amd import BatchMPCController, MPCController, fixtures
+    kw = fixtures.random_lti(2, nx=4, nu=2, Np=6)
+    B = 5
+    st = lambda a: np.broadcast_to(np.asarray(a, dtype=float), (B,) + np.shape(a))
+    rng = np.random.default_rng(0)
+    X, Um1 = rng.standard_normal((B, 4)), 0.1 * rng.standard_normal((B, 2))
+    K = BatchMPCController(st(kw['Ad']), st(kw['Bd']), Np=kw['Np'], x0=st(kw['x0']), uminus1=st(kw['uminus1']), xref=st(kw['xref']), uref=st(kw['uref']),
+                           Qx=st(kw['Qx']), QxN=st(kw['QxN']), Qu=st(kw['Qu']), QDu=st(kw['QDu']), xmin=st(kw['xmin']), xmax=st(kw['xmax']),
+                           umin=st(kw['umin']), umax=st(kw['umax']), Dumin=st(kw['Dumin']), Dumax=st(kw['Dumax']), eps_abs=1e-9, eps_rel=1e-9)
+    K.solver_settings = dict(max_iter=100000)
+    K.setup()
+    assert K.share_factor() == 0
+    K.update(X, Um1)
+    U = K.output()
+    for i in range(B):
+        K1 = MPCController(**dict(kw, x0=X[i], uminus1=Um1[i], eps_abs=1e-9, eps_rel=1e-9)); K1.solver_settings = dict(max_iter=100000); K1.setup()
+        assert np.abs(U[i] - K1.output()).max() <= 1e-6

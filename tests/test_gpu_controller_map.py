@@ -32,3 +32,20 @@ def test_batched_controller_map_matches_the_sequential_calls_and_the_oracle():
             uo = Ko.__controller_function__(X[i], Um1[i])
             assert np.abs(U[i] - uo).max() <= 1e-6 * max(1e-3, np.abs(uo).max()), (i, U[i], uo)
             assert np.abs(u1 - uo).max() <= 1e-6 * max(1e-3, np.abs(uo).max()), (i, u1, uo)
+
+
+def test_one_controller_many_states_on_a_shared_factor():
+    """The reference loop's own order -- ONE controller set up, then only the state moves -- as a batch of copies of that controller on one shared KKT
+    factor (forced streaming backend: the library's choice for a few hundred of these tiny problems is the register-resident inverse, which has nothing to share)."""
+    import controller_map_monte_carlo as ex
+    rng = np.random.default_rng(6)
+    n = 700
+    X, Um1 = rng.random((n, 2)), rng.random((n, 1))
+    kw = ex.point_mass(1e-9)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        U, _ = ex.controller_map(kw, X, Um1, max_iter=200000)
+        U1, K1, sharing = ex.controller_map_one_controller(kw, X, Um1, X[0], Um1[0], max_iter=200000, backend='sweeps')
+    assert sharing == n
+    assert all(inf.status == 1 for inf in K1.prob.infos())
+    assert np.abs(U1 - U).max() <= 1e-6 * max(1e-3, np.abs(U).max())
