@@ -46,7 +46,7 @@ def controller_map(kw, X, Um1, max_iter=None):
 
 
 def controller_map_one_controller(kw, X, Um1, x_setup, um1_setup, max_iter=None, backend=None):
-    """The same map the way the reference's loop runs it: ONE controller is set up (at x_setup, um1_setup -- example_mpc_function.py:62-64), then only its
+    """The same map the way the reference's loop runs it: ONE controller is set up (at x_setup, um1_setup -- example_mpc_function.py:61-64), then only its
     state moves.  Here: B copies of that one controller (same model, same setup state: the batch shares ONE KKT factor, mpcqp_share_factor -- setup()
     arranges it on the streaming backends), update() scatters the states, every instance warm-starts from the setup solution."""
     B = X.shape[0]

@@ -21,6 +21,8 @@
  *   mpcqp_mpc_step        __controller_function__: update(x,u); output() pyMPC/mpc.py:377-384
  *   mpcqp_mpc_run / _loop the caller loop  u = output(); plant; update() examples/example_point_mass.py:88-101,
  *                         (+ LinearStateEstimator update/predict)        pyMPC/mpc.py:688-692, pyMPC/kalman.py:109-134
+ *   mpcqp_share_factor    ONE controller evaluated at many states        test_scripts/example_mpc_function.py:61-64,105-111
+ *                         (copies of it share one KKT factor)
  *
  * The QP is the reference's sparse (non-condensed) formulation, bug-for-bug:
  *   w = [x_0..x_Np | u_0..u_{Nc-1} | eps_0..eps_Np],  n = 2(Np+1)nx + Nc nu
