@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python scripts/fuzz_share.py 0 150 2>&1 | grep -v amdgpu.ids | tail -12
+EXTRA="--backend sweeps --shared-model" bash scripts/pmc_sq.sh r6shared4096 4096 | tail -12
+EXTRA="--backend sweeps" bash scripts/pmc_sq.sh r6sw4096 4096 | tail -12

@@ -1,12 +1,12 @@
 #!/bin/bash
-# usage (on the GPU box, from the repo root): scripts/pmc_sq.sh <tag> <batch> [workload]
+# usage (on the GPU box, from the repo root): [EXTRA="--backend sweeps --shared-model"] scripts/pmc_sq.sh <tag> <batch> [workload]      (EXTRA: more bench flags)
 # SQ counters of the solve kernel under the driver's bench command at that batch (device loop), four passes of five counters each:
 # where the waves' cycles go -- issuing (ACTIVE_INST_*), parked at s_waitcnt / barriers (WAIT_ANY), stalled at issue (WAIT_INST_ANY), matrix pipe busy
 # (VALU_MFMA_BUSY_CYCLES), LDS bank conflicts.  Summary: gpurun_out/<tag>_sq_counters.txt (mean per launch of k_mpc_run).
 tag=$1; B=${2:-128}; wl=${3:-cfg3}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-path --no-refactor-timing --workload $wl --path device_loop --batch $B"
+CMD="python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-other-path --no-refactor-timing --workload $wl --path device_loop --batch $B ${EXTRA:-}"
 i=0
 for grp in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_MFMA SQ_ACTIVE_INST_VALU" "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_WAIT_ANY" "SQ_INST_CYCLES_VMEM SQ_WAIT_INST_ANY SQ_ACTIVE_INST_MISC SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_SCA"; do
   i=$((i+1))
