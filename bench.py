@@ -866,7 +866,12 @@ def dry_run(args, rank, world, dev, seen, torch, dist):
     full = None
     if rank == 0:
         full = {'x0': torch.arange(total * 3, dtype=torch.float64, device=dev).reshape(total, 3), 'Ad': torch.arange(total * 4, dtype=torch.float64, device=dev).reshape(total, 2, 2)}
-    loc = sharding.scatter_instances(full, {'Ad': (2, 2), 'x0': (3,)}, None, dev, total=total)
+    if args.shared_model:      # ONE model broadcast, the states alone scattered (what Shard does with --shared-model); the stand-in model is instance 0's
+        mdl = sharding.broadcast_model({'Ad': full['Ad'][0]} if rank == 0 else None, {'Ad': (2, 2)}, dev)
+        loc = sharding.scatter_instances({'x0': full['x0']} if rank == 0 else None, {'x0': (3,)}, None, dev, total=total)
+        loc['Ad'] = mdl['Ad'].expand(hi - lo, 2, 2).contiguous()
+    else:
+        loc = sharding.scatter_instances(full, {'Ad': (2, 2), 'x0': (3,)}, None, dev, total=total)
     assert loc['x0'].shape == (hi - lo, 3) and loc['Ad'].shape == (hi - lo, 2, 2)
     u = 2.0 * loc['x0'][:, :2] + loc['Ad'][:, 1, 1:2]
     u_all = sharding.gather_inputs(u, total=total)
@@ -880,9 +885,10 @@ def dry_run(args, rank, world, dev, seen, torch, dist):
         dist.barrier()
     if rank == 0:
         x0 = torch.arange(total * 3, dtype=torch.float64).reshape(total, 3)
-        expect = 2.0 * x0[:, :2] + torch.arange(total * 4, dtype=torch.float64).reshape(total, 2, 2)[:, 1, 1:2]
+        Ad_all = torch.arange(total * 4, dtype=torch.float64).reshape(total, 2, 2)
+        expect = 2.0 * x0[:, :2] + (Ad_all[:1].expand(total, 2, 2) if args.shared_model else Ad_all)[:, 1, 1:2]
         ok = bool(torch.equal(u_all.cpu(), expect)) and tuple(tr_all.shape) == (3, total, 2) and bool(torch.equal(tr_all[2].cpu(), expect + 20.0))
-        print(json.dumps(dict(dry_run=True, n_gpus=world, total_batch=total, gathered_ok=ok, per_rank=per_rank, **seen)))
+        print(json.dumps(dict(dry_run=True, n_gpus=world, total_batch=total, gathered_ok=ok, shared_model=bool(args.shared_model), per_rank=per_rank, **seen)))
     if comm_on(world):
         dist.destroy_process_group()
 

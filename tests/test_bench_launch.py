@@ -57,3 +57,12 @@ def test_bench_gpus4_total_batch_1024_is_the_strong_scaling_command():
 def test_bench_total_batch_need_not_divide():
     out = _run({}, '--gpus', '4', '--total-batch', '10')
     assert out['gathered_ok'] is True and [r['instances'] for r in out['per_rank']] == [3, 3, 3, 1]
+
+
+@pytest.mark.timeout(300)
+def test_bench_shared_model_broadcasts_one_model_and_scatters_the_states():
+    """`bench.py --gpus 3 --shared-model --total-batch 8`: ONE model broadcast from rank 0 (sharding.broadcast_model), the states alone scattered
+    (last paragraph), a short last rank."""
+    out = _run({}, '--gpus', '3', '--shared-model', '--total-batch', '8')
+    assert out['n_gpus'] == 3 and out['ranks_seen'] == 3 and out['shared_model'] is True and out['gathered_ok'] is True
+    assert [r['instances'] for r in out['per_rank']] == [3, 3, 2]
