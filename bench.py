@@ -97,6 +97,17 @@ def device_identity(torch, dev):
     return 'index:%d:%s' % (dev.index, p.name)
 
 
+def flush_c_stdio():
+    """RCCL prints a banner (version, host, library path) through C stdio when a communicator is made; on a pipe that buffer is written when the process exits --
+    AFTER the JSON line, which must be the LAST line on stdout.  Push it out now (every rank: under a launcher the ranks share one stdout)."""
+    try:
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+    except Exception:      # noqa: BLE001  (no libc handle: nothing to flush through it)
+        pass
+
+
 def init_distributed(args, torch, dist):
     """Process group + the proof that N ranks on N distinct devices are in it.  Returns (rank, world, local_rank, dev, seen)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -126,6 +137,8 @@ def init_distributed(args, torch, dist):
         got = [None] * world
         dist.all_gather_object(got, seen[0])
         seen = sorted(tuple(g) for g in got)
+        dist.barrier()
+        flush_c_stdio()                                          # (the communicator exists now: its banner goes out here, not behind the JSON line)
     ranks_seen = len({r for r, _ in seen})
     devices_seen = len({d for _, d in seen})
     if ranks_seen < world or devices_seen < world:
@@ -1161,10 +1174,12 @@ def main():
             _, refs5 = cpu_legs(WORKLOADS['cfg5'][:4], args.eps, cfg5_samples, want_baseline=False)
             out['cfg5_leg']['u_err'] = u_err_block(cfg5_samples, refs5)
         out['real_osqp'] = real_osqp_pin() if not args.no_cpu_baseline else {'osqp_available': osqp_available()}
-        emit(out)
     if comm_on(world):
         dist.barrier()
         dist.destroy_process_group()
+    flush_c_stdio()
+    if rank == 0:
+        emit(out)                                                # the LAST thing this job writes to stdout
 
 
 if __name__ == '__main__':

@@ -20,6 +20,7 @@ def _run(extra_env, *flags):
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, r.stdout          # rank 0 prints ONE JSON line
+    assert r.stdout.rstrip().splitlines()[-1] == lines[0], r.stdout[-1500:]      # ... and it is the LAST line
     return json.loads(lines[0])
 
 

@@ -25,6 +25,8 @@ def _bench(force, *flags):
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, r.stdout
+    # the driver parses the LAST stdout line: RCCL's banner (C stdio, written when its buffer is flushed) must not land behind it
+    assert r.stdout.rstrip().splitlines()[-1] == lines[0], r.stdout[-1500:]
     return json.loads(lines[0])
 
 
