@@ -1,5 +1,9 @@
 cd $GRAFT_REPO_ROOT
-MPCQP_BENCH_FORCE_PG=1 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-other-path --no-cpu-baseline > gpurun_out/fpg.out 2> gpurun_out/fpg.err; echo rc=$?
-echo "last line starts with: $(tail -n 1 gpurun_out/fpg.out | cut -c1-60)"; echo "lines: $(wc -l < gpurun_out/fpg.out)"; head -n 3 gpurun_out/fpg.out | cut -c1-80
-timeout 900 python -m pytest tests/test_gpu_rccl_single_rank.py -q 2>&1 | grep -v amdgpu.ids | tail -3
-timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/plain.out 2>/dev/null; echo "plain last: $(tail -n 1 gpurun_out/plain.out | cut -c1-40) lines $(wc -l < gpurun_out/plain.out)"
+MPCQP_BENCH_FORCE_PG=1 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-other-path --no-cpu-baseline 2>/dev/null | tail -n 1 > gpurun_out/r6_bench_rccl_one_rank.json
+MPCQP_BENCH_FORCE_PG=1 timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 --no-other-path --no-cpu-baseline --path stepwise 2>/dev/null | tail -n 1 > gpurun_out/r6_bench_rccl_one_rank_stepwise.json
+MPCQP_BENCH_FORCE_PG=1 timeout 600 python bench.py --gpus 1 --steps 40 --warmup 20 --shared-model --backend sweeps --batch 4096 2>/dev/null | tail -n 1 > gpurun_out/r6_bench_rccl_one_rank_shared_model.json
+python - <<'P'
+import json
+for f in ('r6_bench_rccl_one_rank', 'r6_bench_rccl_one_rank_stepwise', 'r6_bench_rccl_one_rank_shared_model'):
+    d = json.load(open('gpurun_out/%s.json' % f)); print(f, d['value'], d['collective_backend'], d['ranks_seen'], d['per_rank'])
+P
